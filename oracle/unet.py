@@ -1,0 +1,183 @@
+"""Oracle: forward pass of a Keras functional model (the metaseg U-Net) on the CPU.
+TEST INFRASTRUCTURE ONLY.
+
+Restates what ``model.predict_on_batch`` does at src/utils.py:115 for the layer types a Keras U-Net
+``model_config`` holds.  The arithmetic lives in TensorFlow 2.8 (env.yml:11), which is absent from the reference
+tree and not installed here -> PARITY UNPINNED; Keras layer semantics are restated from their published
+definitions and evaluated with torch CPU float32 ops (``conv_numpy`` is an independent numpy cross-check):
+
+* Conv2D: cross-correlation, HWIO kernel, ``same`` = TF padding (total ``k-1`` at stride 1, the extra pixel on
+  the bottom/right), ``valid`` = none; bias; activation.
+* Conv2DTranspose: kernel (kh, kw, out, in); ``out_full[i*s + k] += in[i] * w[k]``; ``same`` crops
+  ``max(k - s, 0)`` (``// 2`` before, rest after) so that the output is ``in * s``.
+* MaxPooling2D (valid, floor), UpSampling2D (nearest | bilinear with half-pixel centres), Concatenate(axis=-1),
+  BatchNormalization (inference; weight order gamma, beta, moving_mean, moving_variance, honouring center/scale),
+  Dropout-like layers = identity, Activation / ReLU / LeakyReLU / Softmax, Add, ZeroPadding2D, Cropping2D,
+  Rescaling.
+The uint8 patch batch is cast to float32 without scaling (Keras casts inputs to the InputLayer dtype).
+"""
+import json
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def _same_pad(k, s, n):
+    out = -(-n // s)
+    total = max((out - 1) * s + k - n, 0)
+    return total // 2, total - total // 2
+
+
+def _act(name, x, cfg=None):
+    if name in (None, 'linear'):
+        return x
+    if name == 'relu':
+        return F.relu(x)
+    if name == 'sigmoid':
+        return torch.sigmoid(x)
+    if name == 'softmax':
+        return F.softmax(x, dim=1)
+    if name == 'tanh':
+        return torch.tanh(x)
+    if name == 'elu':
+        return F.elu(x)
+    raise NotImplementedError('activation %r' % name)
+
+
+def _conv2d(x, cfg, w):
+    kernel = torch.from_numpy(np.ascontiguousarray(w[0])).permute(3, 2, 0, 1).contiguous()
+    bias = torch.from_numpy(np.ascontiguousarray(w[1])) if cfg.get('use_bias', True) else None
+    kh, kw = kernel.shape[2:]
+    sh, sw = cfg.get('strides', [1, 1])
+    assert list(cfg.get('dilation_rate', [1, 1])) == [1, 1] and cfg.get('groups', 1) == 1
+    if cfg['padding'] == 'same':
+        pt, pb = _same_pad(kh, sh, x.shape[2])
+        pl, pr = _same_pad(kw, sw, x.shape[3])
+        x = F.pad(x, (pl, pr, pt, pb))
+    y = F.conv2d(x, kernel, bias, stride=(sh, sw))
+    return _act(cfg.get('activation'), y)
+
+
+def _conv2d_transpose(x, cfg, w):
+    kernel = torch.from_numpy(np.ascontiguousarray(w[0])).permute(3, 2, 0, 1).contiguous()   # (in, out, kh, kw)
+    bias = torch.from_numpy(np.ascontiguousarray(w[1])) if cfg.get('use_bias', True) else None
+    kh, kw = kernel.shape[2:]
+    sh, sw = cfg['strides']
+    y = F.conv_transpose2d(x, kernel, None, stride=(sh, sw))
+    if cfg['padding'] == 'same':
+        H, W = x.shape[2] * sh, x.shape[3] * sw
+        ct, cl = max(kh - sh, 0) // 2, max(kw - sw, 0) // 2
+        y = y[:, :, ct:ct + H, cl:cl + W]
+    if bias is not None:
+        y = y + bias.view(1, -1, 1, 1)
+    return _act(cfg.get('activation'), y)
+
+
+def _batchnorm(x, cfg, w):
+    w = list(w)
+    C = x.shape[1]
+    gamma = torch.from_numpy(w.pop(0)) if cfg.get('scale', True) else torch.ones(C)
+    beta = torch.from_numpy(w.pop(0)) if cfg.get('center', True) else torch.zeros(C)
+    mean, var = torch.from_numpy(w[0]), torch.from_numpy(w[1])
+    inv = gamma / torch.sqrt(var + cfg.get('epsilon', 1e-3))
+    return x * inv.view(1, -1, 1, 1) + (beta - mean * inv).view(1, -1, 1, 1)
+
+
+def forward(model_config, weights, x_nhwc):
+    """``model_config``: dict (or JSON text) of a Keras Functional/Sequential model; ``weights``: {layer name:
+    [arrays in Keras order]}; ``x_nhwc``: (N, H, W, C) any dtype.  Returns float32 NHWC output of the model."""
+    if isinstance(model_config, (str, bytes)):
+        model_config = json.loads(model_config)
+    cfg = model_config['config']
+    layers = cfg['layers'] if isinstance(cfg, dict) else cfg
+    seq = model_config['class_name'] == 'Sequential'
+    vals = {}
+    x = torch.from_numpy(np.ascontiguousarray(x_nhwc).astype(np.float32)).permute(0, 3, 1, 2).contiguous()
+    prev = None
+    with torch.no_grad():
+        for L in layers:
+            cls, lc = L['class_name'], L['config']
+            name = lc['name']
+            if cls == 'InputLayer':
+                vals[name] = x
+                prev = name
+                continue
+            if seq:
+                if prev is None:
+                    vals['__in__'] = x
+                    prev = '__in__'
+                ins = [vals[prev]]
+            else:
+                nodes = L['inbound_nodes']
+                assert len(nodes) == 1, 'shared layers are not supported'
+                ins = [vals[n[0]] for n in nodes[0]]
+            w = weights.get(name, [])
+            a = ins[0]
+            if cls == 'Conv2D':
+                y = _conv2d(a, lc, w)
+            elif cls == 'Conv2DTranspose':
+                y = _conv2d_transpose(a, lc, w)
+            elif cls == 'MaxPooling2D':
+                assert lc.get('padding', 'valid') == 'valid'
+                y = F.max_pool2d(a, tuple(lc['pool_size']), tuple(lc.get('strides') or lc['pool_size']))
+            elif cls == 'UpSampling2D':
+                sz = tuple(lc['size'])
+                if lc.get('interpolation', 'nearest') == 'nearest':
+                    y = a.repeat_interleave(sz[0], dim=2).repeat_interleave(sz[1], dim=3)
+                else:
+                    y = F.interpolate(a, scale_factor=sz, mode='bilinear', align_corners=False)
+            elif cls == 'Concatenate':
+                assert lc.get('axis', -1) in (-1, 3)
+                y = torch.cat(ins, dim=1)
+            elif cls == 'Add':
+                y = ins[0]
+                for t in ins[1:]:
+                    y = y + t
+            elif cls == 'BatchNormalization':
+                y = _batchnorm(a, lc, w)
+            elif cls in ('Dropout', 'SpatialDropout2D', 'GaussianNoise', 'GaussianDropout', 'AlphaDropout'):
+                y = a
+            elif cls == 'Activation':
+                y = _act(lc['activation'], a)
+            elif cls == 'ReLU':
+                assert lc.get('max_value') is None and not lc.get('threshold') and not lc.get('negative_slope')
+                y = F.relu(a)
+            elif cls == 'LeakyReLU':
+                y = F.leaky_relu(a, float(lc.get('alpha', 0.3)))
+            elif cls == 'Softmax':
+                y = F.softmax(a, dim=1)
+            elif cls == 'ZeroPadding2D':
+                (t, b), (l, r) = lc['padding']
+                y = F.pad(a, (l, r, t, b))
+            elif cls == 'Cropping2D':
+                (t, b), (l, r) = lc['cropping']
+                y = a[:, :, t:a.shape[2] - b, l:a.shape[3] - r]
+            elif cls == 'Rescaling':
+                y = a * float(lc['scale']) + float(lc.get('offset', 0.0))
+            else:
+                raise NotImplementedError('Keras layer %s' % cls)
+            vals[name] = y
+            prev = name
+        if seq:
+            out = vals[prev]
+        else:
+            out = vals[cfg['output_layers'][0][0]]
+    return out.permute(0, 2, 3, 1).contiguous().numpy()
+
+
+def conv_numpy(x_nhwc, kernel_hwio, bias, padding='same'):
+    """Independent numpy float32 Conv2D (stride 1) used to cross-check the torch path on small inputs."""
+    x = np.asarray(x_nhwc, np.float32)
+    kh, kw, ci, co = kernel_hwio.shape
+    if padding == 'same':
+        pt, pb = _same_pad(kh, 1, x.shape[1])
+        pl, pr = _same_pad(kw, 1, x.shape[2])
+        x = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+    N, H, W, _ = x.shape
+    Ho, Wo = H - kh + 1, W - kw + 1
+    y = np.zeros((N, Ho, Wo, co), np.float32)
+    for i in range(kh):
+        for j in range(kw):
+            y += np.einsum('nhwc,co->nhwo', x[:, i:i + Ho, j:j + Wo, :], kernel_hwio[i, j]).astype(np.float32)
+    return y + np.asarray(bias, np.float32)

@@ -1,0 +1,301 @@
+"""ctypes binding of libecseg_hip.so (include/ecseg_hip.h).  There is no CPU fallback: when the library is missing
+or no MI355X is visible, every entry point raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libecseg_hip.so')
+
+EXPORTS = [
+    'ecseg_abi_version', 'ecseg_create', 'ecseg_destroy', 'ecseg_last_error', 'ecseg_device_name', 'ecseg_stream',
+    'ecseg_model_load', 'ecseg_model_flops_per_patch', 'ecseg_forward_patches', 'ecseg_read_tensor',
+    'ecseg_segment_images', 'ecseg_segment_images_dev', 'ecseg_set_images_per_group', 'ecseg_preprocess',
+    'ecseg_stitch_argmax', 'ecseg_meta_inference', 'ecseg_meta_inference_dev', 'ecseg_count_cc', 'ecseg_ccl_labels',
+    'ecseg_count_colocalization', 'ecseg_count_hsr', 'ecseg_overlay', 'ecseg_get_timings',
+    'ecseg_set_kernel_profiling', 'ecseg_get_conv_profile',
+]
+
+
+class EcsegError(RuntimeError):
+    pass
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [('buffer', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('c', C.c_int32),
+                ('c_stride', C.c_int32), ('c_offset', C.c_int32)]
+
+
+class OpDesc(C.Structure):
+    _fields_ = [('op', C.c_int32), ('in0', C.c_int32), ('in1', C.c_int32), ('out', C.c_int32),
+                ('kh', C.c_int32), ('kw', C.c_int32), ('stride', C.c_int32),
+                ('pad_top', C.c_int32), ('pad_left', C.c_int32), ('act', C.c_int32), ('mode', C.c_int32),
+                ('w0', C.c_int32), ('w1', C.c_int32), ('alpha', C.c_float)]
+
+
+_lib = None
+
+
+def load_library():
+    """Load libecseg_hip.so and declare the prototypes.  Raises EcsegError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EcsegError('%s not found: build it with `python -m ecseg_amd.build` (hipcc, gfx950)' % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise EcsegError('cannot load %s: %s' % (LIB_PATH, e))
+    vp, i32, u8p = C.c_void_p, C.c_int, C.c_void_p
+    lib.ecseg_abi_version.restype = C.c_int
+    lib.ecseg_create.argtypes = [C.POINTER(vp), i32]
+    lib.ecseg_destroy.argtypes = [vp]; lib.ecseg_destroy.restype = None
+    lib.ecseg_last_error.argtypes = [vp]; lib.ecseg_last_error.restype = C.c_char_p
+    lib.ecseg_device_name.argtypes = [vp, C.c_char_p, i32]
+    lib.ecseg_stream.argtypes = [vp]; lib.ecseg_stream.restype = vp
+    lib.ecseg_model_load.argtypes = [vp, C.POINTER(TensorDesc), i32, i32, C.POINTER(OpDesc), i32,
+                                     C.POINTER(C.c_void_p), C.POINTER(C.c_int64), i32, i32, i32]
+    lib.ecseg_model_flops_per_patch.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.ecseg_forward_patches.argtypes = [vp, u8p, i32, vp]
+    lib.ecseg_read_tensor.argtypes = [vp, i32, i32, vp]
+    lib.ecseg_segment_images.argtypes = [vp, u8p, i32, i32, i32, vp, vp, vp]
+    lib.ecseg_segment_images_dev.argtypes = [vp, u8p, i32, i32, i32, vp, vp, vp]
+    lib.ecseg_set_images_per_group.argtypes = [vp, i32]
+    lib.ecseg_preprocess.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
+    lib.ecseg_stitch_argmax.argtypes = [vp, vp, i32, i32, i32, vp]
+    lib.ecseg_meta_inference.argtypes = [vp, u8p, i32, i32, i32, vp, vp]
+    lib.ecseg_meta_inference_dev.argtypes = [vp, u8p, i32, i32, i32, vp, vp]
+    lib.ecseg_count_cc.argtypes = [vp, u8p, i32, i32, i32, vp, vp]
+    lib.ecseg_ccl_labels.argtypes = [vp, u8p, i32, i32, i32, i32, vp]
+    lib.ecseg_count_colocalization.argtypes = [vp, u8p, u8p, i32, i32, i32, vp]
+    lib.ecseg_count_hsr.argtypes = [vp, u8p, u8p, i32, i32, i32, i32, vp]
+    lib.ecseg_overlay.argtypes = [vp, u8p, u8p, i32, i32, i32, i32, i32, i32, vp]
+    lib.ecseg_get_timings.argtypes = [vp, vp]
+    lib.ecseg_set_kernel_profiling.argtypes = [vp, i32]
+    lib.ecseg_get_conv_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int and name not in ('ecseg_abi_version',):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _u8(a, shape_tail=None):
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.bool_:
+        a = a.view(np.uint8)
+    if a.dtype != np.uint8:
+        raise TypeError('expected a uint8 / bool array, got %s' % a.dtype)
+    return a
+
+
+class Handle:
+    """One per GPU.  Owns the device context, its stream and all device buffers."""
+
+    T_NAMES = ('tile', 'unet', 'tail', 'post', 'count')
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.ecseg_create(C.byref(h), int(device))
+        if rc != 0:
+            raise EcsegError('ecseg_create(device=%d) failed (%d): %s'
+                             % (device, rc, self.lib.ecseg_last_error(None).decode()))
+        self.h = h
+        self.device = int(device)
+        self.plan = None
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.ecseg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise EcsegError('%s failed (%d): %s' % (what, rc, self.lib.ecseg_last_error(self.h).decode()))
+
+    @property
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        self._check(self.lib.ecseg_device_name(self.h, buf, 256), 'ecseg_device_name')
+        return buf.value.decode()
+
+    @property
+    def stream(self):
+        return self.lib.ecseg_stream(self.h)
+
+    # ---- model -----------------------------------------------------------------------------------
+    def load_plan(self, plan):
+        nt, no, nw = len(plan.tensors), len(plan.ops), len(plan.weights)
+        T = (TensorDesc * nt)(*[TensorDesc(t['buffer'], t['h'], t['w'], t['c'], t['c_stride'], t['c_offset'])
+                                for t in plan.tensors])
+        O = (OpDesc * no)(*[OpDesc(o['op'], o['in0'], o['in1'], o['out'], o['kh'], o['kw'], o['stride'], o['pad_top'],
+                                   o['pad_left'], o['act'], o['mode'], o['w0'], o['w1'], float(o['alpha']))
+                            for o in plan.ops])
+        keep = [np.ascontiguousarray(w, np.float32) for w in plan.weights]
+        Wp = (C.c_void_p * max(nw, 1))(*[w.ctypes.data for w in keep])
+        Wl = (C.c_int64 * max(nw, 1))(*[w.size for w in keep])
+        self._check(self.lib.ecseg_model_load(self.h, T, nt, plan.n_buffers, O, no, Wp, Wl, nw, plan.input_tensor,
+                                              plan.output_tensor), 'ecseg_model_load')
+        self.plan = plan
+
+    def flops_per_patch(self):
+        v = C.c_double()
+        self._check(self.lib.ecseg_model_flops_per_patch(self.h, C.byref(v)), 'ecseg_model_flops_per_patch')
+        return v.value
+
+    def set_images_per_group(self, n):
+        self._check(self.lib.ecseg_set_images_per_group(self.h, int(n)), 'ecseg_set_images_per_group')
+
+    def forward_patches(self, patches):
+        """uint8 (N, H, W, C) -> float32 (N, H, W, K): ``model.predict_on_batch`` (reference src/utils.py:115)."""
+        if self.plan is None:
+            raise EcsegError('no model loaded')
+        p = _u8(patches)
+        ti, to = self.plan.tensors[self.plan.input_tensor], self.plan.tensors[self.plan.output_tensor]
+        if p.ndim == 3:
+            p = p[..., None]
+        if p.shape[1:] != (ti['h'], ti['w'], ti['c']):
+            raise ValueError('expected patches of shape (N, %d, %d, %d), got %s' % (ti['h'], ti['w'], ti['c'], p.shape))
+        out = np.empty((p.shape[0], to['h'], to['w'], to['c']), np.float32)
+        self._check(self.lib.ecseg_forward_patches(self.h, _ptr(p), p.shape[0], _ptr(out)), 'ecseg_forward_patches')
+        return out
+
+    def read_tensor(self, tensor, n):
+        t = self.plan.tensors[tensor]
+        out = np.empty((n, t['h'], t['w'], t['c']), np.float32)
+        self._check(self.lib.ecseg_read_tensor(self.h, int(tensor), int(n), _ptr(out)), 'ecseg_read_tensor')
+        return out
+
+    # ---- image pipeline -----------------------------------------------------------------------------
+    def segment_images(self, gray, want_raw=True):
+        """(n, H, W) uint8 pre-processed images -> (raw labels | None, post-processed labels, n_ec)."""
+        g = _u8(gray)
+        if g.ndim == 2:
+            g = g[None]
+        n, H, W = g.shape
+        raw = np.empty((n, H, W), np.uint8) if want_raw else None
+        post = np.empty((n, H, W), np.uint8)
+        nec = np.zeros(n, np.int32)
+        self._check(self.lib.ecseg_segment_images(self.h, _ptr(g), n, H, W, _ptr(raw), _ptr(post), _ptr(nec)),
+                    'ecseg_segment_images')
+        return raw, post, nec
+
+    def segment_images_dev(self, gray_ptr, n, H, W, raw_ptr, post_ptr, nec_ptr):
+        self._check(self.lib.ecseg_segment_images_dev(self.h, C.c_void_p(gray_ptr), n, H, W,
+                                                      C.c_void_p(raw_ptr) if raw_ptr else None, C.c_void_p(post_ptr),
+                                                      C.c_void_p(nec_ptr) if nec_ptr else None),
+                    'ecseg_segment_images_dev')
+
+    def preprocess(self, imgs):
+        """(n, H, W[, C]) uint8 / uint16 -> ((n, H, W) uint8 gray, inverted flags): meta_preprocess."""
+        a = np.ascontiguousarray(imgs)
+        if a.dtype not in (np.uint8, np.uint16):
+            raise TypeError('meta_preprocess takes uint8 or uint16 images, got %s' % a.dtype)
+        if a.ndim == 3:
+            a = a[..., None]
+        n, H, W, Cc = a.shape
+        gray = np.empty((n, H, W), np.uint8)
+        inv = np.zeros(n, np.int32)
+        self._check(self.lib.ecseg_preprocess(self.h, _ptr(a), n, H, W, Cc, a.dtype.itemsize, _ptr(gray), _ptr(inv)),
+                    'ecseg_preprocess')
+        return gray, inv
+
+    def stitch_argmax(self, probs, n_img, H, W):
+        p = np.ascontiguousarray(probs, np.float32)
+        out = np.empty((n_img, H, W), np.uint8)
+        self._check(self.lib.ecseg_stitch_argmax(self.h, _ptr(p), n_img, H, W, _ptr(out)), 'ecseg_stitch_argmax')
+        return out
+
+    def meta_inference(self, labels):
+        a = _u8(labels)
+        single = a.ndim == 2
+        if single:
+            a = a[None]
+        n, H, W = a.shape
+        out = np.empty_like(a)
+        nec = np.zeros(n, np.int32)
+        self._check(self.lib.ecseg_meta_inference(self.h, _ptr(a), n, H, W, _ptr(out), _ptr(nec)), 'ecseg_meta_inference')
+        return (out[0], int(nec[0])) if single else (out, nec)
+
+    def meta_inference_dev(self, in_ptr, n, H, W, out_ptr, nec_ptr):
+        self._check(self.lib.ecseg_meta_inference_dev(self.h, C.c_void_p(in_ptr), n, H, W, C.c_void_p(out_ptr),
+                                                      C.c_void_p(nec_ptr) if nec_ptr else None), 'ecseg_meta_inference_dev')
+
+    # ---- counting -----------------------------------------------------------------------------------
+    @staticmethod
+    def _stack(a):
+        a = _u8(a)
+        return (a[None], True) if a.ndim == 2 else (a, False)
+
+    def count_cc(self, mask):
+        a, single = self._stack(mask)
+        n, H, W = a.shape
+        cnt = np.zeros(n, np.int32); px = np.zeros(n, np.int64)
+        self._check(self.lib.ecseg_count_cc(self.h, _ptr(a), n, H, W, _ptr(cnt), _ptr(px)), 'ecseg_count_cc')
+        return (int(cnt[0]), int(px[0])) if single else (cnt, px)
+
+    def ccl_labels(self, mask, connectivity=8):
+        a, single = self._stack(mask)
+        n, H, W = a.shape
+        out = np.empty((n, H, W), np.int32)
+        self._check(self.lib.ecseg_ccl_labels(self.h, _ptr(a), n, H, W, int(connectivity), _ptr(out)), 'ecseg_ccl_labels')
+        return out[0] if single else out
+
+    def count_colocalization(self, ob1, ob2):
+        a, single = self._stack(ob1)
+        b, _ = self._stack(ob2)
+        n, H, W = a.shape
+        cnt = np.zeros(n, np.int32)
+        self._check(self.lib.ecseg_count_colocalization(self.h, _ptr(a), _ptr(b), n, H, W, _ptr(cnt)),
+                    'ecseg_count_colocalization')
+        return int(cnt[0]) if single else cnt
+
+    def count_hsr(self, chrom, fish, size_threshold=20):
+        a, single = self._stack(chrom)
+        b, _ = self._stack(fish)
+        n, H, W = a.shape
+        cnt = np.zeros(n, np.int32)
+        self._check(self.lib.ecseg_count_hsr(self.h, _ptr(a), _ptr(b), n, H, W, int(size_threshold), _ptr(cnt)),
+                    'ecseg_count_hsr')
+        return int(cnt[0]) if single else cnt
+
+    def overlay(self, labels, rgb, sensitivity, hsr_size_threshold=20):
+        a, single = self._stack(labels)
+        r = _u8(rgb)
+        if r.ndim == 3:
+            r = r[None]
+        n, H, W = a.shape
+        if r.shape[:3] != (n, H, W) or r.shape[3] < 2:
+            raise ValueError('rgb must be (n, H, W, C>=2) matching labels')
+        out = np.zeros((n, 12), np.int64)
+        self._check(self.lib.ecseg_overlay(self.h, _ptr(a), _ptr(r), n, H, W, r.shape[3], int(sensitivity),
+                                           int(hsr_size_threshold), _ptr(out)), 'ecseg_overlay')
+        return out[0] if single else out
+
+    # ---- timing ---------------------------------------------------------------------------------------
+    def timings(self):
+        t = np.zeros(5, np.float32)
+        self._check(self.lib.ecseg_get_timings(self.h, _ptr(t)), 'ecseg_get_timings')
+        return dict(zip(self.T_NAMES, [float(v) for v in t]))
+
+    def set_kernel_profiling(self, on):
+        self._check(self.lib.ecseg_set_kernel_profiling(self.h, int(bool(on))), 'ecseg_set_kernel_profiling')
+
+    def conv_profile(self):
+        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+        self._check(self.lib.ecseg_get_conv_profile(self.h, C.byref(ms), C.byref(n), C.byref(fl)), 'ecseg_get_conv_profile')
+        return ms.value, n.value, fl.value

@@ -1,0 +1,54 @@
+"""Build libecseg_hip.so (gfx950) in-tree with hipcc.  ``python -m ecseg_amd.build [--force]``."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libecseg_hip.so')
+SOURCES = ['api.hip', 'unet_kernels.hip', 'post_kernels.hip']
+HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'ecseg_hip.h')]
+
+
+def _hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return 'hipcc'
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=True):
+    """Compile every HIP source for gfx950 into one shared library next to this file."""
+    if not force and not needs_build():
+        return LIB
+    objs = []
+    procs = []
+    for s in SOURCES:
+        obj = os.path.join(CSRC, s.replace('.hip', '.o'))
+        cmd = [_hipcc(), '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-Wall', '-Wno-unused-function',
+               '-c', os.path.join(CSRC, s), '-o', obj]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        procs.append((subprocess.Popen(cmd), cmd))
+        objs.append(obj)
+    for p, cmd in procs:
+        if p.wait() != 0:
+            raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
+    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)
+    print(LIB)

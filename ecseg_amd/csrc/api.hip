@@ -1,0 +1,860 @@
+// C ABI of libecseg_hip.so (see include/ecseg_hip.h).  Host-side orchestration only: buffer management, the layer plan
+// interpreter, the image pipeline (tile -> U-Net -> stitch/argmax -> meta_inference -> count) and timing.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "common.h"
+
+using namespace ecseg;
+
+namespace {
+
+std::string g_create_error;
+
+struct OpRt {                 // run-time form of one plan operator
+    ecseg_op_desc d;
+    int path;                 // which kernel family
+    float* wt = nullptr;      // device weights in the layout the chosen kernel wants
+    float* bias = nullptr;
+    float* scale = nullptr;   // AFFINE
+    float* shift = nullptr;
+    int cin_chunks = 0, coutp = 0;
+    double flops = 0.0;       // algorithmic 2*MAC per patch
+};
+enum { PATH_MFMA = 1, PATH_SMALL_CIN = 2, PATH_HEAD = 3, PATH_GENERIC = 4, PATH_OTHER = 5 };
+
+struct StitchPlan {
+    int n_pos = 0;
+    int32_t* pos_dev = nullptr;   // (n_pos, 2) window origins (row, col), reference order
+    int32_t* map_dev = nullptr;   // (H*W) source map
+};
+
+}  // namespace
+
+struct ecseg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    char devname[256] = {0};
+
+    bool has_model = false;
+    std::vector<ecseg_tensor_desc> tensors;
+    std::vector<OpRt> ops;
+    int n_buffers = 0;
+    std::vector<size_t> buf_floats;       // floats per patch of every buffer
+    std::vector<float*> bufs;
+    int cap_patches = 0;
+    std::vector<float*> dev_allocs;       // weight allocations (freed on reload / destroy)
+    int input_tensor = -1, output_tensor = -1;
+    double flops_per_patch = 0.0, mfma_flops_per_patch = 0.0;
+
+    // image pipeline
+    int images_per_group = 8;
+    std::map<std::pair<int, int>, StitchPlan> stitch;
+    uint8_t* d_gray = nullptr; size_t d_gray_cap = 0;
+    uint8_t* d_raw = nullptr; size_t d_raw_cap = 0;
+    uint8_t* d_post = nullptr; size_t d_post_cap = 0;
+    uint8_t* d_aux8 = nullptr; size_t d_aux8_cap = 0;      // second uint8 input (masks, rgb)
+    uint8_t* d_u8in = nullptr; size_t d_u8in_cap = 0;      // uint8 patches of forward_patches
+    int32_t* d_i32 = nullptr; size_t d_i32_cap = 0;        // small int outputs
+    long long* d_i64 = nullptr; size_t d_i64_cap = 0;
+    float* d_probs_in = nullptr; size_t d_probs_cap = 0;
+    uint32_t* d_hist = nullptr; size_t d_hist_cap = 0;
+    PostWorkspace ws{};
+    size_t ws_list_bytes = 0;
+    int post_chunk = 64;
+
+    // timing
+    hipEvent_t ev[ECSEG_T_N + 1] = {};
+    float stage_ms[ECSEG_T_N] = {};
+    bool profile_kernels = false;
+    std::vector<hipEvent_t> prof_events;   // pairs
+    size_t prof_used = 0;
+    double prof_flops = 0.0;
+    double last_conv_ms = 0.0; long long last_conv_launches = 0; double last_conv_flops = 0.0;
+};
+
+namespace {
+
+int fail(ecseg_ctx* h, int code, const std::string& msg) {
+    if (h) h->err = msg; else g_create_error = msg;
+    return code;
+}
+int fail_hip(ecseg_ctx* h, hipError_t e, const char* what) {
+    return fail(h, ECSEG_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(h, call) do { hipError_t _e = (call); if (_e != hipSuccess) return fail_hip((h), _e, #call); } while (0)
+
+template <typename T>
+int ensure(ecseg_ctx* h, T*& ptr, size_t& cap, size_t need_elems) {
+    if (need_elems <= cap && ptr) return ECSEG_OK;
+    if (ptr) { hipError_t e = hipFree(ptr); ptr = nullptr; cap = 0; if (e != hipSuccess) return fail_hip(h, e, "hipFree"); }
+    if (need_elems == 0) need_elems = 1;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&ptr), need_elems * sizeof(T));
+    if (e != hipSuccess) { ptr = nullptr; return fail(h, ECSEG_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    cap = need_elems;
+    return ECSEG_OK;
+}
+
+TView view_of(const ecseg_ctx* h, int t) {
+    const ecseg_tensor_desc& d = h->tensors[t];
+    TView v;
+    v.p = h->bufs[d.buffer] + d.c_offset;
+    v.h = d.h; v.w = d.w; v.c = d.c; v.cs = d.c_stride;
+    return v;
+}
+
+void free_model(ecseg_ctx* h) {
+    for (float* p : h->dev_allocs) (void)hipFree(p);
+    h->dev_allocs.clear();
+    for (float* p : h->bufs) if (p) (void)hipFree(p);
+    h->bufs.clear();
+    h->cap_patches = 0;
+    h->ops.clear(); h->tensors.clear();
+    h->has_model = false;
+}
+
+int upload(ecseg_ctx* h, const std::vector<float>& host, float** dev) {
+    float* p = nullptr;
+    const size_t n = host.empty() ? 1 : host.size();
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(float));
+    if (e != hipSuccess) return fail(h, ECSEG_E_NOMEM, std::string("hipMalloc(weights): ") + hipGetErrorString(e));
+    h->dev_allocs.push_back(p);
+    if (!host.empty()) {
+        e = hipMemcpy(p, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return fail_hip(h, e, "hipMemcpy(weights)");
+    }
+    *dev = p;
+    return ECSEG_OK;
+}
+
+// Keras HWIO kernel -> wt[tap][chunk][half][NP][4] (zero padded)
+std::vector<float> relayout_conv(const float* w, int R, int S, int cin, int cout, int chunks, int np) {
+    std::vector<float> o((size_t)R * S * chunks * 2 * np * 4, 0.f);
+    for (int t = 0; t < R * S; ++t)
+        for (int ci = 0; ci < cin; ++ci) {
+            const int chunk = ci / 8, hh = (ci % 8) / 4, e = ci % 4;
+            const float* src = w + ((size_t)t * cin + ci) * cout;
+            float* dst = o.data() + ((((size_t)t * chunks + chunk) * 2 + hh) * np) * 4 + e;
+            for (int co = 0; co < cout; ++co) dst[(size_t)co * 4] = src[co];
+        }
+    return o;
+}
+// Keras Conv2DTranspose kernel (kh, kw, out, in) -> one-tap GEMM filter over N = (a*kT + b) * coutp + co
+std::vector<float> relayout_convt(const float* w, int kT, int cin, int cout, int chunks, int coutp) {
+    const int np = kT * kT * coutp;
+    std::vector<float> o((size_t)chunks * 2 * np * 4, 0.f);
+    for (int ab = 0; ab < kT * kT; ++ab)
+        for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cin; ++ci) {
+                const int chunk = ci / 8, hh = (ci % 8) / 4, e = ci % 4;
+                o[((((size_t)chunk) * 2 + hh) * np + (size_t)ab * coutp + co) * 4 + e] = w[((size_t)ab * cout + co) * cin + ci];
+            }
+    return o;
+}
+
+int ensure_patches(ecseg_ctx* h, int n) {
+    if (n <= h->cap_patches) return ECSEG_OK;
+    for (float*& p : h->bufs) { if (p) (void)hipFree(p); p = nullptr; }
+    h->bufs.assign(h->n_buffers, nullptr);
+    h->cap_patches = 0;
+    for (int b = 0; b < h->n_buffers; ++b) {
+        const size_t bytes = std::max<size_t>(h->buf_floats[b], 4) * (size_t)n * sizeof(float);
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->bufs[b]), bytes);
+        if (e != hipSuccess) return fail(h, ECSEG_E_NOMEM, std::string("hipMalloc(activations): ") + hipGetErrorString(e));
+    }
+    h->cap_patches = n;
+    return ECSEG_OK;
+}
+
+hipEvent_t* prof_pair(ecseg_ctx* h) {
+    if (h->prof_used + 2 > h->prof_events.size()) {
+        for (int k = 0; k < 2; ++k) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            h->prof_events.push_back(e);
+        }
+    }
+    hipEvent_t* p = &h->prof_events[h->prof_used];
+    h->prof_used += 2;
+    return p;
+}
+
+// Run the whole plan on n patches whose input tensor has already been written.
+int run_plan(ecseg_ctx* h, int n) {
+    hipStream_t s = h->stream;
+    for (const OpRt& o : h->ops) {
+        const ecseg_op_desc& d = o.d;
+        const TView in = view_of(h, d.in0), out = view_of(h, d.out);
+        hipError_t e = hipSuccess;
+        switch (d.op) {
+            case ECSEG_OP_CONV:
+            case ECSEG_OP_CONVT: {
+                const bool softmax = d.act == ECSEG_ACT_SOFTMAX;
+                const int act = (softmax && o.path != PATH_HEAD) ? ECSEG_ACT_LINEAR : d.act;
+                if (o.path == PATH_MFMA) {
+                    ConvParams p{};
+                    p.in = in; p.out = out; p.wt = o.wt; p.bias = o.bias; p.n = n;
+                    p.act = act; p.alpha = d.alpha; p.cin_chunks = o.cin_chunks; p.coutp = o.coutp;
+                    if (d.op == ECSEG_OP_CONV) {
+                        p.R = d.kh; p.S = d.kw; p.pad_top = d.pad_top; p.pad_left = d.pad_left; p.convt = 0;
+                    } else {
+                        p.R = 1; p.S = 1; p.pad_top = 0; p.pad_left = 0; p.convt = 1; p.kT = d.kh;
+                        p.crop_top = d.pad_top; p.crop_left = d.pad_left;
+                    }
+                    hipEvent_t* ev = h->profile_kernels ? prof_pair(h) : nullptr;
+                    if (ev) (void)hipEventRecord(ev[0], s);
+                    e = launch_conv_mfma(p, s);
+                    if (ev) { (void)hipEventRecord(ev[1], s); h->prof_flops += o.flops * n; }
+                } else if (o.path == PATH_SMALL_CIN) {
+                    e = launch_conv_small_cin(in, out, o.wt, o.bias, n, d.kh, d.kw, d.pad_top, d.pad_left, act, d.alpha, s);
+                } else if (o.path == PATH_HEAD) {
+                    e = launch_conv_head(in, out, o.wt, o.bias, n, d.act, d.alpha, s);
+                } else if (d.op == ECSEG_OP_CONV) {
+                    e = launch_conv_generic(in, out, o.wt, o.bias, n, d.kh, d.kw, d.pad_top, d.pad_left, act, d.alpha, s);
+                } else {
+                    e = launch_convt_generic(in, out, o.wt, o.bias, n, d.kh, d.kw, d.stride, d.pad_top, d.pad_left, act, d.alpha, s);
+                }
+                if (e == hipSuccess && softmax && o.path != PATH_HEAD) e = launch_softmax(out, out, n, s);
+                break;
+            }
+            case ECSEG_OP_MAXPOOL: e = launch_maxpool(in, out, n, d.kh, d.kw, d.stride, s); break;
+            case ECSEG_OP_UPSAMPLE: e = launch_upsample(in, out, n, d.stride, d.mode, s); break;
+            case ECSEG_OP_AFFINE:
+                if (d.act == ECSEG_ACT_SOFTMAX) {
+                    e = launch_affine(in, out, o.scale, o.shift, n, ECSEG_ACT_LINEAR, d.alpha, s);
+                    if (e == hipSuccess) e = launch_softmax(out, out, n, s);
+                } else {
+                    e = launch_affine(in, out, o.scale, o.shift, n, d.act, d.alpha, s);
+                }
+                break;
+            case ECSEG_OP_ACT:
+                if (d.act == ECSEG_ACT_SOFTMAX) e = launch_softmax(in, out, n, s);
+                else e = launch_affine(in, out, nullptr, nullptr, n, d.act, d.alpha, s);
+                break;
+            case ECSEG_OP_ADD: e = launch_add(in, view_of(h, d.in1), out, n, d.act, d.alpha, s); break;
+            case ECSEG_OP_COPY: e = launch_copy(in, out, n, d.pad_top, d.pad_left, s); break;
+            default: return fail(h, ECSEG_E_INVALID, "unknown op in plan");
+        }
+        if (e != hipSuccess) return fail_hip(h, e, "plan kernel launch");
+    }
+    return ECSEG_OK;
+}
+
+void prof_begin(ecseg_ctx* h) { h->prof_used = 0; h->prof_flops = 0.0; }
+void prof_end(ecseg_ctx* h) {   // stream must be idle
+    double ms = 0.0;
+    for (size_t k = 0; k + 1 < h->prof_used; k += 2) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, h->prof_events[k], h->prof_events[k + 1]) == hipSuccess) ms += t;
+    }
+    h->last_conv_ms = ms; h->last_conv_launches = (long long)(h->prof_used / 2); h->last_conv_flops = h->prof_flops;
+}
+
+// ---- tiling / stitch geometry (reference src/image_tools.py:148-252), computed once per image size ----
+std::vector<int> window_starts(int dim) {
+    const int cropped = dim - 50, spw = 206;
+    std::vector<int> s;
+    for (int e = 0; e < cropped / spw; ++e) s.push_back(spw * e);
+    if (cropped % spw) s.push_back(cropped - spw);
+    return s;
+}
+
+int get_stitch(ecseg_ctx* h, int H, int W, StitchPlan** out) {
+    auto key = std::make_pair(H, W);
+    auto it = h->stitch.find(key);
+    if (it != h->stitch.end()) { *out = &it->second; return ECSEG_OK; }
+    if (H < 256 || W < 256) return fail(h, ECSEG_E_INVALID, "image smaller than one 256x256 window");
+    if ((long long)H * W >= (1ll << 31)) return fail(h, ECSEG_E_INVALID, "image too large");
+    const std::vector<int> Lh = window_starts(H), Lw = window_starts(W);
+    std::vector<int32_t> pos;
+    for (int w : Lw) for (int hh : Lh) { pos.push_back(hh); pos.push_back(w); }   // meshgrid order: columns outer
+    const int n = (int)pos.size() / 2;
+    if (n >= 32768) return fail(h, ECSEG_E_INVALID, "too many patches per image");
+    const int h_l = Lh.back(), w_l = Lw.back();
+    const int Hc = h_l + 256, Wc = w_l + 256;    // == H, W
+    std::vector<int32_t> map((size_t)Hc * Wc, -1);
+    auto put = [&](int i, int dr0, int dr1, int dc0, int dc1, int sr0, int sc0) {
+        for (int r = dr0; r < dr1; ++r)
+            for (int c = dc0; c < dc1; ++c)
+                map[(size_t)r * Wc + c] = (i << 16) | ((sr0 + r - dr0) << 8) | (sc0 + c - dc0);
+    };
+    const int o = 25, lo = 25, hi = 231;
+    for (int i = 0; i < n; ++i) {
+        const int ph = pos[2 * i], pw = pos[2 * i + 1];
+        if (ph == 0) {
+            if (pw == 0) { put(i, 0, o, 0, o, 0, 0); put(i, lo, hi, 0, o, lo, 0); put(i, 0, o, lo, hi, 0, lo); }
+            else { if (pw == w_l) put(i, 0, o, Wc - o, Wc, 0, hi); put(i, 0, o, pw + lo, pw + hi, 0, lo); }
+        }
+        if (pw == 0 && ph != 0) put(i, ph + lo, ph + hi, 0, o, lo, 0);
+        if (ph == h_l) {
+            if (pw == w_l) {
+                put(i, Hc - o, Hc, Wc - o, Wc, hi, hi);
+                put(i, h_l + lo, Hc - o, Wc - o, Wc, lo, hi);
+                put(i, Hc - o, Hc, w_l + lo, Wc - o, hi, lo);
+            } else {
+                if (pw == 0) put(i, Hc - o, Hc, 0, o, hi, 0);
+                put(i, Hc - o, Hc, pw + lo, pw + hi, hi, lo);
+            }
+        }
+        if (pw == w_l && pw != h_l) put(i, ph + lo, ph + hi, Wc - o, Wc, lo, hi);   // sic: column start vs h_l (:242)
+    }
+    for (int i = 0; i < n; ++i) put(i, pos[2 * i] + lo, pos[2 * i] + hi, pos[2 * i + 1] + lo, pos[2 * i + 1] + hi, lo, lo);
+    StitchPlan sp;
+    sp.n_pos = n;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&sp.pos_dev), pos.size() * sizeof(int32_t)));
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&sp.map_dev), map.size() * sizeof(int32_t)));
+    HIP_TRY(h, hipMemcpy(sp.pos_dev, pos.data(), pos.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(sp.map_dev, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    auto ins = h->stitch.emplace(key, sp);
+    *out = &ins.first->second;
+    return ECSEG_OK;
+}
+
+int ensure_post(ecseg_ctx* h, int n_img, size_t px) {
+    PostWorkspace& w = h->ws;
+    if (n_img <= w.cap_img && px <= w.cap_px && w.L) return ECSEG_OK;
+    const int ni = std::max(n_img, w.cap_img);
+    const size_t np = std::max(px, w.cap_px);
+    void* ptrs[] = {w.L, w.area, w.sumy, w.sumx, w.flag, w.tmpA, w.tmpB, w.list, w.g};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    w = PostWorkspace{};
+    const size_t tot = (size_t)ni * np;
+    // Root lists of the nucleus-in-metaphase test: run_meta_inference uses px/4 + (H+W)/2 + 4 entries per image
+    // (>= ceil(H/2)*ceil(W/2), the most 8-connected components an image can hold); (H+W)/2 <= px/2 + 1, and every
+    // entry costs 4 B (nucleus root) + 16 B (chromosome centroid).
+    const size_t list_cap = np / 4 + np / 2 + 8;
+    const size_t list_bytes = (size_t)ni * list_cap * 20 + 256;
+    hipError_t e = hipSuccess;
+    auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 16); };
+    A(reinterpret_cast<void**>(&w.L), tot * 4);
+    A(reinterpret_cast<void**>(&w.area), tot * 4);
+    A(reinterpret_cast<void**>(&w.sumy), tot * 8);
+    A(reinterpret_cast<void**>(&w.sumx), tot * 8);
+    A(reinterpret_cast<void**>(&w.flag), tot * 4);
+    A(reinterpret_cast<void**>(&w.tmpA), tot);
+    A(reinterpret_cast<void**>(&w.tmpB), tot);
+    A(reinterpret_cast<void**>(&w.list), list_bytes);
+    A(reinterpret_cast<void**>(&w.g), (size_t)ni * G_STRIDE * 4);
+    if (e != hipSuccess) return fail(h, ECSEG_E_NOMEM, std::string("hipMalloc(post workspace): ") + hipGetErrorString(e));
+    w.cap_img = ni; w.cap_px = np;
+    h->ws_list_bytes = list_bytes;
+    return ECSEG_OK;
+}
+
+int check_model(ecseg_ctx* h) {
+    if (!h) return ECSEG_E_INVALID;
+    if (!h->has_model) return fail(h, ECSEG_E_NOMODEL, "no model loaded (call ecseg_model_load first)");
+    return ECSEG_OK;
+}
+
+float stage_elapsed(hipEvent_t a, hipEvent_t b) {
+    float t = 0.f;
+    return hipEventElapsedTime(&t, a, b) == hipSuccess ? t : 0.f;
+}
+
+// Device-resident pipeline: gray (n_img, H, W) -> raw labels, post labels, counts.  All pointers are device pointers.
+int segment_dev(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint8_t* raw, uint8_t* post, int32_t* n_ec) {
+    int rc = check_model(h);
+    if (rc) return rc;
+    const ecseg_tensor_desc& ti = h->tensors[h->input_tensor];
+    const ecseg_tensor_desc& to = h->tensors[h->output_tensor];
+    if (ti.h != 256 || ti.w != 256 || ti.c != 1 || ti.c_stride != 1)
+        return fail(h, ECSEG_E_INVALID, "segment: model input must be (256, 256, 1)");
+    if (to.h != 256 || to.w != 256 || to.c != 4)
+        return fail(h, ECSEG_E_INVALID, "segment: model output must be (256, 256, 4)");
+    StitchPlan* sp = nullptr;
+    if ((rc = get_stitch(h, H, W, &sp))) return rc;
+    const size_t px = (size_t)H * W;
+    hipStream_t s = h->stream;
+    const int grp = std::max(1, h->images_per_group);
+    if ((rc = ensure_patches(h, std::min(grp, n_img) * sp->n_pos))) return rc;
+    if ((rc = ensure_post(h, std::min(n_img, h->post_chunk), px))) return rc;
+    for (float& v : h->stage_ms) v = 0.f;
+    prof_begin(h);
+    std::vector<hipEvent_t> evs;   // per group: 4 events (tile start, unet start, tail start, tail end)
+    for (int i0 = 0; i0 < n_img; i0 += grp) {
+        const int ni = std::min(grp, n_img - i0);
+        hipEvent_t e4[4];
+        for (auto& e : e4) { HIP_TRY(h, hipEventCreate(&e)); evs.push_back(e); }
+        HIP_TRY(h, hipEventRecord(e4[0], s));
+        HIP_TRY(h, launch_tile_patches(gray + (size_t)i0 * px, ni, H, W, sp->pos_dev, sp->n_pos,
+                                       view_of(h, h->input_tensor).p, s));
+        HIP_TRY(h, hipEventRecord(e4[1], s));
+        if ((rc = run_plan(h, ni * sp->n_pos))) return rc;
+        HIP_TRY(h, hipEventRecord(e4[2], s));
+        const TView pv = view_of(h, h->output_tensor);
+        HIP_TRY(h, launch_stitch_argmax(pv.p, pv.cs, sp->map_dev, ni, sp->n_pos, H, W, raw + (size_t)i0 * px, s));
+        HIP_TRY(h, hipEventRecord(e4[3], s));
+    }
+    HIP_TRY(h, hipEventRecord(h->ev[0], s));
+    if (post != raw) HIP_TRY(h, hipMemcpyAsync(post, raw, px * n_img, hipMemcpyDeviceToDevice, s));
+    for (int i0 = 0; i0 < n_img; i0 += h->post_chunk) {
+        const int ni = std::min(h->post_chunk, n_img - i0);
+        HIP_TRY(h, run_meta_inference(h->ws, post + (size_t)i0 * px, ni, H, W, n_ec ? n_ec + i0 : nullptr, s));
+    }
+    HIP_TRY(h, hipEventRecord(h->ev[1], s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    for (size_t k = 0; k + 3 < evs.size(); k += 4) {
+        h->stage_ms[ECSEG_T_TILE] += stage_elapsed(evs[k], evs[k + 1]);
+        h->stage_ms[ECSEG_T_UNET] += stage_elapsed(evs[k + 1], evs[k + 2]);
+        h->stage_ms[ECSEG_T_TAIL] += stage_elapsed(evs[k + 2], evs[k + 3]);
+    }
+    for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+    h->stage_ms[ECSEG_T_POST] = stage_elapsed(h->ev[0], h->ev[1]);
+    prof_end(h);
+    return ECSEG_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================================
+extern "C" {
+
+int ecseg_abi_version(void) { return ECSEG_ABI_VERSION; }
+
+int ecseg_create(ecseg_ctx** out, int device_id) {
+    if (!out) return fail(nullptr, ECSEG_E_INVALID, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(nullptr, ECSEG_E_HIP, std::string("no HIP device: ") + hipGetErrorString(e));
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, ECSEG_E_INVALID, "device_id out of range");
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return fail_hip(nullptr, e, "hipSetDevice");
+    ecseg_ctx* h = new ecseg_ctx();
+    h->device = device_id;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
+        snprintf(h->devname, sizeof(h->devname), "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) {
+        delete h;
+        return fail_hip(nullptr, e, "hipStreamCreate");
+    }
+    for (auto& ev : h->ev) (void)hipEventCreate(&ev);
+    *out = h;
+    return ECSEG_OK;
+}
+
+void ecseg_destroy(ecseg_ctx* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    free_model(h);
+    for (auto& kv : h->stitch) { (void)hipFree(kv.second.pos_dev); (void)hipFree(kv.second.map_dev); }
+    void* ptrs[] = {h->d_gray, h->d_raw, h->d_post, h->d_aux8, h->d_u8in, h->d_i32, h->d_i64, h->d_probs_in, h->d_hist,
+                    h->ws.L, h->ws.area, h->ws.sumy, h->ws.sumx, h->ws.flag, h->ws.tmpA, h->ws.tmpB, h->ws.list, h->ws.g};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char* ecseg_last_error(ecseg_ctx* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int ecseg_device_name(ecseg_ctx* h, char* buf, int buflen) {
+    if (!h || !buf || buflen <= 0) return ECSEG_E_INVALID;
+    snprintf(buf, buflen, "%s", h->devname);
+    return ECSEG_OK;
+}
+
+void* ecseg_stream(ecseg_ctx* h) { return h ? (void*)h->stream : nullptr; }
+
+int ecseg_set_images_per_group(ecseg_ctx* h, int n) {
+    if (!h || n < 1) return ECSEG_E_INVALID;
+    h->images_per_group = n;
+    return ECSEG_OK;
+}
+
+int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tensors, int n_buffers, const ecseg_op_desc* ops,
+                     int n_ops, const float* const* weights, const int64_t* weight_len, int n_weights, int input_tensor,
+                     int output_tensor) {
+    if (!h) return ECSEG_E_INVALID;
+    if (!tensors || !ops || n_tensors <= 0 || n_ops <= 0 || n_buffers <= 0) return fail(h, ECSEG_E_INVALID, "empty plan");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    free_model(h);
+    h->tensors.assign(tensors, tensors + n_tensors);
+    h->n_buffers = n_buffers;
+    h->buf_floats.assign(n_buffers, 0);
+    for (int t = 0; t < n_tensors; ++t) {
+        const ecseg_tensor_desc& d = tensors[t];
+        if (d.buffer < 0 || d.buffer >= n_buffers || d.h <= 0 || d.w <= 0 || d.c <= 0 || d.c_offset < 0 ||
+            d.c_stride < d.c_offset + d.c)
+            return fail(h, ECSEG_E_INVALID, "bad tensor descriptor " + std::to_string(t));
+        h->buf_floats[d.buffer] = std::max(h->buf_floats[d.buffer], (size_t)d.h * d.w * d.c_stride);
+    }
+    if (input_tensor < 0 || input_tensor >= n_tensors || output_tensor < 0 || output_tensor >= n_tensors)
+        return fail(h, ECSEG_E_INVALID, "bad input/output tensor index");
+    h->input_tensor = input_tensor; h->output_tensor = output_tensor;
+    h->flops_per_patch = 0.0; h->mfma_flops_per_patch = 0.0;
+
+    auto W = [&](int idx, int64_t expect, const char* what, const float** out) -> int {
+        *out = nullptr;
+        if (idx < 0) return ECSEG_OK;
+        if (idx >= n_weights || !weights || !weights[idx]) return fail(h, ECSEG_E_INVALID, std::string("missing weight for ") + what);
+        if (weight_len[idx] != expect)
+            return fail(h, ECSEG_E_INVALID, std::string("weight size mismatch for ") + what + ": got " +
+                                                std::to_string(weight_len[idx]) + ", expected " + std::to_string(expect));
+        *out = weights[idx];
+        return ECSEG_OK;
+    };
+
+    for (int k = 0; k < n_ops; ++k) {
+        OpRt o;
+        o.d = ops[k];
+        const ecseg_op_desc& d = o.d;
+        if (d.in0 < 0 || d.in0 >= n_tensors || d.out < 0 || d.out >= n_tensors || (d.op == ECSEG_OP_ADD && (d.in1 < 0 || d.in1 >= n_tensors)))
+            return fail(h, ECSEG_E_INVALID, "bad tensor index in op " + std::to_string(k));
+        const ecseg_tensor_desc& ti = tensors[d.in0];
+        const ecseg_tensor_desc& to = tensors[d.out];
+        o.path = PATH_OTHER;
+        int rc;
+        if (d.op == ECSEG_OP_CONV || d.op == ECSEG_OP_CONVT) {
+            if (d.kh <= 0 || d.kw <= 0 || d.stride <= 0) return fail(h, ECSEG_E_INVALID, "bad conv geometry in op " + std::to_string(k));
+            const int cin = ti.c, cout = to.c;
+            const float *kw = nullptr, *kb = nullptr;
+            if ((rc = W(d.w0, (int64_t)d.kh * d.kw * cin * cout, "conv kernel", &kw))) return rc;
+            if (!kw) return fail(h, ECSEG_E_INVALID, "conv without kernel in op " + std::to_string(k));
+            if ((rc = W(d.w1, cout, "conv bias", &kb))) return rc;
+            if (kb) { if ((rc = upload(h, std::vector<float>(kb, kb + cout), &o.bias))) return rc; }
+            const bool in_al = (ti.c_stride % 4 == 0) && (ti.c_offset % 4 == 0) && (cin % 4 == 0);
+            const bool out_al = (to.c_stride % 4 == 0) && (to.c_offset % 4 == 0);
+            if (d.op == ECSEG_OP_CONV) {
+                if (d.stride != 1) return fail(h, ECSEG_E_UNSUPPORTED, "strided Conv2D is not supported");
+                if (to.h + d.kh - 1 > ti.h + d.kh - 1 || to.w + d.kw - 1 > ti.w + d.kw - 1)
+                    return fail(h, ECSEG_E_INVALID, "conv output larger than its input in op " + std::to_string(k));
+                o.flops = 2.0 * d.kh * d.kw * cin * cout * (double)to.h * to.w;
+                const bool taps_ok = d.kh == d.kw && (d.kh == 1 || d.kh == 2 || d.kh == 3);
+                if (cin <= 4 && cout % 4 == 0 && out_al) {
+                    o.path = PATH_SMALL_CIN;
+                    if ((rc = upload(h, std::vector<float>(kw, kw + (size_t)d.kh * d.kw * cin * cout), &o.wt))) return rc;
+                } else if (d.kh == 1 && d.kw == 1 && cout <= 8 && in_al) {
+                    o.path = PATH_HEAD;
+                    if ((rc = upload(h, std::vector<float>(kw, kw + (size_t)cin * cout), &o.wt))) return rc;
+                } else if (taps_ok && in_al && cin >= 8 && cout >= 16) {
+                    o.path = PATH_MFMA;
+                    const int bn = conv_mfma_ntile(cout);
+                    o.coutp = (cout + bn - 1) / bn * bn;
+                    o.cin_chunks = (cin + 7) / 8;
+                    if ((rc = upload(h, relayout_conv(kw, d.kh, d.kw, cin, cout, o.cin_chunks, o.coutp), &o.wt))) return rc;
+                    h->mfma_flops_per_patch += o.flops;
+                } else {
+                    o.path = PATH_GENERIC;
+                    if ((rc = upload(h, std::vector<float>(kw, kw + (size_t)d.kh * d.kw * cin * cout), &o.wt))) return rc;
+                }
+            } else {
+                o.flops = 2.0 * d.kh * d.kw * cin * cout * (double)ti.h * ti.w;
+                if (d.kh == d.kw && d.kh == d.stride && in_al && cin >= 8 && cout >= 16 && d.pad_top == 0 && d.pad_left == 0) {
+                    o.path = PATH_MFMA;
+                    const int bn = conv_mfma_ntile(cout);
+                    o.coutp = (cout + bn - 1) / bn * bn;
+                    o.cin_chunks = (cin + 7) / 8;
+                    if ((rc = upload(h, relayout_convt(kw, d.kh, cin, cout, o.cin_chunks, o.coutp), &o.wt))) return rc;
+                    h->mfma_flops_per_patch += o.flops;
+                } else {
+                    o.path = PATH_GENERIC;
+                    if ((rc = upload(h, std::vector<float>(kw, kw + (size_t)d.kh * d.kw * cin * cout), &o.wt))) return rc;
+                }
+            }
+            h->flops_per_patch += o.flops;
+        } else if (d.op == ECSEG_OP_AFFINE) {
+            const float *sc = nullptr, *sh = nullptr;
+            if ((rc = W(d.w0, to.c, "affine scale", &sc))) return rc;
+            if ((rc = W(d.w1, to.c, "affine shift", &sh))) return rc;
+            if (!sc || !sh) return fail(h, ECSEG_E_INVALID, "affine without scale/shift in op " + std::to_string(k));
+            if ((rc = upload(h, std::vector<float>(sc, sc + to.c), &o.scale))) return rc;
+            if ((rc = upload(h, std::vector<float>(sh, sh + to.c), &o.shift))) return rc;
+        } else if (d.op == ECSEG_OP_MAXPOOL || d.op == ECSEG_OP_UPSAMPLE) {
+            if (d.stride <= 0) return fail(h, ECSEG_E_INVALID, "bad stride in op " + std::to_string(k));
+            if (d.op == ECSEG_OP_MAXPOOL && (d.kh <= 0 || d.kw <= 0 || (to.h - 1) * d.stride + d.kh > ti.h || (to.w - 1) * d.stride + d.kw > ti.w))
+                return fail(h, ECSEG_E_INVALID, "max-pool window leaves the input in op " + std::to_string(k));
+            if (d.op == ECSEG_OP_UPSAMPLE && (to.h != ti.h * d.stride || to.w != ti.w * d.stride))
+                return fail(h, ECSEG_E_INVALID, "bad upsample shape in op " + std::to_string(k));
+        } else if (d.op == ECSEG_OP_ACT || d.op == ECSEG_OP_ADD || d.op == ECSEG_OP_COPY) {
+            // nothing to prepare
+        } else {
+            return fail(h, ECSEG_E_INVALID, "unknown op code in op " + std::to_string(k));
+        }
+        if (d.op != ECSEG_OP_CONV && d.op != ECSEG_OP_CONVT && d.op != ECSEG_OP_MAXPOOL && d.op != ECSEG_OP_UPSAMPLE &&
+            d.op != ECSEG_OP_COPY && (ti.h != to.h || ti.w != to.w || ti.c != to.c))
+            return fail(h, ECSEG_E_INVALID, "shape mismatch in element-wise op " + std::to_string(k));
+        h->ops.push_back(o);
+    }
+    h->has_model = true;
+    return ECSEG_OK;
+}
+
+int ecseg_model_flops_per_patch(ecseg_ctx* h, double* flops) {
+    int rc = check_model(h);
+    if (rc) return rc;
+    if (flops) *flops = h->flops_per_patch;
+    return ECSEG_OK;
+}
+
+int ecseg_forward_patches(ecseg_ctx* h, const uint8_t* patches, int n, float* out) {
+    int rc = check_model(h);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!patches || !out))) return fail(h, ECSEG_E_INVALID, "forward_patches: bad arguments");
+    if (n == 0) return ECSEG_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const ecseg_tensor_desc& ti = h->tensors[h->input_tensor];
+    const ecseg_tensor_desc& to = h->tensors[h->output_tensor];
+    if (ti.c_stride != ti.c || ti.c_offset != 0) return fail(h, ECSEG_E_INVALID, "input tensor must be compact");
+    const size_t in_per = (size_t)ti.h * ti.w * ti.c, out_per = (size_t)to.h * to.w * to.c;
+    const int chunk = std::max(1, h->images_per_group * 35);
+    if ((rc = ensure_patches(h, std::min(n, chunk)))) return rc;
+    if ((rc = ensure(h, h->d_u8in, h->d_u8in_cap, in_per * std::min(n, chunk)))) return rc;
+    hipStream_t s = h->stream;
+    prof_begin(h);
+    for (int i0 = 0; i0 < n; i0 += chunk) {
+        const int ni = std::min(chunk, n - i0);
+        HIP_TRY(h, hipMemcpyAsync(h->d_u8in, patches + (size_t)i0 * in_per, in_per * ni, hipMemcpyHostToDevice, s));
+        HIP_TRY(h, launch_u8_to_f32(h->d_u8in, view_of(h, h->input_tensor).p, in_per * ni, s));
+        if ((rc = run_plan(h, ni))) return rc;
+        const TView ov = view_of(h, h->output_tensor);
+        HIP_TRY(h, hipMemcpy2DAsync(out + (size_t)i0 * out_per, (size_t)to.c * sizeof(float), ov.p, (size_t)ov.cs * sizeof(float),
+                                    (size_t)to.c * sizeof(float), (size_t)to.h * to.w * ni, hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+    }
+    prof_end(h);
+    return ECSEG_OK;
+}
+
+int ecseg_read_tensor(ecseg_ctx* h, int tensor, int n, float* out) {
+    int rc = check_model(h);
+    if (rc) return rc;
+    if (tensor < 0 || tensor >= (int)h->tensors.size() || n <= 0 || n > h->cap_patches || !out)
+        return fail(h, ECSEG_E_INVALID, "read_tensor: bad arguments");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const ecseg_tensor_desc& t = h->tensors[tensor];
+    const TView v = view_of(h, tensor);
+    HIP_TRY(h, hipMemcpy2DAsync(out, (size_t)t.c * sizeof(float), v.p, (size_t)v.cs * sizeof(float), (size_t)t.c * sizeof(float),
+                                (size_t)t.h * t.w * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return ECSEG_OK;
+}
+
+int ecseg_segment_images_dev(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint8_t* raw, uint8_t* post, int32_t* n_ec) {
+    if (!h) return ECSEG_E_INVALID;
+    if (n_img < 0 || (n_img > 0 && (!gray || !post))) return fail(h, ECSEG_E_INVALID, "segment: bad arguments");
+    if (n_img == 0) return ECSEG_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t px = (size_t)H * W;
+    int rc;
+    uint8_t* raw_buf = raw;
+    if (!raw_buf) {
+        if ((rc = ensure(h, h->d_raw, h->d_raw_cap, px * n_img))) return rc;
+        raw_buf = h->d_raw;
+    }
+    return segment_dev(h, gray, n_img, H, W, raw_buf, post, n_ec);
+}
+
+int ecseg_segment_images(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint8_t* raw, uint8_t* post, int32_t* n_ec) {
+    if (!h) return ECSEG_E_INVALID;
+    if (n_img < 0 || (n_img > 0 && (!gray || !post))) return fail(h, ECSEG_E_INVALID, "segment: bad arguments");
+    if (n_img == 0) return ECSEG_OK;
+    int rc = check_model(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t px = (size_t)H * W, tot = px * n_img;
+    if ((rc = ensure(h, h->d_gray, h->d_gray_cap, tot))) return rc;
+    if ((rc = ensure(h, h->d_raw, h->d_raw_cap, tot))) return rc;
+    if ((rc = ensure(h, h->d_post, h->d_post_cap, tot))) return rc;
+    if ((rc = ensure(h, h->d_i32, h->d_i32_cap, (size_t)n_img))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->d_gray, gray, tot, hipMemcpyHostToDevice, h->stream));
+    if ((rc = segment_dev(h, h->d_gray, n_img, H, W, h->d_raw, h->d_post, h->d_i32))) return rc;
+    if (raw) HIP_TRY(h, hipMemcpyAsync(raw, h->d_raw, tot, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(post, h->d_post, tot, hipMemcpyDeviceToHost, h->stream));
+    if (n_ec) HIP_TRY(h, hipMemcpyAsync(n_ec, h->d_i32, (size_t)n_img * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return ECSEG_OK;
+}
+
+int ecseg_preprocess(ecseg_ctx* h, const void* img, int n_img, int H, int W, int C, int bps, uint8_t* gray_out, int32_t* inverted_out) {
+    if (!h) return ECSEG_E_INVALID;
+    if (n_img < 0 || H <= 0 || W <= 0 || (C != 1 && C != 3 && C != 4) || (bps != 1 && bps != 2) || (n_img > 0 && (!img || !gray_out)))
+        return fail(h, ECSEG_E_INVALID, "preprocess: bad arguments");
+    if (n_img == 0) return ECSEG_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t px = (size_t)H * W, tot = px * n_img, in_bytes = tot * C * bps;
+    int rc;
+    if ((rc = ensure(h, h->d_aux8, h->d_aux8_cap, in_bytes))) return rc;
+    if ((rc = ensure(h, h->d_gray, h->d_gray_cap, tot))) return rc;
+    if ((rc = ensure(h, h->d_i32, h->d_i32_cap, (size_t)n_img))) return rc;
+    if ((rc = ensure(h, h->d_hist, h->d_hist_cap, (size_t)n_img * 256))) return rc;
+    hipStream_t s = h->stream;
+    HIP_TRY(h, hipMemcpyAsync(h->d_aux8, img, in_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, run_preprocess(h->d_aux8, n_img, H, W, C, bps, h->d_gray, h->d_i32, h->d_hist, s));
+    HIP_TRY(h, hipMemcpyAsync(gray_out, h->d_gray, tot, hipMemcpyDeviceToHost, s));
+    if (inverted_out) HIP_TRY(h, hipMemcpyAsync(inverted_out, h->d_i32, (size_t)n_img * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return ECSEG_OK;
+}
+
+int ecseg_stitch_argmax(ecseg_ctx* h, const float* probs, int n_img, int H, int W, uint8_t* labels_raw) {
+    if (!h) return ECSEG_E_INVALID;
+    if (n_img < 0 || (n_img > 0 && (!probs || !labels_raw))) return fail(h, ECSEG_E_INVALID, "stitch_argmax: bad arguments");
+    if (n_img == 0) return ECSEG_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    StitchPlan* sp = nullptr;
+    int rc;
+    if ((rc = get_stitch(h, H, W, &sp))) return rc;
+    const size_t px = (size_t)H * W, nfl = (size_t)n_img * sp->n_pos * 65536 * 4;
+    if ((rc = ensure(h, h->d_probs_in, h->d_probs_cap, nfl))) return rc;
+    if ((rc = ensure(h, h->d_raw, h->d_raw_cap, px * n_img))) return rc;
+    hipStream_t s = h->stream;
+    HIP_TRY(h, hipMemcpyAsync(h->d_probs_in, probs, nfl * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, launch_stitch_argmax(h->d_probs_in, 4, sp->map_dev, n_img, sp->n_pos, H, W, h->d_raw, s));
+    HIP_TRY(h, hipMemcpyAsync(labels_raw, h->d_raw, px * n_img, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return ECSEG_OK;
+}
+
+int ecseg_meta_inference_dev(ecseg_ctx* h, const uint8_t* in, int n_img, int H, int W, uint8_t* out, int32_t* n_ec) {
+    if (!h) return ECSEG_E_INVALID;
+    if (n_img < 0 || H <= 0 || W <= 0 || (n_img > 0 && (!in || !out))) return fail(h, ECSEG_E_INVALID, "meta_inference: bad arguments");
+    if (n_img == 0) return ECSEG_OK;
+    if ((long long)H * W >= (1ll << 31)) return fail(h, ECSEG_E_INVALID, "image too large");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t px = (size_t)H * W;
+    int rc;
+    if ((rc = ensure_post(h, std::min(n_img, h->post_chunk), px))) return rc;
+    hipStream_t s = h->stream;
+    if (out != in) HIP_TRY(h, hipMemcpyAsync(out, in, px * n_img, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(h, hipEventRecord(h->ev[0], s));
+    for (int i0 = 0; i0 < n_img; i0 += h->post_chunk) {
+        const int ni = std::min(h->post_chunk, n_img - i0);
+        HIP_TRY(h, run_meta_inference(h->ws, out + (size_t)i0 * px, ni, H, W, n_ec ? n_ec + i0 : nullptr, s));
+    }
+    HIP_TRY(h, hipEventRecord(h->ev[1], s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    for (float& v : h->stage_ms) v = 0.f;
+    h->stage_ms[ECSEG_T_POST] = stage_elapsed(h->ev[0], h->ev[1]);
+    return ECSEG_OK;
+}
+
+int ecseg_meta_inference(ecseg_ctx* h, const uint8_t* in, int n_img, int H, int W, uint8_t* out, int32_t* n_ec) {
+    if (!h) return ECSEG_E_INVALID;
+    if (n_img < 0 || H <= 0 || W <= 0 || (n_img > 0 && (!in || !out))) return fail(h, ECSEG_E_INVALID, "meta_inference: bad arguments");
+    if (n_img == 0) return ECSEG_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t tot = (size_t)H * W * n_img;
+    int rc;
+    if ((rc = ensure(h, h->d_post, h->d_post_cap, tot))) return rc;
+    if ((rc = ensure(h, h->d_i32, h->d_i32_cap, (size_t)n_img))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->d_post, in, tot, hipMemcpyHostToDevice, h->stream));
+    if ((rc = ecseg_meta_inference_dev(h, h->d_post, n_img, H, W, h->d_post, h->d_i32))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(out, h->d_post, tot, hipMemcpyDeviceToHost, h->stream));
+    if (n_ec) HIP_TRY(h, hipMemcpyAsync(n_ec, h->d_i32, (size_t)n_img * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return ECSEG_OK;
+}
+
+// shared driver of the mask-counting entry points: uploads one or two mask stacks, chunks over images
+static int count_driver(ecseg_ctx* h, const uint8_t* a, const uint8_t* b, int n_img, int H, int W, int kind, int arg,
+                        int32_t* n_out, int64_t* px_out, int32_t* labels_out) {
+    if (!h) return ECSEG_E_INVALID;
+    if (n_img < 0 || H <= 0 || W <= 0 || (n_img > 0 && !a)) return fail(h, ECSEG_E_INVALID, "count: bad arguments");
+    if (n_img == 0) return ECSEG_OK;
+    if ((long long)H * W >= (1ll << 31)) return fail(h, ECSEG_E_INVALID, "image too large");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t px = (size_t)H * W;
+    const int chunk = h->post_chunk;
+    int rc;
+    if ((rc = ensure_post(h, std::min(n_img, chunk), px))) return rc;
+    if ((rc = ensure(h, h->d_gray, h->d_gray_cap, px * std::min(n_img, chunk)))) return rc;
+    if (b && (rc = ensure(h, h->d_aux8, h->d_aux8_cap, px * std::min(n_img, chunk)))) return rc;
+    if ((rc = ensure(h, h->d_i32, h->d_i32_cap, labels_out ? px * std::min(n_img, chunk) : (size_t)chunk))) return rc;
+    if ((rc = ensure(h, h->d_i64, h->d_i64_cap, (size_t)chunk))) return rc;
+    hipStream_t s = h->stream;
+    for (int i0 = 0; i0 < n_img; i0 += chunk) {
+        const int ni = std::min(chunk, n_img - i0);
+        HIP_TRY(h, hipMemcpyAsync(h->d_gray, a + (size_t)i0 * px, px * ni, hipMemcpyHostToDevice, s));
+        if (b) HIP_TRY(h, hipMemcpyAsync(h->d_aux8, b + (size_t)i0 * px, px * ni, hipMemcpyHostToDevice, s));
+        hipError_t e = hipSuccess;
+        if (kind == 0) e = run_count_cc(h->ws, h->d_gray, ni, H, W, h->d_i32, h->d_i64, s);
+        else if (kind == 1) e = run_count_coloc(h->ws, h->d_gray, h->d_aux8, ni, H, W, h->d_i32, s);
+        else if (kind == 2) e = run_count_hsr(h->ws, h->d_gray, h->d_aux8, ni, H, W, arg, h->d_i32, s);
+        else e = run_ccl_labels(h->ws, h->d_gray, ni, H, W, arg, h->d_i32, s);
+        if (e != hipSuccess) return fail_hip(h, e, "count kernels");
+        if (labels_out) HIP_TRY(h, hipMemcpyAsync(labels_out + (size_t)i0 * px, h->d_i32, px * ni * 4, hipMemcpyDeviceToHost, s));
+        else if (n_out) HIP_TRY(h, hipMemcpyAsync(n_out + i0, h->d_i32, (size_t)ni * 4, hipMemcpyDeviceToHost, s));
+        if (px_out) HIP_TRY(h, hipMemcpyAsync(px_out + i0, h->d_i64, (size_t)ni * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+    }
+    return ECSEG_OK;
+}
+
+int ecseg_count_cc(ecseg_ctx* h, const uint8_t* mask, int n_img, int H, int W, int32_t* n_out, int64_t* px_out) {
+    return count_driver(h, mask, nullptr, n_img, H, W, 0, 0, n_out, px_out, nullptr);
+}
+int ecseg_ccl_labels(ecseg_ctx* h, const uint8_t* mask, int n_img, int H, int W, int connectivity, int32_t* labels_out) {
+    if (h && connectivity != 4 && connectivity != 8) return fail(h, ECSEG_E_INVALID, "connectivity must be 4 or 8");
+    if (h && n_img > 0 && !labels_out) return fail(h, ECSEG_E_INVALID, "labels_out is NULL");
+    return count_driver(h, mask, nullptr, n_img, H, W, 3, connectivity, nullptr, nullptr, labels_out);
+}
+int ecseg_count_colocalization(ecseg_ctx* h, const uint8_t* ob1, const uint8_t* ob2, int n_img, int H, int W, int32_t* n_out) {
+    if (h && n_img > 0 && !ob2) return fail(h, ECSEG_E_INVALID, "ob2 is NULL");
+    return count_driver(h, ob1, ob2, n_img, H, W, 1, 0, n_out, nullptr, nullptr);
+}
+int ecseg_count_hsr(ecseg_ctx* h, const uint8_t* chrom, const uint8_t* fish, int n_img, int H, int W, int thr, int32_t* n_out) {
+    if (h && n_img > 0 && !fish) return fail(h, ECSEG_E_INVALID, "fish is NULL");
+    return count_driver(h, chrom, fish, n_img, H, W, 2, thr, n_out, nullptr, nullptr);
+}
+
+int ecseg_overlay(ecseg_ctx* h, const uint8_t* labels, const uint8_t* rgb, int n_img, int H, int W, int C, int sens, int hsr_thr,
+                  int64_t* out) {
+    if (!h) return ECSEG_E_INVALID;
+    if (n_img < 0 || H <= 0 || W <= 0 || C < 2 || (n_img > 0 && (!labels || !rgb || !out)))
+        return fail(h, ECSEG_E_INVALID, "overlay: bad arguments");
+    if (n_img == 0) return ECSEG_OK;
+    if ((long long)H * W >= (1ll << 31)) return fail(h, ECSEG_E_INVALID, "image too large");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t px = (size_t)H * W;
+    const int chunk = h->post_chunk;
+    int rc;
+    if ((rc = ensure_post(h, std::min(n_img, chunk), px))) return rc;
+    if ((rc = ensure(h, h->d_gray, h->d_gray_cap, px * std::min(n_img, chunk)))) return rc;
+    if ((rc = ensure(h, h->d_aux8, h->d_aux8_cap, px * C * std::min(n_img, chunk)))) return rc;
+    if ((rc = ensure(h, h->d_i64, h->d_i64_cap, (size_t)chunk * 12))) return rc;
+    hipStream_t s = h->stream;
+    for (int i0 = 0; i0 < n_img; i0 += chunk) {
+        const int ni = std::min(chunk, n_img - i0);
+        HIP_TRY(h, hipMemcpyAsync(h->d_gray, labels + (size_t)i0 * px, px * ni, hipMemcpyHostToDevice, s));
+        HIP_TRY(h, hipMemcpyAsync(h->d_aux8, rgb + (size_t)i0 * px * C, px * C * ni, hipMemcpyHostToDevice, s));
+        HIP_TRY(h, run_overlay(h->ws, h->d_gray, h->d_aux8, ni, H, W, C, sens, hsr_thr, h->d_i64, s));
+        HIP_TRY(h, hipMemcpyAsync(out + (size_t)i0 * 12, h->d_i64, (size_t)ni * 12 * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+    }
+    return ECSEG_OK;
+}
+
+int ecseg_get_timings(ecseg_ctx* h, float* ms_out) {
+    if (!h || !ms_out) return ECSEG_E_INVALID;
+    for (int k = 0; k < ECSEG_T_N; ++k) ms_out[k] = h->stage_ms[k];
+    return ECSEG_OK;
+}
+
+int ecseg_set_kernel_profiling(ecseg_ctx* h, int enabled) {
+    if (!h) return ECSEG_E_INVALID;
+    h->profile_kernels = enabled != 0;
+    return ECSEG_OK;
+}
+
+int ecseg_get_conv_profile(ecseg_ctx* h, double* total_ms, int64_t* launches, double* flops) {
+    if (!h) return ECSEG_E_INVALID;
+    if (total_ms) *total_ms = h->last_conv_ms;
+    if (launches) *launches = h->last_conv_launches;
+    if (flops) *flops = h->last_conv_flops;
+    return ECSEG_OK;
+}
+
+}  // extern "C"

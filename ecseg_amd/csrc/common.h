@@ -1,0 +1,96 @@
+// Shared declarations of libecseg_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ecseg_hip.h"
+
+namespace ecseg {
+
+// NHWC float32 view into a device buffer: consecutive pixels are `cs` floats apart, `p` points at the view's first
+// channel of pixel (n=0, y=0, x=0).
+struct TView {
+    float* p;
+    int h, w, c, cs;
+};
+
+struct ConvParams {
+    TView in, out;
+    const float* wt;    // re-laid-out kernel (see relayout_* in api.hip)
+    const float* bias;  // may be null
+    int n;              // patches in the batch
+    int R, S;           // taps
+    int pad_top, pad_left;
+    int act;
+    float alpha;
+    int cin_chunks;     // ceil(Cin / 8)
+    int coutp;          // Cout padded to a multiple of the N tile
+    // transposed-conv mode (R = S = 1 in the GEMM, kT x kT stride-kT scatter in the epilogue)
+    int convt;          // 0 | 1
+    int kT, crop_top, crop_left;
+};
+
+// ---- launchers implemented in unet_kernels.hip --------------------------------------------------------------
+hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s);
+bool       conv_mfma_supported(const ConvParams& p);
+int        conv_mfma_ntile(int cout);   // N tile (32 | 64 | 128) used for a given Cout
+
+hipError_t launch_conv_small_cin(const TView& in, const TView& out, const float* w_hwio, const float* bias, int n,
+                                 int R, int S, int pad_top, int pad_left, int act, float alpha, hipStream_t s);
+hipError_t launch_conv_head(const TView& in, const TView& out, const float* w_io, const float* bias, int n, int act,
+                            float alpha, hipStream_t s);
+hipError_t launch_conv_generic(const TView& in, const TView& out, const float* w_hwio, const float* bias, int n,
+                               int R, int S, int pad_top, int pad_left, int act, float alpha, hipStream_t s);
+hipError_t launch_convt_generic(const TView& in, const TView& out, const float* w_hwoi, const float* bias, int n,
+                                int R, int S, int stride, int crop_top, int crop_left, int act, float alpha,
+                                hipStream_t s);
+hipError_t launch_maxpool(const TView& in, const TView& out, int n, int kh, int kw, int stride, hipStream_t s);
+hipError_t launch_upsample(const TView& in, const TView& out, int n, int factor, int mode, hipStream_t s);
+hipError_t launch_affine(const TView& in, const TView& out, const float* scale, const float* shift, int n, int act,
+                         float alpha, hipStream_t s);
+hipError_t launch_add(const TView& a, const TView& b, const TView& out, int n, int act, float alpha, hipStream_t s);
+hipError_t launch_copy(const TView& in, const TView& out, int n, int off_y, int off_x, hipStream_t s);
+hipError_t launch_softmax(const TView& in, const TView& out, int n, hipStream_t s);
+hipError_t launch_u8_to_f32(const uint8_t* in, float* out, size_t count, hipStream_t s);
+// im2patches_overlap on the device: (n_img, H, W) uint8 -> (n_img * n_pos, 256, 256, 1) float32
+hipError_t launch_tile_patches(const uint8_t* gray, int n_img, int H, int W, const int32_t* pos_yx, int n_pos,
+                               float* out, hipStream_t s);
+
+// ---- launchers implemented in post_kernels.hip -----------------------------------------------------------------
+// stitch + img_as_ubyte + argmax; src_map: (H*W) int32 = (patch << 16) | (y << 8) | x, or -1 when never written
+hipError_t launch_stitch_argmax(const float* probs, int prob_cs, const int32_t* src_map, int n_img, int n_pos,
+                                int H, int W, uint8_t* labels, hipStream_t s);
+
+struct PostWorkspace {
+    // all sized for `cap_img` images of `cap_px` pixels
+    int32_t* L;          // union-find parents / final root index per pixel
+    uint32_t* area;      // per-root slots (indexed like L)
+    unsigned long long* sumy;
+    unsigned long long* sumx;
+    uint32_t* flag;      // per-root bit flags
+    uint8_t* tmpA;       // scratch label images
+    uint8_t* tmpB;
+    int32_t* list;       // per image: compacted root lists for the nucleus-in-metaphase test
+    int32_t* g;          // per image: small block of global counters (G_STRIDE ints)
+    int cap_img;
+    size_t cap_px;
+};
+enum { G_STRIDE = 32 };
+
+// meta_inference on n_img uint8 label images, in place; n_ec receives count_cc(img==3)[0] per image
+hipError_t run_meta_inference(PostWorkspace& ws, uint8_t* img, int n_img, int H, int W, int32_t* n_ec_dev,
+                              hipStream_t s);
+hipError_t run_count_cc(PostWorkspace& ws, const uint8_t* mask, int n_img, int H, int W, int32_t* n_dev,
+                        long long* px_dev, hipStream_t s);
+hipError_t run_ccl_labels(PostWorkspace& ws, const uint8_t* mask, int n_img, int H, int W, int conn,
+                          int32_t* labels_dev, hipStream_t s);
+hipError_t run_count_coloc(PostWorkspace& ws, const uint8_t* ob1, const uint8_t* ob2, int n_img, int H, int W,
+                           int32_t* n_dev, hipStream_t s);
+hipError_t run_count_hsr(PostWorkspace& ws, const uint8_t* chrom, const uint8_t* fish, int n_img, int H, int W,
+                         int thr, int32_t* n_dev, hipStream_t s);
+hipError_t run_overlay(PostWorkspace& ws, const uint8_t* labels, const uint8_t* rgb, int n_img, int H, int W, int C,
+                       int sens, int hsr_thr, long long* out_dev, hipStream_t s);
+hipError_t run_preprocess(const void* img, int n_img, int H, int W, int C, int bps, uint8_t* gray, int32_t* inverted,
+                          uint32_t* hist_ws, hipStream_t s);
+
+}  // namespace ecseg

@@ -1,0 +1,899 @@
+// Post-processing kernels for gfx950: stitch + quantised argmax, wavefront-level union-find connected-component
+// labelling, the meta_inference clean-up schedule, component counts, the meta_overlay row and meta_preprocess.
+//
+// All of this is HBM/latency-bound integer work on uint8 label images (n_img, H, W) and int32 parent arrays; no MFMA.
+//
+// Connected components (reference: skimage.measure.label / scipy.ndimage.label, src/image_tools.py:26,42-50,66-67,115)
+//   * a pixel's "key" is a small integer derived from its value through a 4-entry LUT (0 = background); two
+//     neighbouring pixels are connected iff their keys are equal and non-zero, so the disjoint class masks
+//     (img==1, img==2, img==3) are labelled in ONE pass;
+//   * ccl_init: one wavefront owns a 64-pixel row chunk; __ballot over "run starts" gives every pixel the index of
+//     the first pixel of its run without any memory traffic or atomics (label = run head);
+//   * ccl_merge: unions are issued once per (run, upper-run) overlap instead of once per pixel pair - only the lane at
+//     the start of an overlap calls unite(); unite() is the lock-free atomicMin union-find, so the root of a
+//     component is its minimum raster index = its first pixel in raster order (the order scipy/skimage number
+//     components in, which merge_comp's skipped last component depends on, src/image_tools.py:27);
+//   * ccl_flatten: every pixel looks up its root; per-run (not per-pixel) atomics accumulate area / coordinate sums /
+//     flag bits into the root's slot, per-wave popcounts accumulate component and pixel counts per key.
+// blockIdx -> image mapping keeps all blocks of one image on one XCD (equal blockIdx % 8) so that the image's parent
+// array stays in that XCD's L2.
+#include "common.h"
+
+namespace ecseg {
+
+typedef unsigned long long u64;
+
+static constexpr uint32_t LUT_MULTI = 0x03020100u;   // key = value
+static constexpr uint32_t LUT_NONZERO = 0xffffffffu; // key = (value != 0)
+__host__ __device__ constexpr uint32_t lut_eq(int c) { return 1u << (8 * c); }                  // key = (value == c)
+__host__ __device__ constexpr uint32_t lut_ne(int c) { return 0x01010101u & ~(0xffu << (8 * c)); }  // key = (value != c)
+// key = (value != 0 && value != m)
+__host__ __device__ constexpr uint32_t lut_nonzero_except(int m) { return 0x01010100u & ~(0xffu << (8 * m)); }
+
+__device__ __forceinline__ int key_of(uint8_t v, uint32_t lut) {
+    if (lut == LUT_NONZERO) return v != 0;
+    return (lut >> ((v & 3) * 8)) & 0xff;
+}
+
+// per-image global counters
+enum { G_NCOMP = 0 /*[4]*/, G_NPX = 4 /*[4]*/, G_LAST_ROOT = 8, G_NLIST1 = 9, G_NLIST2 = 10,
+       G_CNT0 = 12 /* [8] generic root counters */, G_OTSU_INV = 20 };
+
+// aux modes of ccl_flatten: which per-pixel bits are OR-ed into the root's flag word
+enum { AUX_NONE = 0, AUX_BORDER = 1, AUX_VALUE_EQ = 2, AUX_IMAGE = 3 };
+enum { STAT_AREA = 1, STAT_SUMS = 2 };
+
+// ---------------------------------------------------------------------------------------------------------------
+// geometry helpers: a block = 4 waves; wave w owns the 64-pixel chunk `cx` of rows y0 + w*ROWS .. + ROWS-1
+// ---------------------------------------------------------------------------------------------------------------
+static constexpr int CCL_ROWS = 8;                      // rows per wave
+static constexpr int CCL_BLOCK_ROWS = 4 * CCL_ROWS;     // rows per block
+
+struct CclGeom {
+    int H, W, n_img;
+    int chunks_x, strips_y, blocks_per_img;
+    int img_groups;   // ceil(n_img / 8)
+};
+
+static CclGeom make_geom(int n_img, int H, int W) {
+    CclGeom g;
+    g.H = H; g.W = W; g.n_img = n_img;
+    g.chunks_x = (W + 63) / 64;
+    g.strips_y = (H + CCL_BLOCK_ROWS - 1) / CCL_BLOCK_ROWS;
+    g.blocks_per_img = g.chunks_x * g.strips_y;
+    g.img_groups = (n_img + 7) / 8;
+    return g;
+}
+static unsigned geom_grid(const CclGeom& g) { return (unsigned)(8 * g.img_groups * g.blocks_per_img); }
+
+// block id -> (image, strip, chunk); images with equal (img % 8) share an XCD
+__device__ __forceinline__ bool decode_block(const CclGeom& g, int& img, int& y0, int& cx) {
+    const unsigned b = blockIdx.x;
+    const unsigned xcd = b & 7u, j = b >> 3;
+    img = (int)((j / g.blocks_per_img) * 8 + xcd);
+    if (img >= g.n_img) return false;
+    const unsigned blk = j % g.blocks_per_img;
+    cx = (int)(blk % g.chunks_x);
+    y0 = (int)(blk / g.chunks_x) * CCL_BLOCK_ROWS + (int)(threadIdx.x >> 6) * CCL_ROWS;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// union-find
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int uf_load(const int32_t* L, int i) {
+    return __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int uf_find(const int32_t* L, int x) {
+    int n;
+    while ((n = uf_load(L, x)) != x) x = n;   // parents strictly decrease along a chain -> terminates
+    return x;
+}
+__device__ __forceinline__ void uf_unite(int32_t* L, int a, int b) {
+    for (;;) {
+        a = uf_find(L, a);
+        b = uf_find(L, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(L + a, b);   // link the larger root under the smaller
+        if (old == a) return;
+        a = old;                                // a had just been linked elsewhere: keep merging from its old parent
+    }
+}
+
+__global__ __launch_bounds__(256) void ccl_init_kernel(CclGeom g, const uint8_t* __restrict__ img_all, uint32_t lut,
+                                                       int32_t* __restrict__ L_all, uint32_t* __restrict__ area_all,
+                                                       u64* __restrict__ sumy_all, u64* __restrict__ sumx_all,
+                                                       uint32_t* __restrict__ flag_all, int stat) {
+    int img, y0, cx;
+    if (!decode_block(g, img, y0, cx)) return;
+    const size_t base = (size_t)img * g.H * g.W;
+    const int lane = threadIdx.x & 63;
+    const int x = cx * 64 + lane;
+    for (int r = 0; r < CCL_ROWS; ++r) {
+        const int y = y0 + r;
+        if (y >= g.H) break;                                   // wave-uniform
+        const bool valid = x < g.W;
+        const int p = y * g.W + x;
+        const int key = valid ? key_of(img_all[base + p], lut) : 0;
+        const int kprev = __shfl_up(key, 1, 64);
+        const bool start = key != 0 && (lane == 0 || kprev != key);
+        const u64 S = __ballot(start);
+        if (valid) {
+            int lab = -1;
+            if (key) {
+                const u64 below = S & ((2ull << lane) - 1ull);     // run starts at or below this lane
+                lab = y * g.W + cx * 64 + (63 - __clzll(below));
+            }
+            L_all[base + p] = lab;
+            if (start) {                                           // only run heads can become roots
+                flag_all[base + p] = 0u;
+                if (stat & STAT_AREA) area_all[base + p] = 0u;
+                if (stat & STAT_SUMS) { sumy_all[base + p] = 0ull; sumx_all[base + p] = 0ull; }
+            }
+        }
+    }
+}
+
+template <int CONN>
+__global__ __launch_bounds__(256) void ccl_merge_kernel(CclGeom g, const uint8_t* __restrict__ img_all, uint32_t lut,
+                                                        int32_t* __restrict__ L_all) {
+    int img, y0, cx;
+    if (!decode_block(g, img, y0, cx)) return;
+    const size_t base = (size_t)img * g.H * g.W;
+    const uint8_t* im = img_all + base;
+    int32_t* L = L_all + base;
+    const int lane = threadIdx.x & 63;
+    const int x = cx * 64 + lane;
+    const int W = g.W;
+    for (int r = 0; r < CCL_ROWS; ++r) {
+        const int y = y0 + r;
+        if (y >= g.H) break;
+        if (x >= W) continue;
+        const int p = y * W + x;
+        const int key = key_of(im[p], lut);
+        if (!key) continue;
+        const bool left = x > 0 && key_of(im[p - 1], lut) == key;
+        bool u0 = false, ul = false, ur = false;
+        if (y > 0) {
+            u0 = key_of(im[p - W], lut) == key;
+            ul = x > 0 && key_of(im[p - W - 1], lut) == key;
+            ur = x + 1 < W && key_of(im[p - W + 1], lut) == key;
+        }
+        if (lane == 0 && left) uf_unite(L, p, p - 1);              // runs are cut at chunk boundaries by ccl_init
+        if (CONN == 8) {
+            // one union per (run, upper run) pair: at the first pixel of the run that touches the upper run
+            if (ur && !u0) uf_unite(L, p, p - W + 1);              // an upper run begins at x+1
+            if (!left) {                                           // first pixel of this run
+                if (u0) uf_unite(L, p, p - W);
+                else if (ul) uf_unite(L, p, p - W - 1);
+            }
+        } else {
+            if (u0 && !(left && ul)) uf_unite(L, p, p - W);        // first pixel of the overlap of the two runs
+        }
+    }
+}
+
+// flatten + statistics.  aux_mode selects the bits OR-ed into flag[root]:
+//   AUX_BORDER   bit0 = component touches the image border
+//   AUX_VALUE_EQ bit0 = component holds a pixel with value == aux_c
+//   AUX_IMAGE    bits of aux_img[p]
+__global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8_t* __restrict__ img_all, uint32_t lut,
+                                                          int32_t* __restrict__ L_all, uint32_t* __restrict__ area_all,
+                                                          u64* __restrict__ sumy_all, u64* __restrict__ sumx_all,
+                                                          uint32_t* __restrict__ flag_all, int32_t* __restrict__ G_all,
+                                                          int stat, int aux_mode, int aux_c,
+                                                          const uint8_t* __restrict__ aux_img) {
+    int img, y0, cx;
+    if (!decode_block(g, img, y0, cx)) return;
+    const size_t base = (size_t)img * g.H * g.W;
+    const uint8_t* im = img_all + base;
+    int32_t* L = L_all + base;
+    int32_t* G = G_all + (size_t)img * G_STRIDE;
+    const int lane = threadIdx.x & 63;
+    const int x = cx * 64 + lane;
+    const int W = g.W, H = g.H;
+    int ncomp[4] = {0, 0, 0, 0}, npx[4] = {0, 0, 0, 0};
+    int last_root = 0;
+    for (int r = 0; r < CCL_ROWS; ++r) {
+        const int y = y0 + r;
+        if (y >= H) break;
+        const bool valid = x < W;
+        const int p = y * W + x;
+        uint8_t v = 0;
+        int key = 0, root = -1;
+        if (valid) {
+            v = im[p];
+            key = key_of(v, lut);
+            if (key) { root = uf_find(L, p); L[p] = root; }
+        }
+        // ---- per-key component / pixel counts (wave popcounts) ----
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            const u64 mk = __ballot(key == k);
+            if (mk) {
+                npx[k] += __popcll(mk);
+                ncomp[k] += __popcll(__ballot(key == k && root == p));
+            }
+        }
+        const u64 F = __ballot(key != 0);
+        if (!F) continue;
+        {
+            int rmax = (key && root == p) ? p + 1 : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) rmax = max(rmax, __shfl_xor(rmax, o, 64));
+            last_root = max(last_root, rmax);
+        }
+        // ---- runs of equal root inside the chunk: one atomic per run ----
+        const int rprev = __shfl_up(root, 1, 64);
+        const bool start = key != 0 && (lane == 0 || rprev != root);
+        const u64 S = __ballot(start);
+        uint32_t bits = 0;
+        if (aux_mode == AUX_BORDER) bits = (key && (y == 0 || y == H - 1 || x == 0 || x == W - 1)) ? 1u : 0u;
+        else if (aux_mode == AUX_VALUE_EQ) bits = (key && v == aux_c) ? 1u : 0u;
+        else if (aux_mode == AUX_IMAGE) bits = (key && valid) ? aux_img[base + p] : 0u;
+        u64 B[5];
+        int nb = (aux_mode == AUX_IMAGE) ? 5 : (aux_mode == AUX_NONE ? 0 : 1);
+#pragma unroll
+        for (int b = 0; b < 5; ++b) B[b] = (b < nb) ? __ballot((bits >> b) & 1u) : 0ull;
+        if (start) {
+            const u64 above = ~((2ull << lane) - 1ull);            // lanes strictly above this one
+            const u64 stop = (S | ~F) & above;
+            const int len = stop ? (__ffsll((long long)stop) - 1 - lane) : (64 - lane);
+            const u64 run = (len == 64) ? ~0ull : (((1ull << len) - 1ull) << lane);
+            if (stat & STAT_AREA) atomicAdd(area_all + base + root, (uint32_t)len);
+            if (stat & STAT_SUMS) {
+                atomicAdd(sumy_all + base + root, (u64)y * (u64)len);
+                atomicAdd(sumx_all + base + root, (u64)x * (u64)len + (u64)len * (u64)(len - 1) / 2ull);
+            }
+            uint32_t fb = 0;
+#pragma unroll
+            for (int b = 0; b < 5; ++b) if (B[b] & run) fb |= 1u << b;
+            if (fb) atomicOr(flag_all + base + root, fb);
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            if (ncomp[k]) atomicAdd(G + G_NCOMP + k, ncomp[k]);
+            if (npx[k]) atomicAdd(G + G_NPX + k, npx[k]);
+        }
+        if (last_root) atomicMax(G + G_LAST_ROOT, last_root);
+    }
+}
+
+__global__ void zero_g_kernel(int32_t* G, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) G[i] = 0;
+}
+
+struct CclPass {
+    const uint8_t* key_img;
+    uint32_t lut;
+    int conn;
+    int stat;
+    int aux_mode, aux_c;
+    const uint8_t* aux_img;
+};
+
+static hipError_t run_ccl_pass(PostWorkspace& ws, const CclGeom& g, const CclPass& c, hipStream_t s) {
+    const int ng = g.n_img * G_STRIDE;
+    hipLaunchKernelGGL(zero_g_kernel, dim3((ng + 255) / 256), dim3(256), 0, s, ws.g, ng);
+    const unsigned grid = geom_grid(g);
+    hipLaunchKernelGGL(ccl_init_kernel, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy, ws.sumx,
+                       ws.flag, c.stat);
+    if (c.conn == 8) hipLaunchKernelGGL(ccl_merge_kernel<8>, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L);
+    else hipLaunchKernelGGL(ccl_merge_kernel<4>, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L);
+    hipLaunchKernelGGL(ccl_flatten_kernel, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy,
+                       ws.sumx, ws.flag, ws.g, c.stat, c.aux_mode, c.aux_c, c.aux_img);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// per-pixel "apply" kernels of the meta_inference schedule (one thread per pixel, grid-stride over the batch)
+// ---------------------------------------------------------------------------------------------------------------
+static unsigned px_grid(size_t total) {
+    size_t b = (total + 255) / 256;
+    if (b > 256 * 64) b = 256 * 64;
+    return (unsigned)(b ? b : 1);
+}
+#define PX_LOOP(total) for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < (total); t += (size_t)gridDim.x * blockDim.x)
+
+// fill_holes (src/image_tools.py:36-39): pixels != c whose 4-connected background component does not reach the border
+__global__ __launch_bounds__(256) void apply_fill_kernel(uint8_t* __restrict__ img, const int32_t* __restrict__ L,
+                                                         const uint32_t* __restrict__ flag, size_t total, size_t px, int c) {
+    PX_LOOP(total) {
+        const int r = L[t];
+        if (r >= 0) {
+            const size_t base = (t / px) * px;
+            if (!(flag[base + r] & 1u)) img[t] = (uint8_t)c;
+        }
+    }
+}
+
+// size_thresh (src/image_tools.py:41-59) from ONE multi-class labelling: nuclei smaller than the mean chromosome
+// area -> 0; chromosomes smaller than the mean ecDNA area -> 3; ecDNA components (as labelled before that
+// reassignment) smaller than 15 px -> 0.  Means are exact integer sums divided in float64; NaN compares false.
+__global__ __launch_bounds__(256) void apply_size_thresh_kernel(uint8_t* __restrict__ img, const int32_t* __restrict__ L,
+                                                                const uint32_t* __restrict__ area,
+                                                                const int32_t* __restrict__ G_all, size_t total, size_t px,
+                                                                int ec_thresh) {
+    PX_LOOP(total) {
+        const int r = L[t];
+        if (r < 0) continue;
+        const size_t im = t / px;
+        const int32_t* G = G_all + im * G_STRIDE;
+        const double avg_chrom = G[G_NCOMP + 2] ? (double)G[G_NPX + 2] / (double)G[G_NCOMP + 2] : __longlong_as_double(0x7ff8000000000000LL);
+        const double avg_ec = G[G_NCOMP + 3] ? (double)G[G_NPX + 3] / (double)G[G_NCOMP + 3] : __longlong_as_double(0x7ff8000000000000LL);
+        const double a = (double)area[im * px + r];
+        const uint8_t v = img[t];
+        if (v == 1) { if (a < avg_chrom) img[t] = 0; }
+        else if (v == 2) { if (a < avg_ec) img[t] = 3; }
+        else if (v == 3) { if (a < (double)ec_thresh) img[t] = 0; }
+    }
+}
+
+// img[dilate(img==3) ^ erode(img==3)] = 0 (src/image_tools.py:64): dilation pads with 0, erosion with 1
+__global__ __launch_bounds__(256) void band_removal_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                           size_t total, int H, int W) {
+    const size_t px = (size_t)H * W;
+    PX_LOOP(total) {
+        const size_t q = t % px;
+        const int y = (int)(q / W), x = (int)(q % W);
+        const uint8_t v = in[t];
+        const bool c = v == 3;
+        const bool n = y > 0 ? in[t - W] == 3 : false, s = y < H - 1 ? in[t + W] == 3 : false;
+        const bool w = x > 0 ? in[t - 1] == 3 : false, e = x < W - 1 ? in[t + 1] == 3 : false;
+        const bool dil = c | n | s | w | e;
+        const bool ero = c & (y > 0 ? n : true) & (y < H - 1 ? s : true) & (x > 0 ? w : true) & (x < W - 1 ? e : true);
+        out[t] = (dil != ero) ? 0 : v;
+    }
+}
+
+// img[dilate(img==3)] = 3 (src/image_tools.py:83)
+__global__ __launch_bounds__(256) void ec_dilate_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                        size_t total, int H, int W) {
+    const size_t px = (size_t)H * W;
+    PX_LOOP(total) {
+        const size_t q = t % px;
+        const int y = (int)(q / W), x = (int)(q % W);
+        const uint8_t v = in[t];
+        bool d = v == 3;
+        if (y > 0) d |= in[t - W] == 3;
+        if (y < H - 1) d |= in[t + W] == 3;
+        if (x > 0) d |= in[t - 1] == 3;
+        if (x < W - 1) d |= in[t + 1] == 3;
+        out[t] = d ? 3 : v;
+    }
+}
+
+// Roots of class-1 and class-2 components -> compact per-image lists (nucleus root indices; chromosome centroids).
+__global__ __launch_bounds__(256) void compact_roots_kernel(const uint8_t* __restrict__ img, const int32_t* __restrict__ L,
+                                                            const uint32_t* __restrict__ area, const u64* __restrict__ sumy,
+                                                            const u64* __restrict__ sumx, int32_t* __restrict__ G_all,
+                                                            int32_t* __restrict__ list1, double2* __restrict__ list2,
+                                                            size_t total, size_t px, size_t cap) {
+    PX_LOOP(total) {
+        const size_t im = t / px;
+        const int p = (int)(t - im * px);
+        if (L[t] != p) continue;
+        const uint8_t v = img[t];
+        int32_t* G = G_all + im * G_STRIDE;
+        if (v == 1) {
+            const int k = atomicAdd(G + G_NLIST1, 1);
+            list1[im * cap + k] = p;
+        } else if (v == 2) {
+            const int k = atomicAdd(G + G_NLIST2, 1);
+            const double a = (double)area[t];
+            list2[im * cap + k] = make_double2((double)sumy[t] / a, (double)sumx[t] / a);   // regionprops centroid
+        }
+    }
+}
+
+// Nucleus-in-metaphase test (src/image_tools.py:72-81): more than five chromosome centroids strictly inside each of
+// the four 70-px half bands -> the nucleus is erased.  One block per nucleus (grid-stride), threads stride over the
+// chromosome list; counts saturate so the scan stops as soon as all four exceed the threshold.
+__global__ __launch_bounds__(256) void nucleus_test_kernel(const uint32_t* __restrict__ area, const u64* __restrict__ sumy,
+                                                           const u64* __restrict__ sumx, const int32_t* __restrict__ G_all,
+                                                           const int32_t* __restrict__ list1, const double2* __restrict__ list2,
+                                                           uint32_t* __restrict__ flag, size_t px, size_t cap,
+                                                           int blocks_per_img, double v, int min_count) {
+    const int im = blockIdx.x / blocks_per_img, j = blockIdx.x % blocks_per_img;
+    const int32_t* G = G_all + (size_t)im * G_STRIDE;
+    const int n1 = G[G_NLIST1], n2 = G[G_NLIST2];
+    __shared__ int cnt[4];
+    for (int k = j; k < n1; k += blocks_per_img) {
+        const int root = list1[(size_t)im * cap + k];
+        const size_t slot = (size_t)im * px + root;
+        const double a = (double)area[slot];
+        const double ny = (double)sumy[slot] / a, nx = (double)sumx[slot] / a;
+        if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
+        __syncthreads();
+        for (int c0 = 0; c0 < n2; c0 += blockDim.x) {
+            const int c = c0 + threadIdx.x;
+            int l = 0, r = 0, b = 0, tp = 0;
+            if (c < n2) {
+                const double2 cc = list2[(size_t)im * cap + c];   // (cy, cx)
+                l = (cc.y > nx) && (cc.y < nx + v);
+                r = (cc.y < nx) && (cc.y > nx - v);
+                b = (cc.x < ny) && (cc.x > ny - v);
+                tp = (cc.x > ny) && (cc.x < ny + v);
+            }
+            const int wl = __popcll(__ballot(l)), wr = __popcll(__ballot(r));
+            const int wb = __popcll(__ballot(b)), wt = __popcll(__ballot(tp));
+            if ((threadIdx.x & 63) == 0) {
+                if (wl) atomicAdd(&cnt[0], wl);
+                if (wr) atomicAdd(&cnt[1], wr);
+                if (wb) atomicAdd(&cnt[2], wb);
+                if (wt) atomicAdd(&cnt[3], wt);
+            }
+            __syncthreads();
+            const bool done = cnt[0] > min_count && cnt[1] > min_count && cnt[2] > min_count && cnt[3] > min_count;
+            __syncthreads();
+            if (done) break;
+        }
+        if (threadIdx.x == 0 && cnt[0] > min_count && cnt[1] > min_count && cnt[2] > min_count && cnt[3] > min_count)
+            flag[slot] |= 2u;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void apply_nucleus_kill_kernel(uint8_t* __restrict__ img, const int32_t* __restrict__ L,
+                                                                 const uint32_t* __restrict__ flag, size_t total, size_t px) {
+    PX_LOOP(total) {
+        if (img[t] != 1) continue;
+        const int r = L[t];
+        if (r >= 0 && (flag[(t / px) * px + r] & 2u)) img[t] = 0;
+    }
+}
+
+// merge_comp, first half (src/image_tools.py:19-30): lift class m out (-> 0), turn every component of the remaining
+// non-zero pixels that holds a class-c pixel into c, except the component with the highest scipy label (= the one
+// whose first pixel comes last in raster order).  Output: the working image `t`.
+__global__ __launch_bounds__(256) void apply_merge_kernel(const uint8_t* __restrict__ img, uint8_t* __restrict__ tmp,
+                                                          const int32_t* __restrict__ L, const uint32_t* __restrict__ flag,
+                                                          const int32_t* __restrict__ G_all, size_t total, size_t px,
+                                                          int c, int m) {
+    PX_LOOP(total) {
+        uint8_t v = img[t];
+        if (v == m) v = 0;
+        const int r = L[t];
+        if (r >= 0) {
+            const size_t im = t / px;
+            const int last = G_all[im * G_STRIDE + G_LAST_ROOT] - 1;
+            if ((flag[im * px + r] & 1u) && r != last) v = (uint8_t)c;
+        }
+        tmp[t] = v;
+    }
+}
+
+// grey erosion with the 3x3 cross, borders reflected (= out-of-image neighbours ignored)
+__global__ __launch_bounds__(256) void grey_erode_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                         size_t total, int H, int W) {
+    const size_t px = (size_t)H * W;
+    PX_LOOP(total) {
+        const size_t q = t % px;
+        const int y = (int)(q / W), x = (int)(q % W);
+        uint8_t v = in[t];
+        if (y > 0) v = min(v, in[t - W]);
+        if (y < H - 1) v = min(v, in[t + W]);
+        if (x > 0) v = min(v, in[t - 1]);
+        if (x < W - 1) v = min(v, in[t + 1]);
+        out[t] = v;
+    }
+}
+
+// merge_comp, second half (src/image_tools.py:31-32): grey dilation of the eroded image (= opening), pixels whose
+// opened value equals c become c, lifted class m is restored.
+__global__ __launch_bounds__(256) void open_combine_kernel(uint8_t* __restrict__ img, const uint8_t* __restrict__ tmp,
+                                                           const uint8_t* __restrict__ ero, size_t total, int H, int W,
+                                                           int c, int m) {
+    const size_t px = (size_t)H * W;
+    PX_LOOP(total) {
+        const size_t q = t % px;
+        const int y = (int)(q / W), x = (int)(q % W);
+        uint8_t o = ero[t];
+        if (y > 0) o = max(o, ero[t - W]);
+        if (y < H - 1) o = max(o, ero[t + W]);
+        if (x > 0) o = max(o, ero[t - 1]);
+        if (x < W - 1) o = max(o, ero[t + 1]);
+        const uint8_t orig = img[t];
+        img[t] = (orig == m) ? (uint8_t)m : (o == c ? (uint8_t)c : tmp[t]);
+    }
+}
+
+__global__ void gather_counts_kernel(const int32_t* __restrict__ G_all, int n_img, int key, int32_t* __restrict__ n_out,
+                                     long long* __restrict__ px_out, long long full_px) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_img) return;
+    const int n = G_all[(size_t)i * G_STRIDE + G_NCOMP + key];
+    const long long px = G_all[(size_t)i * G_STRIDE + G_NPX + key];
+    if (n_out) n_out[i] = n;
+    // count_cc's pixel total (src/image_tools.py:116-119) is float 0.0 when nothing is counted: no component, or no
+    // background label for np.unique(...)[1:] to drop (mask without a single zero pixel)
+    if (px_out) px_out[i] = (n == 0 || px == full_px) ? -1 : px;
+}
+
+hipError_t run_meta_inference(PostWorkspace& ws, uint8_t* img, int n_img, int H, int W, int32_t* n_ec_dev, hipStream_t s) {
+    if (n_img <= 0) return hipSuccess;
+    const CclGeom g = make_geom(n_img, H, W);
+    const size_t px = (size_t)H * W, total = px * n_img;
+    const unsigned pg = px_grid(total);
+    hipError_t e;
+    // 1. fill_holes(1), fill_holes(2)
+    for (int c = 1; c <= 2; ++c) {
+        CclPass p{img, lut_ne(c), 4, 0, AUX_BORDER, 0, nullptr};
+        if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(apply_fill_kernel, dim3(pg), dim3(256), 0, s, img, ws.L, ws.flag, total, px, c);
+    }
+    // 2-4. size_thresh
+    {
+        CclPass p{img, LUT_MULTI, 8, STAT_AREA, AUX_NONE, 0, nullptr};
+        if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(apply_size_thresh_kernel, dim3(pg), dim3(256), 0, s, img, ws.L, ws.area, ws.g, total, px, 15);
+    }
+    // 5. ecDNA band removal (img -> tmpA -> img)
+    hipLaunchKernelGGL(band_removal_kernel, dim3(pg), dim3(256), 0, s, img, ws.tmpA, total, H, W);
+    if ((e = hipMemcpyAsync(img, ws.tmpA, total, hipMemcpyDeviceToDevice, s)) != hipSuccess) return e;
+    // 6. nucleus-in-metaphase test
+    {
+        CclPass p{img, LUT_MULTI, 8, STAT_AREA | STAT_SUMS, AUX_NONE, 0, nullptr};
+        if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
+        const size_t cap = px / 4 + (size_t)(H + W) / 2 + 4;
+        int32_t* list1 = ws.list;
+        double2* list2 = reinterpret_cast<double2*>(ws.list + (((size_t)n_img * cap + 3) & ~(size_t)3));
+        hipLaunchKernelGGL(compact_roots_kernel, dim3(pg), dim3(256), 0, s, img, ws.L, ws.area, ws.sumy, ws.sumx, ws.g,
+                           list1, list2, total, px, cap);
+        const int bpi = 8;
+        hipLaunchKernelGGL(nucleus_test_kernel, dim3(n_img * bpi), dim3(256), 0, s, ws.area, ws.sumy, ws.sumx, ws.g, list1,
+                           list2, ws.flag, px, cap, bpi, 70.0, 5);
+        hipLaunchKernelGGL(apply_nucleus_kill_kernel, dim3(pg), dim3(256), 0, s, img, ws.L, ws.flag, total, px);
+    }
+    // 7-8. merge_comp(1), merge_comp(2)
+    for (int c = 1; c <= 2; ++c) {
+        const int m = (c == 1) ? 2 : 1;
+        CclPass p{img, lut_nonzero_except(m), 8, 0, AUX_VALUE_EQ, c, nullptr};
+        if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(apply_merge_kernel, dim3(pg), dim3(256), 0, s, img, ws.tmpA, ws.L, ws.flag, ws.g, total, px, c, m);
+        hipLaunchKernelGGL(grey_erode_kernel, dim3(pg), dim3(256), 0, s, ws.tmpA, ws.tmpB, total, H, W);
+        hipLaunchKernelGGL(open_combine_kernel, dim3(pg), dim3(256), 0, s, img, ws.tmpA, ws.tmpB, total, H, W, c, m);
+    }
+    // 9. final ecDNA dilation
+    hipLaunchKernelGGL(ec_dilate_kernel, dim3(pg), dim3(256), 0, s, img, ws.tmpA, total, H, W);
+    if ((e = hipMemcpyAsync(img, ws.tmpA, total, hipMemcpyDeviceToDevice, s)) != hipSuccess) return e;
+    // 10. count_cc(img == 3)[0]
+    if (n_ec_dev) {
+        CclPass p{img, lut_eq(3), 8, 0, AUX_NONE, 0, nullptr};
+        if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(gather_counts_kernel, dim3((n_img + 63) / 64), dim3(64), 0, s, ws.g, n_img, 1, n_ec_dev,
+                           (long long*)nullptr, (long long)px);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// counting entry points
+// ---------------------------------------------------------------------------------------------------------------
+hipError_t run_count_cc(PostWorkspace& ws, const uint8_t* mask, int n_img, int H, int W, int32_t* n_dev, long long* px_dev,
+                        hipStream_t s) {
+    if (n_img <= 0) return hipSuccess;
+    const CclGeom g = make_geom(n_img, H, W);
+    CclPass p{mask, LUT_NONZERO, 8, 0, AUX_NONE, 0, nullptr};
+    hipError_t e = run_ccl_pass(ws, g, p, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(gather_counts_kernel, dim3((n_img + 63) / 64), dim3(64), 0, s, ws.g, n_img, 1, n_dev, px_dev,
+                       (long long)H * W);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void export_labels_kernel(const int32_t* __restrict__ L, int32_t* __restrict__ out, size_t total) {
+    PX_LOOP(total) out[t] = L[t] + 1;   // background -1 -> 0, component -> 1 + raster index of its first pixel
+}
+
+hipError_t run_ccl_labels(PostWorkspace& ws, const uint8_t* mask, int n_img, int H, int W, int conn, int32_t* labels_dev,
+                          hipStream_t s) {
+    if (n_img <= 0) return hipSuccess;
+    const CclGeom g = make_geom(n_img, H, W);
+    CclPass p{mask, LUT_NONZERO, conn, 0, AUX_NONE, 0, nullptr};
+    hipError_t e = run_ccl_pass(ws, g, p, s);
+    if (e != hipSuccess) return e;
+    const size_t total = (size_t)n_img * H * W;
+    hipLaunchKernelGGL(export_labels_kernel, dim3(px_grid(total)), dim3(256), 0, s, ws.L, labels_dev, total);
+    return hipGetLastError();
+}
+
+// number of roots whose key == key_sel (0 = any) and whose flag word has all bits of `need` -> G[G_CNT0 + slot]
+__global__ __launch_bounds__(256) void count_flagged_roots_kernel(const uint8_t* __restrict__ key_img, uint32_t lut,
+                                                                  const int32_t* __restrict__ L,
+                                                                  const uint32_t* __restrict__ flag,
+                                                                  int32_t* __restrict__ G_all, size_t total, size_t px,
+                                                                  int key_sel, uint32_t need, int slot) {
+    PX_LOOP(total) {
+        const size_t im = t / px;
+        const int p = (int)(t - im * px);
+        if (L[t] != p) continue;
+        if (key_sel && key_of(key_img[t], lut) != key_sel) continue;
+        if ((flag[t] & need) == need) atomicAdd(G_all + im * G_STRIDE + G_CNT0 + slot, 1);
+    }
+}
+
+__global__ void gather_slot_kernel(const int32_t* __restrict__ G_all, int n_img, int slot, int key_for_quirk,
+                                   long long full_px, int32_t* __restrict__ out32, long long* __restrict__ out64,
+                                   int out_stride, int out_off) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_img) return;
+    const int32_t* G = G_all + (size_t)i * G_STRIDE;
+    int v = G[G_CNT0 + slot];
+    // np.unique(regs)[1:] (src/image_tools.py:107,129) drops the only component of a mask without background
+    if (key_for_quirk && G[G_NPX + key_for_quirk] == full_px) v = 0;
+    if (out32) out32[(size_t)i * out_stride + out_off] = v;
+    if (out64) out64[(size_t)i * out_stride + out_off] = v;
+}
+
+__global__ __launch_bounds__(256) void mask_to_bits_kernel(const uint8_t* __restrict__ a, uint8_t* __restrict__ out, size_t total) {
+    PX_LOOP(total) out[t] = a[t] ? 1 : 0;
+}
+
+hipError_t run_count_coloc(PostWorkspace& ws, const uint8_t* ob1, const uint8_t* ob2, int n_img, int H, int W, int32_t* n_dev,
+                           hipStream_t s) {
+    if (n_img <= 0) return hipSuccess;
+    const CclGeom g = make_geom(n_img, H, W);
+    const size_t px = (size_t)H * W, total = px * n_img;
+    hipLaunchKernelGGL(mask_to_bits_kernel, dim3(px_grid(total)), dim3(256), 0, s, ob2, ws.tmpA, total);
+    CclPass p{ob1, LUT_NONZERO, 8, 0, AUX_IMAGE, 0, ws.tmpA};
+    hipError_t e = run_ccl_pass(ws, g, p, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(count_flagged_roots_kernel, dim3(px_grid(total)), dim3(256), 0, s, ob1, LUT_NONZERO, ws.L, ws.flag,
+                       ws.g, total, px, 0, 1u, 0);
+    hipLaunchKernelGGL(gather_slot_kernel, dim3((n_img + 63) / 64), dim3(64), 0, s, ws.g, n_img, 0, 1, (long long)px, n_dev,
+                       (long long*)nullptr, 1, 0);
+    return hipGetLastError();
+}
+
+// remove_small_objects(fish, thr) on a bool image: 4-connected components with area < thr are dropped
+__global__ __launch_bounds__(256) void keep_large_kernel(const int32_t* __restrict__ L, const uint32_t* __restrict__ area,
+                                                         uint8_t* __restrict__ out, size_t total, size_t px, int thr, int bit) {
+    PX_LOOP(total) {
+        const int r = L[t];
+        uint8_t v = out[t];
+        if (r >= 0 && area[(t / px) * px + r] >= (uint32_t)thr) v |= (uint8_t)(1u << bit);
+        out[t] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void zero_u8_kernel(uint8_t* __restrict__ out, size_t total) {
+    PX_LOOP(total) out[t] = 0;
+}
+
+hipError_t run_count_hsr(PostWorkspace& ws, const uint8_t* chrom, const uint8_t* fish, int n_img, int H, int W, int thr,
+                         int32_t* n_dev, hipStream_t s) {
+    if (n_img <= 0) return hipSuccess;
+    const CclGeom g = make_geom(n_img, H, W);
+    const size_t px = (size_t)H * W, total = px * n_img;
+    CclPass p1{fish, LUT_NONZERO, 4, STAT_AREA, AUX_NONE, 0, nullptr};
+    hipError_t e = run_ccl_pass(ws, g, p1, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(zero_u8_kernel, dim3(px_grid(total)), dim3(256), 0, s, ws.tmpA, total);
+    hipLaunchKernelGGL(keep_large_kernel, dim3(px_grid(total)), dim3(256), 0, s, ws.L, ws.area, ws.tmpA, total, px, thr, 0);
+    CclPass p2{chrom, LUT_NONZERO, 8, 0, AUX_IMAGE, 0, ws.tmpA};
+    if ((e = run_ccl_pass(ws, g, p2, s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(count_flagged_roots_kernel, dim3(px_grid(total)), dim3(256), 0, s, chrom, LUT_NONZERO, ws.L, ws.flag,
+                       ws.g, total, px, 0, 1u, 0);
+    hipLaunchKernelGGL(gather_slot_kernel, dim3((n_img + 63) / 64), dim3(64), 0, s, ws.g, n_img, 0, 1, (long long)px, n_dev,
+                       (long long*)nullptr, 1, 0);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// meta_overlay row (src/meta_overlay.py:59-95)
+// ---------------------------------------------------------------------------------------------------------------
+// which: 0 fish  = green & ~nuclei      1 fish2 = red & ~nuclei
+//        2 A     = fish  & ~chrom       3 B     = fish2 & ~chrom
+__global__ __launch_bounds__(256) void overlay_mask_kernel(const uint8_t* __restrict__ labels, const uint8_t* __restrict__ rgb,
+                                                           int C, int sens, int which, uint8_t* __restrict__ out, size_t total) {
+    PX_LOOP(total) {
+        const uint8_t v = labels[t];
+        const bool red = rgb[t * C + 0] > sens, green = rgb[t * C + 1] > sens;
+        bool m = (which & 1) ? red : green;
+        m = m && v != 1;
+        if (which >= 2) m = m && v != 2;
+        out[t] = m ? 1 : 0;
+    }
+}
+
+// aux bits for the (chromosome, ecDNA) labelling: bit0 fish, bit1 fish2, bit2 fish & fish2 (ecDNA colocalisation);
+// bits 3 / 4 (size-filtered fish2 / fish, for HSR) are OR-ed in afterwards by keep_large_kernel.
+__global__ __launch_bounds__(256) void overlay_aux_kernel(const uint8_t* __restrict__ labels, const uint8_t* __restrict__ rgb,
+                                                          int C, int sens, uint8_t* __restrict__ aux, size_t total) {
+    PX_LOOP(total) {
+        const uint8_t v = labels[t];
+        const bool fish2 = rgb[t * C + 0] > sens && v != 1, fish = rgb[t * C + 1] > sens && v != 1;
+        aux[t] = (uint8_t)((fish ? 1 : 0) | (fish2 ? 2 : 0) | ((fish && fish2) ? 4 : 0));
+    }
+}
+
+__global__ void overlay_cc_gather_kernel(const int32_t* __restrict__ G_all, int n_img, int key, long long full_px,
+                                         long long* __restrict__ out, int off) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_img) return;
+    const int n = G_all[(size_t)i * G_STRIDE + G_NCOMP + key];
+    const long long px = G_all[(size_t)i * G_STRIDE + G_NPX + key];
+    out[(size_t)i * 12 + off] = n;
+    out[(size_t)i * 12 + off + 1] = (n == 0 || px == full_px) ? -1 : px;
+}
+
+hipError_t run_overlay(PostWorkspace& ws, const uint8_t* labels, const uint8_t* rgb, int n_img, int H, int W, int C, int sens,
+                       int hsr_thr, long long* out, hipStream_t s) {
+    if (n_img <= 0) return hipSuccess;
+    const CclGeom g = make_geom(n_img, H, W);
+    const size_t px = (size_t)H * W, total = px * n_img;
+    const unsigned pg = px_grid(total);
+    const unsigned ig = (n_img + 63) / 64;
+    uint8_t* aux = ws.tmpB;    // flag bits for the (chrom, ec) labelling
+    uint8_t* msk = ws.tmpA;    // mask being labelled
+    hipError_t e;
+    hipLaunchKernelGGL(overlay_aux_kernel, dim3(pg), dim3(256), 0, s, labels, rgb, C, sens, aux, total);
+    // HSR: size-filtered fish2 (red) -> bit3, fish (green) -> bit4   (4-connectivity, src/image_tools.py:104)
+    for (int k = 0; k < 2; ++k) {
+        const int which = (k == 0) ? 1 : 0;
+        hipLaunchKernelGGL(overlay_mask_kernel, dim3(pg), dim3(256), 0, s, labels, rgb, C, sens, which, msk, total);
+        CclPass p{msk, LUT_NONZERO, 4, STAT_AREA, AUX_NONE, 0, nullptr};
+        if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(keep_large_kernel, dim3(pg), dim3(256), 0, s, ws.L, ws.area, aux, total, px, hsr_thr, 3 + k);
+    }
+    // chromosomes (key 2) and ecDNA (key 3) in one labelling
+    {
+        const uint32_t lut = 0x03020000u;
+        CclPass p{labels, lut, 8, 0, AUX_IMAGE, 0, aux};
+        if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(overlay_cc_gather_kernel, dim3(ig), dim3(64), 0, s, ws.g, n_img, 3, (long long)px, out, 0);
+        const struct { int key; uint32_t need; int slot; int off; } q[5] = {
+            {3, 1u, 0, 6}, {3, 2u, 1, 7}, {3, 4u, 2, 9}, {2, 8u, 3, 10}, {2, 16u, 4, 11}};
+        for (int k = 0; k < 5; ++k) {
+            hipLaunchKernelGGL(count_flagged_roots_kernel, dim3(pg), dim3(256), 0, s, labels, lut, ws.L, ws.flag, ws.g, total,
+                               px, q[k].key, q[k].need, q[k].slot);
+            hipLaunchKernelGGL(gather_slot_kernel, dim3(ig), dim3(64), 0, s, ws.g, n_img, q[k].slot, q[k].key, (long long)px,
+                               (int32_t*)nullptr, out, 12, q[k].off);
+        }
+    }
+    // A = fish & ~chrom: count_cc(A), coloc(A, B)
+    {
+        hipLaunchKernelGGL(overlay_mask_kernel, dim3(pg), dim3(256), 0, s, labels, rgb, C, sens, 2, msk, total);
+        hipLaunchKernelGGL(overlay_mask_kernel, dim3(pg), dim3(256), 0, s, labels, rgb, C, sens, 3, aux, total);
+        CclPass p{msk, LUT_NONZERO, 8, 0, AUX_IMAGE, 0, aux};
+        if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(overlay_cc_gather_kernel, dim3(ig), dim3(64), 0, s, ws.g, n_img, 1, (long long)px, out, 2);
+        hipLaunchKernelGGL(count_flagged_roots_kernel, dim3(pg), dim3(256), 0, s, msk, LUT_NONZERO, ws.L, ws.flag, ws.g, total,
+                           px, 0, 1u, 0);
+        hipLaunchKernelGGL(gather_slot_kernel, dim3(ig), dim3(64), 0, s, ws.g, n_img, 0, 1, (long long)px, (int32_t*)nullptr,
+                           out, 12, 8);
+    }
+    // B = fish2 & ~chrom: count_cc(B)
+    {
+        CclPass p{aux, LUT_NONZERO, 8, 0, AUX_NONE, 0, nullptr};
+        if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(overlay_cc_gather_kernel, dim3(ig), dim3(64), 0, s, ws.g, n_img, 1, (long long)px, out, 4);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// stitch + img_as_ubyte + argmax (src/image_tools.py:188-252, src/utils.py:117-118)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stitch_argmax_kernel(const float* __restrict__ probs, int prob_cs,
+                                                            const int32_t* __restrict__ src_map, int n_pos, size_t px,
+                                                            uint8_t* __restrict__ labels, size_t total) {
+    PX_LOOP(total) {
+        const size_t im = t / px, q = t - im * px;
+        const int src = src_map[q];
+        uint8_t lab = 0;                       // never-written canvas pixels stay 0.0 in every channel -> argmax 0
+        if (src >= 0) {
+            const size_t patch = im * n_pos + (size_t)(src >> 16);
+            const float* pp = probs + ((patch << 16) + (size_t)(src & 0xffff)) * prob_cs;
+            int best = -1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                // float64(p) * 255 is exact; rint = round half to even; clip to [0, 255]
+                double v = rint((double)pp[c] * 255.0);
+                v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+                const int qv = (int)v;
+                if (qv > best) { best = qv; lab = (uint8_t)c; }   // strict '>' keeps the first maximum
+            }
+        }
+        labels[t] = lab;
+    }
+}
+
+hipError_t launch_stitch_argmax(const float* probs, int prob_cs, const int32_t* src_map, int n_img, int n_pos, int H, int W,
+                                uint8_t* labels, hipStream_t s) {
+    const size_t px = (size_t)H * W, total = px * n_img;
+    if (!total) return hipSuccess;
+    hipLaunchKernelGGL(stitch_argmax_kernel, dim3(px_grid(total)), dim3(256), 0, s, probs, prob_cs, src_map, n_pos, px,
+                       labels, total);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// meta_preprocess (src/image_tools.py:86-101)
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void extract_gray_kernel(const T* __restrict__ img, int C, uint8_t* __restrict__ gray,
+                                                           size_t total) {
+    const int ch = C > 1 ? 2 : 0;
+    PX_LOOP(total) {
+        const T v = img[t * C + ch];
+        if (sizeof(T) == 2) {
+            // cv2.convertScaleAbs(alpha = 255/65535): saturate_cast<uchar>(|float(v) * float(alpha)|), round half even
+            const float f = fabsf((float)v * (float)(255.0 / 65535.0));
+            int r = __float2int_rn(f);
+            gray[t] = (uint8_t)(r > 255 ? 255 : r);
+        } else {
+            gray[t] = (uint8_t)v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void hist256_kernel(const uint8_t* __restrict__ gray, size_t px, uint32_t* __restrict__ hist,
+                                                      int blocks_per_img) {
+    __shared__ uint32_t h[256];
+    const int im = blockIdx.x / blocks_per_img, j = blockIdx.x % blocks_per_img;
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint8_t* g = gray + (size_t)im * px;
+    for (size_t t = (size_t)j * 256 + threadIdx.x; t < px; t += (size_t)blocks_per_img * 256) atomicAdd(&h[g[t]], 1u);
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(hist + (size_t)im * 256 + threadIdx.x, h[threadIdx.x]);
+}
+
+// Otsu threshold (OpenCV getThreshVal_Otsu_8u restated) + the "> 50 % white" decision; one thread per image
+__global__ void otsu_decide_kernel(const uint32_t* __restrict__ hist, int n_img, size_t px, int32_t* __restrict__ inverted) {
+    const int im = blockIdx.x * blockDim.x + threadIdx.x;
+    if (im >= n_img) return;
+    const uint32_t* h = hist + (size_t)im * 256;
+    const double scale = 1.0 / (double)px;
+    double mu = 0.0;
+    for (int i = 0; i < 256; ++i) mu += (double)i * (double)h[i];
+    mu *= scale;
+    double mu1 = 0.0, q1 = 0.0, max_sigma = 0.0;
+    int max_val = 0;
+    const double eps = 1.1920928955078125e-07;   // FLT_EPSILON
+    for (int i = 0; i < 256; ++i) {
+        const double p_i = (double)h[i] * scale;
+        mu1 *= q1;
+        q1 += p_i;
+        const double q2 = 1.0 - q1;
+        if (fmin(q1, q2) < eps || fmax(q1, q2) > 1.0 - eps) continue;
+        mu1 = (mu1 + (double)i * p_i) / q1;
+        const double mu2 = (mu - q1 * mu1) / q2;
+        const double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+        if (sigma > max_sigma) { max_sigma = sigma; max_val = i; }
+    }
+    unsigned long long white = 0;
+    for (int i = max_val + 1; i < 256; ++i) white += h[i];
+    inverted[im] = ((double)white > (double)px * 0.5) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void invert_kernel(uint8_t* __restrict__ gray, const int32_t* __restrict__ inverted,
+                                                     size_t px, size_t total) {
+    PX_LOOP(total) {
+        if (inverted[t / px]) gray[t] = (uint8_t)~gray[t];
+    }
+}
+
+hipError_t run_preprocess(const void* img, int n_img, int H, int W, int C, int bps, uint8_t* gray, int32_t* inverted,
+                          uint32_t* hist_ws, hipStream_t s) {
+    if (n_img <= 0) return hipSuccess;
+    const size_t px = (size_t)H * W, total = px * n_img;
+    const unsigned pg = px_grid(total);
+    if (bps == 2) hipLaunchKernelGGL(extract_gray_kernel<uint16_t>, dim3(pg), dim3(256), 0, s, (const uint16_t*)img, C, gray, total);
+    else hipLaunchKernelGGL(extract_gray_kernel<uint8_t>, dim3(pg), dim3(256), 0, s, (const uint8_t*)img, C, gray, total);
+    hipError_t e = hipMemsetAsync(hist_ws, 0, (size_t)n_img * 256 * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    const int bpi = 64;
+    hipLaunchKernelGGL(hist256_kernel, dim3(n_img * bpi), dim3(256), 0, s, gray, px, hist_ws, bpi);
+    hipLaunchKernelGGL(otsu_decide_kernel, dim3((n_img + 63) / 64), dim3(64), 0, s, hist_ws, n_img, px, inverted);
+    hipLaunchKernelGGL(invert_kernel, dim3(pg), dim3(256), 0, s, gray, inverted, px, total);
+    return hipGetLastError();
+}
+
+}  // namespace ecseg

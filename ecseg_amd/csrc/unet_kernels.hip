@@ -1,0 +1,658 @@
+// U-Net layer kernels for gfx950 (MI355X).  NHWC float32 everywhere.
+//
+// The hot kernel is conv_mfma: an im2col-free implicit-GEMM convolution on the f32-input matrix cores
+// (v_mfma_f32_32x32x2_f32, exact f32 fma chains).  Per workgroup: 128 output pixels (a TH x TW spatial tile of one
+// patch) x BN output channels; the input halo tile and the filter slab of one 8-channel K-chunk are staged in LDS and
+// every one of the R*S taps is served from that single staged halo (no im2col buffer, no re-read of the input).
+//
+//   M (MFMA rows)  = output pixels, lane i = l & 31 -> pixel i of the wave's 32-pixel strip
+//   N (MFMA cols)  = output channels
+//   K              = (tap, input channel); one MFMA consumes channels {e, 4 + e} of the chunk for one tap, so a
+//                    single ds_read_b128 per operand feeds four MFMAs (k-order inside a chunk is permuted
+//                    identically for A and B, which only re-orders the exact f32 accumulation).
+//
+// LDS images (conflict-free ds_read_b128: consecutive lanes read consecutive 16-byte slots)
+//   As[half h][halo pixel][4 ch]           channels 4h .. 4h+3 of the chunk
+//   Bs[tap][half h][out channel][4 ch]
+// Global filter layout (re-laid out once at model load): wt[tap][chunk][h][N padded][4].
+#include "common.h"
+
+namespace ecseg {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float apply_act(float v, int act, float alpha) {
+    switch (act) {
+        case ECSEG_ACT_RELU: return v > 0.f ? v : 0.f;
+        case ECSEG_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        case ECSEG_ACT_LEAKY: return v > 0.f ? v : alpha * v;
+        case ECSEG_ACT_TANH: return tanhf(v);
+        case ECSEG_ACT_ELU: return v > 0.f ? v : (expf(v) - 1.f);
+        default: return v;
+    }
+}
+
+// T1: give every XCD (blocks with equal blockIdx % 8 share one L2) a contiguous range of logical block ids.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+template <int NT, int TW, int R, int S>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p, int tiles_x, int tiles_y, int nblk_n, int np_total) {
+    constexpr int TH = 128 / TW;
+    constexpr int HH = TH + R - 1, HW = TW + S - 1;
+    constexpr int NPIX = HH * HW;
+    constexpr int BN = NT * 32;
+    constexpr int A_PIECES = NPIX * 2;
+    constexpr int A_PER_T = (A_PIECES + 255) / 256;
+    constexpr int B_PIECES = R * S * 2 * BN;
+    constexpr int B_PER_T = (B_PIECES + 255) / 256;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* As = reinterpret_cast<f32x4*>(smem);   // [2][NPIX]
+    f32x4* Bs = As + 2 * NPIX;                    // [R*S][2][BN]
+
+    const int tid = threadIdx.x;
+    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nb = bid % nblk_n; bid /= nblk_n;
+    const int tx0 = (bid % tiles_x) * TW; bid /= tiles_x;
+    const int ty0 = (bid % tiles_y) * TH; bid /= tiles_y;
+    const int img = bid;
+    const int n0 = nb * BN;
+
+    const int Hin = p.in.h, Win = p.in.w, Cin = p.in.c;
+    const size_t in_img = (size_t)img * Hin * Win * p.in.cs;
+
+    // ---- per-thread staging descriptors (fixed over the K loop) ----
+    long a_off[A_PER_T];     // float offset of this thread's 16-byte piece for chunk 0, or -1 when zero-filled
+    int a_ch[A_PER_T];       // first channel of the piece inside chunk 0
+    int a_lds[A_PER_T];
+#pragma unroll
+    for (int k = 0; k < A_PER_T; ++k) {
+        const int q = tid + k * 256;
+        a_off[k] = -1; a_lds[k] = -1; a_ch[k] = 0;
+        if (q < A_PIECES) {
+            const int pix = q >> 1, h = q & 1;
+            const int hy = pix / HW, hx = pix - hy * HW;
+            const int iy = ty0 - p.pad_top + hy, ix = tx0 - p.pad_left + hx;
+            a_lds[k] = h * NPIX + pix;
+            a_ch[k] = h * 4;
+            if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win)
+                a_off[k] = (long)(in_img + ((size_t)iy * Win + ix) * p.in.cs + h * 4);
+        }
+    }
+    const size_t chunk_stride = (size_t)2 * np_total * 4;          // floats between consecutive chunks of one tap
+    const size_t tap_stride = chunk_stride * p.cin_chunks;
+    long b_off[B_PER_T];
+#pragma unroll
+    for (int k = 0; k < B_PER_T; ++k) {
+        const int q = tid + k * 256;
+        b_off[k] = -1;
+        if (q < B_PIECES) {
+            const int tap = q / (2 * BN), rem = q - tap * 2 * BN;
+            const int h = rem / BN, j = rem - h * BN;
+            b_off[k] = (long)(tap * tap_stride + ((size_t)h * np_total + n0 + j) * 4);
+        }
+    }
+
+    f32x4 a_reg[A_PER_T], b_reg[B_PER_T];
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int k = 0; k < A_PER_T; ++k) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (a_off[k] >= 0 && c * 8 + a_ch[k] < Cin)
+                v = *reinterpret_cast<const f32x4*>(p.in.p + a_off[k] + (size_t)c * 8);
+            a_reg[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < B_PER_T; ++k) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b_off[k] >= 0) v = *reinterpret_cast<const f32x4*>(p.wt + b_off[k] + (size_t)c * chunk_stride);
+            b_reg[k] = v;
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int k = 0; k < A_PER_T; ++k)
+            if (a_lds[k] >= 0) As[a_lds[k]] = a_reg[k];
+#pragma unroll
+        for (int k = 0; k < B_PER_T; ++k) {
+            const int q = tid + k * 256;
+            if (q < B_PIECES) Bs[q] = b_reg[k];
+        }
+    };
+
+    // ---- wave / lane roles ----
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    int ty, tx;
+    if (TW == 32) { ty = wave; tx = li; } else { ty = 2 * wave + (li >> 4); tx = li & 15; }
+    const f32x4* Ap = As + lh * NPIX + ty * HW + tx;
+    const f32x4* Bp = Bs + lh * BN + li;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+
+    load_chunk(0);
+    for (int c = 0; c < p.cin_chunks; ++c) {
+        store_chunk();
+        __syncthreads();
+        if (c + 1 < p.cin_chunks) load_chunk(c + 1);   // next chunk's HBM/L2 latency hides under this chunk's MFMAs
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const f32x4 a = Ap[r * HW + s];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const f32x4 b = Bp[(r * S + s) * 2 * BN + nt * 32];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[nt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias + activation, 128-byte row segments per half wave ----
+    const int Hout = p.out.h, Wout = p.out.w;
+    const int Ht = p.convt ? Hin : Hout, Wt = p.convt ? Win : Wout;   // extent the tiles walk over
+    int co_base = n0, oa = 0, ob = 0, Cout = p.out.c;
+    if (p.convt) {
+        const int ab = n0 / p.coutp;
+        co_base = n0 - ab * p.coutp;
+        oa = ab / p.kT; ob = ab - oa * p.kT;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = co_base + nt * 32 + li;
+        const bool co_ok = co < Cout;
+        const float bv = (p.bias != nullptr && co_ok) ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;   // pixel index inside the wave's 32-pixel strip
+            int py, px;
+            if (TW == 32) { py = wave; px = row; } else { py = 2 * wave + (row >> 4); px = row & 15; }
+            const int tyy = ty0 + py, txx = tx0 + px;              // position in the tiled extent
+            int oy = tyy, ox = txx;
+            bool ok = co_ok && tyy < Ht && txx < Wt;               // the tile may overhang the extent
+            if (p.convt) {
+                oy = tyy * p.kT + oa - p.crop_top;
+                ox = txx * p.kT + ob - p.crop_left;
+                ok = ok && oy >= 0 && oy < Hout && ox >= 0 && ox < Wout;
+            }
+            if (ok) {
+                const size_t o = (((size_t)img * Hout + oy) * Wout + ox) * p.out.cs + co;
+                p.out.p[o] = apply_act(acc[nt][e] + bv, p.act, p.alpha);
+            }
+        }
+    }
+}
+
+int conv_mfma_ntile(int cout) {
+    if (cout % 128 == 0) return 128;
+    if (cout % 64 == 0 || cout > 64) return 64;
+    return 32;
+}
+
+bool conv_mfma_supported(const ConvParams& p) {
+    const bool taps_ok = (p.R == 3 && p.S == 3) || (p.R == 2 && p.S == 2) || (p.R == 1 && p.S == 1);
+    const bool align_ok = (p.in.cs % 4 == 0) && (p.in.c % 4 == 0) && (((uintptr_t)p.in.p) % 16 == 0);
+    return taps_ok && align_ok && p.in.c >= 8 && p.out.c >= 16;
+}
+
+template <int NT, int TW, int R, int S>
+static hipError_t launch_conv_mfma_t(const ConvParams& p, hipStream_t s) {
+    constexpr int TH = 128 / TW;
+    constexpr int BN = NT * 32;
+    const int ext_h = p.convt ? p.in.h : p.out.h, ext_w = p.convt ? p.in.w : p.out.w;
+    const int tiles_x = (ext_w + TW - 1) / TW, tiles_y = (ext_h + TH - 1) / TH;
+    const int np_total = p.convt ? p.kT * p.kT * p.coutp : p.coutp;
+    const int nblk_n = np_total / BN;
+    const size_t lds = (size_t)(2 * (TH + R - 1) * (TW + S - 1) + R * S * 2 * BN) * 16;
+    const size_t grid = (size_t)p.n * tiles_x * tiles_y * nblk_n;
+    if (grid == 0) return hipSuccess;
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((conv_mfma_kernel<NT, TW, R, S>), dim3((unsigned)grid), dim3(256), lds, s, p, tiles_x, tiles_y,
+                       nblk_n, np_total);
+    return hipGetLastError();
+}
+
+template <int NT, int TW>
+static hipError_t launch_conv_mfma_rs(const ConvParams& p, hipStream_t s) {
+    if (p.R == 3) return launch_conv_mfma_t<NT, TW, 3, 3>(p, s);
+    if (p.R == 2) return launch_conv_mfma_t<NT, TW, 2, 2>(p, s);
+    return launch_conv_mfma_t<NT, TW, 1, 1>(p, s);
+}
+
+hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
+    const int bn = conv_mfma_ntile(p.out.c);
+    const bool wide = (p.convt ? p.in.w : p.out.w) >= 32;
+    if (bn == 128) return wide ? launch_conv_mfma_rs<4, 32>(p, s) : launch_conv_mfma_rs<4, 16>(p, s);
+    if (bn == 64) return wide ? launch_conv_mfma_rs<2, 32>(p, s) : launch_conv_mfma_rs<2, 16>(p, s);
+    return wide ? launch_conv_mfma_rs<1, 32>(p, s) : launch_conv_mfma_rs<1, 16>(p, s);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Direct kernels (HBM-bound layers: first conv with Cin <= 4, the 1x1 head, and generic fall-backs)
+// ------------------------------------------------------------------------------------------------------------
+
+// Cin <= 4, Cout % 4 == 0: thread = (pixel, 4 output channels); a wave writes 1 KiB contiguous.
+__global__ __launch_bounds__(256) void conv_small_cin_kernel(TView in, TView out, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, size_t total, int R, int S,
+                                                             int pad_top, int pad_left, int act, float alpha) {
+    const int quads = out.c >> 2;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(t % quads);
+        size_t pix = t / quads;
+        const int ox = (int)(pix % out.w); pix /= out.w;
+        const int oy = (int)(pix % out.h);
+        const size_t img = pix / out.h;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (bias) acc = *reinterpret_cast<const f32x4*>(bias + q * 4);
+        for (int r = 0; r < R; ++r) {
+            const int iy = oy - pad_top + r;
+            if (iy < 0 || iy >= in.h) continue;
+            for (int s = 0; s < S; ++s) {
+                const int ix = ox - pad_left + s;
+                if (ix < 0 || ix >= in.w) continue;
+                const float* ip = in.p + ((img * in.h + iy) * in.w + ix) * in.cs;
+                for (int ci = 0; ci < in.c; ++ci) {
+                    const float v = ip[ci];
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(w + ((size_t)((r * S + s) * in.c + ci)) * out.c + q * 4);
+                    acc[0] = fmaf(v, wv[0], acc[0]); acc[1] = fmaf(v, wv[1], acc[1]);
+                    acc[2] = fmaf(v, wv[2], acc[2]); acc[3] = fmaf(v, wv[3], acc[3]);
+                }
+            }
+        }
+        float* op = out.p + ((img * out.h + oy) * out.w + ox) * out.cs + q * 4;
+        f32x4 o;
+        o[0] = apply_act(acc[0], act, alpha); o[1] = apply_act(acc[1], act, alpha);
+        o[2] = apply_act(acc[2], act, alpha); o[3] = apply_act(acc[3], act, alpha);
+        *reinterpret_cast<f32x4*>(op) = o;
+    }
+}
+
+hipError_t launch_conv_small_cin(const TView& in, const TView& out, const float* w, const float* bias, int n, int R, int S,
+                                 int pad_top, int pad_left, int act, float alpha, hipStream_t s) {
+    const size_t total = (size_t)n * out.h * out.w * (out.c / 4);
+    if (!total) return hipSuccess;
+    const unsigned grid = (unsigned)((total + 255) / 256 > 65536 * 16 ? 65536 * 16 : (total + 255) / 256);
+    hipLaunchKernelGGL(conv_small_cin_kernel, dim3(grid), dim3(256), 0, s, in, out, w, bias, total, R, S, pad_top,
+                       pad_left, act, alpha);
+    return hipGetLastError();
+}
+
+// 1x1 conv with few outputs (the 4-class head) + optional channel softmax.  16 lanes share one pixel: each lane
+// reads float4 slices of the pixel's channel vector (256 B contiguous per pixel at Cin = 64), partial sums are
+// reduced with wave shuffles, lane 0 of the group finishes bias / softmax and writes the pixel.
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_head_kernel(TView in, TView out, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, size_t npix, int act, float alpha) {
+    const int sub = threadIdx.x & 15;
+    const int c4n = in.c >> 2;
+    for (size_t pix = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; ; pix += ((size_t)gridDim.x * blockDim.x) >> 4) {
+        // all 16 lanes of a group share `pix`; groups of one wave may run out at different times, so keep the whole
+        // wave in the loop and mask the work instead of breaking (shuffles need every lane present)
+        const size_t wave_first = pix - (((size_t)threadIdx.x & 63) >> 4);
+        if (wave_first >= npix) break;
+        const bool live = pix < npix;
+        float acc[COUT];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+        if (live) {
+            const float* ip = in.p + pix * in.cs;
+            for (int c4 = sub; c4 < c4n; c4 += 16) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ip + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float* wr = w + (size_t)(c4 * 4 + e) * COUT;
+#pragma unroll
+                    for (int o = 0; o < COUT; ++o) acc[o] = fmaf(v[e], wr[o], acc[o]);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+            float v = acc[o];
+            v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64);
+            v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+            acc[o] = v;
+        }
+        if (live && sub == 0) {
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) acc[o] += bias ? bias[o] : 0.f;
+            if (act == ECSEG_ACT_SOFTMAX) {
+                float m = acc[0];
+#pragma unroll
+                for (int o = 1; o < COUT; ++o) m = fmaxf(m, acc[o]);
+                float sum = 0.f;
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) { acc[o] = expf(acc[o] - m); sum += acc[o]; }
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) acc[o] = acc[o] / sum;
+            } else {
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) acc[o] = apply_act(acc[o], act, alpha);
+            }
+            float* op = out.p + pix * out.cs;
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) op[o] = acc[o];
+        }
+    }
+}
+
+hipError_t launch_conv_head(const TView& in, const TView& out, const float* w, const float* bias, int n, int act,
+                            float alpha, hipStream_t s) {
+    const size_t npix = (size_t)n * out.h * out.w;
+    if (!npix) return hipSuccess;
+    size_t blocks = (npix * 16 + 255) / 256;
+    if (blocks > 65536 * 8) blocks = 65536 * 8;
+#define HEAD_CASE(C) case C: hipLaunchKernelGGL(conv_head_kernel<C>, dim3((unsigned)blocks), dim3(256), 0, s, in, out, w, bias, npix, act, alpha); break;
+    switch (out.c) {
+        HEAD_CASE(1) HEAD_CASE(2) HEAD_CASE(3) HEAD_CASE(4) HEAD_CASE(5) HEAD_CASE(6) HEAD_CASE(7) HEAD_CASE(8)
+        default: return hipErrorInvalidValue;
+    }
+#undef HEAD_CASE
+    return hipGetLastError();
+}
+
+// Generic direct convolution: thread = (pixel, output channel).  Correctness fall-back for shapes the MFMA kernel
+// does not take (odd channel counts, large taps).
+__global__ __launch_bounds__(256) void conv_generic_kernel(TView in, TView out, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, size_t total, int R, int S,
+                                                           int pad_top, int pad_left, int act, float alpha) {
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(t % out.c);
+        size_t pix = t / out.c;
+        const int ox = (int)(pix % out.w); pix /= out.w;
+        const int oy = (int)(pix % out.h);
+        const size_t img = pix / out.h;
+        float acc = bias ? bias[co] : 0.f;
+        for (int r = 0; r < R; ++r) {
+            const int iy = oy - pad_top + r;
+            if (iy < 0 || iy >= in.h) continue;
+            for (int s = 0; s < S; ++s) {
+                const int ix = ox - pad_left + s;
+                if (ix < 0 || ix >= in.w) continue;
+                const float* ip = in.p + ((img * in.h + iy) * in.w + ix) * in.cs;
+                const float* wp = w + (size_t)(r * S + s) * in.c * out.c + co;
+                for (int ci = 0; ci < in.c; ++ci) acc = fmaf(ip[ci], wp[(size_t)ci * out.c], acc);
+            }
+        }
+        out.p[((img * out.h + oy) * out.w + ox) * out.cs + co] = apply_act(acc, act, alpha);
+    }
+}
+
+hipError_t launch_conv_generic(const TView& in, const TView& out, const float* w, const float* bias, int n, int R, int S,
+                               int pad_top, int pad_left, int act, float alpha, hipStream_t s) {
+    const size_t total = (size_t)n * out.h * out.w * out.c;
+    if (!total) return hipSuccess;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 65536 * 16) blocks = 65536 * 16;
+    hipLaunchKernelGGL(conv_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, out, w, bias, total, R, S, pad_top,
+                       pad_left, act, alpha);
+    return hipGetLastError();
+}
+
+// Generic transposed convolution (Keras kernel layout (kh, kw, out, in)): thread = (output pixel, output channel),
+// gathers every (input pixel, tap) pair that lands on it.
+__global__ __launch_bounds__(256) void convt_generic_kernel(TView in, TView out, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, size_t total, int R, int S,
+                                                            int stride, int crop_top, int crop_left, int act, float alpha) {
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(t % out.c);
+        size_t pix = t / out.c;
+        const int ox = (int)(pix % out.w); pix /= out.w;
+        const int oy = (int)(pix % out.h);
+        const size_t img = pix / out.h;
+        float acc = bias ? bias[co] : 0.f;
+        const int fy = oy + crop_top, fx = ox + crop_left;   // coordinates in the uncropped output
+        for (int a = 0; a < R; ++a) {
+            const int ny = fy - a;
+            if (ny < 0 || ny % stride) continue;
+            const int iy = ny / stride;
+            if (iy >= in.h) continue;
+            for (int b = 0; b < S; ++b) {
+                const int nx = fx - b;
+                if (nx < 0 || nx % stride) continue;
+                const int ix = nx / stride;
+                if (ix >= in.w) continue;
+                const float* ip = in.p + ((img * in.h + iy) * in.w + ix) * in.cs;
+                const float* wp = w + ((size_t)(a * S + b) * out.c + co) * in.c;
+                for (int ci = 0; ci < in.c; ++ci) acc = fmaf(ip[ci], wp[ci], acc);
+            }
+        }
+        out.p[((img * out.h + oy) * out.w + ox) * out.cs + co] = apply_act(acc, act, alpha);
+    }
+}
+
+hipError_t launch_convt_generic(const TView& in, const TView& out, const float* w, const float* bias, int n, int R, int S,
+                                int stride, int crop_top, int crop_left, int act, float alpha, hipStream_t s) {
+    const size_t total = (size_t)n * out.h * out.w * out.c;
+    if (!total) return hipSuccess;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 65536 * 16) blocks = 65536 * 16;
+    hipLaunchKernelGGL(convt_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, out, w, bias, total, R, S, stride,
+                       crop_top, crop_left, act, alpha);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Element-wise / resampling kernels (HBM-bound; float4 fast path when every view is 16-byte aligned)
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool view_vec4(const TView& v) {
+    return (v.c % 4 == 0) && (v.cs % 4 == 0) && ((((uintptr_t)v.p) & 15) == 0);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void maxpool_kernel(TView in, TView out, size_t total, int kh, int kw, int stride) {
+    constexpr int V = VEC ? 4 : 1;
+    const int cq = out.c / V;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % cq) * V;
+        size_t pix = t / cq;
+        const int ox = (int)(pix % out.w); pix /= out.w;
+        const int oy = (int)(pix % out.h);
+        const size_t img = pix / out.h;
+        float m[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) m[e] = -INFINITY;
+        for (int r = 0; r < kh; ++r)
+            for (int s = 0; s < kw; ++s) {
+                const float* ip = in.p + ((img * in.h + (oy * stride + r)) * in.w + (ox * stride + s)) * in.cs + c;
+                if (VEC) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(ip);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) m[e] = fmaxf(m[e], v[e]);
+                } else {
+                    m[0] = fmaxf(m[0], ip[0]);
+                }
+            }
+        float* op = out.p + ((img * out.h + oy) * out.w + ox) * out.cs + c;
+        if (VEC) {
+            f32x4 o; o[0] = m[0]; o[1] = m[V > 1 ? 1 : 0]; o[2] = m[V > 2 ? 2 : 0]; o[3] = m[V > 3 ? 3 : 0];
+            *reinterpret_cast<f32x4*>(op) = o;
+        } else {
+            op[0] = m[0];
+        }
+    }
+}
+
+static unsigned grid_for(size_t total) {
+    size_t b = (total + 255) / 256;
+    if (b > 65536 * 16) b = 65536 * 16;
+    return (unsigned)(b ? b : 1);
+}
+
+hipError_t launch_maxpool(const TView& in, const TView& out, int n, int kh, int kw, int stride, hipStream_t s) {
+    const bool vec = (in.c % 4 == 0) && (in.cs % 4 == 0) && (out.cs % 4 == 0) && ((((uintptr_t)in.p) | ((uintptr_t)out.p)) & 15) == 0;
+    const size_t total = (size_t)n * out.h * out.w * (vec ? out.c / 4 : out.c);
+    if (!total) return hipSuccess;
+    if (vec) hipLaunchKernelGGL(maxpool_kernel<true>, dim3(grid_for(total)), dim3(256), 0, s, in, out, total, kh, kw, stride);
+    else hipLaunchKernelGGL(maxpool_kernel<false>, dim3(grid_for(total)), dim3(256), 0, s, in, out, total, kh, kw, stride);
+    return hipGetLastError();
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void upsample_kernel(TView in, TView out, size_t total, int f, int mode) {
+    constexpr int V = VEC ? 4 : 1;
+    const int cq = out.c / V;
+    const float inv = 1.f / (float)f;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % cq) * V;
+        size_t pix = t / cq;
+        const int ox = (int)(pix % out.w); pix /= out.w;
+        const int oy = (int)(pix % out.h);
+        const size_t img = pix / out.h;
+        float o[V];
+        if (mode == 0) {
+            const float* ip = in.p + ((img * in.h + oy / f) * in.w + ox / f) * in.cs + c;
+#pragma unroll
+            for (int e = 0; e < V; ++e) o[e] = ip[e];
+        } else {
+            // half-pixel centres: src = (dst + 0.5) / f - 0.5, edges clamped
+            const float sy = ((float)oy + 0.5f) * inv - 0.5f, sx = ((float)ox + 0.5f) * inv - 0.5f;
+            const float fy = floorf(sy), fx = floorf(sx);
+            const int y0 = max((int)fy, 0), y1 = min((int)ceilf(sy), in.h - 1);
+            const int x0 = max((int)fx, 0), x1 = min((int)ceilf(sx), in.w - 1);
+            const float ly = sy - fy, lx = sx - fx;
+            const float* r0 = in.p + (img * in.h + y0) * (size_t)in.w * in.cs + c;
+            const float* r1 = in.p + (img * in.h + min(y1, in.h - 1)) * (size_t)in.w * in.cs + c;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float tl = r0[(size_t)x0 * in.cs + e], tr = r0[(size_t)x1 * in.cs + e];
+                const float bl = r1[(size_t)x0 * in.cs + e], br = r1[(size_t)x1 * in.cs + e];
+                const float top = tl + (tr - tl) * lx, bot = bl + (br - bl) * lx;
+                o[e] = top + (bot - top) * ly;
+            }
+        }
+        float* op = out.p + ((img * out.h + oy) * out.w + ox) * out.cs + c;
+#pragma unroll
+        for (int e = 0; e < V; ++e) op[e] = o[e];
+    }
+}
+
+hipError_t launch_upsample(const TView& in, const TView& out, int n, int factor, int mode, hipStream_t s) {
+    const bool vec = (in.c % 4 == 0);
+    const size_t total = (size_t)n * out.h * out.w * (vec ? out.c / 4 : out.c);
+    if (!total) return hipSuccess;
+    if (vec) hipLaunchKernelGGL(upsample_kernel<true>, dim3(grid_for(total)), dim3(256), 0, s, in, out, total, factor, mode);
+    else hipLaunchKernelGGL(upsample_kernel<false>, dim3(grid_for(total)), dim3(256), 0, s, in, out, total, factor, mode);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void affine_kernel(TView in, TView out, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, size_t total, int act, float alpha) {
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % out.c);
+        const size_t pix = t / out.c;
+        float v = in.p[pix * in.cs + c];
+        if (scale) v = v * scale[c] + shift[c];
+        out.p[pix * out.cs + c] = apply_act(v, act, alpha);
+    }
+}
+
+hipError_t launch_affine(const TView& in, const TView& out, const float* scale, const float* shift, int n, int act,
+                         float alpha, hipStream_t s) {
+    const size_t total = (size_t)n * out.h * out.w * out.c;
+    if (!total) return hipSuccess;
+    hipLaunchKernelGGL(affine_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out, scale, shift, total, act, alpha);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void add_kernel(TView a, TView b, TView out, size_t total, int act, float alpha) {
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % out.c);
+        const size_t pix = t / out.c;
+        out.p[pix * out.cs + c] = apply_act(a.p[pix * a.cs + c] + b.p[pix * b.cs + c], act, alpha);
+    }
+}
+
+hipError_t launch_add(const TView& a, const TView& b, const TView& out, int n, int act, float alpha, hipStream_t s) {
+    const size_t total = (size_t)n * out.h * out.w * out.c;
+    if (!total) return hipSuccess;
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(total)), dim3(256), 0, s, a, b, out, total, act, alpha);
+    return hipGetLastError();
+}
+
+// y[oy][ox] = x[oy - off_y][ox - off_x] or 0 outside: ZeroPadding2D (off > 0), Cropping2D (off < 0), plain copy (0)
+__global__ __launch_bounds__(256) void copy_kernel(TView in, TView out, size_t total, int off_y, int off_x) {
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % out.c);
+        size_t pix = t / out.c;
+        const int ox = (int)(pix % out.w); pix /= out.w;
+        const int oy = (int)(pix % out.h);
+        const size_t img = pix / out.h;
+        const int iy = oy - off_y, ix = ox - off_x;
+        float v = 0.f;
+        if (iy >= 0 && iy < in.h && ix >= 0 && ix < in.w) v = in.p[((img * in.h + iy) * in.w + ix) * in.cs + c];
+        out.p[((img * out.h + oy) * out.w + ox) * out.cs + c] = v;
+    }
+}
+
+hipError_t launch_copy(const TView& in, const TView& out, int n, int off_y, int off_x, hipStream_t s) {
+    const size_t total = (size_t)n * out.h * out.w * out.c;
+    if (!total) return hipSuccess;
+    hipLaunchKernelGGL(copy_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out, total, off_y, off_x);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void softmax_kernel(TView in, TView out, size_t npix) {
+    for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (size_t)gridDim.x * blockDim.x) {
+        const float* ip = in.p + pix * in.cs;
+        float* op = out.p + pix * out.cs;
+        float m = ip[0];
+        for (int c = 1; c < in.c; ++c) m = fmaxf(m, ip[c]);
+        float sum = 0.f;
+        for (int c = 0; c < in.c; ++c) sum += expf(ip[c] - m);
+        for (int c = 0; c < in.c; ++c) op[c] = expf(ip[c] - m) / sum;
+    }
+}
+
+hipError_t launch_softmax(const TView& in, const TView& out, int n, hipStream_t s) {
+    const size_t npix = (size_t)n * out.h * out.w;
+    if (!npix) return hipSuccess;
+    hipLaunchKernelGGL(softmax_kernel, dim3(grid_for(npix)), dim3(256), 0, s, in, out, npix);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void u8_to_f32_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, size_t count) {
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += (size_t)gridDim.x * blockDim.x)
+        out[t] = (float)in[t];
+}
+
+hipError_t launch_u8_to_f32(const uint8_t* in, float* out, size_t count, hipStream_t s) {
+    if (!count) return hipSuccess;
+    hipLaunchKernelGGL(u8_to_f32_kernel, dim3(grid_for(count)), dim3(256), 0, s, in, out, count);
+    return hipGetLastError();
+}
+
+// im2patches_overlap (reference src/image_tools.py:181-184): patch k of image i = gray[i, y0:y0+256, x0:x0+256]
+__global__ __launch_bounds__(256) void tile_patches_kernel(const uint8_t* __restrict__ gray, int H, int W,
+                                                           const int32_t* __restrict__ pos, int n_pos,
+                                                           float* __restrict__ out, size_t total) {
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(t & 255), y = (int)((t >> 8) & 255);
+        const size_t pk = t >> 16;
+        const int k = (int)(pk % n_pos);
+        const size_t img = pk / n_pos;
+        out[t] = (float)gray[(img * H + pos[2 * k] + y) * W + pos[2 * k + 1] + x];
+    }
+}
+
+hipError_t launch_tile_patches(const uint8_t* gray, int n_img, int H, int W, const int32_t* pos_yx, int n_pos, float* out,
+                               hipStream_t s) {
+    const size_t total = (size_t)n_img * n_pos * 65536;
+    if (!total) return hipSuccess;
+    hipLaunchKernelGGL(tile_patches_kernel, dim3(grid_for(total)), dim3(256), 0, s, gray, H, W, pos_yx, n_pos, out, total);
+    return hipGetLastError();
+}
+
+}  // namespace ecseg

@@ -1,0 +1,196 @@
+"""Synthetic workloads (no network, no datasets): the canonical U-Net written as a Keras ``model_config`` with
+seeded weights, and seeded DAPI / FISH / label images of the shapes BASELINE.json names."""
+import numpy as np
+
+
+def unet_config(base=64, depth=4, in_ch=1, n_classes=4, up='transpose', batchnorm=False, name='metaseg_synth'):
+    """Keras-2 functional ``model_config`` of the classic U-Net: (conv3-relu x2, pool) x depth, bottleneck,
+    (2x2 up-conv, concat skip, conv3-relu x2) x depth, 1x1 softmax head.  ``up='transpose'`` uses Conv2DTranspose
+    2x2/s2, ``up='upsample'`` uses UpSampling2D + Conv2D 2x2 'same' (both occur in public Keras U-Nets)."""
+    layers = []
+    counter = {}
+
+    def nm(kind):
+        k = counter.get(kind, 0)
+        counter[kind] = k + 1
+        return kind if k == 0 else '%s_%d' % (kind, k)
+
+    def L(cls, kind, inbound, **cfg):
+        name_ = nm(kind)
+        cfg = dict(cfg, name=name_)
+        layers.append({'class_name': cls, 'name': name_, 'config': cfg,
+                       'inbound_nodes': [[[i, 0, 0, {}] for i in inbound]] if inbound else []})
+        return name_
+
+    def conv(x, filters, k=3, act='relu'):
+        y = L('Conv2D', 'conv2d', [x], filters=filters, kernel_size=[k, k], strides=[1, 1], padding='same',
+              data_format='channels_last', dilation_rate=[1, 1], groups=1,
+              activation='linear' if batchnorm and act == 'relu' else act, use_bias=True, trainable=True, dtype='float32')
+        if batchnorm and act == 'relu':
+            y = L('BatchNormalization', 'batch_normalization', [y], axis=[3], momentum=0.99, epsilon=1e-3, center=True,
+                  scale=True)
+            y = L('Activation', 'activation', [y], activation='relu')
+        return y
+
+    x = L('InputLayer', 'input', [], batch_input_shape=[None, 256, 256, in_ch], dtype='float32', sparse=False, ragged=False)
+    skips = []
+    f = base
+    for _ in range(depth):
+        x = conv(conv(x, f), f)
+        skips.append(x)
+        x = L('MaxPooling2D', 'max_pooling2d', [x], pool_size=[2, 2], padding='valid', strides=[2, 2],
+              data_format='channels_last')
+        f *= 2
+    x = conv(conv(x, f), f)
+    for d in range(depth):
+        f //= 2
+        if up == 'transpose':
+            u = L('Conv2DTranspose', 'conv2d_transpose', [x], filters=f, kernel_size=[2, 2], strides=[2, 2], padding='same',
+                  data_format='channels_last', dilation_rate=[1, 1], activation='linear', use_bias=True, output_padding=None)
+        else:
+            u = L('UpSampling2D', 'up_sampling2d', [x], size=[2, 2], data_format='channels_last', interpolation='nearest')
+            u = conv(u, f, k=2)
+        x = L('Concatenate', 'concatenate', [skips[depth - 1 - d], u], axis=3)
+        x = conv(conv(x, f), f)
+    out = conv(x, n_classes, k=1, act='softmax')
+    return {'class_name': 'Functional',
+            'config': {'name': name, 'layers': layers, 'input_layers': [[layers[0]['name'], 0, 0]],
+                       'output_layers': [[out, 0, 0]]}}
+
+
+def unet_weights(config, seed=0, input_scale=1.0 / 255.0, head_gain=6.0):
+    """Seeded He-normal kernels.  The first convolution is scaled by ``input_scale`` because the reference feeds raw
+    0..255 pixel values (no normalisation anywhere in src/utils.py:109-120); the head is scaled up so that the
+    softmax is decisive rather than uniform."""
+    rng = np.random.default_rng(seed)
+    weights = {}
+    first = True
+    layers = config['config']['layers']
+    cin = {}
+    for Ld in layers:
+        cls, lc, name = Ld['class_name'], Ld['config'], Ld['config']['name']
+        if cls == 'InputLayer':
+            cin[name] = lc['batch_input_shape'][3]
+            continue
+        srcs = [r[0] for r in Ld['inbound_nodes'][0]]
+        c_in = sum(cin[s] for s in srcs) if cls == 'Concatenate' else cin[srcs[0]]
+        if cls == 'Conv2D':
+            kh, kw = lc['kernel_size']
+            co = lc['filters']
+            k = rng.normal(size=(kh, kw, c_in, co)) * np.sqrt(2.0 / (kh * kw * c_in))
+            if first:
+                k *= input_scale
+                first = False
+            if lc['activation'] == 'softmax':
+                k *= head_gain
+            weights[name] = [k.astype(np.float32), (rng.normal(size=co) * 0.05).astype(np.float32)]
+            cin[name] = co
+        elif cls == 'Conv2DTranspose':
+            kh, kw = lc['kernel_size']
+            co = lc['filters']
+            k = rng.normal(size=(kh, kw, co, c_in)) * np.sqrt(1.0 / c_in)
+            weights[name] = [k.astype(np.float32), (rng.normal(size=co) * 0.05).astype(np.float32)]
+            cin[name] = co
+        elif cls == 'BatchNormalization':
+            weights[name] = [rng.uniform(0.8, 1.2, c_in).astype(np.float32), (rng.normal(size=c_in) * 0.05).astype(np.float32),
+                             (rng.normal(size=c_in) * 0.05).astype(np.float32), rng.uniform(0.8, 1.2, c_in).astype(np.float32)]
+            cin[name] = c_in
+        else:
+            cin[name] = c_in
+    return weights
+
+
+def _blur(img, sigma):
+    r = int(3 * sigma + 0.5)
+    x = np.arange(-r, r + 1)
+    k = np.exp(-0.5 * (x / sigma) ** 2)
+    k /= k.sum()
+    pad = np.pad(img, ((r, r), (r, r)), mode='edge')
+    tmp = sum(k[i] * pad[i:i + img.shape[0], :] for i in range(2 * r + 1))
+    return sum(k[i] * tmp[:, i:i + img.shape[1]] for i in range(2 * r + 1))
+
+
+def dapi_image(idx, H=1040, W=1392, rgb=False):
+    """Seeded synthetic DAPI metaphase image (uint8): dim noisy background, a few nuclei discs, a cluster of
+    chromosome ellipses, ecDNA dots; blurred with sigma 1.5.  ``rgb=True`` puts it in channel 2 and adds red /
+    green FISH spot fields in channels 0 / 1."""
+    rng = np.random.default_rng(1234 + idx)
+    img = np.clip(rng.normal(6, 4, size=(H, W)), 0, 255)
+    yy, xx = np.ogrid[:H, :W]
+    for _ in range(int(rng.integers(2, 5))):
+        r = rng.integers(60, 121)
+        cy, cx = rng.integers(0, H), rng.integers(0, W)
+        m = (yy - cy) ** 2 + (xx - cx) ** 2 <= r * r
+        img[m] = np.clip(rng.normal(160, 25), 60, 255)
+    cy0, cx0 = rng.integers(H // 4, 3 * H // 4), rng.integers(W // 4, 3 * W // 4)
+    for _ in range(int(rng.integers(40, 71))):
+        a, b = rng.uniform(8, 25), rng.uniform(4, 9)
+        cy, cx = cy0 + rng.integers(-250, 251), cx0 + rng.integers(-250, 251)
+        th = rng.uniform(0, np.pi)
+        y0, y1 = max(int(cy - 30), 0), min(int(cy + 30), H)
+        x0, x1 = max(int(cx - 30), 0), min(int(cx + 30), W)
+        if y0 >= y1 or x0 >= x1:
+            continue
+        sy, sx = np.ogrid[y0:y1, x0:x1]
+        u = (sx - cx) * np.cos(th) + (sy - cy) * np.sin(th)
+        v = -(sx - cx) * np.sin(th) + (sy - cy) * np.cos(th)
+        m = (u / a) ** 2 + (v / b) ** 2 <= 1
+        img[y0:y1, x0:x1][m] = np.clip(rng.normal(200, 30), 80, 255)
+    for _ in range(int(rng.integers(50, 201))):
+        r = rng.integers(2, 5)
+        cy, cx = rng.integers(r, H - r), rng.integers(r, W - r)
+        sy, sx = np.ogrid[cy - r:cy + r + 1, cx - r:cx + r + 1]
+        m = (sy - cy) ** 2 + (sx - cx) ** 2 <= r * r
+        img[cy - r:cy + r + 1, cx - r:cx + r + 1][m] = np.clip(rng.normal(180, 40), 60, 255)
+    gray = np.clip(np.rint(_blur(img, 1.5)), 0, 255).astype(np.uint8)
+    if not rgb:
+        return gray
+    out = np.zeros((H, W, 3), np.uint8)
+    out[..., 2] = gray
+    for ch in (0, 1):
+        f = np.clip(rng.normal(20, 8, size=(H, W)), 0, 255)
+        for _ in range(int(rng.integers(50, 151))):
+            r = rng.integers(1, 4)
+            cy, cx = rng.integers(r, H - r), rng.integers(r, W - r)
+            sy, sx = np.ogrid[cy - r:cy + r + 1, cx - r:cx + r + 1]
+            m = (sy - cy) ** 2 + (sx - cx) ** 2 <= r * r
+            f[cy - r:cy + r + 1, cx - r:cx + r + 1][m] = rng.integers(120, 256)
+        out[..., ch] = f.astype(np.uint8)
+    return out
+
+
+def label_map(idx, H=1040, W=1392, salt=0.002):
+    """Seeded synthetic label image (uint8 0..3) from the same kind of scene, independent of any network: class by
+    blob type plus salt noise.  Used for post-processing / CCL measurements."""
+    rng = np.random.default_rng(4321 + idx)
+    lab = np.zeros((H, W), np.uint8)
+    yy, xx = np.ogrid[:H, :W]
+    for _ in range(int(rng.integers(2, 5))):
+        r = rng.integers(60, 121)
+        cy, cx = rng.integers(0, H), rng.integers(0, W)
+        d2 = (yy - cy) ** 2 + (xx - cx) ** 2
+        lab[d2 <= r * r] = 1
+        if rng.random() < 0.5:
+            lab[d2 <= (r // 4) ** 2] = 0
+    cy0, cx0 = rng.integers(H // 4, 3 * H // 4), rng.integers(W // 4, 3 * W // 4)
+    for _ in range(int(rng.integers(40, 71))):
+        a, b = rng.uniform(8, 25), rng.uniform(4, 9)
+        cy, cx = cy0 + rng.integers(-250, 251), cx0 + rng.integers(-250, 251)
+        th = rng.uniform(0, np.pi)
+        y0, y1 = max(int(cy - 30), 0), min(int(cy + 30), H)
+        x0, x1 = max(int(cx - 30), 0), min(int(cx + 30), W)
+        if y0 >= y1 or x0 >= x1:
+            continue
+        sy, sx = np.ogrid[y0:y1, x0:x1]
+        u = (sx - cx) * np.cos(th) + (sy - cy) * np.sin(th)
+        v = -(sx - cx) * np.sin(th) + (sy - cy) * np.cos(th)
+        lab[y0:y1, x0:x1][(u / a) ** 2 + (v / b) ** 2 <= 1] = 2
+    for _ in range(int(rng.integers(50, 201))):
+        r = rng.integers(2, 5)
+        cy, cx = rng.integers(r, H - r), rng.integers(r, W - r)
+        sy, sx = np.ogrid[cy - r:cy + r + 1, cx - r:cx + r + 1]
+        lab[cy - r:cy + r + 1, cx - r:cx + r + 1][(sy - cy) ** 2 + (sx - cx) ** 2 <= r * r] = 3
+    if salt > 0:
+        m = rng.random((H, W)) < salt
+        lab[m] = rng.integers(0, 4, size=int(m.sum()))
+    return lab

@@ -1,0 +1,171 @@
+/*
+ * ecseg_hip.h - C ABI of libecseg_hip.so: the MI355X (gfx950) implementation of ecSeg's metaseg hot path.
+ *
+ * The reference (UCRajkumar/ecSeg) is pure Python and has no FFI of its own; the boundary it exposes is three
+ * Python call shapes plus a file contract.  Each entry point below names the reference
+ * interface it stands in for (file:line relative to the reference repository).  The ctypes binding that a
+ * maintainer would add on the reference side is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C: opaque handle, plain pointers and sizes, no C++/torch types;
+ *   - every call returns 0 on success or a negative ECSEG_E_* code; the text of the last failure is available
+ *     from ecseg_last_error(); nothing throws across the ABI;
+ *   - the caller owns host memory, the handle owns device memory and its HIP stream;
+ *   - one handle per GPU; a handle is not thread-safe, different handles may be driven from different threads;
+ *   - all calls are synchronous with respect to the host (results are complete on return);
+ *   - "_dev" variants take DEVICE pointers (e.g. torch tensors' data_ptr) and run on the handle's stream without
+ *     host copies; they still return only after the stream has drained unless stated otherwise.
+ *   - images are row-major (H, W[, C]); label images are uint8 with values 0..3
+ *     (0 background, 1 nucleus, 2 chromosome, 3 ecDNA: src/utils.py:128-131).
+ */
+#ifndef ECSEG_HIP_H
+#define ECSEG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ECSEG_ABI_VERSION 1
+
+#define ECSEG_OK             0
+#define ECSEG_E_INVALID     -1   /* bad argument / shape / plan */
+#define ECSEG_E_HIP         -2   /* a HIP runtime call failed */
+#define ECSEG_E_NOMODEL     -3   /* a model-dependent call before ecseg_model_load */
+#define ECSEG_E_NOMEM       -4
+#define ECSEG_E_UNSUPPORTED -5
+
+typedef struct ecseg_ctx ecseg_ctx;
+
+/* ---- lifetime ------------------------------------------------------------------------------------------- */
+int         ecseg_abi_version(void);
+int         ecseg_create(ecseg_ctx** out, int device_id);
+void        ecseg_destroy(ecseg_ctx* h);
+const char* ecseg_last_error(ecseg_ctx* h);        /* h may be NULL: error of the last failed ecseg_create */
+int         ecseg_device_name(ecseg_ctx* h, char* buf, int buflen);
+/* The HIP stream all work of this handle is launched on (hipStream_t as void*), for event timing by the caller. */
+void*       ecseg_stream(ecseg_ctx* h);
+
+/* ---- model plan: replaces tf.keras.models.load_model (src/utils.py:27-33) -------------------------------- */
+/* Kernel-level operators of the U-Net plan.  The host (ecseg_amd/keras_plan.py) lowers the Keras model_config
+ * found in metaseg.h5 to this list; tensors are NHWC float32 "views" into device buffers so that Concatenate
+ * costs nothing (producers write straight into the concatenated buffer). */
+enum {
+    ECSEG_OP_CONV      = 1,  /* Conv2D kh x kw, stride 1, zero padding (pad_top, pad_left), bias, activation */
+    ECSEG_OP_CONVT     = 2,  /* Conv2DTranspose kh x kw, stride s, crop (pad_top, pad_left), bias, activation */
+    ECSEG_OP_MAXPOOL   = 3,  /* MaxPooling2D kh x kw stride s (valid) */
+    ECSEG_OP_UPSAMPLE  = 4,  /* UpSampling2D x s, mode: 0 nearest, 1 bilinear (half-pixel centres) */
+    ECSEG_OP_AFFINE    = 5,  /* y = act(x * scale[c] + shift[c]): BatchNormalization (inference), Rescaling */
+    ECSEG_OP_ACT       = 6,  /* y = act(x) */
+    ECSEG_OP_ADD       = 7,  /* y = act(a + b) */
+    ECSEG_OP_COPY      = 8   /* y = x (materialise a view, ZeroPadding2D / Cropping2D via offsets) */
+};
+enum { ECSEG_ACT_LINEAR = 0, ECSEG_ACT_RELU = 1, ECSEG_ACT_SOFTMAX = 2, ECSEG_ACT_SIGMOID = 3,
+       ECSEG_ACT_LEAKY = 4, ECSEG_ACT_TANH = 5, ECSEG_ACT_ELU = 6 };
+
+typedef struct ecseg_tensor_desc {
+    int32_t buffer;     /* index of the device buffer this view lives in */
+    int32_t h, w, c;    /* per-patch logical shape */
+    int32_t c_stride;   /* floats between consecutive pixels in the buffer (>= c_offset + c) */
+    int32_t c_offset;   /* first channel of the view inside a pixel */
+} ecseg_tensor_desc;
+
+typedef struct ecseg_op_desc {
+    int32_t op;
+    int32_t in0, in1;           /* tensor indices (in1 = -1 when unused) */
+    int32_t out;
+    int32_t kh, kw, stride;
+    int32_t pad_top, pad_left;  /* CONV: zero padding before; CONVT: rows/cols cropped from the full output;
+                                   COPY: offset of the input inside the output (>0) or crop (<0) */
+    int32_t act;
+    int32_t mode;               /* UPSAMPLE interpolation */
+    int32_t w0, w1;             /* weight array indices: CONV/CONVT kernel + bias (-1 none); AFFINE scale + shift */
+    float   alpha;              /* LEAKY slope */
+} ecseg_op_desc;
+
+/* weights[i] is a host float32 array of weight_len[i] elements, Keras layout
+ * (Conv2D kernel HWIO; Conv2DTranspose kernel (kh, kw, out, in)).  The library re-lays kernels out for its MFMA
+ * kernels once, on the device.  input_tensor must be (256, 256, 1)-shaped per patch for the segment calls. */
+int ecseg_model_load(ecseg_ctx* h,
+                     const ecseg_tensor_desc* tensors, int n_tensors, int n_buffers,
+                     const ecseg_op_desc* ops, int n_ops,
+                     const float* const* weights, const int64_t* weight_len, int n_weights,
+                     int input_tensor, int output_tensor);
+int ecseg_model_flops_per_patch(ecseg_ctx* h, double* flops);   /* algorithmic 2*MAC count of the loaded plan */
+
+/* ---- model.predict_on_batch(uint8[N,256,256,C]) -> float32[N,256,256,K] (src/utils.py:115) --------------- */
+int ecseg_forward_patches(ecseg_ctx* h, const uint8_t* patches_nhwc, int n, float* out_nhwc);
+/* Debug/parity: copy any plan tensor (compact NHWC float32) after the last forward of n patches. */
+int ecseg_read_tensor(ecseg_ctx* h, int tensor, int n, float* out_nhwc);
+
+/* ---- meta_segment minus file I/O (src/utils.py:111-119) + count_cc(I==3)[0] (src/metaseg.py:46) ---------- */
+/* gray: n_img pre-processed uint8 images (H, W) (the output of meta_preprocess).  Steps on the device:
+ * im2patches_overlap (src/image_tools.py:148-186) -> U-Net -> patches2im_overlap (:188-252) -> img_as_ubyte ->
+ * argmax (src/utils.py:117-118) -> meta_inference (src/image_tools.py:15-84) -> count_cc(I==3)[0].
+ * labels_raw (optional, may be NULL) receives the argmax labels, labels_post the post-processed labels,
+ * n_ec one int32 per image. */
+int ecseg_segment_images(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W,
+                         uint8_t* labels_raw, uint8_t* labels_post, int32_t* n_ec);
+int ecseg_segment_images_dev(ecseg_ctx* h, const uint8_t* gray_dev, int n_img, int H, int W,
+                             uint8_t* labels_raw_dev, uint8_t* labels_post_dev, int32_t* n_ec_dev);
+/* Upper bound on images per internal U-Net launch group (default 8). */
+int ecseg_set_images_per_group(ecseg_ctx* h, int n);
+
+/* ---- meta_preprocess (src/image_tools.py:86-101) ---------------------------------------------------------- */
+/* img: n_img images (H, W, C) of uint8 (bytes_per_sample 1) or uint16 (2), C in {1,3,4}.  u16 -> u8 as
+ * cv2.convertScaleAbs(alpha=255/65535); channel 2 when C > 1; Otsu; inverted when more than half is white.
+ * gray_out: (n_img, H, W) uint8; inverted_out (optional) one flag per image. */
+int ecseg_preprocess(ecseg_ctx* h, const void* img, int n_img, int H, int W, int C, int bytes_per_sample,
+                     uint8_t* gray_out, int32_t* inverted_out);
+
+/* ---- stitched probabilities -> labels only (src/utils.py:116-118), for parity of the tail in isolation ---- */
+/* probs: (n_img * n_patches, 256, 256, 4) float32 patch predictions in reference patch order. */
+int ecseg_stitch_argmax(ecseg_ctx* h, const float* probs, int n_img, int H, int W, uint8_t* labels_raw);
+
+/* ---- meta_inference(I) (src/image_tools.py:15-84) + count_cc(I==3)[0] on given label images -------------- */
+int ecseg_meta_inference(ecseg_ctx* h, const uint8_t* labels_in, int n_img, int H, int W,
+                         uint8_t* labels_out, int32_t* n_ec);
+int ecseg_meta_inference_dev(ecseg_ctx* h, const uint8_t* labels_in_dev, int n_img, int H, int W,
+                             uint8_t* labels_out_dev, int32_t* n_ec_dev);
+
+/* ---- counting (src/image_tools.py:103-134) ---------------------------------------------------------------- */
+/* masks are uint8 (non-zero = True), (n_img, H, W). */
+/* count_cc (:114-119): n_out = number of 8-connected components; px_out = total pixels, or -1 where the
+ * reference returns float 0.0 (no component, or a mask without any background pixel). */
+int ecseg_count_cc(ecseg_ctx* h, const uint8_t* mask, int n_img, int H, int W, int32_t* n_out, int64_t* px_out);
+/* Connected-component labels themselves: 0 background, else 1 + raster index of the component's first pixel
+ * (connectivity 4 or 8); used by the parity tests of the union-find kernels. */
+int ecseg_ccl_labels(ecseg_ctx* h, const uint8_t* mask, int n_img, int H, int W, int connectivity,
+                     int32_t* labels_out);
+/* count_colocalization (:126-134) */
+int ecseg_count_colocalization(ecseg_ctx* h, const uint8_t* ob1, const uint8_t* ob2, int n_img, int H, int W,
+                               int32_t* n_out);
+/* count_HSR (:103-112) */
+int ecseg_count_hsr(ecseg_ctx* h, const uint8_t* chrom, const uint8_t* fish, int n_img, int H, int W,
+                    int size_threshold, int32_t* n_out);
+
+/* ---- meta_overlay row (src/meta_overlay.py:59-95, src/image_tools.py:136-146) ----------------------------- */
+/* labels: (n_img, H, W) uint8 post-processed labels (what read_seg loads, src/utils.py:125-132);
+ * rgb: (n_img, H, W, C>=2) uint8, channel 0 red, channel 1 green; sensitivity: color_sensitivity.
+ * out: n_img rows of 12 int64, in final CSV column order (src/meta_overlay.py:98-100):
+ *   [0,1]  count_cc(ec)                 (n, px)   px = -1 stands for the reference's float 0.0
+ *   [2,3]  count_cc(green & ~nuclei & ~chrom)
+ *   [4,5]  count_cc(red   & ~nuclei & ~chrom)
+ *   [6]    coloc(ec, green')   [7] coloc(ec, red')   [8] coloc(green' & ~chrom, red' & ~chrom)
+ *   [9]    coloc(ec, red' & green')   [10] HSR(red)   [11] HSR(green)          (x' = x & ~nuclei) */
+int ecseg_overlay(ecseg_ctx* h, const uint8_t* labels, const uint8_t* rgb, int n_img, int H, int W, int C,
+                  int sensitivity, int hsr_size_threshold, int64_t* out);
+
+/* ---- per-stage device timings of the last segment call (milliseconds, HIP events on the handle's stream) -- */
+enum { ECSEG_T_TILE = 0, ECSEG_T_UNET = 1, ECSEG_T_TAIL = 2, ECSEG_T_POST = 3, ECSEG_T_COUNT = 4, ECSEG_T_N = 5 };
+int ecseg_get_timings(ecseg_ctx* h, float* ms_out /* [ECSEG_T_N] */);
+/* Average duration (ms) and launch count of the dominant kernel (MFMA conv) over the last segment/forward call,
+ * measured with HIP events around every launch when profiling is enabled (adds a little launch overhead). */
+int ecseg_set_kernel_profiling(ecseg_ctx* h, int enabled);
+int ecseg_get_conv_profile(ecseg_ctx* h, double* total_ms, int64_t* launches, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ECSEG_HIP_H */

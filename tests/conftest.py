@@ -16,3 +16,12 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope='session')
+def gpu():
+    """One libecseg_hip handle on cuda:0 for the whole session; fails loudly when the library or GPU is missing."""
+    from ecseg_amd._lib import Handle
+    h = Handle(0)
+    yield h
+    h.close()

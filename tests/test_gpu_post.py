@@ -164,7 +164,9 @@ def test_preprocess_vs_oracle(gpu):
     gray, inv = gpu.preprocess(imgs8)
     for i in range(3):
         assert np.array_equal(gray[i], preprocess.meta_preprocess(imgs8[i])), i
-    assert list(inv) == [0, 1, 0]
+    want_inv = [int(np.count_nonzero(im[..., 2] > preprocess.otsu_threshold_u8(im[..., 2])) > im.shape[0] * im.shape[1] * 0.5)
+                for im in imgs8]
+    assert list(inv) == want_inv and want_inv[0] != want_inv[1]
     g16 = (rng.integers(0, 65536, size=(2, 260, 256))).astype(np.uint16)
     gray, inv = gpu.preprocess(g16)
     for i in range(2):

@@ -48,16 +48,7 @@ def test_canonical_unet_matches_oracle(gpu, base, up, bn):
     want = oracle_unet.forward(cfg, weights, x)
     err = np.abs(got - want).max()
     assert err < TOL, err
-    # every intermediate tensor that still exists in the fused plan must match the oracle's activation
-    inter = _oracle_intermediates(cfg, weights, x)
-    for name, t in plan.layer_tensor.items():
-        if name in inter and plan.tensors[t]['buffer'] == plan.tensors[plan.output_tensor]['buffer']:
-            continue
-    assert np.argmax(got, -1).shape == (2, 256, 256)
-
-
-def _oracle_intermediates(cfg, weights, x):
-    return {}
+    np.testing.assert_allclose(got.sum(-1), 1.0, atol=1e-5)
 
 
 def test_intermediate_layers_first_block(gpu):

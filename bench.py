@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py - metaseg hot path on MI355X: DAPI images/s (1392x1040, 4-class metaseg).
+
+One "step" = one pass of the whole device pipeline over a batch of synthetic 1040x1392 uint8 DAPI images that are
+already resident in HBM: im2patches (35 tiles of 256x256 per image) -> U-Net (fp32, MFMA) -> stitch + uint8
+quantise + argmax -> meta_inference clean-up -> connected-component ecDNA count, followed - when more than one
+rank runs - by the path's only exchange: an all-gather of the per-image result records (RCCL over xGMI).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--images B] [--base 64]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  The workload is BASELINE.json configs[1] (single-GPU fp32 U-Net forward + argmax at
+1392x1040) extended with the post-processing and count that the metric's "CCL ms/image" names; weights are the
+canonical classic U-Net (base width 64, 23 conv layers, 96.2 GFLOP per 256x256 patch), random-initialised with a fixed
+seed because metaseg.h5 is not distributable.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W = 1040, 1392
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(cfg, weights, n_images=1):
+    """The oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample."""
+    import torch
+    from ecseg_amd import synth
+    from oracle import pipeline as op
+    imgs = [synth.dapi_image(900 + i, H, W) for i in range(n_images)]
+    t_unet = t_post = 0.0
+    t0 = time.perf_counter()
+    for im in imgs:
+        from oracle import postproc, tiling, unet
+        pos = tiling.patch_positions(H, W)
+        patches = tiling.extract_patches(im[..., None], pos)
+        a = time.perf_counter()
+        preds = np.concatenate([unet.forward(cfg, weights, patches[i:i + 7]) for i in range(0, len(patches), 7)])
+        b = time.perf_counter()
+        raw = op.raw_labels_from_probs(preds, pos)
+        post = postproc.meta_inference(raw)
+        postproc.count_cc(post == 3)
+        c = time.perf_counter()
+        t_unet += b - a
+        t_post += c - b
+    dt = time.perf_counter() - t0
+    return {'value': n_images / dt, 'unit': 'images/s', 'cores': int(torch.get_num_threads()), 'kind': 'port',
+            'sample': '%d synthetic 1040x1392 image(s), full path (U-Net via torch CPU fp32: %.1f s, stitch+argmax+'
+                      'meta_inference+count via numpy/scipy: %.1f s)' % (n_images, t_unet, t_post)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--images', type=int, default=8, help='images per GPU per step')
+    ap.add_argument('--base', type=int, default=64, help='U-Net base width of the synthetic model')
+    ap.add_argument('--group', type=int, default=4, help='images per internal U-Net launch group')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-profile', action='store_true')
+    args = ap.parse_args()
+
+    import torch                      # first: libecseg_hip.so then binds to the HIP runtime torch already loaded
+    import torch.distributed as dist
+    from ecseg_amd import dist as edist
+    from ecseg_amd import synth
+    from ecseg_amd.model import MetasegModel
+
+    rank, world = edist.init_process_group()
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != max(1, args.gpus) and rank == 0:
+        print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no HIP device visible); there is no CPU fallback')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    cfg = synth.unet_config(base=args.base)
+    weights = synth.unet_weights(cfg, seed=0)
+    model = MetasegModel(cfg, weights, device=local)
+    hnd = model.handle
+    hnd.set_images_per_group(args.group)
+    B = args.images
+    total_images = B * world                       # weak scaling: per-GPU work fixed
+    start, stop, per = edist.shard_bounds(total_images, rank, world)
+
+    # synthetic inputs, resident in HBM before the timed region
+    host = np.stack([synth.dapi_image(i, H, W) for i in range(start, stop)])
+    gray = torch.from_numpy(host).to(dev)
+    raw = torch.empty_like(gray)
+    post = torch.empty_like(gray)
+    nec = torch.zeros(B, dtype=torch.int32, device=dev)
+    rec = torch.from_numpy(edist.make_records(start, stop - start, per)).to(dev)
+
+    def step():
+        hnd.segment_images_dev(gray.data_ptr(), B, H, W, raw.data_ptr(), post.data_ptr(), nec.data_ptr())
+        rec[:B, edist.F_NEC] = nec.to(torch.int64)
+        return edist.allgather_records(rec)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    hnd.set_kernel_profiling(not args.no_kernel_profile)
+    stage = {k: 0.0 for k in hnd.T_NAMES}
+    conv_ms = conv_flops = 0.0
+    conv_launches = 0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+        for k, v in hnd.timings().items():
+            stage[k] += v
+        ms, nl, fl = hnd.conv_profile()
+        conv_ms += ms; conv_launches += nl; conv_flops += fl
+    barrier()
+    dt = time.perf_counter() - t0
+    hnd.set_kernel_profiling(False)
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        counts = edist.compact_records(out)[:, edist.F_NEC]
+        assert len(counts) == total_images
+        value = total_images * args.steps / dt
+        gflop_patch = model.plan.flops_per_patch() / 1e9
+        res = {
+            'metric': 'DAPI images/sec (1392x1040, 4-class metaseg)', 'value': round(value, 3), 'unit': 'images/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1] + post-process: %d synthetic 1040x1392 uint8 DAPI images per GPU per '
+                                   'step, 35 tiles of 256x256 each, canonical U-Net base %d (%.1f GFLOP/patch, seeded random '
+                                   'weights) -> stitch/uint8-quantise/argmax -> meta_inference -> ecDNA count'
+                                   % (B, args.base, gflop_patch),
+                       'images_per_gpu_per_step': B, 'unet_base': args.base, 'patches_per_image': 35,
+                       'parallelism': 'image-parallel x%d, all-gather of 128-B records' % world},
+            'stage_ms_per_image': {k: round(v / (args.steps * B), 4) for k, v in stage.items()},
+            'ccl_ms_per_image': round(stage['post'] / (args.steps * B), 4),
+        }
+        if conv_launches:
+            ach = conv_flops / (conv_ms * 1e-3) / 1e12
+            res['roofline'] = {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM)',
+                               'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                               'avg_launch_ms': round(conv_ms / conv_launches, 4), 'launches': int(conv_launches),
+                               'flop_per_launch_avg': conv_flops / conv_launches}
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(cfg, weights, 1)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,83 @@
+"""Image-parallel sharding across the GPUs of one node and the one exchange step of the path: an all-gather of
+fixed-size per-image result records (RCCL over xGMI when the tensors live on GPUs; gloo on CPU in the tests).
+
+The reference's only parallelism is ``tf.distribute.MirroredStrategy`` around ``load_model``
+(src/metaseg.py:33-36), which splits one image's patch batch over replicas; images themselves are processed in a
+serial loop (src/metaseg.py:42).  Every image is independent, so here whole images are sharded and nothing but the
+result records ever crosses devices.
+"""
+import os
+
+import numpy as np
+
+RECORD_INT64 = 16      # 128 bytes per image
+# record layout (int64): [0] global image index (-1 = padding) [1] status (0 ok) [2] n_ec
+#                        [3..14] the twelve overlay fields of ecseg_overlay [15] reserved
+F_INDEX, F_STATUS, F_NEC, F_OVERLAY = 0, 1, 2, 3
+
+
+def shard_bounds(n_items, rank, world):
+    """Contiguous blocks of ceil(n/world) items in sorted order: -> (start, stop, padded_len)."""
+    per = -(-n_items // world) if n_items else 0
+    start = min(rank * per, n_items)
+    stop = min(start + per, n_items)
+    return start, stop, per
+
+
+def make_records(start, n_local, padded_len, n_ec=None, overlay=None, status=None):
+    rec = np.zeros((padded_len, RECORD_INT64), np.int64)
+    rec[:, F_INDEX] = -1
+    rec[:n_local, F_INDEX] = np.arange(start, start + n_local)
+    if n_ec is not None:
+        rec[:n_local, F_NEC] = np.asarray(n_ec, np.int64)[:n_local]
+    if overlay is not None:
+        rec[:n_local, F_OVERLAY:F_OVERLAY + 12] = np.asarray(overlay, np.int64)[:n_local]
+    if status is not None:
+        rec[:n_local, F_STATUS] = np.asarray(status, np.int64)[:n_local]
+    return rec
+
+
+def init_process_group(backend=None):
+    """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE / MASTER_*)."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world == 1:
+        return 0, 1
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29500')
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    kw = {}
+    if backend == 'nccl':
+        local = int(os.environ.get('LOCAL_RANK', rank))
+        torch.cuda.set_device(local)
+        try:
+            kw['device_id'] = torch.device('cuda', local)
+        except Exception:
+            kw = {}
+    dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, world
+
+
+def allgather_records(records):
+    """records: torch int64 tensor (padded_len, RECORD_INT64) on this rank's device (equal shape on all ranks).
+    One collective; returns (world * padded_len, RECORD_INT64) on the same device, rank-major."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return records
+    world = dist.get_world_size()
+    out = torch.empty((world * records.shape[0], records.shape[1]), dtype=records.dtype, device=records.device)
+    dist.all_gather_into_tensor(out, records.contiguous())
+    return out
+
+
+def compact_records(gathered):
+    """Drop padding rows and order by global image index -> numpy (n_images, RECORD_INT64)."""
+    g = gathered.cpu().numpy() if hasattr(gathered, 'cpu') else np.asarray(gathered)
+    g = g[g[:, F_INDEX] >= 0]
+    return g[np.argsort(g[:, F_INDEX], kind='stable')]

@@ -11,10 +11,10 @@ LIB_PATH = os.path.join(HERE, 'libecseg_hip.so')
 EXPORTS = [
     'ecseg_abi_version', 'ecseg_create', 'ecseg_destroy', 'ecseg_last_error', 'ecseg_device_name', 'ecseg_stream',
     'ecseg_model_load', 'ecseg_model_flops_per_patch', 'ecseg_forward_patches', 'ecseg_read_tensor',
-    'ecseg_segment_images', 'ecseg_segment_images_dev', 'ecseg_set_images_per_group', 'ecseg_preprocess',
+    'ecseg_segment_images', 'ecseg_segment_images_dev', 'ecseg_set_images_per_group', 'ecseg_preprocess', 'ecseg_u16_to_u8',
     'ecseg_stitch_argmax', 'ecseg_meta_inference', 'ecseg_meta_inference_dev', 'ecseg_count_cc', 'ecseg_ccl_labels',
     'ecseg_count_colocalization', 'ecseg_count_hsr', 'ecseg_overlay', 'ecseg_get_timings',
-    'ecseg_set_kernel_profiling', 'ecseg_get_conv_profile',
+    'ecseg_set_kernel_profiling', 'ecseg_get_conv_profile', 'ecseg_lzw_decode', 'ecseg_lzw_encode',
 ]
 
 
@@ -64,6 +64,7 @@ def load_library():
     lib.ecseg_segment_images_dev.argtypes = [vp, u8p, i32, i32, i32, vp, vp, vp]
     lib.ecseg_set_images_per_group.argtypes = [vp, i32]
     lib.ecseg_preprocess.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
+    lib.ecseg_u16_to_u8.argtypes = [vp, vp, C.c_longlong, vp]
     lib.ecseg_stitch_argmax.argtypes = [vp, vp, i32, i32, i32, vp]
     lib.ecseg_meta_inference.argtypes = [vp, u8p, i32, i32, i32, vp, vp]
     lib.ecseg_meta_inference_dev.argtypes = [vp, u8p, i32, i32, i32, vp, vp]
@@ -75,6 +76,9 @@ def load_library():
     lib.ecseg_get_timings.argtypes = [vp, vp]
     lib.ecseg_set_kernel_profiling.argtypes = [vp, i32]
     lib.ecseg_get_conv_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    for fn in (lib.ecseg_lzw_decode, lib.ecseg_lzw_encode):
+        fn.argtypes = [vp, C.c_longlong, vp, C.c_longlong]
+        fn.restype = C.c_longlong
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ('ecseg_abi_version',):
@@ -213,6 +217,12 @@ class Handle:
         self._check(self.lib.ecseg_preprocess(self.h, _ptr(a), n, H, W, Cc, a.dtype.itemsize, _ptr(gray), _ptr(inv)),
                     'ecseg_preprocess')
         return gray, inv
+
+    def u16_to_u8(self, a):
+        a = np.ascontiguousarray(a, np.uint16)
+        out = np.empty(a.shape, np.uint8)
+        self._check(self.lib.ecseg_u16_to_u8(self.h, _ptr(a), a.size, _ptr(out)), 'ecseg_u16_to_u8')
+        return out
 
     def stitch_argmax(self, probs, n_img, H, W):
         p = np.ascontiguousarray(probs, np.float32)

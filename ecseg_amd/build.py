@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libecseg_hip.so')
-SOURCES = ['api.hip', 'unet_kernels.hip', 'post_kernels.hip']
+SOURCES = ['api.hip', 'unet_kernels.hip', 'post_kernels.hip', 'host_codec.cpp']
 HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'ecseg_hip.h')]
 
 
@@ -32,7 +32,7 @@ def build(force=False, verbose=True):
     objs = []
     procs = []
     for s in SOURCES:
-        obj = os.path.join(CSRC, s.replace('.hip', '.o'))
+        obj = os.path.join(CSRC, os.path.splitext(s)[0] + '.o')
         cmd = [_hipcc(), '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-Wall', '-Wno-unused-function',
                '-c', os.path.join(CSRC, s), '-o', obj]
         if verbose:

@@ -699,6 +699,22 @@ int ecseg_preprocess(ecseg_ctx* h, const void* img, int n_img, int H, int W, int
     return ECSEG_OK;
 }
 
+int ecseg_u16_to_u8(ecseg_ctx* h, const uint16_t* in, long long count, uint8_t* out) {
+    if (!h) return ECSEG_E_INVALID;
+    if (count < 0 || (count > 0 && (!in || !out))) return fail(h, ECSEG_E_INVALID, "u16_to_u8: bad arguments");
+    if (count == 0) return ECSEG_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure(h, h->d_aux8, h->d_aux8_cap, (size_t)count * 2))) return rc;
+    if ((rc = ensure(h, h->d_gray, h->d_gray_cap, (size_t)count))) return rc;
+    hipStream_t s = h->stream;
+    HIP_TRY(h, hipMemcpyAsync(h->d_aux8, in, (size_t)count * 2, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, launch_u16_to_u8(reinterpret_cast<const uint16_t*>(h->d_aux8), h->d_gray, (size_t)count, s));
+    HIP_TRY(h, hipMemcpyAsync(out, h->d_gray, (size_t)count, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return ECSEG_OK;
+}
+
 int ecseg_stitch_argmax(ecseg_ctx* h, const float* probs, int n_img, int H, int W, uint8_t* labels_raw) {
     if (!h) return ECSEG_E_INVALID;
     if (n_img < 0 || (n_img > 0 && (!probs || !labels_raw))) return fail(h, ECSEG_E_INVALID, "stitch_argmax: bad arguments");

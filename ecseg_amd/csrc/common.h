@@ -90,6 +90,7 @@ hipError_t run_count_hsr(PostWorkspace& ws, const uint8_t* chrom, const uint8_t*
                          int thr, int32_t* n_dev, hipStream_t s);
 hipError_t run_overlay(PostWorkspace& ws, const uint8_t* labels, const uint8_t* rgb, int n_img, int H, int W, int C,
                        int sens, int hsr_thr, long long* out_dev, hipStream_t s);
+hipError_t launch_u16_to_u8(const uint16_t* in, uint8_t* out, size_t count, hipStream_t s);
 hipError_t run_preprocess(const void* img, int n_img, int H, int W, int C, int bps, uint8_t* gray, int32_t* inverted,
                           uint32_t* hist_ws, hipStream_t s);
 

@@ -833,6 +833,12 @@ __global__ __launch_bounds__(256) void extract_gray_kernel(const T* __restrict__
     }
 }
 
+hipError_t launch_u16_to_u8(const uint16_t* in, uint8_t* out, size_t count, hipStream_t s) {
+    if (!count) return hipSuccess;
+    hipLaunchKernelGGL(extract_gray_kernel<uint16_t>, dim3(px_grid(count)), dim3(256), 0, s, in, 1, out, count);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void hist256_kernel(const uint8_t* __restrict__ gray, size_t px, uint32_t* __restrict__ hist,
                                                       int blocks_per_img) {
     __shared__ uint32_t h[256];

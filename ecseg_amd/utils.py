@@ -1,0 +1,52 @@
+"""Mirror of the metaseg part of the reference's ``src/utils.py``: ``load_model``, ``get_imgs``, ``meta_segment``,
+``save_img``, ``read_seg`` with the same names and argument meaning."""
+import glob
+import os
+
+import numpy as np
+
+from . import image_io, image_tools
+from .model import MetasegModel
+
+
+def load_model(model_name, device=None):
+    """src/utils.py:27-33: ``models/<name>`` (``interseg_models/`` for the interSeg classifiers), relative to the CWD."""
+    folder = 'interseg_models' if model_name in ('interseg', 'ecseg_c') else 'models'
+    path = os.path.join(folder, model_name)
+    dev = int(os.environ.get('ECSEG_DEVICE', os.environ.get('LOCAL_RANK', '0'))) if device is None else device
+    model = MetasegModel.from_h5(path, device=dev)
+    image_tools.set_default_handle(model.handle)
+    return model
+
+
+def get_imgs(inpath):
+    """src/utils.py:105-107 (glob ``*.tif`` + ``*.npy``).  The reference keeps the OS directory order; sorted here so
+    that sharding across GPUs is deterministic."""
+    return sorted(glob.glob(os.path.join(inpath, '*.tif'))) + sorted(glob.glob(os.path.join(inpath, '*.npy')))
+
+
+def save_img(I, path, folder):
+    """src/utils.py:122-123: ``cv2.imwrite(join(path[0], folder, path[1]), I)`` for an 8-bit gray image."""
+    out = os.path.join(path[0], folder, path[1])
+    if out.lower().endswith(('.tif', '.tiff')):
+        image_io.write_tiff_gray8(out, I)
+    elif out.lower().endswith('.png'):
+        image_io.write_png(out, I)
+    else:
+        np.save(out, I)
+
+
+def meta_segment(model, image_path):
+    """src/utils.py:109-120 for one image: read, pre-process, write ``dapi/<name>``, segment -> int64 labels."""
+    I = image_io.imread(image_path)
+    gray = image_tools.meta_preprocess(I, handle=model.handle)
+    save_img(~gray, os.path.split(image_path), 'dapi')
+    post, _ = model.segment(gray)
+    return post.astype(np.int64)
+
+
+def read_seg(image_path):
+    """src/utils.py:125-132."""
+    path_split = os.path.split(image_path)
+    seg_I = np.load(os.path.join(path_split[0], 'labels', path_split[1][:-4] + '.npy'))
+    return seg_I == 0, seg_I == 1, seg_I == 2, seg_I == 3

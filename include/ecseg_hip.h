@@ -119,6 +119,10 @@ int ecseg_set_images_per_group(ecseg_ctx* h, int n);
 int ecseg_preprocess(ecseg_ctx* h, const void* img, int n_img, int H, int W, int C, int bytes_per_sample,
                      uint8_t* gray_out, int32_t* inverted_out);
 
+/* u16_to_u8 alone (src/image_tools.py:98-101, used by split_FISH_channels :142): count uint16 samples ->
+ * uint8 with cv2.convertScaleAbs(alpha = 255/65535) rounding. */
+int ecseg_u16_to_u8(ecseg_ctx* h, const uint16_t* in, long long count, uint8_t* out);
+
 /* ---- stitched probabilities -> labels only (src/utils.py:116-118), for parity of the tail in isolation ---- */
 /* probs: (n_img * n_patches, 256, 256, 4) float32 patch predictions in reference patch order. */
 int ecseg_stitch_argmax(ecseg_ctx* h, const float* probs, int n_img, int H, int W, uint8_t* labels_raw);
@@ -164,6 +168,12 @@ int ecseg_get_timings(ecseg_ctx* h, float* ms_out /* [ECSEG_T_N] */);
  * measured with HIP events around every launch when profiling is enabled (adds a little launch overhead). */
 int ecseg_set_kernel_profiling(ecseg_ctx* h, int enabled);
 int ecseg_get_conv_profile(ecseg_ctx* h, double* total_ms, int64_t* launches, double* flops);
+
+/* ---- host-side byte codecs for the file I/O around the path (no GPU work) ---------------------------------- */
+/* TIFF LZW (MSB-first, 9..12-bit codes, early change): inputs read by imread (src/utils.py:110) and the
+ * dapi/<name>.tif written by cv2.imwrite (src/utils.py:122-123).  Return bytes written, or -1 on error. */
+long long ecseg_lzw_decode(const uint8_t* src, long long n, uint8_t* dst, long long dst_cap);
+long long ecseg_lzw_encode(const uint8_t* src, long long n, uint8_t* dst, long long dst_cap);
 
 #ifdef __cplusplus
 }

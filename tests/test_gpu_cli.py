@@ -1,0 +1,112 @@
+"""`make metaseg` / `make meta_overlay` end to end on the GPU: config.yaml in, labels/*.npy + *.png, dapi/*.tif,
+ec_quantification.csv and fish_quantification.csv out, compared with the CPU oracle driven over the same files."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+import yaml
+from PIL import Image
+
+from ecseg_amd import hdf5_min, image_io, synth
+from oracle import overlay as oracle_overlay
+from oracle import pipeline as oracle_pipeline
+from oracle import postproc, preprocess
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def workdir(tmp_path, golden_dir, monkeypatch):
+    os.makedirs(tmp_path / 'models')
+    shutil.copy(os.path.join(golden_dir, 'metaseg_synth_b8.h5'), tmp_path / 'models' / 'metaseg.h5')
+    inp = tmp_path / 'images'
+    os.makedirs(inp)
+    for k in range(3):
+        rgb = synth.dapi_image(40 + k, 300, 400, rgb=True)
+        if k == 1:
+            rgb[..., 2] = 255 - rgb[..., 2]                 # white background: meta_preprocess must invert it
+        Image.fromarray(rgb).save(str(inp / ('img%d.tif' % k)), compression='tiff_lzw')
+    image_io.write_tiff_gray8(str(inp / 'gray.tif'), synth.dapi_image(50, 280, 300))     # a gray image of another size
+    with open(tmp_path / 'config.yaml', 'w') as f:
+        yaml.safe_dump({'metaseg': {'inpath': str(inp)}, 'meta_overlay': {'inpath': str(inp), 'color_sensitivity': 85}}, f)
+    monkeypatch.chdir(tmp_path)
+    return tmp_path, inp
+
+
+def test_metaseg_then_overlay_cli(workdir):
+    from ecseg_amd import meta_overlay, metaseg
+    tmp, inp = workdir
+    metaseg.main([])
+    cfg, weights = hdf5_min.load_keras_h5(str(tmp / 'models' / 'metaseg.h5'))
+    names = sorted(os.listdir(inp))
+    tifs = [n for n in names if n.endswith('.tif')]
+    assert tifs == ['gray.tif', 'img0.tif', 'img1.tif', 'img2.tif']
+    rows = []
+    for n in tifs:
+        img = image_io.imread(str(inp / n))
+        gray = preprocess.meta_preprocess(img)
+        assert np.array_equal(image_io.read_tiff(str(inp / 'dapi' / n)), 255 - gray), n     # cv2.bitwise_not(I)
+        lab = np.load(str(inp / 'labels' / (n[:-4] + '.npy')))
+        assert lab.dtype == np.int64 and lab.shape == gray.shape
+        want = oracle_pipeline.segment_gray(cfg, weights, gray)
+        if not np.array_equal(lab, want):
+            # only legitimate when the raw argmax differs on near-ties; then the clean-up of the GPU's own raw labels
+            # must still be exact, which test_gpu_pipeline checks.  Report it loudly here.
+            pytest.fail('%s: %d label pixels differ from the oracle' % (n, int((lab != want).sum())))
+        png = np.array(Image.open(str(inp / 'labels' / (n[:-4] + '.png'))))
+        assert np.array_equal(png, image_io.LABEL_COLORS[lab])
+        rows.append([n, postproc.count_cc(want == 3)[0]])
+    text = open(str(inp / 'ec_quantification.csv')).read()
+    assert text == oracle_overlay.csv_text(oracle_overlay.METASEG_COLUMNS, rows)
+    assert open(str(inp / 'ec_quantifications.csv')).read() == text
+
+    meta_overlay.main([])
+    rows = []
+    for n in tifs:
+        img = image_io.imread(str(inp / n))
+        if img.ndim < 3:
+            continue
+        lab = np.load(str(inp / 'labels' / (n[:-4] + '.npy')))
+        rows.append([n] + oracle_overlay.overlay_row(lab, img, 85))
+        assert np.array_equal(np.array(Image.open(str(inp / 'red' / (n + '.png')))), 255 - img[..., 0])
+        assert np.array_equal(np.array(Image.open(str(inp / 'green' / (n + '.png')))), 255 - img[..., 1])
+    assert open(str(inp / 'fish_quantification.csv')).read() == oracle_overlay.csv_text(oracle_overlay.OVERLAY_COLUMNS, rows)
+
+
+def test_metaseg_cli_exit_codes(tmp_path, monkeypatch):
+    from ecseg_amd import meta_overlay, metaseg
+    with open(tmp_path / 'config.yaml', 'w') as f:
+        yaml.safe_dump({'metaseg': {'inpath': str(tmp_path / 'nope')},
+                        'meta_overlay': {'inpath': str(tmp_path), 'color_sensitivity': 300}}, f)
+    monkeypatch.chdir(tmp_path)
+    with pytest.raises(SystemExit) as e:
+        metaseg.main([])
+    assert e.value.code == 2
+    with pytest.raises(SystemExit) as e:                 # labels/ missing
+        meta_overlay.main([])
+    assert e.value.code == 2
+    os.makedirs(tmp_path / 'labels'); os.makedirs(tmp_path / 'dapi')
+    with pytest.raises(SystemExit) as e:                 # sensitivity out of range
+        meta_overlay.main([])
+    assert e.value.code == 2
+
+
+def test_u16_and_reference_call_shapes(gpu):
+    from ecseg_amd import image_tools
+    image_tools.set_default_handle(gpu)
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 65536, size=(50, 60, 3)).astype(np.uint16)
+    assert np.array_equal(image_tools.u16_to_u8(a), preprocess.u16_to_u8(a))
+    m = rng.random((80, 90)) < 0.3
+    assert image_tools.count_cc(m) == postproc.count_cc(m)
+    assert image_tools.count_cc(np.zeros((8, 8), bool)) == (0, 0.0)
+    m2 = rng.random((80, 90)) < 0.3
+    assert image_tools.count_colocalization(m, m2) == postproc.count_colocalization(m, m2)
+    assert image_tools.count_HSR(m, m2, 20) == postproc.count_HSR(m, m2, 20)
+    lab = synth.label_map(3, 120, 150)
+    out = image_tools.meta_inference(lab.astype(np.int64))
+    assert out.dtype == np.int64 and np.array_equal(out, postproc.meta_inference(lab))
+    img, patches, pos = image_tools.im2patches_overlap(np.zeros((300, 462, 1), np.uint8))
+    from oracle import tiling
+    assert np.array_equal(np.array(pos), tiling.patch_positions(300, 462))

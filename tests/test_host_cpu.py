@@ -1,0 +1,177 @@
+"""Host-side logic that needs no GPU: the C ABI exports what include/ecseg_hip.h declares, the HDF5 reader, the
+Keras -> plan lowering, the sharding / record all-gather (gloo, world_size 2)."""
+import json
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from ecseg_amd import dist as edist
+from ecseg_amd import hdf5_min, keras_plan, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from ecseg_amd._lib import EXPORTS, load_library
+    header = open(os.path.join(ROOT, 'include', 'ecseg_hip.h')).read()
+    declared = set(re.findall(r'\b(ecseg_[a-z0-9_]+)\s*\(', header))
+    assert declared, 'no prototypes found'
+    lib = load_library()
+    for name in sorted(declared):
+        assert hasattr(lib, name), 'libecseg_hip.so does not export %s' % name
+    assert declared == set(EXPORTS)
+    assert lib.ecseg_abi_version() == 1
+
+
+def test_missing_gpu_fails_loudly():
+    """No silent CPU fallback: without a HIP device the product raises."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from ecseg_amd._lib import EcsegError, Handle
+    with pytest.raises(EcsegError):
+        Handle(0)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, 'ecseg_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', text, re.M), f
+
+
+def test_hdf5_reader_on_keras_fixture(golden_dir):
+    cfg, weights = hdf5_min.load_keras_h5(os.path.join(golden_dir, 'keras_tiny.h5'))
+    exp = np.load(os.path.join(golden_dir, 'keras_tiny_expected.npz'))
+    assert json.loads(cfg) == json.loads(str(exp['model_config']))
+    f = hdf5_min.File(os.path.join(golden_dir, 'keras_tiny.h5'))
+    assert f.attrs['keras_version'] == '2.8.0' and f.attrs['backend'] == 'tensorflow'
+    n = 0
+    for lname in hdf5_min._attr_list(f['model_weights'].attrs, 'layer_names'):
+        for wn in hdf5_min._attr_list(f['model_weights'][lname].attrs, 'weight_names'):
+            key = wn.replace('/', '__').replace(':', '_')
+            got = f['model_weights'][lname][wn].read()
+            assert got.dtype == np.float32 and np.array_equal(got, exp[key]), wn
+            n += 1
+    assert n == 18
+    assert [a.shape for a in weights['conv2d_transpose']] == [(2, 2, 4, 8), (4,)]
+    with pytest.raises(hdf5_min.Hdf5Error):
+        hdf5_min.File(__file__)
+
+
+def _check_plan(plan):
+    """Every op reads tensors that are still intact: no op writes a buffer that holds a tensor needed later."""
+    last_read = {}
+    for k, o in enumerate(plan.ops):
+        for t in (o['in0'], o['in1']):
+            if t >= 0:
+                last_read[t] = k
+    last_read[plan.output_tensor] = len(plan.ops)
+    written_at = {plan.input_tensor: -1}
+    for k, o in enumerate(plan.ops):
+        written_at.setdefault(o['out'], k)
+    for k, o in enumerate(plan.ops):
+        out = plan.tensors[o['out']]
+        lo, hi = out['c_offset'], out['c_offset'] + out['c']
+        for t, w in written_at.items():
+            if t == o['out'] or w >= k or last_read.get(t, -1) < k:
+                continue
+            tt = plan.tensors[t]
+            if tt['buffer'] != out['buffer']:
+                continue
+            same_layout = tt['c_stride'] == out['c_stride'] and (tt['h'], tt['w']) == (out['h'], out['w'])
+            disjoint = same_layout and (tt['c_offset'] + tt['c'] <= lo or hi <= tt['c_offset'])
+            assert disjoint, 'op %d overwrites live tensor %d' % (k, t)
+    for t in plan.tensors:
+        assert t['h'] * t['w'] * t['c_stride'] <= plan.buffer_floats[t['buffer']]
+
+
+@pytest.mark.parametrize('base,up,bn', [(64, 'transpose', False), (16, 'upsample', True), (32, 'transpose', True)])
+def test_plan_of_canonical_unet(base, up, bn):
+    cfg = synth.unet_config(base=base, up=up, batchnorm=bn)
+    w = synth.unet_weights(cfg)
+    for fuse in (False, True):
+        plan = keras_plan.build_plan(cfg, w, fuse=fuse)
+        _check_plan(plan)
+        ti, to = plan.tensors[plan.input_tensor], plan.tensors[plan.output_tensor]
+        assert (ti['h'], ti['w'], ti['c']) == (256, 256, 1) and (to['h'], to['w'], to['c']) == (256, 256, 4)
+        if fuse:
+            assert all(o['op'] not in (keras_plan.OP_AFFINE, keras_plan.OP_ACT) for o in plan.ops)
+            assert all(o['op'] != keras_plan.OP_COPY for o in plan.ops)     # concatenation is free
+    if base == 64 and up == 'transpose':
+        assert abs(plan.flops_per_patch() / 1e9 - 96.2) < 0.1
+        assert sum(plan.buffer_floats) * 4 < 80e6                           # liveness re-use: < 80 MB per patch
+
+
+def test_plan_rejects_what_it_cannot_lower():
+    cfg = synth.unet_config(base=16, depth=1)
+    w = synth.unet_weights(cfg)
+    bad = json.loads(json.dumps(cfg))
+    bad['config']['layers'][1]['class_name'] = 'SeparableConv2D'
+    with pytest.raises(keras_plan.PlanError):
+        keras_plan.build_plan(bad, w)
+    bad = json.loads(json.dumps(cfg))
+    bad['config']['layers'][1]['config']['strides'] = [2, 2]
+    with pytest.raises(keras_plan.PlanError):
+        keras_plan.build_plan(bad, w)
+
+
+def test_shard_bounds_and_records():
+    for n, world in [(4096, 8), (10, 4), (3, 8), (0, 2), (7, 1)]:
+        seen = []
+        per0 = None
+        for r in range(world):
+            a, b, per = edist.shard_bounds(n, r, world)
+            per0 = per if per0 is None else per0
+            assert per == per0 and b - a <= per
+            seen += list(range(a, b))
+        assert seen == list(range(n))
+    rec = edist.make_records(5, 3, 4, n_ec=[7, 8, 9])
+    assert rec.shape == (4, 16) and rec.nbytes == 4 * 128
+    assert list(rec[:, 0]) == [5, 6, 7, -1] and list(rec[:3, 2]) == [7, 8, 9]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_images, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      LOCAL_RANK=str(rank))
+    import torch
+    r, w = edist.init_process_group('gloo')
+    a, b, per = edist.shard_bounds(n_images, r, w)
+    n_ec = [1000 + i for i in range(a, b)]                       # stands in for this rank's device results
+    rec = torch.from_numpy(edist.make_records(a, b - a, per, n_ec=n_ec))
+    out = edist.compact_records(edist.allgather_records(rec))
+    q.put((rank, out[:, edist.F_INDEX].tolist(), out[:, edist.F_NEC].tolist()))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_images', [7, 8])
+def test_allgather_records_gloo_world2(n_images):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_images, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, idx, nec in res:
+        assert idx == list(range(n_images))
+        assert nec == [1000 + i for i in range(n_images)]

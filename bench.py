@@ -65,7 +65,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--images', type=int, default=8, help='images per GPU per step')
     ap.add_argument('--base', type=int, default=64, help='U-Net base width of the synthetic model')
-    ap.add_argument('--group', type=int, default=4, help='images per internal U-Net launch group')
+    ap.add_argument('--group', type=int, default=8, help='images per internal U-Net launch group')
+    ap.add_argument('--overlap', action='store_true', help='run post-processing on a second stream')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     args = ap.parse_args()
@@ -90,6 +91,7 @@ def main():
     model = MetasegModel(cfg, weights, device=local)
     hnd = model.handle
     hnd.set_images_per_group(args.group)
+    hnd.set_option('overlap_post', 1 if args.overlap else 0)
     B = args.images
     total_images = B * world                       # weak scaling: per-GPU work fixed
     start, stop, per = edist.shard_bounds(total_images, rank, world)
@@ -154,10 +156,17 @@ def main():
             'ccl_ms_per_image': round(stage['post'] / (args.steps * B), 4),
         }
         if conv_launches:
+            traffic = None
+            try:        # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+                pmc = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_pmc_traffic.json'))
+                if pmc and args.base == 64:
+                    traffic = json.load(open(os.path.join(ROOT, 'profiles', pmc[-1])))['conv_mfma_all']['hbm_bytes_per_launch']
+            except Exception:
+                traffic = None
             ach = conv_flops / (conv_ms * 1e-3) / 1e12
             res['roofline'] = {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM)',
                                'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                               'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
                                'avg_launch_ms': round(conv_ms / conv_launches, 4), 'launches': int(conv_launches),
                                'flop_per_launch_avg': conv_flops / conv_launches}
         if world == 1 and not args.no_cpu_baseline:

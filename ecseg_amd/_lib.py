@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, 'libecseg_hip.so')
 EXPORTS = [
     'ecseg_abi_version', 'ecseg_create', 'ecseg_destroy', 'ecseg_last_error', 'ecseg_device_name', 'ecseg_stream',
     'ecseg_model_load', 'ecseg_model_flops_per_patch', 'ecseg_forward_patches', 'ecseg_read_tensor',
-    'ecseg_segment_images', 'ecseg_segment_images_dev', 'ecseg_set_images_per_group', 'ecseg_preprocess', 'ecseg_u16_to_u8',
+    'ecseg_segment_images', 'ecseg_segment_images_dev', 'ecseg_set_images_per_group', 'ecseg_set_option', 'ecseg_preprocess', 'ecseg_u16_to_u8',
     'ecseg_stitch_argmax', 'ecseg_meta_inference', 'ecseg_meta_inference_dev', 'ecseg_count_cc', 'ecseg_ccl_labels',
     'ecseg_count_colocalization', 'ecseg_count_hsr', 'ecseg_overlay', 'ecseg_get_timings',
     'ecseg_set_kernel_profiling', 'ecseg_get_conv_profile', 'ecseg_lzw_decode', 'ecseg_lzw_encode',
@@ -63,6 +63,7 @@ def load_library():
     lib.ecseg_segment_images.argtypes = [vp, u8p, i32, i32, i32, vp, vp, vp]
     lib.ecseg_segment_images_dev.argtypes = [vp, u8p, i32, i32, i32, vp, vp, vp]
     lib.ecseg_set_images_per_group.argtypes = [vp, i32]
+    lib.ecseg_set_option.argtypes = [vp, C.c_char_p, i32]
     lib.ecseg_preprocess.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
     lib.ecseg_u16_to_u8.argtypes = [vp, vp, C.c_longlong, vp]
     lib.ecseg_stitch_argmax.argtypes = [vp, vp, i32, i32, i32, vp]
@@ -163,6 +164,9 @@ class Handle:
 
     def set_images_per_group(self, n):
         self._check(self.lib.ecseg_set_images_per_group(self.h, int(n)), 'ecseg_set_images_per_group')
+
+    def set_option(self, key, value):
+        self._check(self.lib.ecseg_set_option(self.h, key.encode(), int(value)), 'ecseg_set_option(%s)' % key)
 
     def forward_patches(self, patches):
         """uint8 (N, H, W, C) -> float32 (N, H, W, K): ``model.predict_on_batch`` (reference src/utils.py:115)."""

@@ -40,6 +40,7 @@ struct StitchPlan {
 struct ecseg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // post-processing of group g overlaps the U-Net of group g+1
     std::string err;
     char devname[256] = {0};
 
@@ -69,6 +70,7 @@ struct ecseg_ctx {
     PostWorkspace ws{};
     size_t ws_list_bytes = 0;
     int post_chunk = 64;
+    int overlap_post = 0;
 
     // timing
     hipEvent_t ev[ECSEG_T_N + 1] = {};
@@ -341,7 +343,7 @@ int ensure_post(ecseg_ctx* h, int n_img, size_t px) {
     A(reinterpret_cast<void**>(&w.tmpA), tot);
     A(reinterpret_cast<void**>(&w.tmpB), tot);
     A(reinterpret_cast<void**>(&w.list), list_bytes);
-    A(reinterpret_cast<void**>(&w.g), (size_t)ni * G_STRIDE * 4);
+    A(reinterpret_cast<void**>(&w.g), (size_t)ni * G_STRIDE * G_SHARDS * 4);
     if (e != hipSuccess) return fail(h, ECSEG_E_NOMEM, std::string("hipMalloc(post workspace): ") + hipGetErrorString(e));
     w.cap_img = ni; w.cap_px = np;
     h->ws_list_bytes = list_bytes;
@@ -372,42 +374,45 @@ int segment_dev(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint
     StitchPlan* sp = nullptr;
     if ((rc = get_stitch(h, H, W, &sp))) return rc;
     const size_t px = (size_t)H * W;
-    hipStream_t s = h->stream;
+    hipStream_t s = h->stream, s2 = h->overlap_post ? h->stream2 : h->stream;
     const int grp = std::max(1, h->images_per_group);
     if ((rc = ensure_patches(h, std::min(grp, n_img) * sp->n_pos))) return rc;
-    if ((rc = ensure_post(h, std::min(n_img, h->post_chunk), px))) return rc;
+    if ((rc = ensure_post(h, std::min(n_img, grp), px))) return rc;
     for (float& v : h->stage_ms) v = 0.f;
     prof_begin(h);
-    std::vector<hipEvent_t> evs;   // per group: 4 events (tile start, unet start, tail start, tail end)
+    // Per group: tile -> U-Net -> stitch/argmax on the main stream; the group's clean-up + count then runs on the second
+    // stream while the main stream already computes the next group's U-Net (MFMA-bound convs and latency-bound
+    // integer kernels co-exist well).  6 events per group: tile start, unet start, tail start, tail end, post start/end.
+    std::vector<hipEvent_t> evs;
     for (int i0 = 0; i0 < n_img; i0 += grp) {
         const int ni = std::min(grp, n_img - i0);
-        hipEvent_t e4[4];
-        for (auto& e : e4) { HIP_TRY(h, hipEventCreate(&e)); evs.push_back(e); }
-        HIP_TRY(h, hipEventRecord(e4[0], s));
+        hipEvent_t e6[6];
+        for (auto& e : e6) { HIP_TRY(h, hipEventCreate(&e)); evs.push_back(e); }
+        HIP_TRY(h, hipEventRecord(e6[0], s));
         HIP_TRY(h, launch_tile_patches(gray + (size_t)i0 * px, ni, H, W, sp->pos_dev, sp->n_pos,
                                        view_of(h, h->input_tensor).p, s));
-        HIP_TRY(h, hipEventRecord(e4[1], s));
+        HIP_TRY(h, hipEventRecord(e6[1], s));
         if ((rc = run_plan(h, ni * sp->n_pos))) return rc;
-        HIP_TRY(h, hipEventRecord(e4[2], s));
+        HIP_TRY(h, hipEventRecord(e6[2], s));
         const TView pv = view_of(h, h->output_tensor);
         HIP_TRY(h, launch_stitch_argmax(pv.p, pv.cs, sp->map_dev, ni, sp->n_pos, H, W, raw + (size_t)i0 * px, s));
-        HIP_TRY(h, hipEventRecord(e4[3], s));
+        HIP_TRY(h, hipEventRecord(e6[3], s));
+        if (s2 != s) HIP_TRY(h, hipStreamWaitEvent(s2, e6[3], 0));
+        HIP_TRY(h, hipEventRecord(e6[4], s2));
+        if (post != raw)
+            HIP_TRY(h, hipMemcpyAsync(post + (size_t)i0 * px, raw + (size_t)i0 * px, px * ni, hipMemcpyDeviceToDevice, s2));
+        HIP_TRY(h, run_meta_inference(h->ws, post + (size_t)i0 * px, ni, H, W, n_ec ? n_ec + i0 : nullptr, s2));
+        HIP_TRY(h, hipEventRecord(e6[5], s2));
     }
-    HIP_TRY(h, hipEventRecord(h->ev[0], s));
-    if (post != raw) HIP_TRY(h, hipMemcpyAsync(post, raw, px * n_img, hipMemcpyDeviceToDevice, s));
-    for (int i0 = 0; i0 < n_img; i0 += h->post_chunk) {
-        const int ni = std::min(h->post_chunk, n_img - i0);
-        HIP_TRY(h, run_meta_inference(h->ws, post + (size_t)i0 * px, ni, H, W, n_ec ? n_ec + i0 : nullptr, s));
-    }
-    HIP_TRY(h, hipEventRecord(h->ev[1], s));
     HIP_TRY(h, hipStreamSynchronize(s));
-    for (size_t k = 0; k + 3 < evs.size(); k += 4) {
+    HIP_TRY(h, hipStreamSynchronize(s2));
+    for (size_t k = 0; k + 5 < evs.size(); k += 6) {
         h->stage_ms[ECSEG_T_TILE] += stage_elapsed(evs[k], evs[k + 1]);
         h->stage_ms[ECSEG_T_UNET] += stage_elapsed(evs[k + 1], evs[k + 2]);
         h->stage_ms[ECSEG_T_TAIL] += stage_elapsed(evs[k + 2], evs[k + 3]);
+        h->stage_ms[ECSEG_T_POST] += stage_elapsed(evs[k + 4], evs[k + 5]);
     }
     for (hipEvent_t e : evs) (void)hipEventDestroy(e);
-    h->stage_ms[ECSEG_T_POST] = stage_elapsed(h->ev[0], h->ev[1]);
     prof_end(h);
     return ECSEG_OK;
 }
@@ -437,6 +442,11 @@ int ecseg_create(ecseg_ctx** out, int device_id) {
         delete h;
         return fail_hip(nullptr, e, "hipStreamCreate");
     }
+    if ((e = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking)) != hipSuccess) {
+        (void)hipStreamDestroy(h->stream);
+        delete h;
+        return fail_hip(nullptr, e, "hipStreamCreate");
+    }
     for (auto& ev : h->ev) (void)hipEventCreate(&ev);
     *out = h;
     return ECSEG_OK;
@@ -446,6 +456,7 @@ void ecseg_destroy(ecseg_ctx* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    (void)hipStreamSynchronize(h->stream2);
     free_model(h);
     for (auto& kv : h->stitch) { (void)hipFree(kv.second.pos_dev); (void)hipFree(kv.second.map_dev); }
     void* ptrs[] = {h->d_gray, h->d_raw, h->d_post, h->d_aux8, h->d_u8in, h->d_i32, h->d_i64, h->d_probs_in, h->d_hist,
@@ -453,6 +464,7 @@ void ecseg_destroy(ecseg_ctx* h) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(h->stream2);
     (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -470,6 +482,16 @@ void* ecseg_stream(ecseg_ctx* h) { return h ? (void*)h->stream : nullptr; }
 int ecseg_set_images_per_group(ecseg_ctx* h, int n) {
     if (!h || n < 1) return ECSEG_E_INVALID;
     h->images_per_group = n;
+    return ECSEG_OK;
+}
+
+int ecseg_set_option(ecseg_ctx* h, const char* key, int value) {
+    if (!h || !key) return ECSEG_E_INVALID;
+    const std::string k(key);
+    if (k == "overlap_post") h->overlap_post = value != 0;
+    else if (k == "post_chunk" && value >= 1) h->post_chunk = value;
+    else if (k == "images_per_group" && value >= 1) h->images_per_group = value;
+    else return fail(h, ECSEG_E_INVALID, "unknown option or bad value: " + k);
     return ECSEG_OK;
 }
 

@@ -75,7 +75,7 @@ struct PostWorkspace {
     int cap_img;
     size_t cap_px;
 };
-enum { G_STRIDE = 32 };
+enum { G_STRIDE = 32, G_SHARDS = 16 };
 
 // meta_inference on n_img uint8 label images, in place; n_ec receives count_cc(img==3)[0] per image
 hipError_t run_meta_inference(PostWorkspace& ws, uint8_t* img, int n_img, int H, int W, int32_t* n_ec_dev,

@@ -7,12 +7,13 @@
 //   * a pixel's "key" is a small integer derived from its value through a 4-entry LUT (0 = background); two
 //     neighbouring pixels are connected iff their keys are equal and non-zero, so the disjoint class masks
 //     (img==1, img==2, img==3) are labelled in ONE pass;
-//   * ccl_init: one wavefront owns a 64-pixel row chunk; __ballot over "run starts" gives every pixel the index of
-//     the first pixel of its run without any memory traffic or atomics (label = run head);
-//   * ccl_merge: unions are issued once per (run, upper-run) overlap instead of once per pixel pair - only the lane at
-//     the start of an overlap calls unite(); unite() is the lock-free atomicMin union-find, so the root of a
-//     component is its minimum raster index = its first pixel in raster order (the order scipy/skimage number
-//     components in, which merge_comp's skipped last component depends on, src/image_tools.py:27);
+//   * ccl_local: a workgroup labels one 64 x 32 tile in LDS.  One wavefront owns a 64-pixel row chunk; __ballot over
+//     "run starts" gives every pixel the first pixel of its run without memory traffic or atomics; unions are issued
+//     once per (run, upper-run) overlap instead of once per pixel pair - only the lane at the start of an overlap
+//     calls unite(), the lock-free atomicMin union-find, so a root is the minimum raster index of its component;
+//   * ccl_border: the same rule on the pixels along tile borders, on the global parent array; the root of a component
+//     is its first pixel in raster order (the order scipy/skimage number components in, which merge_comp's skipped
+//     last component depends on, src/image_tools.py:27);
 //   * ccl_flatten: every pixel looks up its root; per-run (not per-pixel) atomics accumulate area / coordinate sums /
 //     flag bits into the root's slot, per-wave popcounts accumulate component and pixel counts per key.
 // blockIdx -> image mapping keeps all blocks of one image on one XCD (equal blockIdx % 8) so that the image's parent
@@ -35,9 +36,13 @@ __device__ __forceinline__ int key_of(uint8_t v, uint32_t lut) {
     return (lut >> ((v & 3) * 8)) & 0xff;
 }
 
-// per-image global counters
+// per-image global counters.  ccl_flatten adds into one of G_SHARDS replicas (each on its own 128-B line: thousands of
+// workgroups of one image adding to ONE line serialise at ~60 ns per atomic, which used to cost ~1 ms per labelling);
+// reduce_g_kernel folds the replicas into replica 0, which is what every consumer reads.
 enum { G_NCOMP = 0 /*[4]*/, G_NPX = 4 /*[4]*/, G_LAST_ROOT = 8, G_NLIST1 = 9, G_NLIST2 = 10,
        G_CNT0 = 12 /* [8] generic root counters */, G_OTSU_INV = 20 };
+enum { NEED_NCOMP = 1, NEED_NPX = 2, NEED_LAST = 4 };
+static constexpr int G_IMG = G_STRIDE * G_SHARDS;     // ints per image
 
 // aux modes of ccl_flatten: which per-pixel bits are OR-ed into the root's flag word
 enum { AUX_NONE = 0, AUX_BORDER = 1, AUX_VALUE_EQ = 2, AUX_IMAGE = 3 };
@@ -101,165 +106,300 @@ __device__ __forceinline__ void uf_unite(int32_t* L, int a, int b) {
     }
 }
 
-__global__ __launch_bounds__(256) void ccl_init_kernel(CclGeom g, const uint8_t* __restrict__ img_all, uint32_t lut,
-                                                       int32_t* __restrict__ L_all, uint32_t* __restrict__ area_all,
-                                                       u64* __restrict__ sumy_all, u64* __restrict__ sumx_all,
-                                                       uint32_t* __restrict__ flag_all, int stat) {
+// ---- phase 1: label one 64 x 32 tile entirely in LDS ---------------------------------------------------------------
+// Every workgroup labels its tile as if it were a stand-alone image: run heads by ballot, one LDS atomicMin union per
+// (run, upper run) overlap, then every pixel's tile-local root is converted to a global pixel index and written out.
+// Parent chains that phase 2 / ccl_flatten have to walk in global memory are thereby bounded by the number of tiles a
+// component crosses, not by its height in pixels (a 1040-row background region used to cost ~1000 dependent loads).
+__device__ __forceinline__ int lds_find(const volatile int* Ls, int x) {
+    int n;
+    while ((n = Ls[x]) != x) x = n;
+    return x;
+}
+__device__ __forceinline__ void lds_unite(int* Ls, int a, int b) {
+    for (;;) {
+        a = lds_find(Ls, a);
+        b = lds_find(Ls, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(Ls + a, b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+template <int CONN>
+__global__ __launch_bounds__(256) void ccl_local_kernel(CclGeom g, const uint8_t* __restrict__ img_all, uint32_t lut,
+                                                        int32_t* __restrict__ L_all, uint32_t* __restrict__ area_all,
+                                                        u64* __restrict__ sumy_all, u64* __restrict__ sumx_all,
+                                                        uint32_t* __restrict__ flag_all, int stat) {
+    __shared__ int Ls[CCL_BLOCK_ROWS * 64];
+    __shared__ uint8_t Ks[CCL_BLOCK_ROWS * 64];
     int img, y0, cx;
-    if (!decode_block(g, img, y0, cx)) return;
+    if (!decode_block(g, img, y0, cx)) return;            // block-uniform
     const size_t base = (size_t)img * g.H * g.W;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = cx * 64 + lane;
+    const int yblk = y0 - wave * CCL_ROWS;                 // first row of the tile
+    int keys[CCL_ROWS];
+#pragma unroll
     for (int r = 0; r < CCL_ROWS; ++r) {
-        const int y = y0 + r;
-        if (y >= g.H) break;                                   // wave-uniform
-        const bool valid = x < g.W;
-        const int p = y * g.W + x;
-        const int key = valid ? key_of(img_all[base + p], lut) : 0;
+        const int y = y0 + r, li = (wave * CCL_ROWS + r) * 64 + lane;
+        const bool valid = y < g.H && x < g.W;
+        const int key = valid ? key_of(img_all[base + (size_t)y * g.W + x], lut) : 0;
+        keys[r] = key;
         const int kprev = __shfl_up(key, 1, 64);
         const bool start = key != 0 && (lane == 0 || kprev != key);
         const u64 S = __ballot(start);
-        if (valid) {
-            int lab = -1;
-            if (key) {
-                const u64 below = S & ((2ull << lane) - 1ull);     // run starts at or below this lane
-                lab = y * g.W + cx * 64 + (63 - __clzll(below));
+        const u64 below = S & ((2ull << lane) - 1ull);
+        Ks[li] = (uint8_t)key;
+        Ls[li] = key ? (li - lane) + (63 - __clzll(below)) : -1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < CCL_ROWS; ++r) {
+        const int ly = wave * CCL_ROWS + r, li = ly * 64 + lane;
+        const int key = keys[r];
+        if (!key || ly == 0) continue;
+        const bool left = lane > 0 && Ks[li - 1] == key;
+        const bool u0 = Ks[li - 64] == key;
+        const bool ul = lane > 0 && Ks[li - 65] == key;
+        const bool ur = lane < 63 && Ks[li - 63] == key;
+        if (CONN == 8) {
+            if (ur && !u0) lds_unite(Ls, li, li - 63);
+            if (!left) {
+                if (u0) lds_unite(Ls, li, li - 64);
+                else if (ul) lds_unite(Ls, li, li - 65);
             }
-            L_all[base + p] = lab;
-            if (start) {                                           // only run heads can become roots
-                flag_all[base + p] = 0u;
-                if (stat & STAT_AREA) area_all[base + p] = 0u;
-                if (stat & STAT_SUMS) { sumy_all[base + p] = 0ull; sumx_all[base + p] = 0ull; }
+        } else {
+            if (u0 && !(left && ul)) lds_unite(Ls, li, li - 64);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < CCL_ROWS; ++r) {
+        const int y = y0 + r, li = (wave * CCL_ROWS + r) * 64 + lane;
+        const int key = keys[r];
+        // run heads look the tile root up, the rest of the run takes it by shuffle
+        const int kprev = __shfl_up(key, 1, 64);
+        const bool head = key != 0 && (lane == 0 || kprev != key);
+        const u64 Sh = __ballot(head);
+        int head_root = -1;
+        if (head) head_root = lds_find(Ls, li);
+        const u64 below = Sh & ((2ull << lane) - 1ull);
+        const int rl = __shfl(head_root, below ? 63 - __clzll(below) : 0, 64);
+        if (y < g.H && x < g.W) {
+            const size_t p = base + (size_t)y * g.W + x;
+            int lab = -1;
+            if (key) lab = (yblk + (rl >> 6)) * g.W + cx * 64 + (rl & 63);
+            L_all[p] = lab;
+            if (key && rl == li) {                                 // only tile roots can become global roots
+                flag_all[p] = 0u;
+                if (stat & STAT_AREA) area_all[p] = 0u;
+                if (stat & STAT_SUMS) { sumy_all[p] = 0ull; sumx_all[p] = 0ull; }
             }
         }
     }
 }
 
+// ---- phase 2: unions across tile borders (global atomicMin union-find) ----------------------------------------------
 template <int CONN>
-__global__ __launch_bounds__(256) void ccl_merge_kernel(CclGeom g, const uint8_t* __restrict__ img_all, uint32_t lut,
-                                                        int32_t* __restrict__ L_all) {
+__global__ __launch_bounds__(256) void ccl_border_kernel(CclGeom g, const uint8_t* __restrict__ img_all, uint32_t lut,
+                                                         int32_t* __restrict__ L_all) {
     int img, y0, cx;
     if (!decode_block(g, img, y0, cx)) return;
     const size_t base = (size_t)img * g.H * g.W;
     const uint8_t* im = img_all + base;
     int32_t* L = L_all + base;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = cx * 64 + lane;
     const int W = g.W;
     for (int r = 0; r < CCL_ROWS; ++r) {
         const int y = y0 + r;
         if (y >= g.H) break;
-        if (x >= W) continue;
+        const bool top = (wave == 0 && r == 0 && y > 0);          // first row of a tile
+        if (!(top || lane == 0 || lane == 63) || x >= W) continue;
         const int p = y * W + x;
         const int key = key_of(im[p], lut);
         if (!key) continue;
         const bool left = x > 0 && key_of(im[p - 1], lut) == key;
-        bool u0 = false, ul = false, ur = false;
-        if (y > 0) {
-            u0 = key_of(im[p - W], lut) == key;
-            ul = x > 0 && key_of(im[p - W - 1], lut) == key;
-            ur = x + 1 < W && key_of(im[p - W + 1], lut) == key;
-        }
-        if (lane == 0 && left) uf_unite(L, p, p - 1);              // runs are cut at chunk boundaries by ccl_init
-        if (CONN == 8) {
-            // one union per (run, upper run) pair: at the first pixel of the run that touches the upper run
-            if (ur && !u0) uf_unite(L, p, p - W + 1);              // an upper run begins at x+1
-            if (!left) {                                           // first pixel of this run
-                if (u0) uf_unite(L, p, p - W);
-                else if (ul) uf_unite(L, p, p - W - 1);
+        if (lane == 0 && left) uf_unite(L, p, p - 1);
+        if (y == 0) continue;
+        const bool u0 = key_of(im[p - W], lut) == key;
+        const bool ul = x > 0 && key_of(im[p - W - 1], lut) == key;
+        const bool ur = x + 1 < W && key_of(im[p - W + 1], lut) == key;
+        if (top) {
+            if (CONN == 8) {
+                if (ur && !u0) uf_unite(L, p, p - W + 1);
+                if (!left) {
+                    if (u0) uf_unite(L, p, p - W);
+                    else if (ul) uf_unite(L, p, p - W - 1);
+                }
+            } else {
+                if (u0 && !(left && ul)) uf_unite(L, p, p - W);
             }
-        } else {
-            if (u0 && !(left && ul)) uf_unite(L, p, p - W);        // first pixel of the overlap of the two runs
+        } else if (CONN == 8) {                                    // diagonal contacts across a vertical tile border
+            if (lane == 0 && ul) uf_unite(L, p, p - W - 1);
+            if (lane == 63 && ur) uf_unite(L, p, p - W + 1);
         }
     }
 }
 
-// flatten + statistics.  aux_mode selects the bits OR-ed into flag[root]:
+// ---- phase 3: flatten + statistics ------------------------------------------------------------------------------------
+// aux_mode selects the bits OR-ed into flag[root]:
 //   AUX_BORDER   bit0 = component touches the image border
 //   AUX_VALUE_EQ bit0 = component holds a pixel with value == aux_c
 //   AUX_IMAGE    bits of aux_img[p]
+// After ccl_local every pixel points at its tile root, so all per-component sums are first accumulated per TILE ROOT
+// in LDS (one LDS atomic per run) and only the tile roots touch global memory: one chain walk and at most four global
+// atomics per (tile, component).  A noisy label image with millions of runs inside a few huge components therefore
+// no longer funnels millions of atomics into a handful of addresses.
 __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8_t* __restrict__ img_all, uint32_t lut,
                                                           int32_t* __restrict__ L_all, uint32_t* __restrict__ area_all,
                                                           u64* __restrict__ sumy_all, u64* __restrict__ sumx_all,
                                                           uint32_t* __restrict__ flag_all, int32_t* __restrict__ G_all,
                                                           int stat, int aux_mode, int aux_c,
-                                                          const uint8_t* __restrict__ aux_img) {
+                                                          const uint8_t* __restrict__ aux_img, int need) {
+    constexpr int TP = CCL_BLOCK_ROWS * 64;                    // pixels per tile
+    __shared__ int red[16];                                    // ncomp[1..3], npx[1..3], -, -, last root (64 B keeps the dynamic LDS base 16-B aligned)
+    __shared__ int groot_s[TP];                                // tile root -> global root
+    __shared__ uint32_t area_s[TP];
+    __shared__ uint32_t flag_s[TP];
+    __shared__ uint32_t used_s[TP / 32];                       // bit per slot: some run accumulated into it
+    extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+    u64* sumy_s = reinterpret_cast<u64*>(dyn_smem);            // [TP] only when STAT_SUMS
+    u64* sumx_s = sumy_s + TP;
     int img, y0, cx;
-    if (!decode_block(g, img, y0, cx)) return;
+    if (!decode_block(g, img, y0, cx)) return;                 // block-uniform
+    const int tid = threadIdx.x;
+    if (tid < 9) red[tid] = 0;
+    if (tid < TP / 32) used_s[tid] = 0u;
+    for (int i = tid; i < TP; i += 256) {
+        area_s[i] = 0u; flag_s[i] = 0u;
+        if (stat & STAT_SUMS) { sumy_s[i] = 0ull; sumx_s[i] = 0ull; }
+    }
+    __syncthreads();
     const size_t base = (size_t)img * g.H * g.W;
     const uint8_t* im = img_all + base;
     int32_t* L = L_all + base;
-    int32_t* G = G_all + (size_t)img * G_STRIDE;
-    const int lane = threadIdx.x & 63;
+    int32_t* G = G_all + (size_t)img * G_IMG + (size_t)((blockIdx.x >> 3) % G_SHARDS) * G_STRIDE;
+    const int lane = tid & 63, wave = tid >> 6;
     const int x = cx * 64 + lane;
     const int W = g.W, H = g.H;
-    int ncomp[4] = {0, 0, 0, 0}, npx[4] = {0, 0, 0, 0};
-    int last_root = 0;
+    const int yblk = y0 - wave * CCL_ROWS;
+    int npx[4] = {0, 0, 0, 0};
+    int troot[CCL_ROWS];                                       // tile-local index of this pixel's tile root, -1 = background
+    // ---- A: per-run accumulation into the tile root's LDS slot ----
+#pragma unroll
     for (int r = 0; r < CCL_ROWS; ++r) {
         const int y = y0 + r;
-        if (y >= H) break;
-        const bool valid = x < W;
+        const bool valid = y < H && x < W;
         const int p = y * W + x;
         uint8_t v = 0;
-        int key = 0, root = -1;
+        int key = 0, lab = -1;
         if (valid) {
             v = im[p];
             key = key_of(v, lut);
-            if (key) { root = uf_find(L, p); L[p] = root; }
+            if (key) lab = L[p];
         }
-        // ---- per-key component / pixel counts (wave popcounts) ----
+        // Slot of this pixel's tile component: the tile root it points at.  A tile root that ccl_border has meanwhile
+        // linked to a pixel of another tile no longer points into the tile: it keeps its own slot (the other pixels
+        // of its tile component still point at it).
+        int tr = -1;
+        if (key) {
+            const int ry = lab / W, rx = lab - ry * W;
+            const int dy = ry - yblk, dx = rx - cx * 64;
+            tr = ((unsigned)dy < (unsigned)CCL_BLOCK_ROWS && (unsigned)dx < 64u) ? dy * 64 + dx
+                                                                                    : (wave * CCL_ROWS + r) * 64 + lane;
+        }
+        troot[r] = tr;
+        if (need & NEED_NPX) {
 #pragma unroll
-        for (int k = 1; k < 4; ++k) {
-            const u64 mk = __ballot(key == k);
-            if (mk) {
-                npx[k] += __popcll(mk);
-                ncomp[k] += __popcll(__ballot(key == k && root == p));
-            }
+            for (int k = 1; k < 4; ++k) npx[k] += __popcll(__ballot(key == k));
         }
         const u64 F = __ballot(key != 0);
-        if (!F) continue;
-        {
-            int rmax = (key && root == p) ? p + 1 : 0;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) rmax = max(rmax, __shfl_xor(rmax, o, 64));
-            last_root = max(last_root, rmax);
-        }
-        // ---- runs of equal root inside the chunk: one atomic per run ----
-        const int rprev = __shfl_up(root, 1, 64);
-        const bool start = key != 0 && (lane == 0 || rprev != root);
+        if (!F) continue;                                      // wave-uniform
+        const int tprev = __shfl_up(tr, 1, 64);
+        const bool start = key != 0 && (lane == 0 || tprev != tr);
         const u64 S = __ballot(start);
         uint32_t bits = 0;
         if (aux_mode == AUX_BORDER) bits = (key && (y == 0 || y == H - 1 || x == 0 || x == W - 1)) ? 1u : 0u;
         else if (aux_mode == AUX_VALUE_EQ) bits = (key && v == aux_c) ? 1u : 0u;
-        else if (aux_mode == AUX_IMAGE) bits = (key && valid) ? aux_img[base + p] : 0u;
+        else if (aux_mode == AUX_IMAGE) bits = key ? aux_img[base + p] : 0u;
         u64 B[5];
-        int nb = (aux_mode == AUX_IMAGE) ? 5 : (aux_mode == AUX_NONE ? 0 : 1);
+        const int nb = (aux_mode == AUX_IMAGE) ? 5 : (aux_mode == AUX_NONE ? 0 : 1);
 #pragma unroll
         for (int b = 0; b < 5; ++b) B[b] = (b < nb) ? __ballot((bits >> b) & 1u) : 0ull;
         if (start) {
-            const u64 above = ~((2ull << lane) - 1ull);            // lanes strictly above this one
+            const u64 above = ~((2ull << lane) - 1ull);
             const u64 stop = (S | ~F) & above;
             const int len = stop ? (__ffsll((long long)stop) - 1 - lane) : (64 - lane);
             const u64 run = (len == 64) ? ~0ull : (((1ull << len) - 1ull) << lane);
-            if (stat & STAT_AREA) atomicAdd(area_all + base + root, (uint32_t)len);
+            atomicOr(&used_s[tr >> 5], 1u << (tr & 31));
+            if (stat & STAT_AREA) atomicAdd(&area_s[tr], (uint32_t)len);
             if (stat & STAT_SUMS) {
-                atomicAdd(sumy_all + base + root, (u64)y * (u64)len);
-                atomicAdd(sumx_all + base + root, (u64)x * (u64)len + (u64)len * (u64)(len - 1) / 2ull);
+                atomicAdd(&sumy_s[tr], (u64)y * (u64)len);
+                atomicAdd(&sumx_s[tr], (u64)x * (u64)len + (u64)len * (u64)(len - 1) / 2ull);
             }
             uint32_t fb = 0;
 #pragma unroll
             for (int b = 0; b < 5; ++b) if (B[b] & run) fb |= 1u << b;
-            if (fb) atomicOr(flag_all + base + root, fb);
+            if (fb) atomicOr(&flag_s[tr], fb);
         }
     }
-    if (lane == 0) {
+    __syncthreads();
+    // ---- B: slot owners (tile roots) resolve their global root and forward the slot's sums ----
+    int ncomp[4] = {0, 0, 0, 0};
+    int last_root = 0;
 #pragma unroll
-        for (int k = 1; k < 4; ++k) {
-            if (ncomp[k]) atomicAdd(G + G_NCOMP + k, ncomp[k]);
-            if (npx[k]) atomicAdd(G + G_NPX + k, npx[k]);
+    for (int r = 0; r < CCL_ROWS; ++r) {
+        const int li = (wave * CCL_ROWS + r) * 64 + lane;
+        if (!((used_s[li >> 5] >> (li & 31)) & 1u)) continue;  // nothing accumulated here: not a slot owner
+        const int p = (y0 + r) * W + x;
+        const int gr = uf_find(L, p);
+        groot_s[li] = gr;
+        if (stat & STAT_AREA) atomicAdd(area_all + base + gr, area_s[li]);
+        if (stat & STAT_SUMS) { atomicAdd(sumy_all + base + gr, sumy_s[li]); atomicAdd(sumx_all + base + gr, sumx_s[li]); }
+        if (flag_s[li]) atomicOr(flag_all + base + gr, flag_s[li]);
+        if (gr == p) {                                         // a global root lives in this tile
+            if (need & NEED_NCOMP) ncomp[key_of(im[p], lut) & 3] += 1;
+            last_root = max(last_root, p + 1);
         }
-        if (last_root) atomicMax(G + G_LAST_ROOT, last_root);
     }
+    __syncthreads();
+    // ---- C: every pixel takes its component's global root ----
+#pragma unroll
+    for (int r = 0; r < CCL_ROWS; ++r) {
+        const int y = y0 + r;
+        if (troot[r] >= 0 && y < H && x < W) L[y * W + x] = groot_s[troot[r]];
+    }
+    // ---- per-image counters: registers -> LDS -> one global atomic per workgroup and counter ----
+    if (need & NEED_NCOMP) {
+#pragma unroll
+        for (int k = 1; k < 4; ++k) if (ncomp[k]) atomicAdd(&red[k - 1], ncomp[k]);
+    }
+    if ((need & NEED_LAST) && last_root) atomicMax(&red[8], last_root);
+    if ((need & NEED_NPX) && lane == 0) {
+#pragma unroll
+        for (int k = 1; k < 4; ++k) if (npx[k]) atomicAdd(&red[3 + k - 1], npx[k]);
+    }
+    __syncthreads();
+    if (tid < 3) { if (red[tid]) atomicAdd(G + G_NCOMP + 1 + tid, red[tid]); }
+    else if (tid < 6) { if (red[tid]) atomicAdd(G + G_NPX + 1 + (tid - 3), red[tid]); }
+    else if (tid == 8) { if (red[8]) atomicMax(G + G_LAST_ROOT, red[8]); }
+}
+
+// fold the G_SHARDS replicas of every image's counter block into replica 0
+__global__ void reduce_g_kernel(int32_t* __restrict__ G_all, int n_img) {
+    const int im = blockIdx.x, t = threadIdx.x;          // blockDim = G_STRIDE
+    if (im >= n_img) return;
+    int32_t* G = G_all + (size_t)im * G_IMG;
+    int v = G[t];
+    for (int sh = 1; sh < G_SHARDS; ++sh) {
+        const int w = G[sh * G_STRIDE + t];
+        v = (t == G_LAST_ROOT) ? max(v, w) : v + w;
+    }
+    G[t] = v;
 }
 
 __global__ void zero_g_kernel(int32_t* G, int n) {
@@ -274,18 +414,26 @@ struct CclPass {
     int stat;
     int aux_mode, aux_c;
     const uint8_t* aux_img;
+    int need;      // NEED_* counters this pass has to produce
 };
 
 static hipError_t run_ccl_pass(PostWorkspace& ws, const CclGeom& g, const CclPass& c, hipStream_t s) {
-    const int ng = g.n_img * G_STRIDE;
+    const int ng = g.n_img * G_IMG;
     hipLaunchKernelGGL(zero_g_kernel, dim3((ng + 255) / 256), dim3(256), 0, s, ws.g, ng);
     const unsigned grid = geom_grid(g);
-    hipLaunchKernelGGL(ccl_init_kernel, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy, ws.sumx,
-                       ws.flag, c.stat);
-    if (c.conn == 8) hipLaunchKernelGGL(ccl_merge_kernel<8>, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L);
-    else hipLaunchKernelGGL(ccl_merge_kernel<4>, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L);
-    hipLaunchKernelGGL(ccl_flatten_kernel, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy,
-                       ws.sumx, ws.flag, ws.g, c.stat, c.aux_mode, c.aux_c, c.aux_img);
+    if (c.conn == 8) {
+        hipLaunchKernelGGL(ccl_local_kernel<8>, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy,
+                           ws.sumx, ws.flag, c.stat);
+        hipLaunchKernelGGL(ccl_border_kernel<8>, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L);
+    } else {
+        hipLaunchKernelGGL(ccl_local_kernel<4>, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy,
+                           ws.sumx, ws.flag, c.stat);
+        hipLaunchKernelGGL(ccl_border_kernel<4>, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L);
+    }
+    const size_t dyn = (c.stat & STAT_SUMS) ? (size_t)CCL_BLOCK_ROWS * 64 * 16 : 0;
+    hipLaunchKernelGGL(ccl_flatten_kernel, dim3(grid), dim3(256), dyn, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy,
+                       ws.sumx, ws.flag, ws.g, c.stat, c.aux_mode, c.aux_c, c.aux_img, c.need);
+    if (c.need) hipLaunchKernelGGL(reduce_g_kernel, dim3(g.n_img), dim3(G_STRIDE), 0, s, ws.g, g.n_img);
     return hipGetLastError();
 }
 
@@ -322,7 +470,7 @@ __global__ __launch_bounds__(256) void apply_size_thresh_kernel(uint8_t* __restr
         const int r = L[t];
         if (r < 0) continue;
         const size_t im = t / px;
-        const int32_t* G = G_all + im * G_STRIDE;
+        const int32_t* G = G_all + im * G_IMG;
         const double avg_chrom = G[G_NCOMP + 2] ? (double)G[G_NPX + 2] / (double)G[G_NCOMP + 2] : __longlong_as_double(0x7ff8000000000000LL);
         const double avg_ec = G[G_NCOMP + 3] ? (double)G[G_NPX + 3] / (double)G[G_NCOMP + 3] : __longlong_as_double(0x7ff8000000000000LL);
         const double a = (double)area[im * px + r];
@@ -368,50 +516,73 @@ __global__ __launch_bounds__(256) void ec_dilate_kernel(const uint8_t* __restric
 }
 
 // Roots of class-1 and class-2 components -> compact per-image lists (nucleus root indices; chromosome centroids).
+// Roots of class-1 and class-2 components -> compact per-image lists (nucleus root indices; chromosome centroids).
 __global__ __launch_bounds__(256) void compact_roots_kernel(const uint8_t* __restrict__ img, const int32_t* __restrict__ L,
                                                             const uint32_t* __restrict__ area, const u64* __restrict__ sumy,
                                                             const u64* __restrict__ sumx, int32_t* __restrict__ G_all,
                                                             int32_t* __restrict__ list1, double2* __restrict__ list2,
                                                             size_t total, size_t px, size_t cap) {
-    PX_LOOP(total) {
-        const size_t im = t / px;
-        const int p = (int)(t - im * px);
-        if (L[t] != p) continue;
-        const uint8_t v = img[t];
-        int32_t* G = G_all + im * G_STRIDE;
-        if (v == 1) {
-            const int k = atomicAdd(G + G_NLIST1, 1);
-            list1[im * cap + k] = p;
-        } else if (v == 2) {
-            const int k = atomicAdd(G + G_NLIST2, 1);
-            const double a = (double)area[t];
-            list2[im * cap + k] = make_double2((double)sumy[t] / a, (double)sumx[t] / a);   // regionprops centroid
+    // grid-stride in whole waves so that the ballots below see full wavefronts; one atomic per wave and class
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const int lane = threadIdx.x & 63;
+    for (size_t t0 = (size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); t0 < total; t0 += stride) {
+        const size_t t = t0 + lane;
+        int cls = 0;
+        size_t im = 0;
+        int p = 0;
+        if (t < total) {
+            im = t / px;
+            p = (int)(t - im * px);
+            if (L[t] == p) { const uint8_t v = img[t]; cls = (v == 1) ? 1 : (v == 2 ? 2 : 0); }
+        }
+        const size_t im0 = t0 / px;                              // image of lane 0; a wave may straddle two images
+#pragma unroll
+        for (int c = 1; c <= 2; ++c) {
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const bool mine = cls == c && ((im == im0) == (side == 0));
+                const u64 m = __ballot(mine);
+                if (!m) continue;
+                const int leader = __ffsll((long long)m) - 1;
+                int basek = 0;
+                if (lane == leader)
+                    basek = atomicAdd(G_all + im * G_IMG + (c == 1 ? G_NLIST1 : G_NLIST2), __popcll(m));
+                basek = __shfl(basek, leader, 64);
+                if (mine) {
+                    const int k = basek + __popcll(m & ((1ull << lane) - 1ull));
+                    if (c == 1) list1[im * cap + k] = p;
+                    else {
+                        const double a = (double)area[t];
+                        list2[im * cap + k] = make_double2((double)sumy[t] / a, (double)sumx[t] / a);   // regionprops centroid
+                    }
+                }
+            }
         }
     }
 }
 
 // Nucleus-in-metaphase test (src/image_tools.py:72-81): more than five chromosome centroids strictly inside each of
-// the four 70-px half bands -> the nucleus is erased.  One block per nucleus (grid-stride), threads stride over the
-// chromosome list; counts saturate so the scan stops as soon as all four exceed the threshold.
+// the four 70-px half bands -> the nucleus is erased.  One wavefront per nucleus (grid-stride), lanes stride over the
+// chromosome list; the scan stops as soon as all four counts exceed the threshold.
 __global__ __launch_bounds__(256) void nucleus_test_kernel(const uint32_t* __restrict__ area, const u64* __restrict__ sumy,
                                                            const u64* __restrict__ sumx, const int32_t* __restrict__ G_all,
                                                            const int32_t* __restrict__ list1, const double2* __restrict__ list2,
                                                            uint32_t* __restrict__ flag, size_t px, size_t cap,
                                                            int blocks_per_img, double v, int min_count) {
     const int im = blockIdx.x / blocks_per_img, j = blockIdx.x % blocks_per_img;
-    const int32_t* G = G_all + (size_t)im * G_STRIDE;
+    const int32_t* G = G_all + (size_t)im * G_IMG;
     const int n1 = G[G_NLIST1], n2 = G[G_NLIST2];
-    __shared__ int cnt[4];
-    for (int k = j; k < n1; k += blocks_per_img) {
+    const int lane = threadIdx.x & 63;
+    const int wave = j * 4 + (threadIdx.x >> 6), nwaves = blocks_per_img * 4;
+    for (int k = wave; k < n1; k += nwaves) {                       // wave-uniform loop
         const int root = list1[(size_t)im * cap + k];
         const size_t slot = (size_t)im * px + root;
         const double a = (double)area[slot];
         const double ny = (double)sumy[slot] / a, nx = (double)sumx[slot] / a;
-        if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
-        __syncthreads();
-        for (int c0 = 0; c0 < n2; c0 += blockDim.x) {
-            const int c = c0 + threadIdx.x;
-            int l = 0, r = 0, b = 0, tp = 0;
+        int cl = 0, cr = 0, cb = 0, ct = 0;
+        for (int c0 = 0; c0 < n2; c0 += 64) {
+            const int c = c0 + lane;
+            bool l = false, r = false, b = false, tp = false;
             if (c < n2) {
                 const double2 cc = list2[(size_t)im * cap + c];   // (cy, cx)
                 l = (cc.y > nx) && (cc.y < nx + v);
@@ -419,22 +590,11 @@ __global__ __launch_bounds__(256) void nucleus_test_kernel(const uint32_t* __res
                 b = (cc.x < ny) && (cc.x > ny - v);
                 tp = (cc.x > ny) && (cc.x < ny + v);
             }
-            const int wl = __popcll(__ballot(l)), wr = __popcll(__ballot(r));
-            const int wb = __popcll(__ballot(b)), wt = __popcll(__ballot(tp));
-            if ((threadIdx.x & 63) == 0) {
-                if (wl) atomicAdd(&cnt[0], wl);
-                if (wr) atomicAdd(&cnt[1], wr);
-                if (wb) atomicAdd(&cnt[2], wb);
-                if (wt) atomicAdd(&cnt[3], wt);
-            }
-            __syncthreads();
-            const bool done = cnt[0] > min_count && cnt[1] > min_count && cnt[2] > min_count && cnt[3] > min_count;
-            __syncthreads();
-            if (done) break;
+            cl += __popcll(__ballot(l)); cr += __popcll(__ballot(r));
+            cb += __popcll(__ballot(b)); ct += __popcll(__ballot(tp));
+            if (cl > min_count && cr > min_count && cb > min_count && ct > min_count) break;
         }
-        if (threadIdx.x == 0 && cnt[0] > min_count && cnt[1] > min_count && cnt[2] > min_count && cnt[3] > min_count)
-            flag[slot] |= 2u;
-        __syncthreads();
+        if (lane == 0 && cl > min_count && cr > min_count && cb > min_count && ct > min_count) flag[slot] |= 2u;
     }
 }
 
@@ -460,7 +620,7 @@ __global__ __launch_bounds__(256) void apply_merge_kernel(const uint8_t* __restr
         const int r = L[t];
         if (r >= 0) {
             const size_t im = t / px;
-            const int last = G_all[im * G_STRIDE + G_LAST_ROOT] - 1;
+            const int last = G_all[im * G_IMG + G_LAST_ROOT] - 1;
             if ((flag[im * px + r] & 1u) && r != last) v = (uint8_t)c;
         }
         tmp[t] = v;
@@ -506,8 +666,8 @@ __global__ void gather_counts_kernel(const int32_t* __restrict__ G_all, int n_im
                                      long long* __restrict__ px_out, long long full_px) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_img) return;
-    const int n = G_all[(size_t)i * G_STRIDE + G_NCOMP + key];
-    const long long px = G_all[(size_t)i * G_STRIDE + G_NPX + key];
+    const int n = G_all[(size_t)i * G_IMG + G_NCOMP + key];
+    const long long px = G_all[(size_t)i * G_IMG + G_NPX + key];
     if (n_out) n_out[i] = n;
     // count_cc's pixel total (src/image_tools.py:116-119) is float 0.0 when nothing is counted: no component, or no
     // background label for np.unique(...)[1:] to drop (mask without a single zero pixel)
@@ -522,13 +682,13 @@ hipError_t run_meta_inference(PostWorkspace& ws, uint8_t* img, int n_img, int H,
     hipError_t e;
     // 1. fill_holes(1), fill_holes(2)
     for (int c = 1; c <= 2; ++c) {
-        CclPass p{img, lut_ne(c), 4, 0, AUX_BORDER, 0, nullptr};
+        CclPass p{img, lut_ne(c), 4, 0, AUX_BORDER, 0, nullptr, 0};
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
         hipLaunchKernelGGL(apply_fill_kernel, dim3(pg), dim3(256), 0, s, img, ws.L, ws.flag, total, px, c);
     }
     // 2-4. size_thresh
     {
-        CclPass p{img, LUT_MULTI, 8, STAT_AREA, AUX_NONE, 0, nullptr};
+        CclPass p{img, LUT_MULTI, 8, STAT_AREA, AUX_NONE, 0, nullptr, NEED_NCOMP | NEED_NPX};
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
         hipLaunchKernelGGL(apply_size_thresh_kernel, dim3(pg), dim3(256), 0, s, img, ws.L, ws.area, ws.g, total, px, 15);
     }
@@ -537,14 +697,14 @@ hipError_t run_meta_inference(PostWorkspace& ws, uint8_t* img, int n_img, int H,
     if ((e = hipMemcpyAsync(img, ws.tmpA, total, hipMemcpyDeviceToDevice, s)) != hipSuccess) return e;
     // 6. nucleus-in-metaphase test
     {
-        CclPass p{img, LUT_MULTI, 8, STAT_AREA | STAT_SUMS, AUX_NONE, 0, nullptr};
+        CclPass p{img, LUT_MULTI, 8, STAT_AREA | STAT_SUMS, AUX_NONE, 0, nullptr, 0};
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
         const size_t cap = px / 4 + (size_t)(H + W) / 2 + 4;
         int32_t* list1 = ws.list;
         double2* list2 = reinterpret_cast<double2*>(ws.list + (((size_t)n_img * cap + 3) & ~(size_t)3));
         hipLaunchKernelGGL(compact_roots_kernel, dim3(pg), dim3(256), 0, s, img, ws.L, ws.area, ws.sumy, ws.sumx, ws.g,
                            list1, list2, total, px, cap);
-        const int bpi = 8;
+        const int bpi = 32;
         hipLaunchKernelGGL(nucleus_test_kernel, dim3(n_img * bpi), dim3(256), 0, s, ws.area, ws.sumy, ws.sumx, ws.g, list1,
                            list2, ws.flag, px, cap, bpi, 70.0, 5);
         hipLaunchKernelGGL(apply_nucleus_kill_kernel, dim3(pg), dim3(256), 0, s, img, ws.L, ws.flag, total, px);
@@ -552,7 +712,7 @@ hipError_t run_meta_inference(PostWorkspace& ws, uint8_t* img, int n_img, int H,
     // 7-8. merge_comp(1), merge_comp(2)
     for (int c = 1; c <= 2; ++c) {
         const int m = (c == 1) ? 2 : 1;
-        CclPass p{img, lut_nonzero_except(m), 8, 0, AUX_VALUE_EQ, c, nullptr};
+        CclPass p{img, lut_nonzero_except(m), 8, 0, AUX_VALUE_EQ, c, nullptr, NEED_LAST};
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
         hipLaunchKernelGGL(apply_merge_kernel, dim3(pg), dim3(256), 0, s, img, ws.tmpA, ws.L, ws.flag, ws.g, total, px, c, m);
         hipLaunchKernelGGL(grey_erode_kernel, dim3(pg), dim3(256), 0, s, ws.tmpA, ws.tmpB, total, H, W);
@@ -563,7 +723,7 @@ hipError_t run_meta_inference(PostWorkspace& ws, uint8_t* img, int n_img, int H,
     if ((e = hipMemcpyAsync(img, ws.tmpA, total, hipMemcpyDeviceToDevice, s)) != hipSuccess) return e;
     // 10. count_cc(img == 3)[0]
     if (n_ec_dev) {
-        CclPass p{img, lut_eq(3), 8, 0, AUX_NONE, 0, nullptr};
+        CclPass p{img, lut_eq(3), 8, 0, AUX_NONE, 0, nullptr, NEED_NCOMP | NEED_NPX};
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
         hipLaunchKernelGGL(gather_counts_kernel, dim3((n_img + 63) / 64), dim3(64), 0, s, ws.g, n_img, 1, n_ec_dev,
                            (long long*)nullptr, (long long)px);
@@ -578,7 +738,7 @@ hipError_t run_count_cc(PostWorkspace& ws, const uint8_t* mask, int n_img, int H
                         hipStream_t s) {
     if (n_img <= 0) return hipSuccess;
     const CclGeom g = make_geom(n_img, H, W);
-    CclPass p{mask, LUT_NONZERO, 8, 0, AUX_NONE, 0, nullptr};
+    CclPass p{mask, LUT_NONZERO, 8, 0, AUX_NONE, 0, nullptr, NEED_NCOMP | NEED_NPX};
     hipError_t e = run_ccl_pass(ws, g, p, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(gather_counts_kernel, dim3((n_img + 63) / 64), dim3(64), 0, s, ws.g, n_img, 1, n_dev, px_dev,
@@ -594,7 +754,7 @@ hipError_t run_ccl_labels(PostWorkspace& ws, const uint8_t* mask, int n_img, int
                           hipStream_t s) {
     if (n_img <= 0) return hipSuccess;
     const CclGeom g = make_geom(n_img, H, W);
-    CclPass p{mask, LUT_NONZERO, conn, 0, AUX_NONE, 0, nullptr};
+    CclPass p{mask, LUT_NONZERO, conn, 0, AUX_NONE, 0, nullptr, 0};
     hipError_t e = run_ccl_pass(ws, g, p, s);
     if (e != hipSuccess) return e;
     const size_t total = (size_t)n_img * H * W;
@@ -608,12 +768,23 @@ __global__ __launch_bounds__(256) void count_flagged_roots_kernel(const uint8_t*
                                                                   const uint32_t* __restrict__ flag,
                                                                   int32_t* __restrict__ G_all, size_t total, size_t px,
                                                                   int key_sel, uint32_t need, int slot) {
-    PX_LOOP(total) {
-        const size_t im = t / px;
-        const int p = (int)(t - im * px);
-        if (L[t] != p) continue;
-        if (key_sel && key_of(key_img[t], lut) != key_sel) continue;
-        if ((flag[t] & need) == need) atomicAdd(G_all + im * G_STRIDE + G_CNT0 + slot, 1);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const int lane = threadIdx.x & 63;
+    for (size_t t0 = (size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); t0 < total; t0 += stride) {
+        const size_t t = t0 + lane;
+        bool hit = false;
+        size_t im = 0;
+        if (t < total) {
+            im = t / px;
+            const int p = (int)(t - im * px);
+            hit = L[t] == p && (!key_sel || key_of(key_img[t], lut) == key_sel) && (flag[t] & need) == need;
+        }
+        const size_t im0 = t0 / px;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {                   // a wave may straddle two images
+            const u64 m = __ballot(hit && ((im == im0) == (side == 0)));
+            if (m && lane == __ffsll((long long)m) - 1) atomicAdd(G_all + im * G_IMG + G_CNT0 + slot, __popcll(m));
+        }
     }
 }
 
@@ -622,7 +793,7 @@ __global__ void gather_slot_kernel(const int32_t* __restrict__ G_all, int n_img,
                                    int out_stride, int out_off) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_img) return;
-    const int32_t* G = G_all + (size_t)i * G_STRIDE;
+    const int32_t* G = G_all + (size_t)i * G_IMG;
     int v = G[G_CNT0 + slot];
     // np.unique(regs)[1:] (src/image_tools.py:107,129) drops the only component of a mask without background
     if (key_for_quirk && G[G_NPX + key_for_quirk] == full_px) v = 0;
@@ -640,7 +811,7 @@ hipError_t run_count_coloc(PostWorkspace& ws, const uint8_t* ob1, const uint8_t*
     const CclGeom g = make_geom(n_img, H, W);
     const size_t px = (size_t)H * W, total = px * n_img;
     hipLaunchKernelGGL(mask_to_bits_kernel, dim3(px_grid(total)), dim3(256), 0, s, ob2, ws.tmpA, total);
-    CclPass p{ob1, LUT_NONZERO, 8, 0, AUX_IMAGE, 0, ws.tmpA};
+    CclPass p{ob1, LUT_NONZERO, 8, 0, AUX_IMAGE, 0, ws.tmpA, NEED_NPX};
     hipError_t e = run_ccl_pass(ws, g, p, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(count_flagged_roots_kernel, dim3(px_grid(total)), dim3(256), 0, s, ob1, LUT_NONZERO, ws.L, ws.flag,
@@ -670,12 +841,12 @@ hipError_t run_count_hsr(PostWorkspace& ws, const uint8_t* chrom, const uint8_t*
     if (n_img <= 0) return hipSuccess;
     const CclGeom g = make_geom(n_img, H, W);
     const size_t px = (size_t)H * W, total = px * n_img;
-    CclPass p1{fish, LUT_NONZERO, 4, STAT_AREA, AUX_NONE, 0, nullptr};
+    CclPass p1{fish, LUT_NONZERO, 4, STAT_AREA, AUX_NONE, 0, nullptr, 0};
     hipError_t e = run_ccl_pass(ws, g, p1, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(zero_u8_kernel, dim3(px_grid(total)), dim3(256), 0, s, ws.tmpA, total);
     hipLaunchKernelGGL(keep_large_kernel, dim3(px_grid(total)), dim3(256), 0, s, ws.L, ws.area, ws.tmpA, total, px, thr, 0);
-    CclPass p2{chrom, LUT_NONZERO, 8, 0, AUX_IMAGE, 0, ws.tmpA};
+    CclPass p2{chrom, LUT_NONZERO, 8, 0, AUX_IMAGE, 0, ws.tmpA, NEED_NPX};
     if ((e = run_ccl_pass(ws, g, p2, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(count_flagged_roots_kernel, dim3(px_grid(total)), dim3(256), 0, s, chrom, LUT_NONZERO, ws.L, ws.flag,
                        ws.g, total, px, 0, 1u, 0);
@@ -716,8 +887,8 @@ __global__ void overlay_cc_gather_kernel(const int32_t* __restrict__ G_all, int 
                                          long long* __restrict__ out, int off) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_img) return;
-    const int n = G_all[(size_t)i * G_STRIDE + G_NCOMP + key];
-    const long long px = G_all[(size_t)i * G_STRIDE + G_NPX + key];
+    const int n = G_all[(size_t)i * G_IMG + G_NCOMP + key];
+    const long long px = G_all[(size_t)i * G_IMG + G_NPX + key];
     out[(size_t)i * 12 + off] = n;
     out[(size_t)i * 12 + off + 1] = (n == 0 || px == full_px) ? -1 : px;
 }
@@ -737,14 +908,14 @@ hipError_t run_overlay(PostWorkspace& ws, const uint8_t* labels, const uint8_t* 
     for (int k = 0; k < 2; ++k) {
         const int which = (k == 0) ? 1 : 0;
         hipLaunchKernelGGL(overlay_mask_kernel, dim3(pg), dim3(256), 0, s, labels, rgb, C, sens, which, msk, total);
-        CclPass p{msk, LUT_NONZERO, 4, STAT_AREA, AUX_NONE, 0, nullptr};
+        CclPass p{msk, LUT_NONZERO, 4, STAT_AREA, AUX_NONE, 0, nullptr, 0};
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
         hipLaunchKernelGGL(keep_large_kernel, dim3(pg), dim3(256), 0, s, ws.L, ws.area, aux, total, px, hsr_thr, 3 + k);
     }
     // chromosomes (key 2) and ecDNA (key 3) in one labelling
     {
         const uint32_t lut = 0x03020000u;
-        CclPass p{labels, lut, 8, 0, AUX_IMAGE, 0, aux};
+        CclPass p{labels, lut, 8, 0, AUX_IMAGE, 0, aux, NEED_NCOMP | NEED_NPX};
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
         hipLaunchKernelGGL(overlay_cc_gather_kernel, dim3(ig), dim3(64), 0, s, ws.g, n_img, 3, (long long)px, out, 0);
         const struct { int key; uint32_t need; int slot; int off; } q[5] = {
@@ -760,7 +931,7 @@ hipError_t run_overlay(PostWorkspace& ws, const uint8_t* labels, const uint8_t* 
     {
         hipLaunchKernelGGL(overlay_mask_kernel, dim3(pg), dim3(256), 0, s, labels, rgb, C, sens, 2, msk, total);
         hipLaunchKernelGGL(overlay_mask_kernel, dim3(pg), dim3(256), 0, s, labels, rgb, C, sens, 3, aux, total);
-        CclPass p{msk, LUT_NONZERO, 8, 0, AUX_IMAGE, 0, aux};
+        CclPass p{msk, LUT_NONZERO, 8, 0, AUX_IMAGE, 0, aux, NEED_NCOMP | NEED_NPX};
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
         hipLaunchKernelGGL(overlay_cc_gather_kernel, dim3(ig), dim3(64), 0, s, ws.g, n_img, 1, (long long)px, out, 2);
         hipLaunchKernelGGL(count_flagged_roots_kernel, dim3(pg), dim3(256), 0, s, msk, LUT_NONZERO, ws.L, ws.flag, ws.g, total,
@@ -770,7 +941,7 @@ hipError_t run_overlay(PostWorkspace& ws, const uint8_t* labels, const uint8_t* 
     }
     // B = fish2 & ~chrom: count_cc(B)
     {
-        CclPass p{aux, LUT_NONZERO, 8, 0, AUX_NONE, 0, nullptr};
+        CclPass p{aux, LUT_NONZERO, 8, 0, AUX_NONE, 0, nullptr, NEED_NCOMP | NEED_NPX};
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
         hipLaunchKernelGGL(overlay_cc_gather_kernel, dim3(ig), dim3(64), 0, s, ws.g, n_img, 1, (long long)px, out, 4);
     }

@@ -111,6 +111,10 @@ int ecseg_segment_images_dev(ecseg_ctx* h, const uint8_t* gray_dev, int n_img, i
                              uint8_t* labels_raw_dev, uint8_t* labels_post_dev, int32_t* n_ec_dev);
 /* Upper bound on images per internal U-Net launch group (default 8). */
 int ecseg_set_images_per_group(ecseg_ctx* h, int n);
+/* Tuning knobs: "overlap_post" (1: clean-up + count of group g run on a second stream beside the U-Net of group g+1;
+ * 0 (default): everything on one stream - measured equal, the MFMA convs already fill the chip), "post_chunk"
+ * (images per post-processing launch set), "images_per_group". */
+int ecseg_set_option(ecseg_ctx* h, const char* key, int value);
 
 /* ---- meta_preprocess (src/image_tools.py:86-101) ---------------------------------------------------------- */
 /* img: n_img images (H, W, C) of uint8 (bytes_per_sample 1) or uint16 (2), C in {1,3,4}.  u16 -> u8 as

@@ -21,6 +21,8 @@ struct OpRt {                 // run-time form of one plan operator
     ecseg_op_desc d;
     int path;                 // which kernel family
     float* wt = nullptr;      // device weights in the layout the chosen kernel wants
+    float* wt_wino = nullptr; // Winograd-transformed filter (16 points) when the op is eligible
+    int coutp_wino = 0;
     float* bias = nullptr;
     float* scale = nullptr;   // AFFINE
     float* shift = nullptr;
@@ -71,6 +73,7 @@ struct ecseg_ctx {
     size_t ws_list_bytes = 0;
     int post_chunk = 64;
     int overlap_post = 0;
+    int use_winograd = 1;
 
     // timing
     hipEvent_t ev[ECSEG_T_N + 1] = {};
@@ -148,6 +151,25 @@ std::vector<float> relayout_conv(const float* w, int R, int S, int cin, int cout
         }
     return o;
 }
+// Winograd F(2x2,3x3) filter transform U = G g G^T (float64), as 16 "taps" in HWIO order [a*4+b][cin][cout]
+std::vector<float> winograd_filter(const float* w, int cin, int cout) {
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    std::vector<float> u((size_t)16 * cin * cout);
+    for (int ci = 0; ci < cin; ++ci)
+        for (int co = 0; co < cout; ++co) {
+            double g[3][3], t[4][3];
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) g[r][c] = w[((size_t)(r * 3 + c) * cin + ci) * cout + co];
+            for (int a = 0; a < 4; ++a)
+                for (int c = 0; c < 3; ++c) t[a][c] = G[a][0] * g[0][c] + G[a][1] * g[1][c] + G[a][2] * g[2][c];
+            for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < 4; ++b)
+                    u[((size_t)(a * 4 + b) * cin + ci) * cout + co] =
+                        (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]);
+        }
+    return u;
+}
+
 // Keras Conv2DTranspose kernel (kh, kw, out, in) -> one-tap GEMM filter over N = (a*kT + b) * coutp + co
 std::vector<float> relayout_convt(const float* w, int kT, int cin, int cout, int chunks, int coutp) {
     const int np = kT * kT * coutp;
@@ -212,6 +234,10 @@ int run_plan(ecseg_ctx* h, int n) {
                     }
                     hipEvent_t* ev = h->profile_kernels ? prof_pair(h) : nullptr;
                     if (ev) (void)hipEventRecord(ev[0], s);
+                    if (h->use_winograd && o.wt_wino && out.h >= 4 && out.w >= 8) {
+                        p.wt = o.wt_wino; p.coutp = o.coutp_wino;
+                        e = launch_conv_wino(p, s);
+                    } else
                     e = launch_conv_mfma(p, s);
                     if (ev) { (void)hipEventRecord(ev[1], s); h->prof_flops += o.flops * n; }
                 } else if (o.path == PATH_SMALL_CIN) {
@@ -489,6 +515,7 @@ int ecseg_set_option(ecseg_ctx* h, const char* key, int value) {
     if (!h || !key) return ECSEG_E_INVALID;
     const std::string k(key);
     if (k == "overlap_post") h->overlap_post = value != 0;
+    else if (k == "winograd") h->use_winograd = value != 0;
     else if (k == "post_chunk" && value >= 1) h->post_chunk = value;
     else if (k == "images_per_group" && value >= 1) h->images_per_group = value;
     else return fail(h, ECSEG_E_INVALID, "unknown option or bad value: " + k);
@@ -568,6 +595,12 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
                     o.cin_chunks = (cin + 7) / 8;
                     if ((rc = upload(h, relayout_conv(kw, d.kh, d.kw, cin, cout, o.cin_chunks, o.coutp), &o.wt))) return rc;
                     h->mfma_flops_per_patch += o.flops;
+                    if (d.kh == 3 && d.pad_top == 1 && d.pad_left == 1 && to.h == ti.h && to.w == ti.w && cout >= 32) {
+                        const int bnw = conv_wino_ntile(cout);
+                        o.coutp_wino = (cout + bnw - 1) / bnw * bnw;
+                        const std::vector<float> u = winograd_filter(kw, cin, cout);
+                        if ((rc = upload(h, relayout_conv(u.data(), 4, 4, cin, cout, o.cin_chunks, o.coutp_wino), &o.wt_wino))) return rc;
+                    }
                 } else {
                     o.path = PATH_GENERIC;
                     if ((rc = upload(h, std::vector<float>(kw, kw + (size_t)d.kh * d.kw * cin * cout), &o.wt))) return rc;

@@ -34,6 +34,10 @@ struct ConvParams {
 hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s);
 bool       conv_mfma_supported(const ConvParams& p);
 int        conv_mfma_ntile(int cout);   // N tile (32 | 64 | 128) used for a given Cout
+// Winograd F(2x2,3x3) variant for 3x3 / stride 1 / pad 1 convolutions; p.wt = 16 transformed taps, p.coutp padded to
+// conv_wino_ntile()
+hipError_t launch_conv_wino(const ConvParams& p, hipStream_t s);
+int        conv_wino_ntile(int cout);
 
 hipError_t launch_conv_small_cin(const TView& in, const TView& out, const float* w_hwio, const float* bias, int n,
                                  int R, int S, int pad_top, int pad_left, int act, float alpha, hipStream_t s);

@@ -195,6 +195,218 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p, int tiles_
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3) on the fp32 matrix cores: 16 instead of 36 multiplies per 2x2 output block (2.25x fewer MFMAs).
+//
+//   Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A        d: 4x4 input tile, g: 3x3 filter, Y: 2x2 outputs
+//
+// The filter transform U = G g G^T is done once at model load (float64 on the host).  A workgroup owns 4 x 8 tiles
+// (8 x 16 output pixels) x BN output channels; its four waves split the 16 transform points by ROW a of the 4x4
+// transform domain: wave a reads the two raw input rows its row transform needs straight from the staged halo in LDS,
+// forms t = B^T[a,:] d and the four column points V[a][0..3] in registers (32 packed adds per 32 MFMAs - free beside
+// the matrix pipe) and multiplies them with U[a][b] on the MFMA.  No transformed input ever touches LDS or HBM.
+// After the K loop each wave folds its own row (R_a = M[a][:] A) in registers, the four rows meet once through LDS,
+// and Y = A^T R (+ bias, activation) is written as 128-byte row segments.
+//
+// LDS: As[h][col parity][10 rows][12 (9 used)][4ch] - even / odd halo columns in separate planes and a row pitch of
+// 12 slots make every ds_read_b128 of the 4 x 8 tile lanes conflict-free; Bs[point 16][h][BN][4ch].
+template <int NT>
+__global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p, int tiles_x, int tiles_y, int nblk_n) {
+    constexpr int TTY = 4, TTX = 8;
+    constexpr int HR = 2 * TTY + 2, HC = 2 * TTX + 2;       // 10 x 18 halo pixels
+    constexpr int CS = 12;                                   // slots per (plane, row): 9 used
+    constexpr int PLANE = HR * CS;                           // 120
+    constexpr int A_SLOTS = 4 * PLANE;                       // [h][parity]
+    constexpr int BN = NT * 32;
+    constexpr int A_PIECES = HR * HC * 2;                    // 360
+    constexpr int A_PER_T = (A_PIECES + 255) / 256;
+    constexpr int B_PIECES = 16 * 2 * BN;
+    constexpr int B_PER_T = B_PIECES / 256;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* As = reinterpret_cast<f32x4*>(smem);
+    f32x4* Bs = As + A_SLOTS;
+
+    const int tid = threadIdx.x;
+    // spatial position fastest, output-channel block slowest: the workgroups that run together on one XCD stream the
+    // same filter slabs
+    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = bid % tiles_x; bid /= tiles_x;
+    const int by = bid % tiles_y; bid /= tiles_y;
+    const int img = bid % p.n; bid /= p.n;
+    const int nb = bid;
+    const int ox0 = bx * (2 * TTX), oy0 = by * (2 * TTY);
+    const int n0 = nb * BN;
+    const int Hin = p.in.h, Win = p.in.w, Cin = p.in.c;
+    const size_t in_img = (size_t)img * Hin * Win * p.in.cs;
+
+    long a_off[A_PER_T];
+    int a_ch[A_PER_T], a_lds[A_PER_T];
+#pragma unroll
+    for (int k = 0; k < A_PER_T; ++k) {
+        const int q = tid + k * 256;
+        a_off[k] = -1; a_lds[k] = -1; a_ch[k] = 0;
+        if (q < A_PIECES) {
+            const int pix = q >> 1, h = q & 1;
+            const int hy = pix / HC, hx = pix - hy * HC;
+            const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+            a_lds[k] = (h * 2 + (hx & 1)) * PLANE + hy * CS + (hx >> 1);
+            a_ch[k] = h * 4;
+            if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win)
+                a_off[k] = (long)(in_img + ((size_t)iy * Win + ix) * p.in.cs + h * 4);
+        }
+    }
+    const size_t chunk_stride = (size_t)2 * p.coutp * 4;
+    const size_t tap_stride = chunk_stride * p.cin_chunks;
+    long b_off[B_PER_T];
+#pragma unroll
+    for (int k = 0; k < B_PER_T; ++k) {
+        const int q = tid + k * 256;
+        const int tap = q / (2 * BN), rem = q - tap * 2 * BN;
+        const int h = rem / BN, j = rem - h * BN;
+        b_off[k] = (long)(tap * tap_stride + ((size_t)h * p.coutp + n0 + j) * 4);
+    }
+    f32x4 a_reg[A_PER_T], b_reg[B_PER_T];
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int k = 0; k < A_PER_T; ++k) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (a_off[k] >= 0 && c * 8 + a_ch[k] < Cin)
+                v = *reinterpret_cast<const f32x4*>(p.in.p + a_off[k] + (size_t)c * 8);
+            a_reg[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < B_PER_T; ++k)
+            b_reg[k] = *reinterpret_cast<const f32x4*>(p.wt + b_off[k] + (size_t)c * chunk_stride);
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int k = 0; k < A_PER_T; ++k)
+            if (a_lds[k] >= 0) As[a_lds[k]] = a_reg[k];
+#pragma unroll
+        for (int k = 0; k < B_PER_T; ++k) Bs[tid + k * 256] = b_reg[k];
+    };
+
+    const int lane = tid & 63, wa = tid >> 6;              // wave = transform row a
+    const int li = lane & 31, lh = lane >> 5;
+    const int ti = li >> 3, tj = li & 7;
+    // row transform of wave a: t = s0 * d[r0] + s1 * d[r1]
+    const int r0 = (wa == 0) ? 0 : 1, r1 = (wa == 3) ? 3 : 2;
+    const float s0 = (wa == 2) ? -1.f : 1.f, s1 = (wa == 0 || wa == 3) ? -1.f : 1.f;
+    const f32x4* A0 = As + (lh * 2) * PLANE + (2 * ti + r0) * CS + tj;     // even columns (j = 0, 2)
+    const f32x4* A1 = As + (lh * 2) * PLANE + (2 * ti + r1) * CS + tj;
+    const f32x4* Bp = Bs + (wa * 4 * 2 + lh) * BN + li;
+
+    f32x16 acc[4][NT];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[b][nt][e] = 0.f;
+
+    load_chunk(0);
+    for (int c = 0; c < p.cin_chunks; ++c) {
+        store_chunk();
+        __syncthreads();
+        if (c + 1 < p.cin_chunks) load_chunk(c + 1);
+        // halo column j of the tile: plane (j & 1), slot + (j >> 1)
+        const f32x4 t0 = s0 * A0[0] + s1 * A1[0];
+        const f32x4 t1 = s0 * A0[PLANE] + s1 * A1[PLANE];
+        const f32x4 t2 = s0 * A0[1] + s1 * A1[1];
+        const f32x4 t3 = s0 * A0[PLANE + 1] + s1 * A1[PLANE + 1];
+        f32x4 V[4];
+        V[0] = t0 - t2; V[1] = t1 + t2; V[2] = t2 - t1; V[3] = t1 - t3;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 w = Bp[b * 2 * BN + nt * 32];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[b][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b][e], w[e], acc[b][nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- R_a = M[a][:] A in registers, exchange through LDS: Rs[a][jp][nt][e/4][lane][4] ----
+    f32x4* Rs = reinterpret_cast<f32x4*>(smem);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            f32x4 ra, rb;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = e4 * 4 + k;
+                ra[k] = acc[0][nt][e] + acc[1][nt][e] + acc[2][nt][e];
+                rb[k] = acc[1][nt][e] - acc[2][nt][e] - acc[3][nt][e];
+            }
+            Rs[(((wa * 2 + 0) * NT + nt) * 4 + e4) * 64 + lane] = ra;
+            Rs[(((wa * 2 + 1) * NT + nt) * 4 + e4) * 64 + lane] = rb;
+        }
+    }
+    __syncthreads();
+    const int Hout = p.out.h, Wout = p.out.w, Cout = p.out.c;
+    for (int combo = wa; combo < 2 * NT; combo += 4) {
+        const int jp = combo & 1, nt = combo >> 1;
+        const int co = n0 + nt * 32 + li;
+        const bool co_ok = co < Cout;
+        const float bv = (p.bias != nullptr && co_ok) ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            const f32x4 q0 = Rs[(((0 * 2 + jp) * NT + nt) * 4 + e4) * 64 + lane];
+            const f32x4 q1 = Rs[(((1 * 2 + jp) * NT + nt) * 4 + e4) * 64 + lane];
+            const f32x4 q2 = Rs[(((2 * 2 + jp) * NT + nt) * 4 + e4) * 64 + lane];
+            const f32x4 q3 = Rs[(((3 * 2 + jp) * NT + nt) * 4 + e4) * 64 + lane];
+            const f32x4 y0v = q0 + q1 + q2;
+            const f32x4 y1v = q1 - q2 - q3;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // accumulator row -> tile: t = (e & 3) + 8 * (e >> 2) + 4 * lh with e = 4 * e4 + k; TTX = 8
+                const int tty = e4, ttx = k + 4 * lh;
+                const int ox = ox0 + 2 * ttx + jp;
+                const int oy = oy0 + 2 * tty;
+                if (co_ok && ox < Wout) {
+                    if (oy < Hout)
+                        p.out.p[(((size_t)img * Hout + oy) * Wout + ox) * p.out.cs + co] = apply_act(y0v[k] + bv, p.act, p.alpha);
+                    if (oy + 1 < Hout)
+                        p.out.p[(((size_t)img * Hout + oy + 1) * Wout + ox) * p.out.cs + co] = apply_act(y1v[k] + bv, p.act, p.alpha);
+                }
+            }
+        }
+    }
+}
+
+template <int NT>
+static hipError_t launch_conv_wino_t(const ConvParams& p, hipStream_t s) {
+    constexpr int BN = NT * 32;
+    const int tiles_x = (p.out.w + 15) / 16, tiles_y = (p.out.h + 7) / 8;
+    const int nblk_n = p.coutp / BN;
+    size_t lds = (size_t)(4 * 120 + 16 * 2 * BN) * 16;
+    const size_t lds_epi = (size_t)4 * 2 * NT * 4 * 64 * 16;
+    if (lds_epi > lds) lds = lds_epi;
+    const size_t grid = (size_t)p.n * tiles_x * tiles_y * nblk_n;
+    if (grid == 0) return hipSuccess;
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_wino_kernel<NT>), dim3((unsigned)grid), dim3(256), lds, s, p, tiles_x, tiles_y, nblk_n);
+    return hipGetLastError();
+}
+
+int conv_wino_ntile(int cout) { return (cout % 64 == 0 || cout > 64) ? 64 : 32; }
+
+hipError_t launch_conv_wino(const ConvParams& p, hipStream_t s) {
+    return conv_wino_ntile(p.out.c) == 64 ? launch_conv_wino_t<2>(p, s) : launch_conv_wino_t<1>(p, s);
+}
+
 int conv_mfma_ntile(int cout) {
     if (cout % 128 == 0) return 128;
     if (cout % 64 == 0 || cout > 64) return 64;

@@ -107,3 +107,32 @@ def test_conv_numpy_crosscheck_of_oracle():
     want = oracle_unet.conv_numpy(x, k, b)
     got = oracle_unet.forward(cfg, {'c': [k, b]}, x)
     assert np.abs(got - want).max() < 1e-4
+
+
+@pytest.mark.parametrize('cin,cout,hw', [(64, 64, (64, 96)), (16, 32, (20, 40)), (128, 192, (16, 16)), (40, 72, (37, 53))])
+def test_winograd_matches_direct_and_oracle(gpu, cin, cout, hw):
+    """The Winograd F(2x2,3x3) kernel and the direct implicit-GEMM kernel are both fp32; they must agree with each other
+    and with the oracle well inside the 1e-3 tolerance (incl. image sizes that are not multiples of the 8x16 tile)."""
+    rng = np.random.default_rng(cin + cout)
+    H, W = hw
+    cfg = {'class_name': 'Functional', 'config': {'name': 'm', 'layers': [
+        {'class_name': 'InputLayer', 'name': 'in', 'config': {'name': 'in', 'batch_input_shape': [None, H, W, cin]},
+         'inbound_nodes': []},
+        {'class_name': 'Conv2D', 'name': 'c', 'config': {'name': 'c', 'filters': cout, 'kernel_size': [3, 3],
+                                                         'strides': [1, 1], 'padding': 'same', 'activation': 'relu',
+                                                         'use_bias': True}, 'inbound_nodes': [[['in', 0, 0, {}]]]}],
+        'input_layers': [['in', 0, 0]], 'output_layers': [['c', 0, 0]]}}
+    weights = {'c': [(rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin) / 64).astype(np.float32),
+                     rng.normal(size=cout).astype(np.float32)]}
+    x = rng.integers(0, 256, size=(3, H, W, cin), dtype=np.uint8)
+    want = oracle_unet.forward(cfg, weights, x)
+    try:
+        gpu.set_option('winograd', 1)
+        wino, _ = _run(gpu, cfg, weights, x, fuse=True)
+        gpu.set_option('winograd', 0)
+        direct = gpu.forward_patches(x)
+    finally:
+        gpu.set_option('winograd', 1)
+    scale = max(1.0, float(np.abs(want).max()))
+    assert np.abs(direct - want).max() < 1e-4 * scale
+    assert np.abs(wino - want).max() < 2e-4 * scale, np.abs(wino - want).max()

@@ -15,6 +15,8 @@
 //   As[half h][halo pixel][4 ch]           channels 4h .. 4h+3 of the chunk
 //   Bs[tap][half h][out channel][4 ch]
 // Global filter layout (re-laid out once at model load): wt[tap][chunk][h][N padded][4].
+#include <cstdlib>
+
 #include "common.h"
 
 namespace ecseg {
@@ -223,9 +225,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p, int til
     constexpr int B_PIECES = 16 * 2 * BN;
     constexpr int B_PER_T = B_PIECES / 256;
 
+    // double-buffered: [As0 | As1 | Bs0 | Bs1]; the filter slab goes global -> LDS directly (LDS-DMA, no VGPR staging)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* As = reinterpret_cast<f32x4*>(smem);
-    f32x4* Bs = As + A_SLOTS;
+    f32x4* Bs = As + 2 * A_SLOTS;
 
     const int tid = threadIdx.x;
     // spatial position fastest, output-channel block slowest: the workgroups that run together on one XCD stream the
@@ -266,8 +269,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p, int til
         const int h = rem / BN, j = rem - h * BN;
         b_off[k] = (long)(tap * tap_stride + ((size_t)h * p.coutp + n0 + j) * 4);
     }
-    f32x4 a_reg[A_PER_T], b_reg[B_PER_T];
-    auto load_chunk = [&](int c) {
+    f32x4 a_reg[A_PER_T];
+    auto load_a = [&](int c) {
 #pragma unroll
         for (int k = 0; k < A_PER_T; ++k) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -275,16 +278,20 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p, int til
                 v = *reinterpret_cast<const f32x4*>(p.in.p + a_off[k] + (size_t)c * 8);
             a_reg[k] = v;
         }
-#pragma unroll
-        for (int k = 0; k < B_PER_T; ++k)
-            b_reg[k] = *reinterpret_cast<const f32x4*>(p.wt + b_off[k] + (size_t)c * chunk_stride);
     };
-    auto store_chunk = [&]() {
+    auto store_a = [&](int buf) {
 #pragma unroll
         for (int k = 0; k < A_PER_T; ++k)
-            if (a_lds[k] >= 0) As[a_lds[k]] = a_reg[k];
+            if (a_lds[k] >= 0) As[buf * A_SLOTS + a_lds[k]] = a_reg[k];
+    };
+    auto dma_b = [&](int c, int buf) {          // LDS destination = wave base + lane * 16: the slab image is lane-linear
 #pragma unroll
-        for (int k = 0; k < B_PER_T; ++k) Bs[tid + k * 256] = b_reg[k];
+        for (int k = 0; k < B_PER_T; ++k) {
+            const float* g = p.wt + b_off[k] + (size_t)c * chunk_stride;
+            typedef const __attribute__((address_space(1))) void* gptr_t;
+            typedef __attribute__((address_space(3))) void* lptr_t;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Bs + buf * B_PIECES + tid + k * 256), 16, 0, 0);
+        }
     };
 
     const int lane = tid & 63, wa = tid >> 6;              // wave = transform row a
@@ -293,9 +300,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p, int til
     // row transform of wave a: t = s0 * d[r0] + s1 * d[r1]
     const int r0 = (wa == 0) ? 0 : 1, r1 = (wa == 3) ? 3 : 2;
     const float s0 = (wa == 2) ? -1.f : 1.f, s1 = (wa == 0 || wa == 3) ? -1.f : 1.f;
-    const f32x4* A0 = As + (lh * 2) * PLANE + (2 * ti + r0) * CS + tj;     // even columns (j = 0, 2)
-    const f32x4* A1 = As + (lh * 2) * PLANE + (2 * ti + r1) * CS + tj;
-    const f32x4* Bp = Bs + (wa * 4 * 2 + lh) * BN + li;
+    const int a0_off = (lh * 2) * PLANE + (2 * ti + r0) * CS + tj;         // even columns (j = 0, 2)
+    const int a1_off = (lh * 2) * PLANE + (2 * ti + r1) * CS + tj;
+    const int b_lane = (wa * 4 * 2 + lh) * BN + li;
 
     f32x16 acc[4][NT];
 #pragma unroll
@@ -305,28 +312,45 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p, int til
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[b][nt][e] = 0.f;
 
-    load_chunk(0);
+    load_a(0);
+    dma_b(0, 0);
+    store_a(0);
+    __syncthreads();                                       // (hipcc drains vmcnt before the barrier: slab 0 has landed)
     for (int c = 0; c < p.cin_chunks; ++c) {
-        store_chunk();
-        __syncthreads();
-        if (c + 1 < p.cin_chunks) load_chunk(c + 1);
+        const int cur = c & 1;
+        const bool more = c + 1 < p.cin_chunks;
+        if (more) { load_a(c + 1); dma_b(c + 1, cur ^ 1); }   // next chunk streams in under this chunk's MFMAs
+        const f32x4* A0 = As + cur * A_SLOTS + a0_off;
+        const f32x4* A1 = As + cur * A_SLOTS + a1_off;
+        const f32x4* Bp = Bs + cur * B_PIECES + b_lane;
+        // issue every LDS read of the chunk first (8 halo + 4*NT filter fragments), then transform, then 32 MFMAs
+        // back to back: one LDS wait per chunk instead of one per transform point
+        const f32x4 d00 = A0[0], d10 = A1[0], d01 = A0[PLANE], d11 = A1[PLANE];
+        const f32x4 d02 = A0[1], d12 = A1[1], d03 = A0[PLANE + 1], d13 = A1[PLANE + 1];
+        f32x4 w[4][NT];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) w[b][nt] = Bp[b * 2 * BN + nt * 32];
         // halo column j of the tile: plane (j & 1), slot + (j >> 1)
-        const f32x4 t0 = s0 * A0[0] + s1 * A1[0];
-        const f32x4 t1 = s0 * A0[PLANE] + s1 * A1[PLANE];
-        const f32x4 t2 = s0 * A0[1] + s1 * A1[1];
-        const f32x4 t3 = s0 * A0[PLANE + 1] + s1 * A1[PLANE + 1];
+        const f32x4 t0 = s0 * d00 + s1 * d10;
+        const f32x4 t1 = s0 * d01 + s1 * d11;
+        const f32x4 t2 = s0 * d02 + s1 * d12;
+        const f32x4 t3 = s0 * d03 + s1 * d13;
         f32x4 V[4];
         V[0] = t0 - t2; V[1] = t1 + t2; V[2] = t2 - t1; V[3] = t1 - t3;
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const f32x4 w = Bp[b * 2 * BN + nt * 32];
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    acc[b][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b][e], w[e], acc[b][nt], 0, 0, 0);
+                    acc[b][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b][e], w[b][nt][e], acc[b][nt], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
+        if (more) store_a(cur ^ 1);
         __syncthreads();
     }
 
@@ -384,9 +408,10 @@ static hipError_t launch_conv_wino_t(const ConvParams& p, hipStream_t s) {
     constexpr int BN = NT * 32;
     const int tiles_x = (p.out.w + 15) / 16, tiles_y = (p.out.h + 7) / 8;
     const int nblk_n = p.coutp / BN;
-    size_t lds = (size_t)(4 * 120 + 16 * 2 * BN) * 16;
+    size_t lds = (size_t)2 * (4 * 120 + 16 * 2 * BN) * 16;
     const size_t lds_epi = (size_t)4 * 2 * NT * 4 * 64 * 16;
     if (lds_epi > lds) lds = lds_epi;
+    if (const char* ev = getenv("ECSEG_WINO_LDS_KB")) { const size_t v = (size_t)atoi(ev) * 1024; if (v > lds) lds = v; }
     const size_t grid = (size_t)p.n * tiles_x * tiles_y * nblk_n;
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -54,6 +55,7 @@ struct ecseg_ctx {
     std::vector<float*> bufs;
     int cap_patches = 0;
     std::vector<float*> dev_allocs;       // weight allocations (freed on reload / destroy)
+    float* zero_page = nullptr;           // 256 bytes of zeros
     int input_tensor = -1, output_tensor = -1;
     double flops_per_patch = 0.0, mfma_flops_per_patch = 0.0;
 
@@ -225,7 +227,8 @@ int run_plan(ecseg_ctx* h, int n) {
                 if (o.path == PATH_MFMA) {
                     ConvParams p{};
                     p.in = in; p.out = out; p.wt = o.wt; p.bias = o.bias; p.n = n;
-                    p.act = act; p.alpha = d.alpha; p.cin_chunks = o.cin_chunks; p.coutp = o.coutp;
+                    p.act = act; p.alpha = d.alpha; p.cin_chunks = o.cin_chunks; p.coutp = o.coutp; p.zero = h->zero_page;
+                    { static const int abl = getenv("ECSEG_WINO_ABLATE") ? atoi(getenv("ECSEG_WINO_ABLATE")) : 0; p.ablate = abl; }
                     if (d.op == ECSEG_OP_CONV) {
                         p.R = d.kh; p.S = d.kw; p.pad_top = d.pad_top; p.pad_left = d.pad_left; p.convt = 0;
                     } else {
@@ -474,6 +477,8 @@ int ecseg_create(ecseg_ctx** out, int device_id) {
         return fail_hip(nullptr, e, "hipStreamCreate");
     }
     for (auto& ev : h->ev) (void)hipEventCreate(&ev);
+    if (hipMalloc(reinterpret_cast<void**>(&h->zero_page), 256) == hipSuccess) (void)hipMemset(h->zero_page, 0, 256);
+    else h->zero_page = nullptr;
     *out = h;
     return ECSEG_OK;
 }
@@ -485,6 +490,7 @@ void ecseg_destroy(ecseg_ctx* h) {
     (void)hipStreamSynchronize(h->stream2);
     free_model(h);
     for (auto& kv : h->stitch) { (void)hipFree(kv.second.pos_dev); (void)hipFree(kv.second.map_dev); }
+    if (h->zero_page) (void)hipFree(h->zero_page);
     void* ptrs[] = {h->d_gray, h->d_raw, h->d_post, h->d_aux8, h->d_u8in, h->d_i32, h->d_i64, h->d_probs_in, h->d_hist,
                     h->ws.L, h->ws.area, h->ws.sumy, h->ws.sumx, h->ws.flag, h->ws.tmpA, h->ws.tmpB, h->ws.list, h->ws.g};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -595,7 +601,7 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
                     o.cin_chunks = (cin + 7) / 8;
                     if ((rc = upload(h, relayout_conv(kw, d.kh, d.kw, cin, cout, o.cin_chunks, o.coutp), &o.wt))) return rc;
                     h->mfma_flops_per_patch += o.flops;
-                    if (d.kh == 3 && d.pad_top == 1 && d.pad_left == 1 && to.h == ti.h && to.w == ti.w && cout >= 32) {
+                    if (d.kh == 3 && d.pad_top == 1 && d.pad_left == 1 && to.h == ti.h && to.w == ti.w && cout >= 32 && cout % 4 == 0 && out_al) {
                         const int bnw = conv_wino_ntile(cout);
                         o.coutp_wino = (cout + bnw - 1) / bnw * bnw;
                         const std::vector<float> u = winograd_filter(kw, cin, cout);

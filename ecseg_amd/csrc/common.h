@@ -28,6 +28,8 @@ struct ConvParams {
     // transposed-conv mode (R = S = 1 in the GEMM, kT x kT stride-kT scatter in the epilogue)
     int convt;          // 0 | 1
     int kT, crop_top, crop_left;
+    const float* zero;  // >= 16 bytes of zeros in device memory (LDS-DMA source for padding / out-of-image pixels)
+    int ablate;         // diagnostics only (ECSEG_WINO_ABLATE): 1 skip DMA, 2 skip transform reads, 4 skip MFMAs
 };
 
 // ---- launchers implemented in unet_kernels.hip --------------------------------------------------------------

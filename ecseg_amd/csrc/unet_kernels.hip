@@ -212,15 +212,65 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p, int tiles_
 //
 // LDS: As[h][col parity][10 rows][12 (9 used)][4ch] - even / odd halo columns in separate planes and a row pitch of
 // 12 slots make every ds_read_b128 of the 4 x 8 tile lanes conflict-free; Bs[point 16][h][BN][4ch].
+// Winograd output stage shared by the kernels below.  The four waves (transform rows a = 0..3) of a row tile fold
+// their own row in registers (R_a = M[a][:] A), meet through LDS in a [a][jp][tile][channel] image, and every lane then
+// finishes 4 consecutive output channels of one pixel pair: Y = A^T R + bias, activation, two 16-byte stores.  A wave
+// instruction writes 4 pixels x 256 B: 8 store instructions per wave instead of 64 dword stores.
 template <int NT>
-__global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p, int tiles_x, int tiles_y, int nblk_n) {
-    constexpr int TTY = 4, TTX = 8;
-    constexpr int HR = 2 * TTY + 2, HC = 2 * TTX + 2;       // 10 x 18 halo pixels
+__device__ __forceinline__ void wino_write_R(float* Rs, const f32x16 (&acc)[4][NT], int wa, int lane) {
+    constexpr int BN = NT * 32;
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int t = (e & 3) + 8 * (e >> 2) + 4 * lh;           // accumulator row = tile index inside the row tile
+            const float ra = acc[0][nt][e] + acc[1][nt][e] + acc[2][nt][e];
+            const float rb = acc[1][nt][e] - acc[2][nt][e] - acc[3][nt][e];
+            Rs[((wa * 2 + 0) * 32 + t) * BN + nt * 32 + li] = ra;
+            Rs[((wa * 2 + 1) * 32 + t) * BN + nt * 32 + li] = rb;
+        }
+}
+
+template <int NT>
+__device__ __forceinline__ void wino_store_Y(const float* Rs, const ConvParams& p, int img, int oy0, int ox0, int n0, int wa,
+                                             int lane) {
+    constexpr int BN = NT * 32;
+    constexpr int QN = BN / 4;                 // channel quads per pixel
+    constexpr int TPI = 64 / QN;               // tiles per wave instruction
+    const int q = lane % QN, tsub = lane / QN;
+    const int Hout = p.out.h, Wout = p.out.w, Cout = p.out.c;
+    const int co = n0 + 4 * q;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr && co + 3 < Cout) bv = *reinterpret_cast<const f32x4*>(p.bias + co);
+    // 32 tiles x 2 column parities, 4 waves x TPI tiles per step
+    for (int it = wa; it < (32 / TPI) * 2; it += 4) {
+        const int jp = it & 1, t = (it >> 1) * TPI + tsub;
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(Rs + ((0 * 2 + jp) * 32 + t) * BN + 4 * q);
+        const f32x4 q1 = *reinterpret_cast<const f32x4*>(Rs + ((1 * 2 + jp) * 32 + t) * BN + 4 * q);
+        const f32x4 q2 = *reinterpret_cast<const f32x4*>(Rs + ((2 * 2 + jp) * 32 + t) * BN + 4 * q);
+        const f32x4 q3 = *reinterpret_cast<const f32x4*>(Rs + ((3 * 2 + jp) * 32 + t) * BN + 4 * q);
+        f32x4 y0 = q0 + q1 + q2 + bv, y1 = q1 - q2 - q3 + bv;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { y0[k] = apply_act(y0[k], p.act, p.alpha); y1[k] = apply_act(y1[k], p.act, p.alpha); }
+        const int oy = oy0 + 2 * (t >> 3), ox = ox0 + 2 * (t & 7) + jp;
+        if (co + 3 < Cout && ox < Wout) {
+            float* o = p.out.p + (((size_t)img * Hout + oy) * Wout + ox) * p.out.cs + co;
+            if (oy < Hout) *reinterpret_cast<f32x4*>(o) = y0;
+            if (oy + 1 < Hout) *reinterpret_cast<f32x4*>(o + (size_t)Wout * p.out.cs) = y1;
+        }
+    }
+}
+
+template <int NT, int MT>
+__global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void conv_wino_kernel(ConvParams p, int tiles_x, int tiles_y, int nblk_n) {
+    constexpr int TTY = 4 * MT, TTX = 8;                     // MT MFMA row tiles of 4 x 8 Winograd tiles each
+    constexpr int HR = 2 * TTY + 2, HC = 2 * TTX + 2;       // halo: (8 MT + 2) x 18 pixels
     constexpr int CS = 12;                                   // slots per (plane, row): 9 used
-    constexpr int PLANE = HR * CS;                           // 120
+    constexpr int PLANE = HR * CS;
     constexpr int A_SLOTS = 4 * PLANE;                       // [h][parity]
     constexpr int BN = NT * 32;
-    constexpr int A_PIECES = HR * HC * 2;                    // 360
+    constexpr int A_PIECES = HR * HC * 2;
     constexpr int A_PER_T = (A_PIECES + 255) / 256;
     constexpr int B_PIECES = 16 * 2 * BN;
     constexpr int B_PER_T = B_PIECES / 256;
@@ -304,13 +354,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p, int til
     const int a1_off = (lh * 2) * PLANE + (2 * ti + r1) * CS + tj;
     const int b_lane = (wa * 4 * 2 + lh) * BN + li;
 
-    f32x16 acc[4][NT];
+    f32x16 acc[MT][4][NT];
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int b = 0; b < 4; ++b)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[b][nt][e] = 0.f;
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[m][b][nt][e] = 0.f;
 
     load_a(0);
     dma_b(0, 0);
@@ -323,92 +375,61 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p, int til
         const f32x4* A0 = As + cur * A_SLOTS + a0_off;
         const f32x4* A1 = As + cur * A_SLOTS + a1_off;
         const f32x4* Bp = Bs + cur * B_PIECES + b_lane;
-        // issue every LDS read of the chunk first (8 halo + 4*NT filter fragments), then transform, then 32 MFMAs
-        // back to back: one LDS wait per chunk instead of one per transform point
-        const f32x4 d00 = A0[0], d10 = A1[0], d01 = A0[PLANE], d11 = A1[PLANE];
-        const f32x4 d02 = A0[1], d12 = A1[1], d03 = A0[PLANE + 1], d13 = A1[PLANE + 1];
+        // issue the LDS reads of the chunk first (8 halo fragments per row tile + 4*NT filter fragments), then
+        // transform, then 32*MT MFMAs back to back; the second row tile's transform overlaps the first one's MFMAs
+        f32x4 d[MT][8];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int ro = m * 8 * CS;                     // row tile m starts 8 halo rows further down
+            d[m][0] = A0[ro]; d[m][1] = A1[ro]; d[m][2] = A0[ro + PLANE]; d[m][3] = A1[ro + PLANE];
+            d[m][4] = A0[ro + 1]; d[m][5] = A1[ro + 1]; d[m][6] = A0[ro + PLANE + 1]; d[m][7] = A1[ro + PLANE + 1];
+        }
         f32x4 w[4][NT];
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) w[b][nt] = Bp[b * 2 * BN + nt * 32];
-        // halo column j of the tile: plane (j & 1), slot + (j >> 1)
-        const f32x4 t0 = s0 * d00 + s1 * d10;
-        const f32x4 t1 = s0 * d01 + s1 * d11;
-        const f32x4 t2 = s0 * d02 + s1 * d12;
-        const f32x4 t3 = s0 * d03 + s1 * d13;
-        f32x4 V[4];
-        V[0] = t0 - t2; V[1] = t1 + t2; V[2] = t2 - t1; V[3] = t1 - t3;
-        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+        for (int m = 0; m < MT; ++m) {
+            // halo column j of the tile: plane (j & 1), slot + (j >> 1)
+            const f32x4 t0 = s0 * d[m][0] + s1 * d[m][1];
+            const f32x4 t1 = s0 * d[m][2] + s1 * d[m][3];
+            const f32x4 t2 = s0 * d[m][4] + s1 * d[m][5];
+            const f32x4 t3 = s0 * d[m][6] + s1 * d[m][7];
+            f32x4 V[4];
+            V[0] = t0 - t2; V[1] = t1 + t2; V[2] = t2 - t1; V[3] = t1 - t3;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
+            for (int b = 0; b < 4; ++b) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    acc[b][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b][e], w[b][nt][e], acc[b][nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[m][b][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b][e], w[b][nt][e], acc[m][b][nt], 0, 0, 0);
+                }
             }
         }
-        __builtin_amdgcn_s_setprio(0);
         if (more) store_a(cur ^ 1);
         __syncthreads();
     }
 
-    // ---- R_a = M[a][:] A in registers, exchange through LDS: Rs[a][jp][nt][e/4][lane][4] ----
-    f32x4* Rs = reinterpret_cast<f32x4*>(smem);
+    // ---- output stage, one row tile at a time (wino_write_R / wino_store_Y) ----
+    float* Rs = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-        for (int e4 = 0; e4 < 4; ++e4) {
-            f32x4 ra, rb;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int e = e4 * 4 + k;
-                ra[k] = acc[0][nt][e] + acc[1][nt][e] + acc[2][nt][e];
-                rb[k] = acc[1][nt][e] - acc[2][nt][e] - acc[3][nt][e];
-            }
-            Rs[(((wa * 2 + 0) * NT + nt) * 4 + e4) * 64 + lane] = ra;
-            Rs[(((wa * 2 + 1) * NT + nt) * 4 + e4) * 64 + lane] = rb;
-        }
-    }
-    __syncthreads();
-    const int Hout = p.out.h, Wout = p.out.w, Cout = p.out.c;
-    for (int combo = wa; combo < 2 * NT; combo += 4) {
-        const int jp = combo & 1, nt = combo >> 1;
-        const int co = n0 + nt * 32 + li;
-        const bool co_ok = co < Cout;
-        const float bv = (p.bias != nullptr && co_ok) ? p.bias[co] : 0.f;
-#pragma unroll
-        for (int e4 = 0; e4 < 4; ++e4) {
-            const f32x4 q0 = Rs[(((0 * 2 + jp) * NT + nt) * 4 + e4) * 64 + lane];
-            const f32x4 q1 = Rs[(((1 * 2 + jp) * NT + nt) * 4 + e4) * 64 + lane];
-            const f32x4 q2 = Rs[(((2 * 2 + jp) * NT + nt) * 4 + e4) * 64 + lane];
-            const f32x4 q3 = Rs[(((3 * 2 + jp) * NT + nt) * 4 + e4) * 64 + lane];
-            const f32x4 y0v = q0 + q1 + q2;
-            const f32x4 y1v = q1 - q2 - q3;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                // accumulator row -> tile: t = (e & 3) + 8 * (e >> 2) + 4 * lh with e = 4 * e4 + k; TTX = 8
-                const int tty = e4, ttx = k + 4 * lh;
-                const int ox = ox0 + 2 * ttx + jp;
-                const int oy = oy0 + 2 * tty;
-                if (co_ok && ox < Wout) {
-                    if (oy < Hout)
-                        p.out.p[(((size_t)img * Hout + oy) * Wout + ox) * p.out.cs + co] = apply_act(y0v[k] + bv, p.act, p.alpha);
-                    if (oy + 1 < Hout)
-                        p.out.p[(((size_t)img * Hout + oy + 1) * Wout + ox) * p.out.cs + co] = apply_act(y1v[k] + bv, p.act, p.alpha);
-                }
-            }
-        }
+    for (int m = 0; m < MT; ++m) {
+        if (m) __syncthreads();
+        wino_write_R<NT>(Rs, acc[m], wa, lane);
+        __syncthreads();
+        wino_store_Y<NT>(Rs, p, img, oy0 + 8 * m, ox0, n0, wa, lane);
     }
 }
 
-template <int NT>
+template <int NT, int MT>
 static hipError_t launch_conv_wino_t(const ConvParams& p, hipStream_t s) {
     constexpr int BN = NT * 32;
-    const int tiles_x = (p.out.w + 15) / 16, tiles_y = (p.out.h + 7) / 8;
+    constexpr int TTY = 4 * MT;
+    const int tiles_x = (p.out.w + 15) / 16, tiles_y = (p.out.h + 2 * TTY - 1) / (2 * TTY);
     const int nblk_n = p.coutp / BN;
-    size_t lds = (size_t)2 * (4 * 120 + 16 * 2 * BN) * 16;
+    size_t lds = (size_t)2 * (4 * (2 * TTY + 2) * 12 + 16 * 2 * BN) * 16;
     const size_t lds_epi = (size_t)4 * 2 * NT * 4 * 64 * 16;
     if (lds_epi > lds) lds = lds_epi;
     if (const char* ev = getenv("ECSEG_WINO_LDS_KB")) { const size_t v = (size_t)atoi(ev) * 1024; if (v > lds) lds = v; }
@@ -417,19 +438,217 @@ static hipError_t launch_conv_wino_t(const ConvParams& p, hipStream_t s) {
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<NT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<NT, MT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_wino_kernel<NT>), dim3((unsigned)grid), dim3(256), lds, s, p, tiles_x, tiles_y, nblk_n);
+    hipLaunchKernelGGL((conv_wino_kernel<NT, MT>), dim3((unsigned)grid), dim3(256), lds, s, p, tiles_x, tiles_y, nblk_n);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Winograd F(2x2,3x3), 8-wave "ping-pong" variant: 8 x 8 tiles (16 x 16 output pixels) x BN channels per workgroup.
+// Waves 0-3 (group A) and 4-7 (group B) own the upper / lower 4 x 8 tiles; inside a group the waves split the transform
+// rows exactly like conv_wino_kernel.  The filter slab (the dominant LDS fill traffic: 256 B per MFMA in the 4-wave
+// kernel) is shared by both groups -> 128 B per MFMA.  Each K-chunk has two phases separated by raw s_barriers:
+//     phase 1: group A issues its 32 MFMAs (operands already in registers)  | group B reads LDS + transforms chunk c
+//     phase 2: group A reads LDS + transforms chunk c+1                      | group B issues its 32 MFMAs
+// so every SIMD (one wave of each group) always has one wave feeding the matrix pipe.  Halo and filter slab both arrive
+// by LDS-DMA (global_load_lds, lane-linear LDS images, zero page for padding) two chunks ahead; the only waits are the
+// hand-placed vmcnt before phase 2 and lgkmcnt before each barrier.
+template <int NT>
+__global__ __launch_bounds__(512, 2) void conv_wino8_kernel(ConvParams p, int tiles_x, int tiles_y, int nblk_n) {
+    constexpr int HR = 18, CS = 12;
+    constexpr int PLANE = HR * CS;                           // 216
+    constexpr int A_SLOTS = 1024;                            // 4 planes x 216 = 864 used, padded to 2 DMA per thread
+    constexpr int BN = NT * 32;
+    constexpr int B_PIECES = 16 * 2 * BN;
+    constexpr int A_PER_T = A_SLOTS / 256;                   // 4: the DMA of a chunk is issued by ONE group (256 threads)
+    constexpr int B_PER_T = B_PIECES / 256;
+    constexpr int NDMA = A_PER_T + B_PER_T;                  // LDS-DMA instructions per issuing wave and chunk
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* As = reinterpret_cast<f32x4*>(smem);              // [2][A_SLOTS]   halo, double-buffered
+    f32x4* Bs = As + 2 * A_SLOTS;                            // [3][B_PIECES]  filter slab, triple-buffered
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    const int tid = threadIdx.x;
+    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = bid % tiles_x; bid /= tiles_x;
+    const int by = bid % tiles_y; bid /= tiles_y;
+    const int img = bid % p.n; bid /= p.n;
+    const int nb = bid;
+    const int ox0 = bx * 16, oy0 = by * 16;
+    const int n0 = nb * BN;
+    const int Hin = p.in.h, Win = p.in.w, Cin = p.in.c;
+    const float* in_base = p.in.p + (size_t)img * Hin * Win * p.in.cs;      // wave-uniform
+    const int nchunks = p.cin_chunks;
+
+    // ---- DMA source descriptors (32-bit offsets).  Thread t of the issuing group handles halo slots t + k * 256 and
+    //      filter pieces t + k * 256, t = tid & 255: the group that is NOT on the matrix pipe in a half-step issues the
+    //      whole chunk, so the MFMA group never spends issue slots on loads ----
+    const int t256 = tid & 255;
+    int a_off[A_PER_T];
+    bool a_hi[A_PER_T];
+#pragma unroll
+    for (int k = 0; k < A_PER_T; ++k) {
+        const int sl = t256 + k * 256;
+        a_off[k] = -1; a_hi[k] = false;
+        if (sl < 4 * PLANE) {
+            const int plane = sl / PLANE, rem = sl - plane * PLANE;
+            const int row = rem / CS, col = rem - row * CS;
+            const int h = plane >> 1, par = plane & 1;
+            const int iy = oy0 - 1 + row, ix = ox0 - 1 + 2 * col + par;
+            a_hi[k] = h != 0;
+            if (col < 9 && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) a_off[k] = (iy * Win + ix) * p.in.cs + h * 4;
+        }
+    }
+    const int chunk_stride = 2 * p.coutp * 4;                // floats between consecutive chunks of one transform point
+    const int tap_stride = chunk_stride * nchunks;
+    int b_off[B_PER_T];
+#pragma unroll
+    for (int k = 0; k < B_PER_T; ++k) {
+        const int q = t256 + k * 256;
+        const int tap = q / (2 * BN), rem = q - tap * 2 * BN;
+        const int h = rem / BN, j = rem - h * BN;
+        b_off[k] = tap * tap_stride + (h * p.coutp + n0 + j) * 4;
+    }
+    auto dma = [&](int c, int abuf, int bbuf) {
+#pragma unroll
+        for (int k = 0; k < A_PER_T; ++k) {
+            const float* g = (a_off[k] >= 0 && c * 8 + (a_hi[k] ? 4 : 0) < Cin) ? in_base + a_off[k] + c * 8 : p.zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(As + abuf * A_SLOTS + t256 + k * 256), 16, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < B_PER_T; ++k) {
+            const float* g = p.wt + b_off[k] + (size_t)c * chunk_stride;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Bs + bbuf * B_PIECES + t256 + k * 256), 16, 0, 0);
+        }
+    };
+
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wa = wave & 3;               // group = tile-row half, wa = transform row a
+    const int li = lane & 31, lh = lane >> 5;
+    const int ti = li >> 3, tj = li & 7;
+    const int r0 = (wa == 0) ? 0 : 1, r1 = (wa == 3) ? 3 : 2;
+    const float s0 = (wa == 2) ? -1.f : 1.f, s1 = (wa == 0 || wa == 3) ? -1.f : 1.f;
+    const int a0_off = (lh * 2) * PLANE + (8 * grp + 2 * ti + r0) * CS + tj;
+    const int a1_off = (lh * 2) * PLANE + (8 * grp + 2 * ti + r1) * CS + tj;
+    const int b_lane = (wa * 4 * 2 + lh) * BN + li;
+
+    f32x16 acc[4][NT];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[b][nt][e] = 0.f;
+    f32x4 V[4];
+
+    auto read_chunk = [&](int abuf) {                         // halo LDS -> registers, input transform
+        const f32x4* A0 = As + abuf * A_SLOTS + a0_off;
+        const f32x4* A1 = As + abuf * A_SLOTS + a1_off;
+        const f32x4 d00 = A0[0], d10 = A1[0], d01 = A0[PLANE], d11 = A1[PLANE];
+        const f32x4 d02 = A0[1], d12 = A1[1], d03 = A0[PLANE + 1], d13 = A1[PLANE + 1];
+        const f32x4 t0 = s0 * d00 + s1 * d10;
+        const f32x4 t1 = s0 * d01 + s1 * d11;
+        const f32x4 t2 = s0 * d02 + s1 * d12;
+        const f32x4 t3 = s0 * d03 + s1 * d13;
+        V[0] = t0 - t2; V[1] = t1 + t2; V[2] = t2 - t1; V[3] = t1 - t3;
+    };
+    auto mfma_chunk = [&](int bbuf) {                         // filter fragments stream from LDS beside the MFMAs
+        const f32x4* Bp = Bs + bbuf * B_PIECES + b_lane;
+        f32x4 wc[NT], wn[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wc[nt] = Bp[nt * 32];
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (b < 3) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) wn[nt] = Bp[(b + 1) * 2 * BN + nt * 32];   // next point's fragments
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[b][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b][e], wc[nt][e], acc[b][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wc[nt] = wn[nt];
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define WINO8_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+    // ---- prologue: group A fetches chunk 0, group B chunk 1; everybody waits for its own share ----
+    if (grp == 0) dma(0, 0, 0);
+    else if (nchunks > 1) dma(1, 1, 1);
+    if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WINO8_BARRIER();
+    // Half-steps hs = -1 .. 2n-1, one barrier each.  Group A issues the MFMAs of chunk c at hs = 2c and transforms chunk
+    // c+1 at hs = 2c+1; group B transforms chunk c at hs = 2c and issues its MFMAs at hs = 2c+1: the same instruction
+    // stream for both groups, shifted by one half-step.  The group that is not on the matrix pipe also issues the DMA of
+    // chunk c+2 (every second half-step), waits for it one full chunk later.
+    for (int hs = -1; hs < 2 * nchunks; ++hs) {
+        const int c = hs >> 1;                                 // chunk whose MFMAs run in this pair of half-steps
+        if (((hs ^ grp) & 1) == 0) {
+            if (c >= 0 && c < nchunks && !(p.ablate & 4)) mfma_chunk(c % 3);
+        } else {
+            const int rc = (hs + 1) >> 1;
+            if (rc < nchunks && !(p.ablate & 2)) read_chunk(rc & 1);
+            // odd hs (reader = group A): chunk c+2 goes into the buffers chunk c-1 / c just vacated
+            if ((hs & 1) && hs > 0 && c + 2 < nchunks && !(p.ablate & 1)) dma(c + 2, c & 1, (c + 2) % 3);
+        }
+        // DMA(c+1) was issued by group A at hs = 2c-1 (or by group B in the prologue for c = 0): it is needed by group A's
+        // transform at hs = 2c+1, so its issuers wait at the end of hs = 2c (one full chunk of flight time)
+        if (!(hs & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WINO8_BARRIER();
+    }
+#undef WINO8_BARRIER
+    __syncthreads();
+
+    // ---- output stage: each group of four waves finishes its own row tile ----
+    float* Rs = reinterpret_cast<float*>(smem) + grp * (4 * 2 * 32 * BN);
+    wino_write_R<NT>(Rs, acc, wa, lane);
+    __syncthreads();
+    if (p.ablate & 8) return;
+    wino_store_Y<NT>(Rs, p, img, oy0 + 8 * grp, ox0, n0, wa, lane);
+}
+
+template <int NT>
+static hipError_t launch_conv_wino8_t(const ConvParams& p, hipStream_t s) {
+    constexpr int BN = NT * 32;
+    const int tiles_x = (p.out.w + 15) / 16, tiles_y = (p.out.h + 15) / 16;
+    const int nblk_n = p.coutp / BN;
+    size_t lds = (size_t)(2 * 1024 + 3 * 16 * 2 * BN) * 16;
+    const size_t lds_epi = (size_t)2 * 4 * 2 * NT * 4 * 64 * 16;
+    if (lds_epi > lds) lds = lds_epi;
+    const size_t grid = (size_t)p.n * tiles_x * tiles_y * nblk_n;
+    if (grid == 0) return hipSuccess;
+    if (grid > 0x7fffffffull || p.zero == nullptr) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino8_kernel<NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_wino8_kernel<NT>), dim3((unsigned)grid), dim3(512), lds, s, p, tiles_x, tiles_y, nblk_n);
     return hipGetLastError();
 }
 
 int conv_wino_ntile(int cout) { return (cout % 64 == 0 || cout > 64) ? 64 : 32; }
 
 hipError_t launch_conv_wino(const ConvParams& p, hipStream_t s) {
-    return conv_wino_ntile(p.out.c) == 64 ? launch_conv_wino_t<2>(p, s) : launch_conv_wino_t<1>(p, s);
+    // ECSEG_WINO_VARIANT: 4 (default) = 4-wave kernel, 8 = 8-wave ping-pong kernel (measured slower), 42 = 4-wave kernel with two row tiles
+    static const int variant = getenv("ECSEG_WINO_VARIANT") ? atoi(getenv("ECSEG_WINO_VARIANT")) : 4;
+    const bool n64 = conv_wino_ntile(p.out.c) == 64;
+    if (variant == 8 && p.out.h >= 16 && p.zero != nullptr) return n64 ? launch_conv_wino8_t<2>(p, s) : launch_conv_wino8_t<1>(p, s);
+    if (variant == 42 && p.out.h >= 16) return n64 ? launch_conv_wino_t<2, 2>(p, s) : launch_conv_wino_t<1, 2>(p, s);
+    return n64 ? launch_conv_wino_t<2, 1>(p, s) : launch_conv_wino_t<1, 1>(p, s);
 }
 
 int conv_mfma_ntile(int cout) {

@@ -640,12 +640,193 @@ static hipError_t launch_conv_wino8_t(const ConvParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Winograd F(2x2,3x3), "whole transform per wave" variant.  Each wave owns a 4 x 8 block of tiles (8 x 16 output pixels)
+// x 32 output channels and ALL 16 transform points (256 accumulator registers, one wave per SIMD); the four waves of a
+// workgroup take four vertically stacked tile blocks (32 x 16 output pixels) and share one filter slab, so a slab
+// fragment is re-used by four MFMA row tiles (64 B of LDS fill per MFMA, like the direct kernel, instead of 256 B when
+// the waves split the transform points).  The 2-D input transform (128 packed adds) runs on the VALU beside the
+// matrix pipe, the next chunk's LDS-DMA pieces are issued one per transform point between the MFMAs, and the output
+// transform happens in registers - no cross-wave exchange at all.
+__global__ __launch_bounds__(256, 1) void conv_wino16_kernel(ConvParams p, int tiles_x, int tiles_y, int nblk_n) {
+    constexpr int HR = 34, CS = 12;
+    constexpr int PLANE = HR * CS;                           // 408
+    constexpr int A_USED = 4 * PLANE;                        // 1632 slots
+    constexpr int A_PER_T = 7;                               // 7 * 256 = 1792 slots (padding fed from the zero page)
+    constexpr int A_SLOTS = A_PER_T * 256;
+    constexpr int BN = 32;
+    constexpr int B_PIECES = 16 * 2 * BN;                    // 1024
+    constexpr int B_PER_T = B_PIECES / 256;                  // 4
+    constexpr int NDMA = A_PER_T + B_PER_T;                  // 11
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* As = reinterpret_cast<f32x4*>(smem);              // [3][A_SLOTS]   three stages: chunk c in use, c+1 landed
+    f32x4* Bs = As + 3 * A_SLOTS;                            // [3][B_PIECES]  or landing, c+2 in flight
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    const int tid = threadIdx.x;
+    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = bid % tiles_x; bid /= tiles_x;
+    const int by = bid % tiles_y; bid /= tiles_y;
+    const int img = bid % p.n; bid /= p.n;
+    const int nb = bid;
+    const int ox0 = bx * 16, oy0 = by * 32;
+    const int n0 = nb * BN;
+    const int Hin = p.in.h, Win = p.in.w, Cin = p.in.c;
+    const float* in_base = p.in.p + (size_t)img * Hin * Win * p.in.cs;
+    const int nchunks = p.cin_chunks;
+
+    int a_off[A_PER_T];
+    unsigned a_himask = 0;
+#pragma unroll
+    for (int k = 0; k < A_PER_T; ++k) {
+        const int sl = tid + k * 256;
+        a_off[k] = -1;
+        if (sl < A_USED) {
+            const int plane = sl / PLANE, rem = sl - plane * PLANE;
+            const int row = rem / CS, col = rem - row * CS;
+            const int h = plane >> 1, par = plane & 1;
+            const int iy = oy0 - 1 + row, ix = ox0 - 1 + 2 * col + par;
+            if (h) a_himask |= 1u << k;
+            if (col < 9 && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) a_off[k] = (iy * Win + ix) * p.in.cs + h * 4;
+        }
+    }
+    const int chunk_stride = 2 * p.coutp * 4;
+    const int tap_stride = chunk_stride * nchunks;
+    int b_off[B_PER_T];
+#pragma unroll
+    for (int k = 0; k < B_PER_T; ++k) {
+        const int q = tid + k * 256;
+        const int tap = q / (2 * BN), rem = q - tap * 2 * BN;
+        const int h = rem / BN, j = rem - h * BN;
+        b_off[k] = tap * tap_stride + (h * p.coutp + n0 + j) * 4;
+    }
+    auto dma_piece = [&](int c, int buf, int k) {            // k is a compile-time constant at every call site
+        if (k < A_PER_T) {
+            const bool ok = a_off[k] >= 0 && c * 8 + (((a_himask >> k) & 1u) ? 4 : 0) < Cin;
+            const float* g = ok ? in_base + a_off[k] + c * 8 : p.zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(As + buf * A_SLOTS + tid + k * 256), 16, 0, 0);
+        } else {
+            const float* g = p.wt + b_off[k - A_PER_T] + (size_t)c * chunk_stride;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Bs + buf * B_PIECES + tid + (k - A_PER_T) * 256), 16, 0, 0);
+        }
+    };
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int ti = li >> 3, tj = li & 7;
+    const int a_lane = (lh * 2) * PLANE + (8 * wave + 2 * ti) * CS + tj;   // raw pixel (r, j): + (j & 1) * PLANE + r * CS + (j >> 1)
+    const int b_lane = lh * BN + li;
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int x = 0; x < 16; ++x)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[x][e] = 0.f;
+
+#pragma unroll
+    for (int k = 0; k < NDMA; ++k) dma_piece(0, 0, k);
+    if (nchunks > 1) {
+#pragma unroll
+        for (int k = 0; k < NDMA; ++k) dma_piece(1, 1, k);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");      // chunk 0 landed, chunk 1 may still fly
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_barrier" ::: "memory");
+    int cur = 0, nxt2 = 2;                                   // stage of chunk c, stage that chunk c+2 goes to
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more2 = c + 2 < nchunks;
+        const f32x4* Ap = As + cur * A_SLOTS + a_lane;
+        const f32x4* Bp = Bs + cur * B_PIECES + b_lane;
+        // every LDS read of the chunk is issued up front (16 raw pixels + 16 filter fragments per lane): one exposed
+        // LDS latency per chunk; the transform of row a+1 then overlaps the MFMAs of row a
+        f32x4 V[16], w[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = (j & 1) * PLANE + (j >> 1);
+            V[0 * 4 + j] = Ap[o]; V[1 * 4 + j] = Ap[o + CS]; V[2 * 4 + j] = Ap[o + 2 * CS]; V[3 * 4 + j] = Ap[o + 3 * CS];
+        }
+#pragma unroll
+        for (int x = 0; x < 16; ++x) w[x] = Bp[x * 2 * BN];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                        // row transform (over the tile's rows), in place
+            const f32x4 d0 = V[0 * 4 + j], d1 = V[1 * 4 + j], d2 = V[2 * 4 + j], d3 = V[3 * 4 + j];
+            V[0 * 4 + j] = d0 - d2; V[1 * 4 + j] = d1 + d2; V[2 * 4 + j] = d2 - d1; V[3 * 4 + j] = d1 - d3;
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const f32x4 t0 = V[a * 4 + 0], t1 = V[a * 4 + 1], t2 = V[a * 4 + 2], t3 = V[a * 4 + 3];
+            V[a * 4 + 0] = t0 - t2; V[a * 4 + 1] = t1 + t2; V[a * 4 + 2] = t2 - t1; V[a * 4 + 3] = t1 - t3;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int x = a * 4 + b;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[x][e], w[x][e], acc[x], 0, 0, 0);
+                if (x < NDMA && more2) dma_piece(c + 2, nxt2, x);    // one LDS-DMA piece per transform point
+            }
+        }
+        // chunk c+1 must have landed; chunk c+2 (just issued) keeps flying across the barrier
+        if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        cur = (cur == 2) ? 0 : cur + 1;
+        nxt2 = (nxt2 == 2) ? 0 : nxt2 + 1;
+    }
+
+    // ---- output transform in registers: Y = A^T M A per (tile, channel), bias, activation, 128-byte row segments ----
+    const int Hout = p.out.h, Wout = p.out.w, Cout = p.out.c;
+    const int co = n0 + li;
+    const bool co_ok = co < Cout;
+    const float bv = (p.bias != nullptr && co_ok) ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        float R[4][2];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            R[a][0] = acc[a * 4 + 0][e] + acc[a * 4 + 1][e] + acc[a * 4 + 2][e];
+            R[a][1] = acc[a * 4 + 1][e] - acc[a * 4 + 2][e] - acc[a * 4 + 3][e];
+        }
+        const int t = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int oy = oy0 + 8 * wave + 2 * (t >> 3), ox = ox0 + 2 * (t & 7);
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+            const float y0 = R[0][jp] + R[1][jp] + R[2][jp] + bv;
+            const float y1 = R[1][jp] - R[2][jp] - R[3][jp] + bv;
+            if (co_ok && ox + jp < Wout) {
+                if (oy < Hout) p.out.p[(((size_t)img * Hout + oy) * Wout + ox + jp) * p.out.cs + co] = apply_act(y0, p.act, p.alpha);
+                if (oy + 1 < Hout) p.out.p[(((size_t)img * Hout + oy + 1) * Wout + ox + jp) * p.out.cs + co] = apply_act(y1, p.act, p.alpha);
+            }
+        }
+    }
+}
+
+static hipError_t launch_conv_wino16(const ConvParams& p, hipStream_t s) {
+    const int tiles_x = (p.out.w + 15) / 16, tiles_y = (p.out.h + 31) / 32;
+    const int nblk_n = p.coutp / 32;
+    const size_t lds = (size_t)3 * (7 * 256 + 1024) * 16;     // 135168 bytes
+    const size_t grid = (size_t)p.n * tiles_x * tiles_y * nblk_n;
+    if (grid == 0) return hipSuccess;
+    if (grid > 0x7fffffffull || p.zero == nullptr) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino16_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_wino16_kernel, dim3((unsigned)grid), dim3(256), lds, s, p, tiles_x, tiles_y, nblk_n);
+    return hipGetLastError();
+}
+
 int conv_wino_ntile(int cout) { return (cout % 64 == 0 || cout > 64) ? 64 : 32; }
 
 hipError_t launch_conv_wino(const ConvParams& p, hipStream_t s) {
     // ECSEG_WINO_VARIANT: 4 (default) = 4-wave kernel, 8 = 8-wave ping-pong kernel (measured slower), 42 = 4-wave kernel with two row tiles
     static const int variant = getenv("ECSEG_WINO_VARIANT") ? atoi(getenv("ECSEG_WINO_VARIANT")) : 4;
     const bool n64 = conv_wino_ntile(p.out.c) == 64;
+    if (variant == 16 && p.out.h >= 32 && p.zero != nullptr && p.coutp % 32 == 0) return launch_conv_wino16(p, s);
     if (variant == 8 && p.out.h >= 16 && p.zero != nullptr) return n64 ? launch_conv_wino8_t<2>(p, s) : launch_conv_wino8_t<1>(p, s);
     if (variant == 42 && p.out.h >= 16) return n64 ? launch_conv_wino_t<2, 2>(p, s) : launch_conv_wino_t<1, 2>(p, s);
     return n64 ? launch_conv_wino_t<2, 1>(p, s) : launch_conv_wino_t<1, 1>(p, s);

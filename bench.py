@@ -67,6 +67,7 @@ def main():
     ap.add_argument('--base', type=int, default=64, help='U-Net base width of the synthetic model')
     ap.add_argument('--group', type=int, default=8, help='images per internal U-Net launch group')
     ap.add_argument('--overlap', action='store_true', help='run post-processing on a second stream')
+    ap.add_argument('--direct', action='store_true', help='direct implicit-GEMM 3x3 kernel instead of Winograd F(2x2,3x3)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     args = ap.parse_args()
@@ -92,6 +93,7 @@ def main():
     hnd = model.handle
     hnd.set_images_per_group(args.group)
     hnd.set_option('overlap_post', 1 if args.overlap else 0)
+    hnd.set_option('winograd', 0 if args.direct else 1)
     B = args.images
     total_images = B * world                       # weak scaling: per-GPU work fixed
     start, stop, per = edist.shard_bounds(total_images, rank, world)
@@ -118,7 +120,7 @@ def main():
         step()
     hnd.set_kernel_profiling(not args.no_kernel_profile)
     stage = {k: 0.0 for k in hnd.T_NAMES}
-    conv_ms = conv_flops = 0.0
+    conv_ms = conv_flops = conv_exec = 0.0
     conv_launches = 0
     barrier()
     t0 = time.perf_counter()
@@ -128,6 +130,7 @@ def main():
             stage[k] += v
         ms, nl, fl = hnd.conv_profile()
         conv_ms += ms; conv_launches += nl; conv_flops += fl
+        conv_exec += hnd.conv_executed_flops()
     barrier()
     dt = time.perf_counter() - t0
     hnd.set_kernel_profiling(False)
@@ -158,17 +161,25 @@ def main():
         if conv_launches:
             traffic = None
             try:        # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-                pmc = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_pmc_traffic.json'))
+                pmc = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_pmc_traffic.json')
+                             and (('direct' in f) == bool(args.direct)))
                 if pmc and args.base == 64:
                     traffic = json.load(open(os.path.join(ROOT, 'profiles', pmc[-1])))['conv_mfma_all']['hbm_bytes_per_launch']
             except Exception:
                 traffic = None
             ach = conv_flops / (conv_ms * 1e-3) / 1e12
-            res['roofline'] = {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM)',
+            exe = conv_exec / (conv_ms * 1e-3) / 1e12
+            res['roofline'] = {'bound': 'mfma',
+                               'kernel': ('conv_mfma_kernel (direct implicit GEMM)' if args.direct else
+                                          'conv_wino_kernel (Winograd F(2x2,3x3)) + conv_mfma_kernel (2x2 up-convs)') +
+                                         ', fp32 v_mfma_f32_32x32x2_f32',
                                'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
                                'avg_launch_ms': round(conv_ms / conv_launches, 4), 'launches': int(conv_launches),
-                               'flop_per_launch_avg': conv_flops / conv_launches}
+                               'flop_per_launch_avg': conv_flops / conv_launches,
+                               'note': 'achieved = ALGORITHMIC (direct-convolution) FLOPs / measured kernel time; Winograd '
+                                       'issues 16/36 of those multiplies, so frac can exceed 1',
+                               'executed_tflops': round(exe, 2), 'executed_frac': round(exe / PEAK_FP32_MFMA_TFLOPS, 4)}
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(cfg, weights, 1)
         print(json.dumps(res), flush=True)

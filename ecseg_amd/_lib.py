@@ -14,7 +14,7 @@ EXPORTS = [
     'ecseg_segment_images', 'ecseg_segment_images_dev', 'ecseg_set_images_per_group', 'ecseg_set_option', 'ecseg_preprocess', 'ecseg_u16_to_u8',
     'ecseg_stitch_argmax', 'ecseg_meta_inference', 'ecseg_meta_inference_dev', 'ecseg_count_cc', 'ecseg_ccl_labels',
     'ecseg_count_colocalization', 'ecseg_count_hsr', 'ecseg_overlay', 'ecseg_get_timings',
-    'ecseg_set_kernel_profiling', 'ecseg_get_conv_profile', 'ecseg_lzw_decode', 'ecseg_lzw_encode',
+    'ecseg_set_kernel_profiling', 'ecseg_get_conv_profile', 'ecseg_get_conv_executed_flops', 'ecseg_lzw_decode', 'ecseg_lzw_encode',
 ]
 
 
@@ -77,6 +77,7 @@ def load_library():
     lib.ecseg_get_timings.argtypes = [vp, vp]
     lib.ecseg_set_kernel_profiling.argtypes = [vp, i32]
     lib.ecseg_get_conv_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    lib.ecseg_get_conv_executed_flops.argtypes = [vp, C.POINTER(C.c_double)]
     for fn in (lib.ecseg_lzw_decode, lib.ecseg_lzw_encode):
         fn.argtypes = [vp, C.c_longlong, vp, C.c_longlong]
         fn.restype = C.c_longlong
@@ -313,3 +314,8 @@ class Handle:
         ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
         self._check(self.lib.ecseg_get_conv_profile(self.h, C.byref(ms), C.byref(n), C.byref(fl)), 'ecseg_get_conv_profile')
         return ms.value, n.value, fl.value
+
+    def conv_executed_flops(self):
+        fl = C.c_double()
+        self._check(self.lib.ecseg_get_conv_executed_flops(self.h, C.byref(fl)), 'ecseg_get_conv_executed_flops')
+        return fl.value

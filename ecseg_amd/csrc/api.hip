@@ -83,8 +83,8 @@ struct ecseg_ctx {
     bool profile_kernels = false;
     std::vector<hipEvent_t> prof_events;   // pairs
     size_t prof_used = 0;
-    double prof_flops = 0.0;
-    double last_conv_ms = 0.0; long long last_conv_launches = 0; double last_conv_flops = 0.0;
+    double prof_flops = 0.0, prof_exec_flops = 0.0;
+    double last_conv_ms = 0.0; long long last_conv_launches = 0; double last_conv_flops = 0.0, last_conv_exec_flops = 0.0;
 };
 
 namespace {
@@ -228,7 +228,7 @@ int run_plan(ecseg_ctx* h, int n) {
                     ConvParams p{};
                     p.in = in; p.out = out; p.wt = o.wt; p.bias = o.bias; p.n = n;
                     p.act = act; p.alpha = d.alpha; p.cin_chunks = o.cin_chunks; p.coutp = o.coutp; p.zero = h->zero_page;
-                    { static const int abl = getenv("ECSEG_WINO_ABLATE") ? atoi(getenv("ECSEG_WINO_ABLATE")) : 0; p.ablate = abl; }
+                    p.ablate = 0;
                     if (d.op == ECSEG_OP_CONV) {
                         p.R = d.kh; p.S = d.kw; p.pad_top = d.pad_top; p.pad_left = d.pad_left; p.convt = 0;
                     } else {
@@ -237,12 +237,18 @@ int run_plan(ecseg_ctx* h, int n) {
                     }
                     hipEvent_t* ev = h->profile_kernels ? prof_pair(h) : nullptr;
                     if (ev) (void)hipEventRecord(ev[0], s);
-                    if (h->use_winograd && o.wt_wino && out.h >= 4 && out.w >= 8) {
+                    const bool wino = h->use_winograd && o.wt_wino && out.h >= 4 && out.w >= 8;
+                    if (wino) {
                         p.wt = o.wt_wino; p.coutp = o.coutp_wino;
                         e = launch_conv_wino(p, s);
-                    } else
-                    e = launch_conv_mfma(p, s);
-                    if (ev) { (void)hipEventRecord(ev[1], s); h->prof_flops += o.flops * n; }
+                    } else {
+                        e = launch_conv_mfma(p, s);
+                    }
+                    if (ev) {
+                        (void)hipEventRecord(ev[1], s);
+                        h->prof_flops += o.flops * n;
+                        h->prof_exec_flops += o.flops * n * (wino ? 16.0 / 36.0 : 1.0);   // multiplies actually issued
+                    }
                 } else if (o.path == PATH_SMALL_CIN) {
                     e = launch_conv_small_cin(in, out, o.wt, o.bias, n, d.kh, d.kw, d.pad_top, d.pad_left, act, d.alpha, s);
                 } else if (o.path == PATH_HEAD) {
@@ -278,7 +284,7 @@ int run_plan(ecseg_ctx* h, int n) {
     return ECSEG_OK;
 }
 
-void prof_begin(ecseg_ctx* h) { h->prof_used = 0; h->prof_flops = 0.0; }
+void prof_begin(ecseg_ctx* h) { h->prof_used = 0; h->prof_flops = 0.0; h->prof_exec_flops = 0.0; }
 void prof_end(ecseg_ctx* h) {   // stream must be idle
     double ms = 0.0;
     for (size_t k = 0; k + 1 < h->prof_used; k += 2) {
@@ -286,6 +292,7 @@ void prof_end(ecseg_ctx* h) {   // stream must be idle
         if (hipEventElapsedTime(&t, h->prof_events[k], h->prof_events[k + 1]) == hipSuccess) ms += t;
     }
     h->last_conv_ms = ms; h->last_conv_launches = (long long)(h->prof_used / 2); h->last_conv_flops = h->prof_flops;
+    h->last_conv_exec_flops = h->prof_exec_flops;
 }
 
 // ---- tiling / stitch geometry (reference src/image_tools.py:148-252), computed once per image size ----
@@ -931,6 +938,12 @@ int ecseg_get_conv_profile(ecseg_ctx* h, double* total_ms, int64_t* launches, do
     if (total_ms) *total_ms = h->last_conv_ms;
     if (launches) *launches = h->last_conv_launches;
     if (flops) *flops = h->last_conv_flops;
+    return ECSEG_OK;
+}
+
+int ecseg_get_conv_executed_flops(ecseg_ctx* h, double* flops) {
+    if (!h || !flops) return ECSEG_E_INVALID;
+    *flops = h->last_conv_exec_flops;
     return ECSEG_OK;
 }
 

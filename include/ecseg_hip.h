@@ -173,6 +173,9 @@ int ecseg_get_timings(ecseg_ctx* h, float* ms_out /* [ECSEG_T_N] */);
  * measured with HIP events around every launch when profiling is enabled (adds a little launch overhead). */
 int ecseg_set_kernel_profiling(ecseg_ctx* h, int enabled);
 int ecseg_get_conv_profile(ecseg_ctx* h, double* total_ms, int64_t* launches, double* flops);
+/* FLOPs the matrix cores actually executed in those launches (Winograd F(2x2,3x3) issues 16/36 of the algorithmic
+ * multiplies of a 3x3 convolution; the direct kernel issues all of them). */
+int ecseg_get_conv_executed_flops(ecseg_ctx* h, double* flops);
 
 /* ---- host-side byte codecs for the file I/O around the path (no GPU work) ---------------------------------- */
 /* TIFF LZW (MSB-first, 9..12-bit codes, early change): inputs read by imread (src/utils.py:110) and the

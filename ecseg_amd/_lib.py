@@ -14,7 +14,7 @@ EXPORTS = [
     'ecseg_segment_images', 'ecseg_segment_images_dev', 'ecseg_set_images_per_group', 'ecseg_set_option', 'ecseg_preprocess', 'ecseg_u16_to_u8',
     'ecseg_stitch_argmax', 'ecseg_meta_inference', 'ecseg_meta_inference_dev', 'ecseg_count_cc', 'ecseg_ccl_labels',
     'ecseg_count_colocalization', 'ecseg_count_hsr', 'ecseg_overlay', 'ecseg_get_timings',
-    'ecseg_set_kernel_profiling', 'ecseg_get_conv_profile', 'ecseg_get_conv_executed_flops', 'ecseg_lzw_decode', 'ecseg_lzw_encode',
+    'ecseg_set_kernel_profiling', 'ecseg_get_conv_profile', 'ecseg_get_conv_executed_flops', 'ecseg_debug_peek', 'ecseg_lzw_decode', 'ecseg_lzw_encode',
 ]
 
 
@@ -78,6 +78,7 @@ def load_library():
     lib.ecseg_set_kernel_profiling.argtypes = [vp, i32]
     lib.ecseg_get_conv_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     lib.ecseg_get_conv_executed_flops.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.ecseg_debug_peek.argtypes = [vp, vp, i32]
     for fn in (lib.ecseg_lzw_decode, lib.ecseg_lzw_encode):
         fn.argtypes = [vp, C.c_longlong, vp, C.c_longlong]
         fn.restype = C.c_longlong
@@ -314,6 +315,11 @@ class Handle:
         ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
         self._check(self.lib.ecseg_get_conv_profile(self.h, C.byref(ms), C.byref(n), C.byref(fl)), 'ecseg_get_conv_profile')
         return ms.value, n.value, fl.value
+
+    def debug_peek(self, n=32):
+        out = np.zeros(n, np.float32)
+        self._check(self.lib.ecseg_debug_peek(self.h, _ptr(out), n), 'ecseg_debug_peek')
+        return out
 
     def conv_executed_flops(self):
         fl = C.c_double()

@@ -941,6 +941,14 @@ int ecseg_get_conv_profile(ecseg_ctx* h, double* total_ms, int64_t* launches, do
     return ECSEG_OK;
 }
 
+// Diagnostics: floats 16.. of the zero page (in-kernel cycle stamps of the ECSEG_WINO_STAMP build).
+int ecseg_debug_peek(ecseg_ctx* h, float* out, int n) {
+    if (!h || !out || n < 0 || n > 48 || !h->zero_page) return ECSEG_E_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpy(out, h->zero_page + 16, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return ECSEG_OK;
+}
+
 int ecseg_get_conv_executed_flops(ecseg_ctx* h, double* flops) {
     if (!h || !flops) return ECSEG_E_INVALID;
     *flops = h->last_conv_exec_flops;

@@ -262,7 +262,7 @@ __device__ __forceinline__ void wino_store_Y(const float* Rs, const ConvParams& 
     }
 }
 
-template <int NT, int MT>
+template <int NT, int MT, bool STAMP = false>
 __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void conv_wino_kernel(ConvParams p, int tiles_x, int tiles_y, int nblk_n) {
     constexpr int TTY = 4 * MT, TTX = 8;                     // MT MFMA row tiles of 4 x 8 Winograd tiles each
     constexpr int HR = 2 * TTY + 2, HC = 2 * TTX + 2;       // halo: (8 MT + 2) x 18 pixels
@@ -364,6 +364,9 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void conv_wino_kernel(ConvP
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[m][b][nt][e] = 0.f;
 
+    unsigned long long st[6] = {0, 0, 0, 0, 0, 0}, tk0 = 0, tk = 0;
+#define WSTAMP(i) do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); st[i] += now - tk; tk = now; __builtin_amdgcn_sched_barrier(0); } } while (0)
+    if (STAMP) { tk0 = tk = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
     load_a(0);
     dma_b(0, 0);
     store_a(0);
@@ -371,7 +374,9 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void conv_wino_kernel(ConvP
     for (int c = 0; c < p.cin_chunks; ++c) {
         const int cur = c & 1;
         const bool more = c + 1 < p.cin_chunks;
+        WSTAMP(0);                                             // [0] barrier exit -> here
         if (more) { load_a(c + 1); dma_b(c + 1, cur ^ 1); }   // next chunk streams in under this chunk's MFMAs
+        WSTAMP(1);                                             // [1] issue of next chunk's loads
         const f32x4* A0 = As + cur * A_SLOTS + a0_off;
         const f32x4* A1 = As + cur * A_SLOTS + a1_off;
         const f32x4* Bp = Bs + cur * B_PIECES + b_lane;
@@ -389,6 +394,8 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void conv_wino_kernel(ConvP
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) w[b][nt] = Bp[b * 2 * BN + nt * 32];
+        if (STAMP) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+        WSTAMP(2);                                             // [2] LDS reads issued + landed
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             // halo column j of the tile: plane (j & 1), slot + (j >> 1)
@@ -408,8 +415,19 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void conv_wino_kernel(ConvP
                 }
             }
         }
+        WSTAMP(3);                                             // [3] transform + MFMA issue
+        if (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        WSTAMP(4);                                             // [4] wait for the next chunk's loads
         if (more) store_a(cur ^ 1);
         __syncthreads();
+        WSTAMP(5);                                             // [5] halo store + barrier
+    }
+#undef WSTAMP
+    if (STAMP && blockIdx.x == gridDim.x / 2 && (tid & 63) == 0) {
+        float* dbg = const_cast<float*>(p.zero) + 16 + (tid >> 6) * 8;
+        for (int i = 0; i < 6; ++i) dbg[i] = (float)st[i];
+        dbg[6] = (float)(__builtin_amdgcn_s_memtime() - tk0);
+        dbg[7] = (float)p.cin_chunks;
     }
 
     // ---- output stage, one row tile at a time (wino_write_R / wino_store_Y) ----
@@ -442,6 +460,12 @@ static hipError_t launch_conv_wino_t(const ConvParams& p, hipStream_t s) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
+    }
+    static const bool stamp = getenv("ECSEG_WINO_STAMP") != nullptr;
+    if (stamp && NT == 2 && MT == 1) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<2, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((conv_wino_kernel<2, 1, true>), dim3((unsigned)grid), dim3(256), lds, s, p, tiles_x, tiles_y, nblk_n);
+        return hipGetLastError();
     }
     hipLaunchKernelGGL((conv_wino_kernel<NT, MT>), dim3((unsigned)grid), dim3(256), lds, s, p, tiles_x, tiles_y, nblk_n);
     return hipGetLastError();

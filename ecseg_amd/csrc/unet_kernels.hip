@@ -41,20 +41,22 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-template <int NT, int TW, int R, int S>
+template <int NT, int TW, int R, int S, int KCH = 1>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p, int tiles_x, int tiles_y, int nblk_n, int np_total) {
+    // KCH = 8-channel K-chunks staged per barrier interval (4 for 1x1 taps: a single tap gives a wave only 4*NT MFMAs
+    // per chunk, too few to amortise the barrier / staging cost)
     constexpr int TH = 128 / TW;
     constexpr int HH = TH + R - 1, HW = TW + S - 1;
     constexpr int NPIX = HH * HW;
     constexpr int BN = NT * 32;
     constexpr int A_PIECES = NPIX * 2;
-    constexpr int A_PER_T = (A_PIECES + 255) / 256;
+    constexpr int A_PER_T = (A_PIECES * KCH + 255) / 256;
     constexpr int B_PIECES = R * S * 2 * BN;
-    constexpr int B_PER_T = (B_PIECES + 255) / 256;
+    constexpr int B_PER_T = (B_PIECES * KCH + 255) / 256;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4* As = reinterpret_cast<f32x4*>(smem);   // [2][NPIX]
-    f32x4* Bs = As + 2 * NPIX;                    // [R*S][2][BN]
+    f32x4* As = reinterpret_cast<f32x4*>(smem);   // [KCH][2][NPIX]
+    f32x4* Bs = As + KCH * 2 * NPIX;              // [KCH][R*S][2][BN]
 
     const int tid = threadIdx.x;
     unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -68,50 +70,56 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p, int tiles_
     const size_t in_img = (size_t)img * Hin * Win * p.in.cs;
 
     // ---- per-thread staging descriptors (fixed over the K loop) ----
-    long a_off[A_PER_T];     // float offset of this thread's 16-byte piece for chunk 0, or -1 when zero-filled
-    int a_ch[A_PER_T];       // first channel of the piece inside chunk 0
+    long a_off[A_PER_T];     // float offset of this thread's 16-byte piece for stage 0, or -1 when zero-filled
+    int a_ch[A_PER_T];       // first channel of the piece inside stage 0
     int a_lds[A_PER_T];
 #pragma unroll
     for (int k = 0; k < A_PER_T; ++k) {
         const int q = tid + k * 256;
         a_off[k] = -1; a_lds[k] = -1; a_ch[k] = 0;
-        if (q < A_PIECES) {
-            const int pix = q >> 1, h = q & 1;
+        if (q < A_PIECES * KCH) {
+            const int kc = q / A_PIECES, qq = q - kc * A_PIECES;
+            const int pix = qq >> 1, h = qq & 1;
             const int hy = pix / HW, hx = pix - hy * HW;
             const int iy = ty0 - p.pad_top + hy, ix = tx0 - p.pad_left + hx;
-            a_lds[k] = h * NPIX + pix;
-            a_ch[k] = h * 4;
+            a_lds[k] = (kc * 2 + h) * NPIX + pix;
+            a_ch[k] = kc * 8 + h * 4;
             if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win)
-                a_off[k] = (long)(in_img + ((size_t)iy * Win + ix) * p.in.cs + h * 4);
+                a_off[k] = (long)(in_img + ((size_t)iy * Win + ix) * p.in.cs + kc * 8 + h * 4);
         }
     }
     const size_t chunk_stride = (size_t)2 * np_total * 4;          // floats between consecutive chunks of one tap
     const size_t tap_stride = chunk_stride * p.cin_chunks;
     long b_off[B_PER_T];
+    int b_kc[B_PER_T];
 #pragma unroll
     for (int k = 0; k < B_PER_T; ++k) {
         const int q = tid + k * 256;
-        b_off[k] = -1;
-        if (q < B_PIECES) {
-            const int tap = q / (2 * BN), rem = q - tap * 2 * BN;
+        b_off[k] = -1; b_kc[k] = 0;
+        if (q < B_PIECES * KCH) {
+            const int kc = q / B_PIECES, qq = q - kc * B_PIECES;
+            const int tap = qq / (2 * BN), rem = qq - tap * 2 * BN;
             const int h = rem / BN, j = rem - h * BN;
-            b_off[k] = (long)(tap * tap_stride + ((size_t)h * np_total + n0 + j) * 4);
+            b_kc[k] = kc;
+            b_off[k] = (long)(tap * tap_stride + kc * chunk_stride + ((size_t)h * np_total + n0 + j) * 4);
         }
     }
+    const int nstages = (p.cin_chunks + KCH - 1) / KCH;
 
     f32x4 a_reg[A_PER_T], b_reg[B_PER_T];
-    auto load_chunk = [&](int c) {
+    auto load_chunk = [&](int st) {
 #pragma unroll
         for (int k = 0; k < A_PER_T; ++k) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (a_off[k] >= 0 && c * 8 + a_ch[k] < Cin)
-                v = *reinterpret_cast<const f32x4*>(p.in.p + a_off[k] + (size_t)c * 8);
+            if (a_off[k] >= 0 && st * KCH * 8 + a_ch[k] < Cin)
+                v = *reinterpret_cast<const f32x4*>(p.in.p + a_off[k] + (size_t)st * KCH * 8);
             a_reg[k] = v;
         }
 #pragma unroll
         for (int k = 0; k < B_PER_T; ++k) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (b_off[k] >= 0) v = *reinterpret_cast<const f32x4*>(p.wt + b_off[k] + (size_t)c * chunk_stride);
+            if (b_off[k] >= 0 && st * KCH + b_kc[k] < p.cin_chunks)
+                v = *reinterpret_cast<const f32x4*>(p.wt + b_off[k] + (size_t)st * KCH * chunk_stride);
             b_reg[k] = v;
         }
     };
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p, int tiles_
 #pragma unroll
         for (int k = 0; k < B_PER_T; ++k) {
             const int q = tid + k * 256;
-            if (q < B_PIECES) Bs[q] = b_reg[k];
+            if (q < B_PIECES * KCH) Bs[q] = b_reg[k];
         }
     };
 
@@ -141,21 +149,24 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p, int tiles_
         for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
 
     load_chunk(0);
-    for (int c = 0; c < p.cin_chunks; ++c) {
+    for (int st = 0; st < nstages; ++st) {
         store_chunk();
         __syncthreads();
-        if (c + 1 < p.cin_chunks) load_chunk(c + 1);   // next chunk's HBM/L2 latency hides under this chunk's MFMAs
+        if (st + 1 < nstages) load_chunk(st + 1);   // next stage's HBM/L2 latency hides under this stage's MFMAs
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
+        for (int kc = 0; kc < KCH; ++kc) {
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const f32x4 a = Ap[r * HW + s];
+            for (int r = 0; r < R; ++r) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const f32x4 b = Bp[(r * S + s) * 2 * BN + nt * 32];
+                for (int s = 0; s < S; ++s) {
+                    const f32x4 a = Ap[kc * 2 * NPIX + r * HW + s];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[nt], 0, 0, 0);
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const f32x4 b = Bp[(kc * R * S + r * S + s) * 2 * BN + nt * 32];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[nt], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -868,7 +879,7 @@ bool conv_mfma_supported(const ConvParams& p) {
     return taps_ok && align_ok && p.in.c >= 8 && p.out.c >= 16;
 }
 
-template <int NT, int TW, int R, int S>
+template <int NT, int TW, int R, int S, int KCH = 1>
 static hipError_t launch_conv_mfma_t(const ConvParams& p, hipStream_t s) {
     constexpr int TH = 128 / TW;
     constexpr int BN = NT * 32;
@@ -876,11 +887,11 @@ static hipError_t launch_conv_mfma_t(const ConvParams& p, hipStream_t s) {
     const int tiles_x = (ext_w + TW - 1) / TW, tiles_y = (ext_h + TH - 1) / TH;
     const int np_total = p.convt ? p.kT * p.kT * p.coutp : p.coutp;
     const int nblk_n = np_total / BN;
-    const size_t lds = (size_t)(2 * (TH + R - 1) * (TW + S - 1) + R * S * 2 * BN) * 16;
+    const size_t lds = (size_t)KCH * (2 * (TH + R - 1) * (TW + S - 1) + R * S * 2 * BN) * 16;
     const size_t grid = (size_t)p.n * tiles_x * tiles_y * nblk_n;
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((conv_mfma_kernel<NT, TW, R, S>), dim3((unsigned)grid), dim3(256), lds, s, p, tiles_x, tiles_y,
+    hipLaunchKernelGGL((conv_mfma_kernel<NT, TW, R, S, KCH>), dim3((unsigned)grid), dim3(256), lds, s, p, tiles_x, tiles_y,
                        nblk_n, np_total);
     return hipGetLastError();
 }
@@ -889,7 +900,7 @@ template <int NT, int TW>
 static hipError_t launch_conv_mfma_rs(const ConvParams& p, hipStream_t s) {
     if (p.R == 3) return launch_conv_mfma_t<NT, TW, 3, 3>(p, s);
     if (p.R == 2) return launch_conv_mfma_t<NT, TW, 2, 2>(p, s);
-    return launch_conv_mfma_t<NT, TW, 1, 1>(p, s);
+    return launch_conv_mfma_t<NT, TW, 1, 1, 4>(p, s);
 }
 
 hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
@@ -940,8 +951,67 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(TView in, TView out
     }
 }
 
+// First layer of the U-Net (Cin = 1, 3x3, 4.4 flop/B: HBM-bound on its 64-channel output).  Thread = 4 output channels
+// x 8 consecutive pixels of one row: the nine filter taps live in registers, the 3 x 10 input window is read once, and
+// 16 lanes (64 channels) complete one pixel's 256-byte line, so the stores of a wave are four full 256-B segments.
+__global__ __launch_bounds__(256) void conv_first_kernel(TView in, TView out, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, size_t total, int pad_top,
+                                                         int pad_left, int act, float alpha) {
+    constexpr int PX = 8;
+    const int quads = out.c >> 2;
+    const int gx = (out.w + PX - 1) / PX;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(t % quads);
+        size_t g = t / quads;
+        const int x0 = (int)(g % gx) * PX; g /= gx;
+        const int oy = (int)(g % out.h);
+        const size_t img = g / out.h;
+        f32x4 wt[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wt[k] = *reinterpret_cast<const f32x4*>(w + (size_t)k * out.c + q * 4);
+        f32x4 acc[PX];
+        const f32x4 b4 = bias ? *reinterpret_cast<const f32x4*>(bias + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < PX; ++i) acc[i] = b4;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int iy = oy - pad_top + r;
+            float v[PX + 2];
+#pragma unroll
+            for (int i = 0; i < PX + 2; ++i) {
+                const int ix = x0 - pad_left + i;
+                v[i] = (iy >= 0 && iy < in.h && ix >= 0 && ix < in.w) ? in.p[((img * in.h + iy) * in.w + ix) * in.cs] : 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int i = 0; i < PX; ++i) {
+                    const f32x4 k4 = wt[r * 3 + s];
+                    acc[i][0] = fmaf(v[i + s], k4[0], acc[i][0]); acc[i][1] = fmaf(v[i + s], k4[1], acc[i][1]);
+                    acc[i][2] = fmaf(v[i + s], k4[2], acc[i][2]); acc[i][3] = fmaf(v[i + s], k4[3], acc[i][3]);
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+            if (x0 + i < out.w) {
+                f32x4 o;
+                o[0] = apply_act(acc[i][0], act, alpha); o[1] = apply_act(acc[i][1], act, alpha);
+                o[2] = apply_act(acc[i][2], act, alpha); o[3] = apply_act(acc[i][3], act, alpha);
+                *reinterpret_cast<f32x4*>(out.p + ((img * out.h + oy) * out.w + x0 + i) * out.cs + q * 4) = o;
+            }
+        }
+    }
+}
+
 hipError_t launch_conv_small_cin(const TView& in, const TView& out, const float* w, const float* bias, int n, int R, int S,
                                  int pad_top, int pad_left, int act, float alpha, hipStream_t s) {
+    if (in.c == 1 && R == 3 && S == 3) {
+        const size_t tot = (size_t)n * out.h * ((out.w + 7) / 8) * (out.c / 4);
+        if (!tot) return hipSuccess;
+        const unsigned g = (unsigned)((tot + 255) / 256 > 65536 * 16 ? 65536 * 16 : (tot + 255) / 256);
+        hipLaunchKernelGGL(conv_first_kernel, dim3(g), dim3(256), 0, s, in, out, w, bias, tot, pad_top, pad_left, act, alpha);
+        return hipGetLastError();
+    }
     const size_t total = (size_t)n * out.h * out.w * (out.c / 4);
     if (!total) return hipSuccess;
     const unsigned grid = (unsigned)((total + 255) / 256 > 65536 * 16 ? 65536 * 16 : (total + 255) / 256);

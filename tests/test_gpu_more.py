@@ -1,0 +1,106 @@
+"""Wider parity cases on the GPU: Keras layer vocabulary beyond the canonical U-Net, odd image geometries for the
+union-find kernels (widths below one 64-pixel chunk, heights below one 32-row tile, single rows / columns), and randomised
+label maps for meta_inference."""
+import numpy as np
+import pytest
+
+from ecseg_amd import keras_plan, synth
+from oracle import postproc
+from oracle import unet as oracle_unet
+
+pytestmark = pytest.mark.gpu
+
+
+def _L(cls, name, inbound, **cfg):
+    return {'class_name': cls, 'name': name, 'config': dict(cfg, name=name),
+            'inbound_nodes': [[[i, 0, 0, {}] for i in inbound]] if inbound else []}
+
+
+def test_keras_layer_vocabulary(gpu):
+    """Conv valid/same, BatchNorm before and after the activation, LeakyReLU / sigmoid / tanh / elu, ZeroPadding2D,
+    Cropping2D, Add, bilinear UpSampling2D, Conv2DTranspose 3x3/s2 (generic path), Rescaling, Softmax layer."""
+    rng = np.random.default_rng(42)
+    H = W = 64
+    layers = [
+        _L('InputLayer', 'in', [], batch_input_shape=[None, H, W, 3]),
+        _L('Rescaling', 'rs', ['in'], scale=1.0 / 255, offset=-0.5),
+        _L('Conv2D', 'c1', ['rs'], filters=16, kernel_size=[3, 3], strides=[1, 1], padding='same', activation='linear', use_bias=False),
+        _L('BatchNormalization', 'bn1', ['c1'], axis=[3], epsilon=1e-3, center=True, scale=True),
+        _L('LeakyReLU', 'lr1', ['bn1'], alpha=0.2),
+        _L('Conv2D', 'c2', ['lr1'], filters=16, kernel_size=[3, 3], strides=[1, 1], padding='valid', activation='tanh', use_bias=True),
+        _L('ZeroPadding2D', 'zp', ['c2'], padding=[[1, 1], [1, 1]]),
+        _L('Add', 'add', ['zp', 'lr1']),
+        _L('MaxPooling2D', 'mp', ['add'], pool_size=[2, 2], strides=[2, 2], padding='valid'),
+        _L('Conv2D', 'c3', ['mp'], filters=32, kernel_size=[3, 3], strides=[1, 1], padding='same', activation='elu', use_bias=True),
+        _L('BatchNormalization', 'bn2', ['c3'], axis=[3], epsilon=1e-5, center=False, scale=True),
+        _L('UpSampling2D', 'up', ['bn2'], size=[2, 2], interpolation='bilinear'),
+        _L('Conv2DTranspose', 'ct', ['mp'], filters=8, kernel_size=[3, 3], strides=[2, 2], padding='same', activation='sigmoid',
+           use_bias=True, output_padding=None),
+        _L('Concatenate', 'cat', ['up', 'ct', 'add'], axis=-1),
+        _L('Cropping2D', 'cr', ['cat'], cropping=[[2, 2], [4, 0]]),
+        _L('Conv2D', 'c4', ['cr'], filters=4, kernel_size=[1, 1], strides=[1, 1], padding='same', activation='linear', use_bias=True),
+        _L('Softmax', 'sm', ['c4'], axis=-1),
+    ]
+    cfg = {'class_name': 'Functional', 'config': {'name': 'm', 'layers': layers, 'input_layers': [['in', 0, 0]],
+                                                  'output_layers': [['sm', 0, 0]]}}
+    k = lambda *s: (rng.normal(size=s) / np.sqrt(np.prod(s[:-1]))).astype(np.float32)
+    weights = {'c1': [k(3, 3, 3, 16)],
+               'bn1': [rng.uniform(.5, 1.5, 16).astype(np.float32), rng.normal(size=16).astype(np.float32) * .1,
+                       rng.normal(size=16).astype(np.float32) * .1, rng.uniform(.5, 1.5, 16).astype(np.float32)],
+               'c2': [k(3, 3, 16, 16), rng.normal(size=16).astype(np.float32) * .1],
+               'c3': [k(3, 3, 16, 32), rng.normal(size=32).astype(np.float32) * .1],
+               'bn2': [rng.uniform(.5, 1.5, 32).astype(np.float32), rng.normal(size=32).astype(np.float32) * .1,
+                       rng.uniform(.5, 1.5, 32).astype(np.float32)],
+               'ct': [(rng.normal(size=(3, 3, 8, 16)) * .2).astype(np.float32), rng.normal(size=8).astype(np.float32) * .1],
+               'c4': [k(1, 1, 56, 4), rng.normal(size=4).astype(np.float32) * .1]}
+    x = rng.integers(0, 256, size=(2, H, W, 3), dtype=np.uint8)
+    want = oracle_unet.forward(cfg, weights, x)
+    for fuse in (False, True):
+        gpu.load_plan(keras_plan.build_plan(cfg, weights, fuse=fuse))
+        got = gpu.forward_patches(x)
+        assert got.shape == want.shape == (2, 60, 60, 4)
+        assert np.abs(got - want).max() < 1e-4, (fuse, np.abs(got - want).max())
+
+
+@pytest.mark.parametrize('H,W', [(1, 1), (1, 200), (200, 1), (5, 63), (31, 65), (33, 64), (70, 130), (3, 3)])
+def test_ccl_and_meta_inference_odd_geometries(gpu, H, W):
+    rng = np.random.default_rng(H * 1000 + W)
+    masks = (rng.random((6, H, W)) < np.array([0.0, 1.0, 0.3, 0.5, 0.62, 0.9])[:, None, None]).astype(np.uint8)
+    for conn, lab_fn in ((8, postproc.label8), (4, postproc.label4)):
+        got = gpu.ccl_labels(masks, conn)
+        for k in range(len(masks)):
+            lab, n = lab_fn(masks[k])
+            assert got[k].max(initial=0) == 0 if n == 0 else True
+            # same partition: every oracle component maps to exactly one GPU label and back
+            pairs = set(zip(lab.ravel().tolist(), got[k].ravel().tolist()))
+            assert len(pairs) == n + (1 if (masks[k] == 0).any() else 0), (H, W, conn, k)
+    n, px = gpu.count_cc(masks)
+    for k in range(len(masks)):
+        wn, wpx = postproc.count_cc(masks[k])
+        assert n[k] == wn and (px[k] == -1) == isinstance(wpx, float) and (px[k] == wpx or px[k] == -1)
+    labs = rng.choice(4, size=(5, H, W), p=[.55, .2, .15, .1]).astype(np.uint8)
+    out, nec = gpu.meta_inference(labs)
+    for k in range(len(labs)):
+        want = postproc.meta_inference(labs[k])
+        assert np.array_equal(out[k], want), (H, W, k)
+        assert nec[k] == postproc.count_cc(want == 3)[0]
+
+
+def test_meta_inference_randomised_scenes(gpu):
+    """40 seeded scenes of varying size / density, batched by size; bit-exact against the oracle."""
+    rng = np.random.default_rng(7)
+    for (H, W) in [(96, 160), (130, 97), (257, 129)]:
+        labs = []
+        for i in range(12):
+            a = synth.label_map(int(rng.integers(0, 10 ** 6)), H, W, salt=float(rng.choice([0, 0.001, 0.01, 0.05])))
+            if i % 4 == 0:          # blocky noise: big components of every class with ragged borders
+                b = rng.integers(0, 4, size=(H // 8 + 1, W // 8 + 1)).astype(np.uint8)
+                a = np.kron(b, np.ones((8, 8), np.uint8))[:H, :W]
+                a[rng.random((H, W)) < 0.05] = 0
+            labs.append(a)
+        labs = np.stack(labs)
+        out, nec = gpu.meta_inference(labs)
+        for k in range(len(labs)):
+            want = postproc.meta_inference(labs[k])
+            assert np.array_equal(out[k], want), (H, W, k)
+            assert nec[k] == postproc.count_cc(want == 3)[0]

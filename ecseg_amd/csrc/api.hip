@@ -141,14 +141,15 @@ int upload(ecseg_ctx* h, const std::vector<float>& host, float** dev) {
     return ECSEG_OK;
 }
 
-// Keras HWIO kernel -> wt[tap][chunk][half][NP][4] (zero padded)
+// Keras HWIO kernel -> wt[tap][chunk][half][NP][4] (zero padded; padded chunk / tap pitches, see common.h)
 std::vector<float> relayout_conv(const float* w, int R, int S, int cin, int cout, int chunks, int np) {
-    std::vector<float> o((size_t)R * S * chunks * 2 * np * 4, 0.f);
+    const size_t cp = (size_t)wt_chunk_pitch(np), tp = (size_t)wt_tap_pitch(np, chunks);
+    std::vector<float> o((size_t)R * S * tp, 0.f);
     for (int t = 0; t < R * S; ++t)
         for (int ci = 0; ci < cin; ++ci) {
             const int chunk = ci / 8, hh = (ci % 8) / 4, e = ci % 4;
             const float* src = w + ((size_t)t * cin + ci) * cout;
-            float* dst = o.data() + ((((size_t)t * chunks + chunk) * 2 + hh) * np) * 4 + e;
+            float* dst = o.data() + (size_t)t * tp + (size_t)chunk * cp + ((size_t)hh * np) * 4 + e;
             for (int co = 0; co < cout; ++co) dst[(size_t)co * 4] = src[co];
         }
     return o;
@@ -175,12 +176,13 @@ std::vector<float> winograd_filter(const float* w, int cin, int cout) {
 // Keras Conv2DTranspose kernel (kh, kw, out, in) -> one-tap GEMM filter over N = (a*kT + b) * coutp + co
 std::vector<float> relayout_convt(const float* w, int kT, int cin, int cout, int chunks, int coutp) {
     const int np = kT * kT * coutp;
-    std::vector<float> o((size_t)chunks * 2 * np * 4, 0.f);
+    const size_t cp = (size_t)wt_chunk_pitch(np), tp = (size_t)wt_tap_pitch(np, chunks);
+    std::vector<float> o(tp, 0.f);
     for (int ab = 0; ab < kT * kT; ++ab)
         for (int co = 0; co < cout; ++co)
             for (int ci = 0; ci < cin; ++ci) {
                 const int chunk = ci / 8, hh = (ci % 8) / 4, e = ci % 4;
-                o[((((size_t)chunk) * 2 + hh) * np + (size_t)ab * coutp + co) * 4 + e] = w[((size_t)ab * cout + co) * cin + ci];
+                o[(size_t)chunk * cp + ((size_t)hh * np + (size_t)ab * coutp + co) * 4 + e] = w[((size_t)ab * cout + co) * cin + ci];
             }
     return o;
 }
@@ -238,8 +240,13 @@ int run_plan(ecseg_ctx* h, int n) {
                     hipEvent_t* ev = h->profile_kernels ? prof_pair(h) : nullptr;
                     if (ev) (void)hipEventRecord(ev[0], s);
                     const bool wino = h->use_winograd && o.wt_wino && out.h >= 4 && out.w >= 8;
+                    {
+                        const int npt = p.convt ? p.kT * p.kT * o.coutp : o.coutp;
+                        p.wt_chunk_stride = wt_chunk_pitch(npt); p.wt_tap_stride = wt_tap_pitch(npt, o.cin_chunks);
+                    }
                     if (wino) {
                         p.wt = o.wt_wino; p.coutp = o.coutp_wino;
+                        p.wt_chunk_stride = wt_chunk_pitch(o.coutp_wino); p.wt_tap_stride = wt_tap_pitch(o.coutp_wino, o.cin_chunks);
                         e = launch_conv_wino(p, s);
                     } else {
                         e = launch_conv_mfma(p, s);

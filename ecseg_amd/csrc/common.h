@@ -29,8 +29,15 @@ struct ConvParams {
     int convt;          // 0 | 1
     int kT, crop_top, crop_left;
     const float* zero;  // >= 16 bytes of zeros in device memory (LDS-DMA source for padding / out-of-image pixels)
-    int ablate;         // diagnostics only (ECSEG_WINO_ABLATE): 1 skip DMA, 2 skip transform reads, 4 skip MFMAs
+    int ablate;         // diagnostics only
+    // filter image strides in floats: [tap][chunk][half][N padded][4] with padded chunk / tap pitches (power-of-two
+    // pitches put the 16 transform points of a K-chunk on the same L2 channel and set)
+    long wt_chunk_stride, wt_tap_stride;
 };
+
+// pitches used by relayout_* (api.hip) and the kernels
+inline long wt_chunk_pitch(int np_total) { return (long)2 * np_total * 4 + 32; }
+inline long wt_tap_pitch(int np_total, int chunks) { return wt_chunk_pitch(np_total) * chunks + 96; }
 
 // ---- launchers implemented in unet_kernels.hip --------------------------------------------------------------
 hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s);

@@ -88,8 +88,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p, int tiles_
                 a_off[k] = (long)(in_img + ((size_t)iy * Win + ix) * p.in.cs + kc * 8 + h * 4);
         }
     }
-    const size_t chunk_stride = (size_t)2 * np_total * 4;          // floats between consecutive chunks of one tap
-    const size_t tap_stride = chunk_stride * p.cin_chunks;
+    const size_t chunk_stride = (size_t)p.wt_chunk_stride;         // floats between consecutive chunks of one tap
+    const size_t tap_stride = (size_t)p.wt_tap_stride;
     long b_off[B_PER_T];
     int b_kc[B_PER_T];
 #pragma unroll
@@ -320,8 +320,8 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void conv_wino_kernel(ConvP
                 a_off[k] = (long)(in_img + ((size_t)iy * Win + ix) * p.in.cs + h * 4);
         }
     }
-    const size_t chunk_stride = (size_t)2 * p.coutp * 4;
-    const size_t tap_stride = chunk_stride * p.cin_chunks;
+    const size_t chunk_stride = (size_t)p.wt_chunk_stride;
+    const size_t tap_stride = (size_t)p.wt_tap_stride;
     long b_off[B_PER_T];
 #pragma unroll
     for (int k = 0; k < B_PER_T; ++k) {
@@ -540,8 +540,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino8_kernel(ConvParams p, int ti
             if (col < 9 && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) a_off[k] = (iy * Win + ix) * p.in.cs + h * 4;
         }
     }
-    const int chunk_stride = 2 * p.coutp * 4;                // floats between consecutive chunks of one transform point
-    const int tap_stride = chunk_stride * nchunks;
+    const int chunk_stride = (int)p.wt_chunk_stride;         // floats between consecutive chunks of one transform point
+    const int tap_stride = (int)p.wt_tap_stride;
     int b_off[B_PER_T];
 #pragma unroll
     for (int k = 0; k < B_PER_T; ++k) {
@@ -727,8 +727,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino16_kernel(ConvParams p, int t
             if (col < 9 && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) a_off[k] = (iy * Win + ix) * p.in.cs + h * 4;
         }
     }
-    const int chunk_stride = 2 * p.coutp * 4;
-    const int tap_stride = chunk_stride * nchunks;
+    const int chunk_stride = (int)p.wt_chunk_stride;
+    const int tap_stride = (int)p.wt_tap_stride;
     int b_off[B_PER_T];
 #pragma unroll
     for (int k = 0; k < B_PER_T; ++k) {

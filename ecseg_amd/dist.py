@@ -45,7 +45,7 @@ def init_process_group(backend=None):
         return dist.get_rank(), dist.get_world_size()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    if world == 1:
+    if world == 1 and not os.environ.get('ECSEG_FORCE_PROCESS_GROUP'):
         return 0, 1
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
@@ -68,7 +68,7 @@ def allgather_records(records):
     One collective; returns (world * padded_len, RECORD_INT64) on the same device, rank-major."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return records
     world = dist.get_world_size()
     out = torch.empty((world * records.shape[0], records.shape[1]), dtype=records.dtype, device=records.device)

@@ -55,7 +55,7 @@ struct ecseg_ctx {
     std::vector<float*> bufs;
     int cap_patches = 0;
     std::vector<float*> dev_allocs;       // weight allocations (freed on reload / destroy)
-    float* zero_page = nullptr;           // 256 bytes of zeros
+    float* zero_page = nullptr;           // 1 KiB: 64 bytes of zeros + diagnostics scratch
     int input_tensor = -1, output_tensor = -1;
     double flops_per_patch = 0.0, mfma_flops_per_patch = 0.0;
 
@@ -491,7 +491,7 @@ int ecseg_create(ecseg_ctx** out, int device_id) {
         return fail_hip(nullptr, e, "hipStreamCreate");
     }
     for (auto& ev : h->ev) (void)hipEventCreate(&ev);
-    if (hipMalloc(reinterpret_cast<void**>(&h->zero_page), 256) == hipSuccess) (void)hipMemset(h->zero_page, 0, 256);
+    if (hipMalloc(reinterpret_cast<void**>(&h->zero_page), 1024) == hipSuccess) (void)hipMemset(h->zero_page, 0, 1024);
     else h->zero_page = nullptr;
     *out = h;
     return ECSEG_OK;
@@ -950,7 +950,7 @@ int ecseg_get_conv_profile(ecseg_ctx* h, double* total_ms, int64_t* launches, do
 
 // Diagnostics: floats 16.. of the zero page (in-kernel cycle stamps of the ECSEG_WINO_STAMP build).
 int ecseg_debug_peek(ecseg_ctx* h, float* out, int n) {
-    if (!h || !out || n < 0 || n > 48 || !h->zero_page) return ECSEG_E_INVALID;
+    if (!h || !out || n < 0 || n > 240 || !h->zero_page) return ECSEG_E_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipMemcpy(out, h->zero_page + 16, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     return ECSEG_OK;

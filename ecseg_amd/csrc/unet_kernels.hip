@@ -492,7 +492,7 @@ static hipError_t launch_conv_wino_t(const ConvParams& p, hipStream_t s) {
 // so every SIMD (one wave of each group) always has one wave feeding the matrix pipe.  Halo and filter slab both arrive
 // by LDS-DMA (global_load_lds, lane-linear LDS images, zero page for padding) two chunks ahead; the only waits are the
 // hand-placed vmcnt before phase 2 and lgkmcnt before each barrier.
-template <int NT>
+template <int NT, bool STAMP = false>
 __global__ __launch_bounds__(512, 2) void conv_wino8_kernel(ConvParams p, int tiles_x, int tiles_y, int nblk_n) {
     constexpr int HR = 18, CS = 12;
     constexpr int PLANE = HR * CS;                           // 216
@@ -550,18 +550,25 @@ __global__ __launch_bounds__(512, 2) void conv_wino8_kernel(ConvParams p, int ti
         const int h = rem / BN, j = rem - h * BN;
         b_off[k] = tap * tap_stride + (h * p.coutp + n0 + j) * 4;
     }
-    auto dma = [&](int c, int abuf, int bbuf) {
+    auto dma_halo = [&](int c, int abuf) {
 #pragma unroll
         for (int k = 0; k < A_PER_T; ++k) {
             const float* g = (a_off[k] >= 0 && c * 8 + (a_hi[k] ? 4 : 0) < Cin) ? in_base + a_off[k] + c * 8 : p.zero;
             __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(As + abuf * A_SLOTS + t256 + k * 256), 16, 0, 0);
         }
+    };
+    auto dma_filter = [&](int c, int bbuf, int k0, int k1) {    // k0, k1 compile-time at every call site
 #pragma unroll
         for (int k = 0; k < B_PER_T; ++k) {
+            if (k < k0 || k >= k1) continue;
             const float* g = p.wt + b_off[k] + (size_t)c * chunk_stride;
             __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Bs + bbuf * B_PIECES + t256 + k * 256), 16, 0, 0);
         }
     };
+    // Issue schedule (balanced: B_EVEN + (B_PER_T - B_EVEN + A_PER_T) pieces per chunk, never issued by the group that
+    // is on the matrix pipe): even half-step 2c, reader = group B: filter pieces [0, B_EVEN) of chunk c+2;
+    // odd half-step 2c+1, reader = group A: the remaining filter pieces and the halo of chunk c+2.
+    constexpr int B_EVEN = (B_PER_T + A_PER_T) / 2 < B_PER_T ? (B_PER_T + A_PER_T) / 2 : B_PER_T;
 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -599,7 +606,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino8_kernel(ConvParams p, int ti
         f32x4 wc[NT], wn[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) wc[nt] = Bp[nt * 32];
-        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             if (b < 3) {
@@ -614,33 +620,61 @@ __global__ __launch_bounds__(512, 2) void conv_wino8_kernel(ConvParams p, int ti
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) wc[nt] = wn[nt];
         }
-        __builtin_amdgcn_s_setprio(0);
     };
 #define WINO8_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-    // ---- prologue: group A fetches chunk 0, group B chunk 1; everybody waits for its own share ----
-    if (grp == 0) dma(0, 0, 0);
-    else if (nchunks > 1) dma(1, 1, 1);
-    if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- prologue: chunks 0 and 1 complete in LDS (group A fetches chunk 0, group B chunk 1) ----
+    if (grp == 0) { dma_halo(0, 0); dma_filter(0, 0, 0, B_PER_T); }
+    else if (nchunks > 1) { dma_halo(1, 1); dma_filter(1, 1, 0, B_PER_T); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     WINO8_BARRIER();
     // Half-steps hs = -1 .. 2n-1, one barrier each.  Group A issues the MFMAs of chunk c at hs = 2c and transforms chunk
     // c+1 at hs = 2c+1; group B transforms chunk c at hs = 2c and issues its MFMAs at hs = 2c+1: the same instruction
-    // stream for both groups, shifted by one half-step.  The group that is not on the matrix pipe also issues the DMA of
-    // chunk c+2 (every second half-step), waits for it one full chunk later.
+    // stream for both groups, shifted by one half-step.  The group that is NOT on the matrix pipe issues its half of the
+    // LDS-DMA pieces of chunk c+2; buffers: halo c&1 (last read at hs = 2c by group B), filter (c+2)%3 (last read at
+    // hs = 2c-1 by group B's MFMAs of chunk c-1).
+    unsigned long long st[6] = {0, 0, 0, 0, 0, 0}, tk = 0, tk0 = 0;
+#define W8STAMP(i) do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); st[i] += now - tk; tk = now; __builtin_amdgcn_sched_barrier(0); } } while (0)
+    if (STAMP) { tk0 = tk = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
     for (int hs = -1; hs < 2 * nchunks; ++hs) {
         const int c = hs >> 1;                                 // chunk whose MFMAs run in this pair of half-steps
+        const bool issue = hs >= 0 && c + 2 < nchunks;
         if (((hs ^ grp) & 1) == 0) {
-            if (c >= 0 && c < nchunks && !(p.ablate & 4)) mfma_chunk(c % 3);
+            if (c >= 0 && c < nchunks) mfma_chunk(c % 3);
+            W8STAMP(0);                                        // [0] MFMA role: filter reads + 32 MFMAs issued
+            // The MFMA group is the one whose earlier DMA shares are needed next:
+            //   group A (even hs): its pieces of chunk c+1 (issued at hs = 2c-1) feed its transform at hs = 2c+1;
+            //   group B (odd hs): its filter pieces of chunk c+1 (issued at hs = 2c-2) feed group A's MFMAs at hs = 2c+2,
+            //                     while its pieces of chunk c+2 (issued at hs = 2c) may keep flying.
+            if (grp == 0 || !issue) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_EVEN) : "memory");
+            W8STAMP(1);                                        // [1] MFMA role: vmcnt wait
+            WINO8_BARRIER();
+            W8STAMP(2);                                        // [2] MFMA role: barrier
         } else {
             const int rc = (hs + 1) >> 1;
-            if (rc < nchunks && !(p.ablate & 2)) read_chunk(rc & 1);
-            // odd hs (reader = group A): chunk c+2 goes into the buffers chunk c-1 / c just vacated
-            if ((hs & 1) && hs > 0 && c + 2 < nchunks && !(p.ablate & 1)) dma(c + 2, c & 1, (c + 2) % 3);
+            // the transforming wave shares its SIMD with a wave that only needs one issue slot per 64 cycles (an MFMA):
+            // give the short VALU / LDS burst priority
+            __builtin_amdgcn_s_setprio(2);
+            if (rc < nchunks) read_chunk(rc & 1);
+            __builtin_amdgcn_s_setprio(0);
+            if (STAMP) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            W8STAMP(3);                                        // [3] reader role: LDS reads + transform
+            if (issue) {
+                if (hs & 1) { dma_filter(c + 2, (c + 2) % 3, B_EVEN, B_PER_T); dma_halo(c + 2, c & 1); }
+                else dma_filter(c + 2, (c + 2) % 3, 0, B_EVEN);
+            }
+            W8STAMP(4);                                        // [4] reader role: DMA issue
+            WINO8_BARRIER();
+            W8STAMP(5);                                        // [5] reader role: barrier
         }
-        // DMA(c+1) was issued by group A at hs = 2c-1 (or by group B in the prologue for c = 0): it is needed by group A's
-        // transform at hs = 2c+1, so its issuers wait at the end of hs = 2c (one full chunk of flight time)
-        if (!(hs & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        WINO8_BARRIER();
+    }
+#undef W8STAMP
+    if (STAMP && blockIdx.x == gridDim.x / 2 && (tid & 63) == 0) {
+        float* dbg = const_cast<float*>(p.zero) + 16 + (tid >> 6) * 8;
+        for (int i = 0; i < 6; ++i) dbg[i] = (float)st[i];
+        dbg[6] = (float)(__builtin_amdgcn_s_memtime() - tk0);
+        dbg[7] = (float)p.cin_chunks;
     }
 #undef WINO8_BARRIER
     __syncthreads();
@@ -670,6 +704,12 @@ static hipError_t launch_conv_wino8_t(const ConvParams& p, hipStream_t s) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
+    }
+    static const bool stamp = getenv("ECSEG_WINO_STAMP") != nullptr;
+    if (stamp && NT == 2) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino8_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((conv_wino8_kernel<2, true>), dim3((unsigned)grid), dim3(512), lds, s, p, tiles_x, tiles_y, nblk_n);
+        return hipGetLastError();
     }
     hipLaunchKernelGGL((conv_wino8_kernel<NT>), dim3((unsigned)grid), dim3(512), lds, s, p, tiles_x, tiles_y, nblk_n);
     return hipGetLastError();

@@ -176,7 +176,7 @@ int ecseg_get_conv_profile(ecseg_ctx* h, double* total_ms, int64_t* launches, do
 /* FLOPs the matrix cores actually executed in those launches (Winograd F(2x2,3x3) issues 16/36 of the algorithmic
  * multiplies of a 3x3 convolution; the direct kernel issues all of them). */
 int ecseg_get_conv_executed_flops(ecseg_ctx* h, double* flops);
-/* Diagnostics only: up to 48 floats of in-kernel cycle stamps written by the ECSEG_WINO_STAMP build of the conv kernel. */
+/* Diagnostics only: up to 240 floats of in-kernel cycle stamps written by the ECSEG_WINO_STAMP build of the conv kernel. */
 int ecseg_debug_peek(ecseg_ctx* h, float* out, int n);
 
 /* ---- host-side byte codecs for the file I/O around the path (no GPU work) ---------------------------------- */

@@ -52,3 +52,41 @@ def test_segment_full_size_properties(model16):
     # batch invariance: the same image inside a batch gives the same answer
     post2, nec2 = model16.segment(np.stack([synth.dapi_image(1), img]))
     assert np.array_equal(post2[1], post) and nec2[1] == nec
+
+
+def test_batch_csv_full_size_vs_oracle(model16):
+    """BASELINE configs[2] in miniature: a batch of full-size (1040x1392) images through the whole device pipeline, the
+    ec_quantification.csv text diffed against the CPU oracle run end to end (U-Net included) on the same inputs."""
+    from ecseg_amd import csvio
+    from oracle import overlay as oracle_overlay
+    n = 3
+    imgs = np.stack([synth.dapi_image(20 + i) for i in range(n)])
+    post, nec, raw = model16.segment(imgs, want_raw=True)
+    rows_gpu = [['img%d.tif' % i, int(nec[i])] for i in range(n)]
+    rows_cpu = []
+    for i in range(n):
+        o_post, o_raw, o_probs, pos = oracle_pipeline.segment_gray(model16.model_config, model16.weights, imgs[i],
+                                                                   return_intermediate=True)
+        mism = int((raw[i] != o_raw).sum())
+        if mism:      # legitimate only on near-ties of the quantised probabilities; then compare the clean-up of equal inputs
+            q = np.sort(quant.quantise_u8(tiling.stitch(o_probs, pos))[raw[i] != o_raw].astype(int), axis=-1)
+            assert (q[:, -1] - q[:, -2] <= 1).all()
+            o_post = postproc.meta_inference(raw[i])
+        assert np.array_equal(post[i], o_post), i
+        rows_cpu.append(['img%d.tif' % i, oracle_pipeline.num_ecdna(o_post)])
+    assert csvio.csv_text(csvio.METASEG_COLUMNS, rows_gpu) == oracle_overlay.csv_text(oracle_overlay.METASEG_COLUMNS, rows_cpu)
+
+
+def test_overlay_full_size_batch_vs_oracle(gpu):
+    """BASELINE configs[4] in miniature: metaseg labels + red/green FISH thresholds over full-size 3-channel images."""
+    from oracle import overlay as oracle_overlay
+    from ecseg_amd import csvio
+    n = 3
+    rgb = np.stack([synth.dapi_image(60 + i, rgb=True) for i in range(n)])
+    labels = np.stack([postproc.meta_inference(synth.label_map(60 + i)).astype(np.uint8) for i in range(n)])
+    rec = gpu.overlay(labels, rgb, 85)
+    for i in range(n):
+        want = oracle_overlay.overlay_row(labels[i], rgb[i], 85)
+        got = csvio.overlay_cells(rec[i])
+        assert csvio.csv_text(csvio.OVERLAY_COLUMNS, [['x.tif'] + got]) == \
+            oracle_overlay.csv_text(oracle_overlay.OVERLAY_COLUMNS, [['x.tif'] + want]), i

@@ -16,9 +16,13 @@ for cin, cout, hw in [(64,64,256),(128,128,128),(512,512,32),(1024,1024,16)]:
     n = min(n, 280)
     x = rng.integers(0, 256, size=(n, hw, hw, cin), dtype=np.uint8)
     h.forward_patches(x); h.forward_patches(x)
-    d = h.debug_peek(32).reshape(4, 8)
+    import os
+    nw = 8 if os.environ.get('ECSEG_WINO_VARIANT') == '8' else 4
+    d = h.debug_peek(nw * 8).reshape(nw, 8)
     nch = d[0,7]
     print('layer %d->%d @%d  n=%d chunks=%d' % (cin, cout, hw, n, nch))
     names = ['bar->top', 'issue loads', 'LDS reads', 'xform+MFMA', 'vmcnt wait', 'store+barrier']
-    for wv in range(4):
+    if nw == 8:
+        names = ['M:mfma', 'M:vmcnt', 'M:barrier', 'R:read+xform', 'R:dma issue', 'R:barrier']
+    for wv in range(nw):
         print('  wave %d total %8.0f per-chunk:' % (wv, d[wv,6]), ' '.join('%s %6.0f' % (names[i], d[wv,i]/max(nch,1)) for i in range(6)), ' sum/chunk %.0f' % (d[wv,:6].sum()/max(nch,1)))

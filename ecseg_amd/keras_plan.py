@@ -78,8 +78,37 @@ def _layers_of(model_config):
     return cfg['layers'], seq, cfg
 
 
-def build_plan(model_config, weights, input_hw=(256, 256), fuse=True):
-    """``model_config``: dict or JSON text; ``weights``: {layer name: [arrays]} -> Plan."""
+def _tfop_affine(L, lc):
+    """``TFOpLambda`` nodes TF 2.x records for plain tensor arithmetic in a functional model (``x / 255.``,
+    ``x * s``, ``x - m``, ``tf.cast``): -> (scale, offset) of y = x * scale + offset, or None."""
+    fn = lc.get('function', '')
+    node = L.get('inbound_nodes', [[]])[0]
+    kwargs = {}
+    if node and isinstance(node[0], (list, tuple)) and len(node[0]) > 3 and isinstance(node[0][3], dict):
+        kwargs = node[0][3]
+    elif node and len(node) > 3 and isinstance(node[3], dict):       # single-input form [name, 0, 0, {kwargs}]
+        kwargs = node[3]
+    const = kwargs.get('y', kwargs.get('x'))
+    if fn in ('cast', 'identity', 'stop_gradient'):
+        return 1.0, 0.0
+    if not isinstance(const, (int, float)):
+        return None
+    if fn in ('math.truediv', 'math.divide', '__operators__.truediv'):
+        return 1.0 / float(const), 0.0
+    if fn in ('math.multiply', '__operators__.mul'):
+        return float(const), 0.0
+    if fn in ('math.add', '__operators__.add'):
+        return 1.0, float(const)
+    if fn in ('math.subtract', '__operators__.sub'):
+        return 1.0, -float(const)
+    return None
+
+
+def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_overrides=None):
+    """``model_config``: dict or JSON text; ``weights``: {layer name: [arrays]} -> Plan.
+    ``lambda_overrides``: {layer name: (scale, offset)} for ``Lambda`` layers (their Python bytecode cannot be
+    interpreted; the common ``Lambda(lambda x: x / 255)`` input normalisation is ``(1/255, 0)``)."""
+    lambda_overrides = lambda_overrides or {}
     if isinstance(model_config, (str, bytes)):
         model_config = json.loads(model_config)
     layers, seq, cfg = _layers_of(model_config)
@@ -119,6 +148,8 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True):
             node = inb[0]
             if isinstance(node, dict):      # Keras 3 style
                 raise PlanError('Keras 3 model_config is not supported (save with TF 2.x / Keras 2)')
+            if node and isinstance(node[0], str):      # single-input short form [name, node, tensor, kwargs]
+                node = [node]
             ins = []
             for ref in node:
                 if ref[0] not in by_name:
@@ -200,6 +231,18 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True):
                       act=0, alpha=0.0)
         elif cls == 'Rescaling':
             sc, of = float(lc['scale']), float(lc.get('offset', 0.0))
+            idx = add(name, 'affine', ins, (h, w, c), scale=np.full(c, sc, np.float32), shift=np.full(c, of, np.float32),
+                      scale64=np.full(c, sc), shift64=np.full(c, of), act=0, alpha=0.0)
+        elif cls in ('TFOpLambda', 'Lambda'):
+            aff = lambda_overrides.get(name) if cls == 'Lambda' or name in lambda_overrides else _tfop_affine(L, lc)
+            if aff is None:
+                raise PlanError('%s layer %s cannot be interpreted; pass lambda_overrides={%r: (scale, offset)} if it is '
+                                'an affine map such as x / 255' % (cls, name, name))
+            sc, of = float(aff[0]), float(aff[1])
+            if sc == 1.0 and of == 0.0:
+                by_name[name] = ins[0]
+                prev = ins[0]
+                continue
             idx = add(name, 'affine', ins, (h, w, c), scale=np.full(c, sc, np.float32), shift=np.full(c, of, np.float32),
                       scale64=np.full(c, sc), shift64=np.full(c, of), act=0, alpha=0.0)
         elif cls in IDENTITY_LAYERS:

@@ -15,21 +15,21 @@ class MetasegModel:
     ``predict_on_batch(uint8[N,256,256,1]) -> float32[N,256,256,4]`` is the call shape of the Keras model
     (src/utils.py:115); ``segment`` runs the whole device pipeline of ``meta_segment`` (src/utils.py:113-119)."""
 
-    def __init__(self, model_config, weights, device=0, fuse=True, handle=None):
+    def __init__(self, model_config, weights, device=0, fuse=True, handle=None, lambda_overrides=None):
         if isinstance(model_config, (str, bytes)):
             model_config = json.loads(model_config)
         self.model_config = model_config
         self.weights = weights
-        self.plan = keras_plan.build_plan(model_config, weights, fuse=fuse)
+        self.plan = keras_plan.build_plan(model_config, weights, fuse=fuse, lambda_overrides=lambda_overrides)
         self.handle = handle if handle is not None else Handle(device)
         self.handle.load_plan(self.plan)
 
     @classmethod
-    def from_h5(cls, path, device=0, fuse=True):
+    def from_h5(cls, path, device=0, fuse=True, lambda_overrides=None):
         if not os.path.exists(path):
             raise FileNotFoundError(path)
         cfg, weights = hdf5_min.load_keras_h5(path)
-        return cls(cfg, weights, device=device, fuse=fuse)
+        return cls(cfg, weights, device=device, fuse=fuse, lambda_overrides=lambda_overrides)
 
     # Keras call shapes -----------------------------------------------------------------------------
     def predict_on_batch(self, x):

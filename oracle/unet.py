@@ -84,7 +84,26 @@ def _batchnorm(x, cfg, w):
     return x * inv.view(1, -1, 1, 1) + (beta - mean * inv).view(1, -1, 1, 1)
 
 
-def forward(model_config, weights, x_nhwc):
+def _tfop(L, lc, a):
+    """TFOpLambda arithmetic with one tensor and one Python constant."""
+    fn = lc.get('function', '')
+    node = L['inbound_nodes'][0]
+    kw = node[3] if (node and isinstance(node[0], str)) else node[0][3]
+    k = kw.get('y', kw.get('x'))
+    if fn in ('cast', 'identity', 'stop_gradient'):
+        return a
+    if fn in ('math.truediv', 'math.divide', '__operators__.truediv'):
+        return a / float(k)
+    if fn in ('math.multiply', '__operators__.mul'):
+        return a * float(k)
+    if fn in ('math.add', '__operators__.add'):
+        return a + float(k)
+    if fn in ('math.subtract', '__operators__.sub'):
+        return a - float(k)
+    raise NotImplementedError('TFOpLambda %s' % fn)
+
+
+def forward(model_config, weights, x_nhwc, lambda_fns=None):
     """``model_config``: dict (or JSON text) of a Keras Functional/Sequential model; ``weights``: {layer name:
     [arrays in Keras order]}; ``x_nhwc``: (N, H, W, C) any dtype.  Returns float32 NHWC output of the model."""
     if isinstance(model_config, (str, bytes)):
@@ -111,7 +130,10 @@ def forward(model_config, weights, x_nhwc):
             else:
                 nodes = L['inbound_nodes']
                 assert len(nodes) == 1, 'shared layers are not supported'
-                ins = [vals[n[0]] for n in nodes[0]]
+                node = nodes[0]
+                if node and isinstance(node[0], str):
+                    node = [node]
+                ins = [vals[n[0]] for n in node]
             w = weights.get(name, [])
             a = ins[0]
             if cls == 'Conv2D':
@@ -153,6 +175,10 @@ def forward(model_config, weights, x_nhwc):
             elif cls == 'Cropping2D':
                 (t, b), (l, r) = lc['cropping']
                 y = a[:, :, t:a.shape[2] - b, l:a.shape[3] - r]
+            elif cls == 'TFOpLambda':
+                y = _tfop(L, lc, a)
+            elif cls == 'Lambda':
+                y = (lambda_fns or {})[name](a)
             elif cls == 'Rescaling':
                 y = a * float(lc['scale']) + float(lc.get('offset', 0.0))
             else:

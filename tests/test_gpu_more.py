@@ -104,3 +104,28 @@ def test_meta_inference_randomised_scenes(gpu):
             want = postproc.meta_inference(labs[k])
             assert np.array_equal(out[k], want), (H, W, k)
             assert nec[k] == postproc.count_cc(want == 3)[0]
+
+
+def test_input_normalisation_lambdas(gpu):
+    """The two ways public Keras U-Nets normalise their uint8 input: a TFOpLambda (``inputs / 255.``) and a Python
+    ``Lambda(lambda x: x / 255)`` (needs lambda_overrides, its bytecode is opaque)."""
+    rng = np.random.default_rng(3)
+    for kind in ('tfop', 'lambda'):
+        norm = (_L('TFOpLambda', 'tf.math.truediv', [], function='math.truediv') if kind == 'tfop'
+                else _L('Lambda', 'lambda', ['in'], function=['4wEAAAA=', None, None], function_type='lambda'))
+        if kind == 'tfop':
+            norm['inbound_nodes'] = [['in', 0, 0, {'y': 255.0, 'name': None}]]
+        layers = [_L('InputLayer', 'in', [], batch_input_shape=[None, 32, 48, 1]), norm,
+                  _L('Conv2D', 'c', [norm['name']], filters=8, kernel_size=[3, 3], strides=[1, 1], padding='same',
+                     activation='relu', use_bias=True)]
+        cfg = {'class_name': 'Functional', 'config': {'name': 'm', 'layers': layers, 'input_layers': [['in', 0, 0]],
+                                                      'output_layers': [['c', 0, 0]]}}
+        weights = {'c': [rng.normal(size=(3, 3, 1, 8)).astype(np.float32), rng.normal(size=8).astype(np.float32) * .1]}
+        x = rng.integers(0, 256, size=(2, 32, 48, 1), dtype=np.uint8)
+        want = oracle_unet.forward(cfg, weights, x, lambda_fns={'lambda': lambda t: t / 255.0})
+        if kind == 'lambda':
+            with pytest.raises(keras_plan.PlanError):
+                keras_plan.build_plan(cfg, weights)
+        gpu.load_plan(keras_plan.build_plan(cfg, weights, lambda_overrides={'lambda': (1 / 255.0, 0.0)}))
+        got = gpu.forward_patches(x)
+        assert np.abs(got - want).max() < 1e-5, kind

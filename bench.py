@@ -67,7 +67,8 @@ def main():
     ap.add_argument('--base', type=int, default=64, help='U-Net base width of the synthetic model')
     ap.add_argument('--group', type=int, default=8, help='images per internal U-Net launch group')
     ap.add_argument('--overlap', action='store_true', help='run post-processing on a second stream')
-    ap.add_argument('--direct', action='store_true', help='direct implicit-GEMM 3x3 kernel instead of Winograd F(2x2,3x3)')
+    ap.add_argument('--direct', action='store_true', help='direct implicit-GEMM 3x3 kernel instead of Winograd')
+    ap.add_argument('--wino', type=int, default=None, help='3x3 kernel: 0 direct, 1 Winograd F(2x2,3x3), 2 F(4x4,3x3) where eligible (default: library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     args = ap.parse_args()
@@ -93,7 +94,11 @@ def main():
     hnd = model.handle
     hnd.set_images_per_group(args.group)
     hnd.set_option('overlap_post', 1 if args.overlap else 0)
-    hnd.set_option('winograd', 0 if args.direct else 1)
+    if args.direct:
+        args.wino = 0
+    if args.wino is not None:
+        hnd.set_option('winograd', args.wino)
+    wino_mode = 2 if args.wino is None else max(0, min(2, args.wino))
     B = args.images
     total_images = B * world                       # weak scaling: per-GPU work fixed
     start, stop, per = edist.shard_bounds(total_images, rank, world)
@@ -161,8 +166,9 @@ def main():
         if conv_launches:
             traffic = None
             try:        # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+                tag = {0: 'direct', 1: 'f2x2', 2: 'f4x4'}[wino_mode]
                 pmc = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_pmc_traffic.json')
-                             and (('direct' in f) == bool(args.direct)))
+                             and tag in f)
                 if pmc and args.base == 64:
                     traffic = json.load(open(os.path.join(ROOT, 'profiles', pmc[-1])))['conv_mfma_all']['hbm_bytes_per_launch']
             except Exception:
@@ -170,15 +176,16 @@ def main():
             ach = conv_flops / (conv_ms * 1e-3) / 1e12
             exe = conv_exec / (conv_ms * 1e-3) / 1e12
             res['roofline'] = {'bound': 'mfma',
-                               'kernel': ('conv_mfma_kernel (direct implicit GEMM)' if args.direct else
-                                          'conv_wino_kernel (Winograd F(2x2,3x3)) + conv_mfma_kernel (2x2 up-convs)') +
+                               'kernel': {0: 'conv_mfma_kernel (direct implicit GEMM)',
+                                          1: 'conv_wino_kernel (Winograd F(2x2,3x3)) + conv_mfma_kernel (2x2 up-convs)',
+                                          2: 'conv_wino4_kernel (Winograd F(4x4,3x3)) + conv_mfma_kernel (2x2 up-convs)'}[wino_mode] +
                                          ', fp32 v_mfma_f32_32x32x2_f32',
                                'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
                                'avg_launch_ms': round(conv_ms / conv_launches, 4), 'launches': int(conv_launches),
                                'flop_per_launch_avg': conv_flops / conv_launches,
                                'note': 'achieved = ALGORITHMIC (direct-convolution) FLOPs / measured kernel time; Winograd '
-                                       'issues 16/36 of those multiplies, so frac can exceed 1',
+                                       'F(4x4,3x3) issues 36/144 (F(2x2): 16/36) of those multiplies, so frac can exceed 1',
                                'executed_tflops': round(exe, 2), 'executed_frac': round(exe / PEAK_FP32_MFMA_TFLOPS, 4)}
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(cfg, weights, 1)

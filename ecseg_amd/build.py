@@ -6,8 +6,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libecseg_hip.so')
-SOURCES = ['api.hip', 'unet_kernels.hip', 'post_kernels.hip', 'host_codec.cpp']
-HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'ecseg_hip.h')]
+SOURCES = ['api.hip', 'unet_kernels.hip', 'wino4_kernel.hip', 'post_kernels.hip', 'host_codec.cpp']
+HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'device_util.h'), os.path.join(HERE, '..', 'include', 'ecseg_hip.h')]
 
 
 def _hipcc():

@@ -23,6 +23,7 @@ struct OpRt {                 // run-time form of one plan operator
     int path;                 // which kernel family
     float* wt = nullptr;      // device weights in the layout the chosen kernel wants
     float* wt_wino = nullptr; // Winograd-transformed filter (16 points) when the op is eligible
+    float* wt_wino4 = nullptr; // F(4x4,3x3) filter image (36 points, per-wave stage layout of wino4_kernel.hip)
     int coutp_wino = 0;
     float* bias = nullptr;
     float* scale = nullptr;   // AFFINE
@@ -75,7 +76,7 @@ struct ecseg_ctx {
     size_t ws_list_bytes = 0;
     int post_chunk = 64;
     int overlap_post = 0;
-    int use_winograd = 1;
+    int use_winograd = 2;     // 0 direct, 1 Winograd F(2x2,3x3), 2 F(4x4,3x3) where eligible (else F(2x2))
 
     // timing
     hipEvent_t ev[ECSEG_T_N + 1] = {};
@@ -173,6 +174,36 @@ std::vector<float> winograd_filter(const float* w, int cin, int cout) {
     return u;
 }
 
+// Winograd F(4x4,3x3) filter transform U = G g G^T (float64, 36 points) written straight in the per-wave stage layout
+// of conv_wino4_kernel: wt4[cout block of 64][stage = 4 input channels][wave = half * 6 + xi][nu][h][cout 32][e], where
+// stage s of 8-channel group s / 2 holds input channels 8 (s / 2) + 4 h + 2 (s % 2) + e.
+std::vector<float> winograd4_filter(const float* w, int cin, int cout) {
+    static const double G[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    const int nblk = cout / 64, nstages = cin / 4;
+    std::vector<float> o((size_t)nblk * nstages * 12 * 768, 0.f);
+    for (int ci = 0; ci < cin; ++ci) {
+        const int grp = ci / 8, r8 = ci % 8;
+        const int hh = r8 / 4, ss = (r8 % 4) / 2, e = r8 % 2;
+        const int stage = 2 * grp + ss;
+        for (int co = 0; co < cout; ++co) {
+            double g[3][3], t[6][3];
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) g[r][c] = w[((size_t)(r * 3 + c) * cin + ci) * cout + co];
+            for (int a = 0; a < 6; ++a)
+                for (int c = 0; c < 3; ++c) t[a][c] = G[a][0] * g[0][c] + G[a][1] * g[1][c] + G[a][2] * g[2][c];
+            const int nb = co / 64, half = (co % 64) / 32, m = co % 32;
+            for (int a = 0; a < 6; ++a)
+                for (int b = 0; b < 6; ++b) {
+                    const double u = t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2];
+                    const size_t idx = (((size_t)nb * nstages + stage) * 12 + (half * 6 + a)) * 768 + (((size_t)b * 2 + hh) * 32 + m) * 2 + e;
+                    o[idx] = (float)u;
+                }
+        }
+    }
+    return o;
+}
+
 // Keras Conv2DTranspose kernel (kh, kw, out, in) -> one-tap GEMM filter over N = (a*kT + b) * coutp + co
 std::vector<float> relayout_convt(const float* w, int kT, int cin, int cout, int chunks, int coutp) {
     const int np = kT * kT * coutp;
@@ -230,7 +261,6 @@ int run_plan(ecseg_ctx* h, int n) {
                     ConvParams p{};
                     p.in = in; p.out = out; p.wt = o.wt; p.bias = o.bias; p.n = n;
                     p.act = act; p.alpha = d.alpha; p.cin_chunks = o.cin_chunks; p.coutp = o.coutp; p.zero = h->zero_page;
-                    p.ablate = 0;
                     if (d.op == ECSEG_OP_CONV) {
                         p.R = d.kh; p.S = d.kw; p.pad_top = d.pad_top; p.pad_left = d.pad_left; p.convt = 0;
                     } else {
@@ -239,12 +269,16 @@ int run_plan(ecseg_ctx* h, int n) {
                     }
                     hipEvent_t* ev = h->profile_kernels ? prof_pair(h) : nullptr;
                     if (ev) (void)hipEventRecord(ev[0], s);
-                    const bool wino = h->use_winograd && o.wt_wino && out.h >= 4 && out.w >= 8;
+                    const bool wino4 = h->use_winograd >= 2 && o.wt_wino4 && conv_wino4_supported(p);
+                    const bool wino = !wino4 && h->use_winograd && o.wt_wino && out.h >= 4 && out.w >= 8;
                     {
                         const int npt = p.convt ? p.kT * p.kT * o.coutp : o.coutp;
                         p.wt_chunk_stride = wt_chunk_pitch(npt); p.wt_tap_stride = wt_tap_pitch(npt, o.cin_chunks);
                     }
-                    if (wino) {
+                    if (wino4) {
+                        p.wt = o.wt_wino4; p.coutp = out.c;
+                        e = launch_conv_wino4(p, s);
+                    } else if (wino) {
                         p.wt = o.wt_wino; p.coutp = o.coutp_wino;
                         p.wt_chunk_stride = wt_chunk_pitch(o.coutp_wino); p.wt_tap_stride = wt_tap_pitch(o.coutp_wino, o.cin_chunks);
                         e = launch_conv_wino(p, s);
@@ -254,7 +288,7 @@ int run_plan(ecseg_ctx* h, int n) {
                     if (ev) {
                         (void)hipEventRecord(ev[1], s);
                         h->prof_flops += o.flops * n;
-                        h->prof_exec_flops += o.flops * n * (wino ? 16.0 / 36.0 : 1.0);   // multiplies actually issued
+                        h->prof_exec_flops += o.flops * n * (wino4 ? 0.25 : wino ? 16.0 / 36.0 : 1.0);   // multiplies actually issued
                     }
                 } else if (o.path == PATH_SMALL_CIN) {
                     e = launch_conv_small_cin(in, out, o.wt, o.bias, n, d.kh, d.kw, d.pad_top, d.pad_left, act, d.alpha, s);
@@ -535,7 +569,7 @@ int ecseg_set_option(ecseg_ctx* h, const char* key, int value) {
     if (!h || !key) return ECSEG_E_INVALID;
     const std::string k(key);
     if (k == "overlap_post") h->overlap_post = value != 0;
-    else if (k == "winograd") h->use_winograd = value != 0;
+    else if (k == "winograd") h->use_winograd = value < 0 ? 0 : value > 2 ? 2 : (int)value;   // 0 direct, 1 F(2x2), 2 F(4x4)
     else if (k == "post_chunk" && value >= 1) h->post_chunk = value;
     else if (k == "images_per_group" && value >= 1) h->images_per_group = value;
     else return fail(h, ECSEG_E_INVALID, "unknown option or bad value: " + k);
@@ -620,6 +654,8 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
                         o.coutp_wino = (cout + bnw - 1) / bnw * bnw;
                         const std::vector<float> u = winograd_filter(kw, cin, cout);
                         if ((rc = upload(h, relayout_conv(u.data(), 4, 4, cin, cout, o.cin_chunks, o.coutp_wino), &o.wt_wino))) return rc;
+                        if (cin % 8 == 0 && cout % 64 == 0 && to.h % 16 == 0 && to.w % 16 == 0)
+                            if ((rc = upload(h, winograd4_filter(kw, cin, cout), &o.wt_wino4))) return rc;
                     }
                 } else {
                     o.path = PATH_GENERIC;

@@ -29,7 +29,6 @@ struct ConvParams {
     int convt;          // 0 | 1
     int kT, crop_top, crop_left;
     const float* zero;  // >= 16 bytes of zeros in device memory (LDS-DMA source for padding / out-of-image pixels)
-    int ablate;         // diagnostics only
     // filter image strides in floats: [tap][chunk][half][N padded][4] with padded chunk / tap pitches (power-of-two
     // pitches put the 16 transform points of a K-chunk on the same L2 channel and set)
     long wt_chunk_stride, wt_tap_stride;
@@ -47,6 +46,9 @@ int        conv_mfma_ntile(int cout);   // N tile (32 | 64 | 128) used for a giv
 // conv_wino_ntile()
 hipError_t launch_conv_wino(const ConvParams& p, hipStream_t s);
 int        conv_wino_ntile(int cout);
+// Winograd F(4x4,3x3) (wino4_kernel.hip); p.wt = image written by winograd4_filter (api.hip)
+hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s);
+bool       conv_wino4_supported(const ConvParams& p);
 
 hipError_t launch_conv_small_cin(const TView& in, const TView& out, const float* w_hwio, const float* bias, int n,
                                  int R, int S, int pad_top, int pad_left, int act, float alpha, hipStream_t s);

@@ -1,0 +1,30 @@
+// Small device-side helpers shared by the kernel sources (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/ecseg_hip.h"
+
+namespace ecseg {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float apply_act(float v, int act, float alpha) {
+    switch (act) {
+        case ECSEG_ACT_RELU: return v > 0.f ? v : 0.f;
+        case ECSEG_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        case ECSEG_ACT_LEAKY: return v > 0.f ? v : alpha * v;
+        case ECSEG_ACT_TANH: return tanhf(v);
+        case ECSEG_ACT_ELU: return v > 0.f ? v : (expf(v) - 1.f);
+        default: return v;
+    }
+}
+
+// T1: give every XCD (blocks with equal blockIdx % 8 share one L2) a contiguous range of logical block ids.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+}  // namespace ecseg

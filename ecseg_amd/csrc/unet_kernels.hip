@@ -18,28 +18,9 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "device_util.h"
 
 namespace ecseg {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-__device__ __forceinline__ float apply_act(float v, int act, float alpha) {
-    switch (act) {
-        case ECSEG_ACT_RELU: return v > 0.f ? v : 0.f;
-        case ECSEG_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
-        case ECSEG_ACT_LEAKY: return v > 0.f ? v : alpha * v;
-        case ECSEG_ACT_TANH: return tanhf(v);
-        case ECSEG_ACT_ELU: return v > 0.f ? v : (expf(v) - 1.f);
-        default: return v;
-    }
-}
-
-// T1: give every XCD (blocks with equal blockIdx % 8 share one L2) a contiguous range of logical block ids.
-__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
-    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-}
 
 template <int NT, int TW, int R, int S, int KCH = 1>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p, int tiles_x, int tiles_y, int nblk_n, int np_total) {
@@ -474,7 +455,7 @@ static hipError_t launch_conv_wino_t(const ConvParams& p, hipStream_t s) {
     }
     static const bool stamp = getenv("ECSEG_WINO_STAMP") != nullptr;
     if (stamp && NT == 2 && MT == 1) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<2, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<2, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((conv_wino_kernel<2, 1, true>), dim3((unsigned)grid), dim3(256), lds, s, p, tiles_x, tiles_y, nblk_n);
         return hipGetLastError();
     }
@@ -501,7 +482,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino8_kernel(ConvParams p, int ti
     constexpr int B_PIECES = 16 * 2 * BN;
     constexpr int A_PER_T = A_SLOTS / 256;                   // 4: the DMA of a chunk is issued by ONE group (256 threads)
     constexpr int B_PER_T = B_PIECES / 256;
-    constexpr int NDMA = A_PER_T + B_PER_T;                  // LDS-DMA instructions per issuing wave and chunk
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* As = reinterpret_cast<f32x4*>(smem);              // [2][A_SLOTS]   halo, double-buffered
@@ -683,7 +663,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino8_kernel(ConvParams p, int ti
     float* Rs = reinterpret_cast<float*>(smem) + grp * (4 * 2 * 32 * BN);
     wino_write_R<NT>(Rs, acc, wa, lane);
     __syncthreads();
-    if (p.ablate & 8) return;
     wino_store_Y<NT>(Rs, p, img, oy0 + 8 * grp, ox0, n0, wa, lane);
 }
 
@@ -707,7 +686,7 @@ static hipError_t launch_conv_wino8_t(const ConvParams& p, hipStream_t s) {
     }
     static const bool stamp = getenv("ECSEG_WINO_STAMP") != nullptr;
     if (stamp && NT == 2) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino8_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino8_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((conv_wino8_kernel<2, true>), dim3((unsigned)grid), dim3(512), lds, s, p, tiles_x, tiles_y, nblk_n);
         return hipGetLastError();
     }

@@ -113,8 +113,9 @@ int ecseg_segment_images_dev(ecseg_ctx* h, const uint8_t* gray_dev, int n_img, i
 int ecseg_set_images_per_group(ecseg_ctx* h, int n);
 /* Tuning knobs: "overlap_post" (1: clean-up + count of group g run on a second stream beside the U-Net of group g+1;
  * 0 (default): everything on one stream - measured equal, the MFMA convs already fill the chip), "post_chunk"
- * (images per post-processing launch set), "images_per_group", "winograd" (1 (default): 3x3 / stride-1 / 'same'
- * convolutions run the Winograd F(2x2,3x3) fp32 MFMA kernel, 0: the direct implicit-GEMM kernel; both are fp32). */
+ * (images per post-processing launch set), "images_per_group", "winograd" (3x3 / stride-1 / 'same'
+ * convolutions: 2 (default) Winograd F(4x4,3x3) where the layer allows it (extents % 16, Cin % 8, Cout % 64), else
+ * F(2x2,3x3); 1: F(2x2,3x3); 0: the direct implicit-GEMM kernel; all three are fp32 MFMA kernels). */
 int ecseg_set_option(ecseg_ctx* h, const char* key, int value);
 
 /* ---- meta_preprocess (src/image_tools.py:86-101) ---------------------------------------------------------- */

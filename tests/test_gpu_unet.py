@@ -132,7 +132,38 @@ def test_winograd_matches_direct_and_oracle(gpu, cin, cout, hw):
         gpu.set_option('winograd', 0)
         direct = gpu.forward_patches(x)
     finally:
-        gpu.set_option('winograd', 1)
+        gpu.set_option('winograd', 2)
     scale = max(1.0, float(np.abs(want).max()))
     assert np.abs(direct - want).max() < 1e-4 * scale
     assert np.abs(wino - want).max() < 2e-4 * scale, np.abs(wino - want).max()
+
+
+@pytest.mark.parametrize('cin,cout,hw,n', [(64, 64, (64, 96), 3), (8, 64, (16, 16), 3), (128, 192, (16, 16), 4),
+                                           (72, 128, (32, 48), 2), (24, 64, (48, 16), 1)])
+def test_winograd_f4x4_matches_direct_and_oracle(gpu, cin, cout, hw, n):
+    """Winograd F(4x4,3x3) (option winograd=2; extents multiples of 16, Cin % 8 == 0, Cout % 64 == 0) is still an fp32
+    kernel: it must agree with the direct kernel and the oracle well inside the 1e-3 tolerance.  Covers an odd number of
+    16x16 regions (the second region of the last workgroup is empty) and regions that span two patches."""
+    rng = np.random.default_rng(cin * 7 + cout)
+    H, W = hw
+    cfg = {'class_name': 'Functional', 'config': {'name': 'm', 'layers': [
+        {'class_name': 'InputLayer', 'name': 'in', 'config': {'name': 'in', 'batch_input_shape': [None, H, W, cin]},
+         'inbound_nodes': []},
+        {'class_name': 'Conv2D', 'name': 'c', 'config': {'name': 'c', 'filters': cout, 'kernel_size': [3, 3],
+                                                         'strides': [1, 1], 'padding': 'same', 'activation': 'relu',
+                                                         'use_bias': True}, 'inbound_nodes': [[['in', 0, 0, {}]]]}],
+        'input_layers': [['in', 0, 0]], 'output_layers': [['c', 0, 0]]}}
+    weights = {'c': [(rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin) / 64).astype(np.float32),
+                     rng.normal(size=cout).astype(np.float32)]}
+    x = rng.integers(0, 256, size=(n, H, W, cin), dtype=np.uint8)
+    want = oracle_unet.forward(cfg, weights, x)
+    try:
+        gpu.set_option('winograd', 2)
+        w4, _ = _run(gpu, cfg, weights, x, fuse=True)
+        gpu.set_option('winograd', 0)
+        direct = gpu.forward_patches(x)
+    finally:
+        gpu.set_option('winograd', 2)
+    scale = max(1.0, float(np.abs(want).max()))
+    assert np.abs(direct - want).max() < 1e-4 * scale
+    assert np.abs(w4 - want).max() < 5e-4 * scale, np.abs(w4 - want).max()

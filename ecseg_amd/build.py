@@ -7,6 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libecseg_hip.so')
 SOURCES = ['api.hip', 'unet_kernels.hip', 'wino4_kernel.hip', 'post_kernels.hip', 'host_codec.cpp']
+# packed f32 VALU ops stall the SIMD beside MFMAs: keep the transform arithmetic of the Winograd kernels scalar
+EXTRA_FLAGS = {'wino4_kernel.hip': ['-fno-slp-vectorize']}
 HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'device_util.h'), os.path.join(HERE, '..', 'include', 'ecseg_hip.h')]
 
 
@@ -33,8 +35,8 @@ def build(force=False, verbose=True):
     procs = []
     for s in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(s)[0] + '.o')
-        cmd = [_hipcc(), '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-Wall', '-Wno-unused-function',
-               '-c', os.path.join(CSRC, s), '-o', obj]
+        cmd = [_hipcc(), '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-Wall', '-Wno-unused-function'] + \
+            EXTRA_FLAGS.get(s, []) + ['-c', os.path.join(CSRC, s), '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((subprocess.Popen(cmd), cmd))

@@ -24,6 +24,7 @@
 // 36 = 4 (mod 16), so all 16 land on different 16-byte bank groups: conflict-free without padding.  The A-operand
 // lane -> tile map follows the hardware's b128 lane groups (see gty below).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "device_util.h"
@@ -45,16 +46,30 @@ __device__ __forceinline__ int w4_inv(int r) {           // regrouped position -
 }
 constexpr int w4_cpos(int v) { return ((v & 3) == 0 ? 0 : (v & 3) == 1 ? 5 : (v & 3) == 2 ? 10 : 14) + (v >> 2); }
 
-typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+
+// One LDS-DMA piece: 64 lanes x 16 bytes, global (per-lane address) -> LDS bytes [lds_dst + 16 * lane].  Issued through
+// inline asm on purpose: for the builtin the compiler orders every later ds_read behind the DMA with s_waitcnt vmcnt(0)
+// (it cannot tell the LDS buffers apart), which serialises a stream that is interleaved with LDS reads.  Here the
+// counted vmcnt waits in the kernel are the only ordering (lds_dst is wave-uniform; M0 is restored).
+template <int OFF>
+__device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {      // source = gsrc + OFF bytes
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst), "n"(OFF) : "memory");
+}
 
 }  // namespace
 
+// ABL: timing-only ablations for tools/layer_probe.py (ECSEG_W4_ABL): 1 no halo LDS reads, 2 no filter DMA, 4 no halo DMA,
+// 8 no MFMA
+template <int ABL, bool STAMP = false>
 __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_x, int regs_y, int npairs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* Hs = reinterpret_cast<f32x4*>(smem);              // [2][W4_HS]        halo, double-buffered
     f32x4* Bs = Hs + 2 * W4_HS;                              // [12][2][W4_BWS]   per-wave filter stages
 
+    const unsigned lds_base = (unsigned)(size_t)(lptr_t)smem;   // LDS byte address of the dynamic segment
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xi = wave % 6, ch = wave / 6;
@@ -77,39 +92,47 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         r_y0[g] = ry * 16; r_x0[g] = rx * 16;
     }
 
-    // ---- halo DMA descriptors: this lane fills slots 64 * k + lane, k = wave and wave + 12 ----
-    const float* h_src[2];
-    int h_step[2];
+    // ---- halo DMA: issued by waves 0-3 only (the first wave of each SIMD wins every arbitration, finishes its
+    //      MFMAs first and would otherwise idle at the barrier).  Wave w fills slots 64 k + lane, k = w + 4 i, i < 6.
+    //      Descriptor per piece: float offset inside the patch | region << 29 | valid << 30 ----
+    // The six per-lane source pointers are computed once and parked in LDS (bit 0 = "advance with the channel group";
+    // padding / out-of-image lanes point at the zero page and do not advance): no registers held during the K loop.
+    unsigned long long* Hd = reinterpret_cast<unsigned long long*>(Bs + 12 * 2 * W4_BWS) + (tid & 255);   // [6][256]
+    if (wave < 4) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int a = 64 * (wave + 12 * k) + lane;
-        h_src[k] = p.zero; h_step[k] = 0;
-        if (a < 2 * 18 * 36) {
-            const int g = a / 648, rem = a - g * 648;
-            const int r = rem / 36, cc = rem - r * 36;
-            const int h = cc / 18, c = cc - h * 18;
-            const int img = g ? r_img[1] : r_img[0];
-            const int iy = (g ? r_y0[1] : r_y0[0]) - 1 + w4_inv(r), ix = (g ? r_x0[1] : r_x0[0]) - 1 + w4_inv(c);
-            if (img >= 0 && iy >= 0 && iy < H && ix >= 0 && ix < W) {
-                h_src[k] = p.in.p + (((size_t)img * H + iy) * W + ix) * p.in.cs + 4 * h;
-                h_step[k] = 8;
+        for (int i = 0; i < 6; ++i) {
+            const int a = 64 * (wave + 4 * i) + lane;
+            unsigned long long d = (unsigned long long)(size_t)p.zero;
+            if (a < 2 * 18 * 36) {
+                const int g = a >= 648 ? 1 : 0, rem = a - g * 648;
+                const int r = rem / 36, cc = rem - r * 36;
+                const int h = cc >= 18 ? 1 : 0, c = cc - h * 18;
+                const int img = g ? r_img[1] : r_img[0];
+                const int iy = (g ? r_y0[1] : r_y0[0]) - 1 + w4_inv(r), ix = (g ? r_x0[1] : r_x0[0]) - 1 + w4_inv(c);
+                if (img >= 0 && iy >= 0 && iy < H && ix >= 0 && ix < W)
+                    d = (unsigned long long)(size_t)(p.in.p + (((size_t)img * H + iy) * W + ix) * p.in.cs + 4 * h) | 1ull;
             }
+            Hd[i * 256] = d;
         }
     }
-    auto dma_halo = [&](int grp, int buf) {
+    auto dma_halo = [&](int grp, int buf) {                  // waves 0-3 only
+        if (ABL & 4) return;
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
-            __builtin_amdgcn_global_load_lds((gptr_t)(h_src[k] + grp * h_step[k]),
-                                             (lptr_t)(Hs + buf * W4_HS + 64 * (wave + 12 * k) + lane), 16, 0, 0);
+        for (int i = 0; i < 6; ++i) {
+            const unsigned long long d = Hd[i * 256];
+            const float* src = reinterpret_cast<const float*>((size_t)(d & ~1ull)) + (d & 1ull ? grp * 8 : 0);
+            glds16<0>(src, lds_base + (unsigned)(buf * W4_HS + 64 * (wave + 4 * i)) * 16u);
+        }
     };
     // ---- filter DMA: wt4[nb][stage][wave][point nu][h][cout 32][k 2], 768 floats per wave and stage ----
     const float* w_src = p.wt + ((size_t)nb * nstages * 12 + wave) * 768 + lane * 4;
     f32x4* Bw = Bs + wave * 2 * W4_BWS;
-    auto dma_filter = [&](int stage, int buf) {
+    auto dma_filter_piece = [&](int stage, int buf, auto kk) {
+        if (ABL & 2) return;
+        constexpr int k = decltype(kk)::value;
         const float* g = w_src + (size_t)stage * (12 * 768);
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            __builtin_amdgcn_global_load_lds((gptr_t)(g + k * 256), (lptr_t)(Bw + buf * W4_BWS + k * 64 + lane), 16, 0, 0);
+        // the instruction offset advances the global AND the LDS address: one M0 for the three pieces
+        glds16<k * 1024>(g, lds_base + (unsigned)(2 * W4_HS + (wave * 2 + buf) * W4_BWS) * 16u);
     };
 
     // ---- A-operand lane -> tile.  ds_read_b128 serves lanes {0-3,12-15,20-27} and {4-11,16-19,28-31} of each half
@@ -137,62 +160,151 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[v][e] = 0.f;
 
-    dma_halo(0, 0);
-    dma_filter(0, 0);
-    for (int grp = 0; grp < ngroups; ++grp) {
-        const bool more = grp + 1 < ngroups;
-        // this wave's pieces of halo group grp have landed (only the 3 pieces of filter stage 2 grp may be in flight);
-        // the barrier publishes everybody's pieces and retires the other buffer's readers
-        asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
-        if (more) dma_halo(grp + 1, (grp + 1) & 1);
-
-        // ---- row transform: t[j] for the six halo columns of the lane's tile, 4 channels each ----
+    f32x4 t[6];
+    // ---- row transform of group grp: t[j] for the six halo columns of the lane's tile, 4 channels each ----
+    auto transform = [&](int grp) {
         const f32x4* A = Hs + (grp & 1) * W4_HS + a_lane;
-        f32x4 t[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             constexpr int cp[6] = {w4_cpos(0), w4_cpos(1), w4_cpos(2), w4_cpos(3), w4_cpos(4), w4_cpos(5)};
+            if (ABL & 1) { t[j] = f32x4{c0, c1, c2, c3} * (float)(j + grp); continue; }
             const f32x4 d0 = A[ro0 + cp[j]], d1 = A[ro1 + cp[j]], d2 = A[ro2 + cp[j]], d3 = A[ro3 + cp[j]];
-            t[j] = c0 * d0 + c1 * d1 + c2 * d2 + c3 * d3;
+            // scalar fmas on purpose (file is built with -fno-slp-vectorize): packed f32 VALU ops (v_pk_fma_f32) stall
+            // the SIMD beside MFMAs, single v_fma_f32 hide in the matrix pipe's shadow
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                t[j][c] = __builtin_fmaf(c3, d3[c], __builtin_fmaf(c2, d2[c], __builtin_fmaf(c1, d1[c], c0 * d0[c])));
             asm volatile("" : "+v"(t[j]));                   // finish this column here: 16 transient registers, not 96
             __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    // ---- one filter stage (2 of the group's 4 channel pairs; buffer ss): column transform + 12 MFMAs ----
+    auto mfma_stage = [&](int ss, int next_stage) {
+        float V[6][2];
 #pragma unroll
-        for (int ss = 0; ss < 2; ++ss) {
-            // stage 2 grp + ss lives in filter buffer ss; start the next stage's stream, then wait for this one
-            if (ss == 0) {
-                dma_filter(2 * grp + 1, 1);
-                if (more) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");     // halo grp+1 (2) + stage+1 (3) may fly
-                else      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            } else {
-                if (more) { dma_filter(2 * grp + 2, 0); asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
-                else      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            // column transform of this stage's two channels: V[nu] = sum_j B^T[nu][j] t[j]
-            f32x2 u[6], V[6];
+        for (int e = 0; e < 2; ++e) {   // V[nu] = sum_j B^T[nu][j] t[j], scalar ops (see transform)
+            const int c = 2 * ss + e;
+            const float u0 = t[0][c], u1 = t[1][c], u2 = t[2][c], u3 = t[3][c], u4 = t[4][c], u5 = t[5][c];
+            const float a42 = __builtin_fmaf(-4.f, u2, u4), a31 = __builtin_fmaf(-4.f, u1, u3);
+            const float b42 = u4 - u2, b31 = 2.f * (u3 - u1);
+            V[0][e] = __builtin_fmaf(4.f, u0, __builtin_fmaf(-5.f, u2, u4));
+            V[1][e] = a42 + a31;
+            V[2][e] = a42 - a31;
+            V[3][e] = b42 + b31;
+            V[4][e] = b42 - b31;
+            V[5][e] = __builtin_fmaf(4.f, u1, __builtin_fmaf(-5.f, u3, u5));
+        }
+        const f32x2* Bp = reinterpret_cast<const f32x2*>(Bw + ss * W4_BWS) + lane;
+        f32x2 w2[6];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) { u[j][0] = t[j][2 * ss]; u[j][1] = t[j][2 * ss + 1]; }
-            {
-                const f32x2 a42 = u[4] - 4.f * u[2], a31 = u[3] - 4.f * u[1];
-                const f32x2 b42 = u[4] - u[2], b31 = 2.f * (u[3] - u[1]);
-                V[0] = 4.f * u[0] - 5.f * u[2] + u[4];
-                V[1] = a42 + a31;
-                V[2] = a42 - a31;
-                V[3] = b42 + b31;
-                V[4] = b42 - b31;
-                V[5] = 4.f * u[1] - 5.f * u[3] + u[5];
-            }
-            const f32x2* Bp = reinterpret_cast<const f32x2*>(Bw + ss * W4_BWS) + lane;
+        for (int v = 0; v < 6; ++v) w2[v] = Bp[v * 64];
+        // 12 MFMAs, channel-major: consecutive MFMAs hit different accumulators (dependency distance 6), so even a lone
+        // wave keeps the matrix pipe full.  The next stage's three filter pieces go out one at a time behind MFMAs 2, 4
+        // and 6 (pinned): the wave's issue slot is free while the pipe works, and the load path never sees a burst.
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
 #pragma unroll
             for (int v = 0; v < 6; ++v) {
-                const f32x2 w2 = Bp[v * 64];
-                acc[v] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[v][0], w2[0], acc[v], 0, 0, 0);
-                acc[v] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[v][1], w2[1], acc[v], 0, 0, 0);
+                if (ABL & 8) acc[v][0] += V[v][e] * w2[v][e];
+                else acc[v] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[v][e], w2[v][e], acc[v], 0, 0, 0);
+                if (e == 0 && (v == 1 || v == 3 || v == 5)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (v == 1) dma_filter_piece(next_stage, ss ^ 1, std::integral_constant<int, 0>{});
+                    if (v == 3) dma_filter_piece(next_stage, ss ^ 1, std::integral_constant<int, 1>{});
+                    if (v == 5) dma_filter_piece(next_stage, ss ^ 1, std::integral_constant<int, 2>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
+    };
+#define W4_WAIT(n) do { if (ABL & 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); } while (0)
+#define W4_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk0 = 0, tk = 0;
+#define WSTAMP(i) do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); st[i] += now - tk; tk = now; __builtin_amdgcn_sched_barrier(0); } } while (0)
+    if (STAMP) { tk0 = tk = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
+    // Phase rotation.  Per 8-channel group a wave has three phases: T (halo LDS reads + row transform, latency-bound),
+    // S0 and S1 (12 MFMAs each).  The barrier would keep the three waves of a SIMD (w, w + 4, w + 8) in the same phase,
+    // with the matrix pipe idle while all of them transform.  So the barrier sits at a different point of each wave's
+    // phase sequence: class 0 (waves 0-3, also the halo loaders) runs T(g) S0(g) S1(g) after barrier g, class 1 runs
+    // S1(g-1) T(g) S0(g), class 2 runs S0(g-1) S1(g-1) T(g): at any time one wave of a SIMD transforms while the other
+    // two feed the matrix pipe.  t[] lives in registers across the barrier; every class executes ngroups barriers and
+    // reads halo group g only between barriers g and g+1.
+#define W4_SB() __builtin_amdgcn_sched_barrier(0)
+#define W4_T(g) do { __builtin_amdgcn_s_setprio(3); transform(g); __builtin_amdgcn_s_setprio(0); } while (0)
+#define W4_S0(g) do { W4_SB(); W4_WAIT(0); W4_SB(); mfma_stage(0, 2 * (g) + 1); } while (0)
+#define W4_S1(g) do { W4_SB(); W4_WAIT(0); W4_SB(); mfma_stage(1, (g) + 1 < ngroups ? 2 * (g) + 2 : 2 * (g)); } while (0)
+    const int cls = wave >> 2;
+    if (cls == 0) dma_halo(0, 0);
+    dma_filter_piece(0, 0, std::integral_constant<int, 0>{});
+    dma_filter_piece(0, 0, std::integral_constant<int, 1>{});
+    dma_filter_piece(0, 0, std::integral_constant<int, 2>{});
+    if (cls == 0) {
+        for (int grp = 0; grp < ngroups; ++grp) {
+            W4_WAIT(0);                                      // own halo pieces of group grp have landed
+            WSTAMP(0);
+            if (!(ABL & 16) || !(grp & 1)) W4_BARRIER();
+            WSTAMP(1);
+            W4_T(grp);
+            WSTAMP(2);
+            W4_S0(grp);
+            WSTAMP(3);
+            W4_S1(grp);
+            WSTAMP(4);
+            if (grp + 1 < ngroups && (!(ABL & 16) || (grp & 1))) {
+                dma_halo(grp + 1, (grp + 1) & 1);
+                if (ABL & 16) dma_halo(grp + 1, (grp + 1) & 1);      // same number of pieces as two groups
+            }
+            WSTAMP(5);
         }
+    } else if (cls == 1) {
+        W4_BARRIER();
+        W4_T(0);
+        W4_S0(0);
+        for (int grp = 1; grp < ngroups; ++grp) {
+            WSTAMP(0);
+            if (!(ABL & 16) || !(grp & 1)) W4_BARRIER();
+            WSTAMP(1);
+            W4_S1(grp - 1);
+            WSTAMP(2);
+            W4_T(grp);
+            WSTAMP(3);
+            W4_S0(grp);
+            WSTAMP(4);
+        }
+        W4_S1(ngroups - 1);
+    } else {
+        W4_BARRIER();
+        W4_T(0);
+        for (int grp = 1; grp < ngroups; ++grp) {
+            WSTAMP(0);
+            if (!(ABL & 16) || !(grp & 1)) W4_BARRIER();
+            WSTAMP(1);
+            W4_S0(grp - 1);
+            WSTAMP(2);
+            W4_S1(grp - 1);
+            WSTAMP(3);
+            W4_T(grp);
+            WSTAMP(4);
+        }
+        W4_S0(ngroups - 1);
+        W4_S1(ngroups - 1);
     }
+#undef W4_T
+#undef W4_S0
+#undef W4_S1
+#undef W4_SB
+    if (STAMP && blockIdx.x == gridDim.x / 2 && lane == 0) {
+        float* dbg = const_cast<float*>(p.zero) + 16 + wave * 10;
+        for (int i = 0; i < 8; ++i) dbg[i] = (float)st[i];
+        dbg[8] = (float)(__builtin_amdgcn_s_memtime() - tk0);
+        dbg[9] = (float)ngroups;
+    }
+#undef WSTAMP
+#undef W4_WAIT
+#undef W4_BARRIER
 
     // ---- output stage: two passes (channel halves) through a [xi][x][tile][32 couts] exchange image ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the compiler does not see the asm LDS-DMAs
     float* Rs = reinterpret_cast<float*>(smem);
     const int Cout = p.out.c;
     for (int pass = 0; pass < 2; ++pass) {
@@ -267,17 +379,29 @@ hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s) {
     const size_t grid = npairs * (size_t)(p.out.c / 64);
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    size_t lds = (size_t)(2 * W4_HS + 12 * 2 * W4_BWS) * 16;
+    size_t lds = (size_t)(2 * W4_HS + 12 * 2 * W4_BWS) * 16 + 6 * 256 * 8;
     const size_t lds_epi = (size_t)24 * W4_RPLANE * 4;
     if (lds_epi > lds) lds = lds_epi;
+    static const int abl = getenv("ECSEG_W4_ABL") ? atoi(getenv("ECSEG_W4_ABL")) : 0;
+    void (*kern)(ConvParams, int, int, int) = conv_wino4_kernel<0>;
+    switch (abl) {
+        case 1: kern = conv_wino4_kernel<1>; break;
+        case 2: kern = conv_wino4_kernel<2>; break;
+        case 3: kern = conv_wino4_kernel<3>; break;
+        case 6: kern = conv_wino4_kernel<6>; break;
+        case 7: kern = conv_wino4_kernel<7>; break;
+        case 8: kern = conv_wino4_kernel<8>; break;
+        case 16: kern = conv_wino4_kernel<16>; break;
+        case 100: kern = conv_wino4_kernel<0, true>; break;        // in-kernel cycle stamps (tools/w4_stamp_probe.py)
+        default: break;
+    }
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv_wino4_kernel, dim3((unsigned)grid), dim3(768), lds, s, p, regs_x, regs_y, (int)npairs);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(768), lds, s, p, regs_x, regs_y, (int)npairs);
     return hipGetLastError();
 }
 

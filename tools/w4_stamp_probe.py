@@ -1,0 +1,37 @@
+"""In-kernel cycle stamps of conv_wino4_kernel (run with ECSEG_W4_ABL=100): per wave and 8-channel group, the cycles
+spent in each phase of the main loop, for one workgroup in the middle of the grid."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402,F401
+from ecseg_amd.model import MetasegModel  # noqa: E402
+from tools.layer_probe import cfg_for  # noqa: E402
+
+SHAPES = [(64, 64, 256, 70), (512, 256, 64, 280), (1024, 1024, 16, 280)]
+NAMES = ['vmwait', 'barrier', 'transform', 'mfma0+dma', 'filt wait', 'mfma1+dma', 'haloDMA', '-']
+
+
+def main():
+    rng = np.random.default_rng(0)
+    for cin, cout, hw, npat in SHAPES:
+        w = {'c': [(rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin) / 64).astype(np.float32),
+                   rng.normal(size=cout).astype(np.float32)]}
+        m = MetasegModel(cfg_for(cin, cout, hw), w)
+        x = rng.integers(0, 256, size=(npat, hw, hw, cin), dtype=np.uint8)
+        m.handle.set_option('winograd', 2)
+        m.handle.forward_patches(x)
+        m.handle.forward_patches(x)
+        d = m.handle.debug_peek(120).reshape(12, 10)
+        ng = d[0, 9]
+        print('%d->%d@%d  groups %d; cycles per group (s_memtime ticks x ~24 at 100 MHz? raw ticks shown):' % (cin, cout, hw, ng))
+        print('  wave ' + ' '.join('%10s' % n for n in NAMES) + '      total/grp')
+        for wv in range(12):
+            print('  %4d ' % wv + ' '.join('%10.1f' % (d[wv, i] / ng) for i in range(8)) + '   %10.1f' % (d[wv, 8] / ng))
+        del m
+
+
+if __name__ == '__main__':
+    main()

@@ -66,9 +66,10 @@ __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {   
 template <int ABL, bool STAMP = false>
 __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_x, int regs_y, int npairs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4* Hs = reinterpret_cast<f32x4*>(smem);              // [2][W4_HS]        halo, double-buffered
-    f32x4* Bs = Hs + 2 * W4_HS;                              // [12][2][W4_BWS]   per-wave filter stages
+    f32x4* Hs = reinterpret_cast<f32x4*>(smem);              // [3][W4_HS]        halo ring (group g -> buffer g % 3)
+    f32x4* Bs = Hs + 3 * W4_HS;                              // [12][2][W4_BWS]   per-wave filter stages
 
+    const unsigned long long t_entry = STAMP ? __builtin_amdgcn_s_memtime() : 0;
     const unsigned lds_base = (unsigned)(size_t)(lptr_t)smem;   // LDS byte address of the dynamic segment
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -92,37 +93,32 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         r_y0[g] = ry * 16; r_x0[g] = rx * 16;
     }
 
-    // ---- halo DMA: issued by waves 0-3 only (the first wave of each SIMD wins every arbitration, finishes its
-    //      MFMAs first and would otherwise idle at the barrier).  Wave w fills slots 64 k + lane, k = w + 4 i, i < 6.
-    //      Descriptor per piece: float offset inside the patch | region << 29 | valid << 30 ----
-    // The six per-lane source pointers are computed once and parked in LDS (bit 0 = "advance with the channel group";
-    // padding / out-of-image lanes point at the zero page and do not advance): no registers held during the K loop.
-    unsigned long long* Hd = reinterpret_cast<unsigned long long*>(Bs + 12 * 2 * W4_BWS) + (tid & 255);   // [6][256]
-    if (wave < 4) {
+    // ---- halo DMA: every wave fills slots 64 k + lane, k = wave and wave + 12, two groups ahead of its use (3-deep
+    //      ring: nobody ever waits for a halo piece to land).  The per-lane source pointers are computed once and parked
+    //      in LDS (bit 0 = "advance with the channel group"; padding / out-of-image lanes point at the zero page and do
+    //      not advance): no registers held during the K loop ----
+    unsigned long long* Hd = reinterpret_cast<unsigned long long*>(Bs + 12 * 2 * W4_BWS) + tid;   // [2][768]
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int a = 64 * (wave + 4 * i) + lane;
-            unsigned long long d = (unsigned long long)(size_t)p.zero;
-            if (a < 2 * 18 * 36) {
-                const int g = a >= 648 ? 1 : 0, rem = a - g * 648;
-                const int r = rem / 36, cc = rem - r * 36;
-                const int h = cc >= 18 ? 1 : 0, c = cc - h * 18;
-                const int img = g ? r_img[1] : r_img[0];
-                const int iy = (g ? r_y0[1] : r_y0[0]) - 1 + w4_inv(r), ix = (g ? r_x0[1] : r_x0[0]) - 1 + w4_inv(c);
-                if (img >= 0 && iy >= 0 && iy < H && ix >= 0 && ix < W)
-                    d = (unsigned long long)(size_t)(p.in.p + (((size_t)img * H + iy) * W + ix) * p.in.cs + 4 * h) | 1ull;
-            }
-            Hd[i * 256] = d;
+    for (int i = 0; i < 2; ++i) {
+        const int a = 64 * (wave + 12 * i) + lane;
+        unsigned long long d = (unsigned long long)(size_t)p.zero;
+        if (a < 2 * 18 * 36) {
+            const int g = a >= 648 ? 1 : 0, rem = a - g * 648;
+            const int r = rem / 36, cc = rem - r * 36;
+            const int h = cc >= 18 ? 1 : 0, c = cc - h * 18;
+            const int img = g ? r_img[1] : r_img[0];
+            const int iy = (g ? r_y0[1] : r_y0[0]) - 1 + w4_inv(r), ix = (g ? r_x0[1] : r_x0[0]) - 1 + w4_inv(c);
+            if (img >= 0 && iy >= 0 && iy < H && ix >= 0 && ix < W)
+                d = (unsigned long long)(size_t)(p.in.p + (((size_t)img * H + iy) * W + ix) * p.in.cs + 4 * h) | 1ull;
         }
+        Hd[i * 768] = d;
     }
-    auto dma_halo = [&](int grp, int buf) {                  // waves 0-3 only
+    auto dma_halo_piece = [&](int grp, auto ii) {            // piece ii (0 | 1) of halo group grp (< ngroups)
         if (ABL & 4) return;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const unsigned long long d = Hd[i * 256];
-            const float* src = reinterpret_cast<const float*>((size_t)(d & ~1ull)) + (d & 1ull ? grp * 8 : 0);
-            glds16<0>(src, lds_base + (unsigned)(buf * W4_HS + 64 * (wave + 4 * i)) * 16u);
-        }
+        constexpr int i = decltype(ii)::value;
+        const unsigned long long d = Hd[i * 768];
+        const float* src = reinterpret_cast<const float*>((size_t)(d & ~1ull)) + (d & 1ull ? grp * 8 : 0);
+        glds16<0>(src, lds_base + (unsigned)((grp % 3) * W4_HS + 64 * (wave + 12 * i)) * 16u);
     };
     // ---- filter DMA: wt4[nb][stage][wave][point nu][h][cout 32][k 2], 768 floats per wave and stage ----
     const float* w_src = p.wt + ((size_t)nb * nstages * 12 + wave) * 768 + lane * 4;
@@ -132,7 +128,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         constexpr int k = decltype(kk)::value;
         const float* g = w_src + (size_t)stage * (12 * 768);
         // the instruction offset advances the global AND the LDS address: one M0 for the three pieces
-        glds16<k * 1024>(g, lds_base + (unsigned)(2 * W4_HS + (wave * 2 + buf) * W4_BWS) * 16u);
+        glds16<k * 1024>(g, lds_base + (unsigned)(3 * W4_HS + (wave * 2 + buf) * W4_BWS) * 16u);
     };
 
     // ---- A-operand lane -> tile.  ds_read_b128 serves lanes {0-3,12-15,20-27} and {4-11,16-19,28-31} of each half
@@ -163,11 +159,12 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
     f32x4 t[6];
     // ---- row transform of group grp: t[j] for the six halo columns of the lane's tile, 4 channels each ----
     auto transform = [&](int grp) {
-        const f32x4* A = Hs + (grp & 1) * W4_HS + a_lane;
+        const f32x4* A = Hs + (grp % 3) * W4_HS + a_lane;
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             constexpr int cp[6] = {w4_cpos(0), w4_cpos(1), w4_cpos(2), w4_cpos(3), w4_cpos(4), w4_cpos(5)};
             if (ABL & 1) { t[j] = f32x4{c0, c1, c2, c3} * (float)(j + grp); continue; }
+            if ((ABL & 32) && j == 5) { t[5] = t[4]; continue; }      // timing model of the (row, column-half) wave split
             const f32x4 d0 = A[ro0 + cp[j]], d1 = A[ro1 + cp[j]], d2 = A[ro2 + cp[j]], d3 = A[ro3 + cp[j]];
             // scalar fmas on purpose (file is built with -fno-slp-vectorize): packed f32 VALU ops (v_pk_fma_f32) stall
             // the SIMD beside MFMAs, single v_fma_f32 hide in the matrix pipe's shadow
@@ -179,7 +176,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         }
     };
     // ---- one filter stage (2 of the group's 4 channel pairs; buffer ss): column transform + 12 MFMAs ----
-    auto mfma_stage = [&](int ss, int next_stage) {
+    auto mfma_stage = [&](int ss, int next_stage, int halo_grp) {     // halo_grp: group to prefetch (stage 0), < 0: none
         float V[6][2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {   // V[nu] = sum_j B^T[nu][j] t[j], scalar ops (see transform)
@@ -190,6 +187,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             V[0][e] = __builtin_fmaf(4.f, u0, __builtin_fmaf(-5.f, u2, u4));
             V[1][e] = a42 + a31;
             V[2][e] = a42 - a31;
+            if (ABL & 32) { V[3][e] = V[0][e]; V[4][e] = V[1][e]; V[5][e] = V[2][e]; continue; }
             V[3][e] = b42 + b31;
             V[4][e] = b42 - b31;
             V[5][e] = __builtin_fmaf(4.f, u1, __builtin_fmaf(-5.f, u3, u5));
@@ -214,6 +212,12 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
                     if (v == 5) dma_filter_piece(next_stage, ss ^ 1, std::integral_constant<int, 2>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if (ss == 0 && e == 1 && (v == 1 || v == 3) && halo_grp >= 0) {       // behind MFMAs 8 and 10
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (v == 1) dma_halo_piece(halo_grp, std::integral_constant<int, 0>{});
+                    if (v == 3) dma_halo_piece(halo_grp, std::integral_constant<int, 1>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
     };
 #define W4_WAIT(n) do { if (ABL & 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); } while (0)
@@ -231,18 +235,26 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
     // reads halo group g only between barriers g and g+1.
 #define W4_SB() __builtin_amdgcn_sched_barrier(0)
 #define W4_T(g) do { __builtin_amdgcn_s_setprio(3); transform(g); __builtin_amdgcn_s_setprio(0); } while (0)
-#define W4_S0(g) do { W4_SB(); W4_WAIT(0); W4_SB(); mfma_stage(0, 2 * (g) + 1); } while (0)
-#define W4_S1(g) do { W4_SB(); W4_WAIT(0); W4_SB(); mfma_stage(1, (g) + 1 < ngroups ? 2 * (g) + 2 : 2 * (g)); } while (0)
+    // S0(g): filter stage 2g has landed (it is the youngest thing this wave issued) -> vmcnt(0); streams stage 2g+1 and
+    // the halo of group g+2.  S1(g): only the two halo pieces issued after stage 2g+1 may still fly -> vmcnt(2).
+#define W4_S0(g) do { W4_SB(); W4_WAIT(0); W4_SB(); mfma_stage(0, 2 * (g) + 1, (g) + 2 < ngroups ? (g) + 2 : -1); } while (0)
+#define W4_S1(g) do { W4_SB(); if ((g) + 2 < ngroups) W4_WAIT(2); else W4_WAIT(0); W4_SB(); \
+                      mfma_stage(1, (g) + 1 < ngroups ? 2 * (g) + 2 : 2 * (g), -1); } while (0)
     const int cls = wave >> 2;
-    if (cls == 0) dma_halo(0, 0);
+    dma_halo_piece(0, std::integral_constant<int, 0>{});
+    dma_halo_piece(0, std::integral_constant<int, 1>{});
+    if (ngroups > 1) {
+        dma_halo_piece(1, std::integral_constant<int, 0>{});
+        dma_halo_piece(1, std::integral_constant<int, 1>{});
+    }
     dma_filter_piece(0, 0, std::integral_constant<int, 0>{});
     dma_filter_piece(0, 0, std::integral_constant<int, 1>{});
     dma_filter_piece(0, 0, std::integral_constant<int, 2>{});
+    W4_WAIT(3);                                              // halo groups 0 and 1 have landed
     if (cls == 0) {
         for (int grp = 0; grp < ngroups; ++grp) {
-            W4_WAIT(0);                                      // own halo pieces of group grp have landed
             WSTAMP(0);
-            if (!(ABL & 16) || !(grp & 1)) W4_BARRIER();
+            W4_BARRIER();
             WSTAMP(1);
             W4_T(grp);
             WSTAMP(2);
@@ -250,11 +262,6 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             WSTAMP(3);
             W4_S1(grp);
             WSTAMP(4);
-            if (grp + 1 < ngroups && (!(ABL & 16) || (grp & 1))) {
-                dma_halo(grp + 1, (grp + 1) & 1);
-                if (ABL & 16) dma_halo(grp + 1, (grp + 1) & 1);      // same number of pieces as two groups
-            }
-            WSTAMP(5);
         }
     } else if (cls == 1) {
         W4_BARRIER();
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         W4_S0(0);
         for (int grp = 1; grp < ngroups; ++grp) {
             WSTAMP(0);
-            if (!(ABL & 16) || !(grp & 1)) W4_BARRIER();
+            W4_BARRIER();
             WSTAMP(1);
             W4_S1(grp - 1);
             WSTAMP(2);
@@ -276,8 +283,9 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         W4_BARRIER();
         W4_T(0);
         for (int grp = 1; grp < ngroups; ++grp) {
+            W4_WAIT(3);                                      // own halo pieces of group grp + 0/1 landed (3 filter pieces may fly)
             WSTAMP(0);
-            if (!(ABL & 16) || !(grp & 1)) W4_BARRIER();
+            W4_BARRIER();
             WSTAMP(1);
             W4_S0(grp - 1);
             WSTAMP(2);
@@ -298,6 +306,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         for (int i = 0; i < 8; ++i) dbg[i] = (float)st[i];
         dbg[8] = (float)(__builtin_amdgcn_s_memtime() - tk0);
         dbg[9] = (float)ngroups;
+        dbg[6] = (float)(tk0 - t_entry);                     // prologue
     }
 #undef WSTAMP
 #undef W4_WAIT
@@ -363,6 +372,11 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             }
         }
     }
+    if (STAMP && blockIdx.x == gridDim.x / 2 && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float* dbg = const_cast<float*>(p.zero) + 16 + wave * 10;
+        dbg[7] = (float)(__builtin_amdgcn_s_memtime() - t_entry);   // whole workgroup, output stores retired
+    }
 }
 
 // Eligibility beyond "3x3, stride 1, pad 1, same size" (checked by the caller): extents multiples of 16, channels
@@ -379,7 +393,7 @@ hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s) {
     const size_t grid = npairs * (size_t)(p.out.c / 64);
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    size_t lds = (size_t)(2 * W4_HS + 12 * 2 * W4_BWS) * 16 + 6 * 256 * 8;
+    size_t lds = (size_t)(3 * W4_HS + 12 * 2 * W4_BWS) * 16 + 2 * 768 * 8;
     const size_t lds_epi = (size_t)24 * W4_RPLANE * 4;
     if (lds_epi > lds) lds = lds_epi;
     static const int abl = getenv("ECSEG_W4_ABL") ? atoi(getenv("ECSEG_W4_ABL")) : 0;
@@ -392,6 +406,7 @@ hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s) {
         case 7: kern = conv_wino4_kernel<7>; break;
         case 8: kern = conv_wino4_kernel<8>; break;
         case 16: kern = conv_wino4_kernel<16>; break;
+        case 32: kern = conv_wino4_kernel<32>; break;
         case 100: kern = conv_wino4_kernel<0, true>; break;        // in-kernel cycle stamps (tools/w4_stamp_probe.py)
         default: break;
     }

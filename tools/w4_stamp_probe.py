@@ -29,7 +29,8 @@ def main():
         print('%d->%d@%d  groups %d; cycles per group (s_memtime ticks x ~24 at 100 MHz? raw ticks shown):' % (cin, cout, hw, ng))
         print('  wave ' + ' '.join('%10s' % n for n in NAMES) + '      total/grp')
         for wv in range(12):
-            print('  %4d ' % wv + ' '.join('%10.1f' % (d[wv, i] / ng) for i in range(8)) + '   %10.1f' % (d[wv, 8] / ng))
+            print('  %4d ' % wv + ' '.join('%10.1f' % (d[wv, i] / ng) for i in range(6)) + '   %10.1f' % (d[wv, 8] / ng) +
+                  '   | prologue %7.0f  K loop %8.0f  whole WG %8.0f  (epilogue %7.0f)' % (d[wv, 6], d[wv, 8], d[wv, 7], d[wv, 7] - d[wv, 8] - d[wv, 6]))
         del m
 
 

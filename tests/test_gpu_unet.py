@@ -167,3 +167,23 @@ def test_winograd_f4x4_matches_direct_and_oracle(gpu, cin, cout, hw, n):
     scale = max(1.0, float(np.abs(want).max()))
     assert np.abs(direct - want).max() < 1e-4 * scale
     assert np.abs(w4 - want).max() < 5e-4 * scale, np.abs(w4 - want).max()
+
+
+def test_base64_unet_f4x4_with_concat_views(gpu):
+    """Base-64 U-Net (depth 2): every 3x3 layer but the first runs the Winograd F(4x4,3x3) kernel, reading and writing
+    the strided channel views of the fused skip connections; the probabilities must stay inside the 1e-3 tolerance and
+    agree with the direct kernel to 1e-4."""
+    cfg = synth.unet_config(base=64, depth=2)
+    weights = synth.unet_weights(cfg, seed=64)
+    x = _patches(2, seed=64)
+    want = oracle_unet.forward(cfg, weights, x)
+    try:
+        gpu.set_option('winograd', 2)
+        got, plan = _run(gpu, cfg, weights, x, fuse=True)
+        gpu.set_option('winograd', 0)
+        direct = gpu.forward_patches(x)
+    finally:
+        gpu.set_option('winograd', 2)
+    assert np.abs(got - want).max() < TOL, np.abs(got - want).max()
+    assert np.abs(got - direct).max() < 1e-4, np.abs(got - direct).max()
+    np.testing.assert_allclose(got.sum(-1), 1.0, atol=1e-5)

@@ -76,6 +76,7 @@ struct ecseg_ctx {
     size_t ws_list_bytes = 0;
     int post_chunk = 64;
     int overlap_post = 0;
+    int fuse_pool = 1;        // 2x2 max-pool written by the producing F(4x4) convolution's output stage
     int use_winograd = 2;     // 0 direct, 1 Winograd F(2x2,3x3), 2 F(4x4,3x3) where eligible (else F(2x2))
 
     // timing
@@ -248,7 +249,8 @@ hipEvent_t* prof_pair(ecseg_ctx* h) {
 // Run the whole plan on n patches whose input tensor has already been written.
 int run_plan(ecseg_ctx* h, int n) {
     hipStream_t s = h->stream;
-    for (const OpRt& o : h->ops) {
+    for (size_t oi = 0; oi < h->ops.size(); ++oi) {
+        const OpRt& o = h->ops[oi];
         const ecseg_op_desc& d = o.d;
         const TView in = view_of(h, d.in0), out = view_of(h, d.out);
         hipError_t e = hipSuccess;
@@ -277,6 +279,18 @@ int run_plan(ecseg_ctx* h, int n) {
                     }
                     if (wino4) {
                         p.wt = o.wt_wino4; p.coutp = out.c;
+                        // a MaxPooling2D(2x2, stride 2) that follows directly is written by the same output stage
+                        if (oi + 1 < h->ops.size()) {
+                            const ecseg_op_desc& nx = h->ops[oi + 1].d;
+                            const TView po = nx.op == ECSEG_OP_MAXPOOL ? view_of(h, nx.out) : TView{};
+                            if (nx.op == ECSEG_OP_MAXPOOL && nx.in0 == d.out && nx.kh == 2 && nx.kw == 2 && nx.stride == 2 &&
+                                h->fuse_pool && !softmax && po.h * 2 == out.h && po.w * 2 == out.w && po.c == out.c && po.cs % 4 == 0 &&
+                                reinterpret_cast<uintptr_t>(po.p) % 16 == 0 &&
+                                h->tensors[nx.out].buffer != h->tensors[d.in0].buffer && h->tensors[nx.out].buffer != h->tensors[d.out].buffer) {
+                                p.pool = po;
+                                ++oi;                          // the pooling op is done
+                            }
+                        }
                         e = launch_conv_wino4(p, s);
                     } else if (wino) {
                         p.wt = o.wt_wino; p.coutp = o.coutp_wino;
@@ -569,6 +583,7 @@ int ecseg_set_option(ecseg_ctx* h, const char* key, int value) {
     if (!h || !key) return ECSEG_E_INVALID;
     const std::string k(key);
     if (k == "overlap_post") h->overlap_post = value != 0;
+    else if (k == "fuse_pool") h->fuse_pool = value != 0;
     else if (k == "winograd") h->use_winograd = value < 0 ? 0 : value > 2 ? 2 : (int)value;   // 0 direct, 1 F(2x2), 2 F(4x4)
     else if (k == "post_chunk" && value >= 1) h->post_chunk = value;
     else if (k == "images_per_group" && value >= 1) h->images_per_group = value;

@@ -29,6 +29,7 @@ struct ConvParams {
     int convt;          // 0 | 1
     int kT, crop_top, crop_left;
     const float* zero;  // >= 16 bytes of zeros in device memory (LDS-DMA source for padding / out-of-image pixels)
+    TView pool;         // pool.p != null: also write MaxPooling2D(2x2, stride 2) of the activated output (conv_wino4 only)
     // filter image strides in floats: [tap][chunk][half][N padded][4] with padded chunk / tap pitches (power-of-two
     // pitches put the 16 transform points of a K-chunk on the same L2 channel and set)
     long wt_chunk_stride, wt_tap_stride;

@@ -316,8 +316,11 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the compiler does not see the asm LDS-DMAs
     float* Rs = reinterpret_cast<float*>(smem);
     const int Cout = p.out.c;
+    unsigned long long et[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ek = STAMP ? __builtin_amdgcn_s_memtime() : 0;
+#define ESTAMP(i) do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); et[i] += now - ek; ek = now; __builtin_amdgcn_sched_barrier(0); } } while (0)
     for (int pass = 0; pass < 2; ++pass) {
         __syncthreads();                                     // main-loop LDS reads / previous pass's combine are done
+        ESTAMP(0);                                           // [0] barrier (K-loop skew / previous combine)
         if (ch == pass) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -331,7 +334,9 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
                 o[3 * W4_RPLANE] = d12 + 8.f * d34 + m5;
             }
         }
+        ESTAMP(1);                                           // [1] fold own row + write R to LDS
         __syncthreads();
+        ESTAMP(2);                                           // [2] barrier
         const int n0 = nb * 64 + pass * 32;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -361,22 +366,38 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             y[3] = d12 + 8.f * d34 + q5 + bv;
             const int oy = (g ? r_y0[1] : r_y0[0]) + 4 * nty, ox = (g ? r_x0[1] : r_x0[0]) + 4 * ntx + x;
             float* o = p.out.p + (((size_t)img * H + oy) * W + ox) * p.out.cs + co;
-            if (co + 3 < Cout) {
 #pragma unroll
-                for (int yy = 0; yy < 4; ++yy) {
-                    f32x4 v = y[yy];
+            for (int yy = 0; yy < 4; ++yy) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = apply_act(v[c], p.act, p.alpha);
-                    *reinterpret_cast<f32x4*>(o + (size_t)yy * W * p.out.cs) = v;
+                for (int c = 0; c < 4; ++c) y[yy][c] = apply_act(y[yy][c], p.act, p.alpha);
+                if (co + 3 < Cout) *reinterpret_cast<f32x4*>(o + (size_t)yy * W * p.out.cs) = y[yy];
+            }
+            if (p.pool.p != nullptr) {
+                // fused MaxPooling2D(2x2, stride 2): rows pair up in registers, the column partner (x ^ 1) is lane ^ 8 of
+                // the same tile, hence of the same region: it is active whenever this lane is
+#pragma unroll
+                for (int yp = 0; yp < 2; ++yp) {
+                    f32x4 m;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float a = fmaxf(y[2 * yp][c], y[2 * yp + 1][c]);
+                        m[c] = fmaxf(a, __shfl_xor(a, 8));
+                    }
+                    if (!(x & 1) && co + 3 < Cout)
+                        *reinterpret_cast<f32x4*>(p.pool.p + (((size_t)img * p.pool.h + (oy >> 1) + yp) * p.pool.w + (ox >> 1)) * p.pool.cs + co) = m;
                 }
             }
         }
+        ESTAMP(3);                                           // [3] combine + output stores issued
     }
     if (STAMP && blockIdx.x == gridDim.x / 2 && lane == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         float* dbg = const_cast<float*>(p.zero) + 16 + wave * 10;
         dbg[7] = (float)(__builtin_amdgcn_s_memtime() - t_entry);   // whole workgroup, output stores retired
+        float* dbe = const_cast<float*>(p.zero) + 16 + 120 + wave * 4;
+        for (int i = 0; i < 4; ++i) dbe[i] = (float)et[i];
     }
+#undef ESTAMP
 }
 
 // Eligibility beyond "3x3, stride 1, pad 1, same size" (checked by the caller): extents multiples of 16, channels

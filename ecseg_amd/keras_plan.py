@@ -347,6 +347,13 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
         first_touch[j] = min(first_touch.get(j, i), i)
         last_use[i] = max(last_use.get(i, i), last_use.get(j, j))
 
+    # a 2x2 max-pool that directly follows its producing convolution may be written by that convolution's output stage
+    # (csrc/api.hip run_plan): the convolution's input must then still be alive when the pool's buffer is chosen
+    for a, b in zip(order, order[1:]):
+        if nodes[b]['kind'] == 'maxpool' and nodes[a]['kind'] == 'conv' and nodes[b]['inputs'] == [a]:
+            for i in nodes[a]['inputs']:
+                last_use[i] = max(last_use.get(i, i), b)
+
     free = []          # (floats, buffer id)
     node_buf = {}      # node -> buffer id (for nodes that own a buffer)
     tensor_of = {}

@@ -106,7 +106,7 @@ def test_plan_of_canonical_unet(base, up, bn):
             assert all(o['op'] != keras_plan.OP_COPY for o in plan.ops)     # concatenation is free
     if base == 64 and up == 'transpose':
         assert abs(plan.flops_per_patch() / 1e9 - 96.2) < 0.1
-        assert sum(plan.buffer_floats) * 4 < 80e6                           # liveness re-use: < 80 MB per patch
+        assert sum(plan.buffer_floats) * 4 < 90e6                           # liveness re-use: < 90 MB per patch
 
 
 def test_plan_rejects_what_it_cannot_lower():

@@ -24,13 +24,18 @@ def main():
         m.handle.set_option('winograd', 2)
         m.handle.forward_patches(x)
         m.handle.forward_patches(x)
-        d = m.handle.debug_peek(120).reshape(12, 10)
+        raw = m.handle.debug_peek(168)
+        d = raw[:120].reshape(12, 10)
+        ep = raw[120:168].reshape(12, 4)
         ng = d[0, 9]
         print('%d->%d@%d  groups %d; cycles per group (s_memtime ticks x ~24 at 100 MHz? raw ticks shown):' % (cin, cout, hw, ng))
         print('  wave ' + ' '.join('%10s' % n for n in NAMES) + '      total/grp')
         for wv in range(12):
             print('  %4d ' % wv + ' '.join('%10.1f' % (d[wv, i] / ng) for i in range(6)) + '   %10.1f' % (d[wv, 8] / ng) +
                   '   | prologue %7.0f  K loop %8.0f  whole WG %8.0f  (epilogue %7.0f)' % (d[wv, 6], d[wv, 8], d[wv, 7], d[wv, 7] - d[wv, 8] - d[wv, 6]))
+        print('  output stage per wave (both passes): barrier / fold+write R / barrier / combine+stores')
+        for wv in range(12):
+            print('  %4d ' % wv + ' '.join('%9.0f' % v for v in ep[wv]))
         del m
 
 

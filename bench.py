@@ -69,6 +69,7 @@ def main():
     ap.add_argument('--overlap', action='store_true', help='run post-processing on a second stream')
     ap.add_argument('--direct', action='store_true', help='direct implicit-GEMM 3x3 kernel instead of Winograd')
     ap.add_argument('--wino', type=int, default=None, help='3x3 kernel: 0 direct, 1 Winograd F(2x2,3x3), 2 F(4x4,3x3) where eligible (default: library default)')
+    ap.add_argument('--opt', action='append', default=[], help='library tuning knob key=value (ecseg_set_option), repeatable')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     args = ap.parse_args()
@@ -99,6 +100,9 @@ def main():
     if args.wino is not None:
         hnd.set_option('winograd', args.wino)
     wino_mode = 2 if args.wino is None else max(0, min(2, args.wino))
+    for kv in args.opt:
+        k, v = kv.split('=')
+        hnd.set_option(k, int(v))
     B = args.images
     total_images = B * world                       # weak scaling: per-GPU work fixed
     start, stop, per = edist.shard_bounds(total_images, rank, world)

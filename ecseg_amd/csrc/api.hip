@@ -26,6 +26,8 @@ struct OpRt {                 // run-time form of one plan operator
     float* wt_wino4 = nullptr; // F(4x4,3x3) filter image (36 points, per-wave stage layout of wino4_kernel.hip)
     int coutp_wino = 0;
     float* bias = nullptr;
+    float* head_w4 = nullptr; // PATH_HEAD with <= 4 classes: [cin][4] / [4] zero-padded copies for the fused output stage
+    float* head_b4 = nullptr;
     float* scale = nullptr;   // AFFINE
     float* shift = nullptr;
     int cin_chunks = 0, coutp = 0;
@@ -58,6 +60,7 @@ struct ecseg_ctx {
     std::vector<float*> dev_allocs;       // weight allocations (freed on reload / destroy)
     float* zero_page = nullptr;           // 1 KiB: 64 bytes of zeros + diagnostics scratch
     int input_tensor = -1, output_tensor = -1;
+    std::vector<int> consumers;   // per tensor: number of operators reading it
     double flops_per_patch = 0.0, mfma_flops_per_patch = 0.0;
 
     // image pipeline
@@ -77,6 +80,7 @@ struct ecseg_ctx {
     int post_chunk = 64;
     int overlap_post = 0;
     int fuse_pool = 1;        // 2x2 max-pool written by the producing F(4x4) convolution's output stage
+    int fuse_head = 1;        // 1x1 head (<= 4 classes) computed by the output stage of the last F(4x4) convolution
     int use_winograd = 2;     // 0 direct, 1 Winograd F(2x2,3x3), 2 F(4x4,3x3) where eligible (else F(2x2))
 
     // timing
@@ -289,6 +293,18 @@ int run_plan(ecseg_ctx* h, int n) {
                                 h->tensors[nx.out].buffer != h->tensors[d.in0].buffer && h->tensors[nx.out].buffer != h->tensors[d.out].buffer) {
                                 p.pool = po;
                                 ++oi;                          // the pooling op is done
+                            }
+                        }
+                        // a 1x1 head (<= 4 classes) that is the only reader of this 64-channel output is computed by the
+                        // same output stage; the 64-channel tensor is then never written
+                        if (p.pool.p == nullptr && oi + 1 < h->ops.size() && h->fuse_head && out.c == 64 && !softmax) {
+                            const OpRt& hx = h->ops[oi + 1];
+                            const ecseg_tensor_desc& td = h->tensors[d.out];
+                            if (hx.d.op == ECSEG_OP_CONV && hx.path == PATH_HEAD && hx.head_w4 && hx.d.in0 == d.out &&
+                                h->consumers[d.out] == 1 && d.out != h->output_tensor && td.c_stride == td.c && td.c_offset == 0) {
+                                p.head_w = hx.head_w4; p.head_b = hx.head_b4; p.head_out = view_of(h, hx.d.out);
+                                p.head_k = p.head_out.c; p.head_act = hx.d.act; p.head_only = 1;
+                                ++oi;                          // the head op is done
                             }
                         }
                         e = launch_conv_wino4(p, s);
@@ -584,6 +600,7 @@ int ecseg_set_option(ecseg_ctx* h, const char* key, int value) {
     const std::string k(key);
     if (k == "overlap_post") h->overlap_post = value != 0;
     else if (k == "fuse_pool") h->fuse_pool = value != 0;
+    else if (k == "fuse_head") h->fuse_head = value != 0;
     else if (k == "winograd") h->use_winograd = value < 0 ? 0 : value > 2 ? 2 : (int)value;   // 0 direct, 1 F(2x2), 2 F(4x4)
     else if (k == "post_chunk" && value >= 1) h->post_chunk = value;
     else if (k == "images_per_group" && value >= 1) h->images_per_group = value;
@@ -657,6 +674,14 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
                 } else if (d.kh == 1 && d.kw == 1 && cout <= 8 && in_al) {
                     o.path = PATH_HEAD;
                     if ((rc = upload(h, std::vector<float>(kw, kw + (size_t)cin * cout), &o.wt))) return rc;
+                    if (cout <= 4) {
+                        std::vector<float> w4((size_t)cin * 4, 0.f), b4(4, 0.f);
+                        for (int ci = 0; ci < cin; ++ci)
+                            for (int co = 0; co < cout; ++co) w4[(size_t)ci * 4 + co] = kw[(size_t)ci * cout + co];
+                        for (int co = 0; co < cout && kb; ++co) b4[co] = kb[co];
+                        if ((rc = upload(h, w4, &o.head_w4))) return rc;
+                        if ((rc = upload(h, b4, &o.head_b4))) return rc;
+                    }
                 } else if (taps_ok && in_al && cin >= 8 && cout >= 16) {
                     o.path = PATH_MFMA;
                     const int bn = conv_mfma_ntile(cout);
@@ -713,6 +738,11 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
             d.op != ECSEG_OP_COPY && (ti.h != to.h || ti.w != to.w || ti.c != to.c))
             return fail(h, ECSEG_E_INVALID, "shape mismatch in element-wise op " + std::to_string(k));
         h->ops.push_back(o);
+    }
+    h->consumers.assign(n_tensors, 0);
+    for (const OpRt& o : h->ops) {
+        if (o.d.in0 >= 0) ++h->consumers[o.d.in0];
+        if (o.d.op == ECSEG_OP_ADD && o.d.in1 >= 0) ++h->consumers[o.d.in1];
     }
     h->has_model = true;
     return ECSEG_OK;

@@ -30,6 +30,10 @@ struct ConvParams {
     int kT, crop_top, crop_left;
     const float* zero;  // >= 16 bytes of zeros in device memory (LDS-DMA source for padding / out-of-image pixels)
     TView pool;         // pool.p != null: also write MaxPooling2D(2x2, stride 2) of the activated output (conv_wino4 only)
+    // fused 1x1 head (conv_wino4 only, Cout == 64): head_w != null: logits = act(out) . head_w[64][4] + head_b[4] (classes
+    // padded to 4), head_act (softmax | linear ...) over head_k classes, written to head_out; the 64-channel output itself
+    // is not written when head_only != 0
+    const float* head_w; const float* head_b; TView head_out; int head_k, head_act, head_only;
     // filter image strides in floats: [tap][chunk][half][N padded][4] with padded chunk / tap pitches (power-of-two
     // pitches put the 16 transform points of a K-chunk on the same L2 channel and set)
     long wt_chunk_stride, wt_tap_stride;

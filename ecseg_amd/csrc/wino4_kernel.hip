@@ -63,7 +63,7 @@ __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {   
 
 // ABL: timing-only ablations for tools/layer_probe.py (ECSEG_W4_ABL): 1 no halo LDS reads, 2 no filter DMA, 4 no halo DMA,
 // 8 no MFMA
-template <int ABL, bool STAMP = false>
+template <int ABL, bool STAMP = false, bool HEAD = false>
 __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_x, int regs_y, int npairs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* Hs = reinterpret_cast<f32x4*>(smem);              // [3][W4_HS]        halo ring (group g -> buffer g % 3)
@@ -318,6 +318,13 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
     const int Cout = p.out.c;
     unsigned long long et[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ek = STAMP ? __builtin_amdgcn_s_memtime() : 0;
 #define ESTAMP(i) do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); et[i] += now - ek; ek = now; __builtin_amdgcn_sched_barrier(0); } } while (0)
+    float hl[2][4][4];                                       // fused 1x1 head: partial logits [item][row][class]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hl[a][b][c] = 0.f;
     for (int pass = 0; pass < 2; ++pass) {
         __syncthreads();                                     // main-loop LDS reads / previous pass's combine are done
         ESTAMP(0);                                           // [0] barrier (K-loop skew / previous combine)
@@ -370,7 +377,16 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             for (int yy = 0; yy < 4; ++yy) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) y[yy][c] = apply_act(y[yy][c], p.act, p.alpha);
-                if (co + 3 < Cout) *reinterpret_cast<f32x4*>(o + (size_t)yy * W * p.out.cs) = y[yy];
+                if (co + 3 < Cout && !(HEAD && p.head_only)) *reinterpret_cast<f32x4*>(o + (size_t)yy * W * p.out.cs) = y[yy];
+            }
+            if (HEAD) {                                      // this lane's 4 channels x 4 classes of the 1x1 head
+                const f32x4* hw = reinterpret_cast<const f32x4*>(p.head_w) + co;
+                const f32x4 w0 = hw[0], w1 = hw[1], w2 = hw[2], w3 = hw[3];
+#pragma unroll
+                for (int yy = 0; yy < 4; ++yy)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        hl[k][yy][c] += y[yy][0] * w0[c] + y[yy][1] * w1[c] + y[yy][2] * w2[c] + y[yy][3] * w3[c];
             }
             if (p.pool.p != nullptr) {
                 // fused MaxPooling2D(2x2, stride 2): rows pair up in registers, the column partner (x ^ 1) is lane ^ 8 of
@@ -389,6 +405,53 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             }
         }
         ESTAMP(3);                                           // [3] combine + output stores issued
+    }
+    if (HEAD) {
+        // the eight lanes q = 0..7 of a pixel column hold partial logits of 8 output channels each: butterfly over q,
+        // then lane q < 4 finishes row q (bias, softmax / activation over head_k classes) and stores it
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int item = tid + k * 768;
+            if (item >= 1024) break;
+            const int q = item & 7, x = (item >> 3) & 3, n = item >> 5;
+            const int nq8 = n >> 2, ntx = n & 3;
+            const int g = (0x96 >> nq8) & 1;
+            const int nty = nq8 < 2 ? 0 : nq8 < 4 ? 1 : nq8 < 6 ? 2 : 3;
+            const int img = g ? r_img[1] : r_img[0];
+            if (img < 0) continue;
+            f32x4 mine = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int yy = 0; yy < 4; ++yy)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float v = hl[k][yy][c];
+                    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+                    if (q == yy) mine[c] = v;
+                }
+            if (q < 4) {
+                const f32x4 hb = *reinterpret_cast<const f32x4*>(p.head_b);
+                float l[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) l[c] = mine[c] + hb[c];
+                if (p.head_act == ECSEG_ACT_SOFTMAX) {
+                    float m = l[0];
+#pragma unroll
+                    for (int c = 1; c < 4; ++c) if (c < p.head_k) m = fmaxf(m, l[c]);
+                    float sum = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { l[c] = c < p.head_k ? expf(l[c] - m) : 0.f; sum += l[c]; }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) l[c] = l[c] / sum;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) l[c] = apply_act(l[c], p.head_act, p.alpha);
+                }
+                const int oy = (g ? r_y0[1] : r_y0[0]) + 4 * nty + q, ox = (g ? r_x0[1] : r_x0[0]) + 4 * ntx + x;
+                float* ho = p.head_out.p + (((size_t)img * H + oy) * W + ox) * p.head_out.cs;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (c < p.head_k) ho[c] = l[c];
+            }
+        }
     }
     if (STAMP && blockIdx.x == gridDim.x / 2 && lane == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -419,7 +482,8 @@ hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s) {
     if (lds_epi > lds) lds = lds_epi;
     static const int abl = getenv("ECSEG_W4_ABL") ? atoi(getenv("ECSEG_W4_ABL")) : 0;
     void (*kern)(ConvParams, int, int, int) = conv_wino4_kernel<0>;
-    switch (abl) {
+    if (p.head_w != nullptr) kern = conv_wino4_kernel<0, false, true>;
+    else switch (abl) {
         case 1: kern = conv_wino4_kernel<1>; break;
         case 2: kern = conv_wino4_kernel<2>; break;
         case 3: kern = conv_wino4_kernel<3>; break;
@@ -431,11 +495,12 @@ hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s) {
         case 100: kern = conv_wino4_kernel<0, true>; break;        // in-kernel cycle stamps (tools/w4_stamp_probe.py)
         default: break;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[2] = {false, false};
+    const int which = p.head_w != nullptr ? 1 : 0;
+    if (!attr_set[which]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[which] = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(768), lds, s, p, regs_x, regs_y, (int)npairs);
     return hipGetLastError();

@@ -117,7 +117,9 @@ int ecseg_set_images_per_group(ecseg_ctx* h, int n);
  * convolutions: 2 (default) Winograd F(4x4,3x3) where the layer allows it (extents % 16, Cin % 8, Cout % 64), else
  * F(2x2,3x3); 1: F(2x2,3x3); 0: the direct implicit-GEMM kernel; all three are fp32 MFMA kernels), "fuse_pool" (1
  * (default): a MaxPooling2D(2x2, stride 2) that directly follows an F(4x4) convolution is written by that convolution's
- * output stage; 0: separate max-pool kernel). */
+ * output stage; 0: separate max-pool kernel), "fuse_head" (1 (default): a 1x1 convolution with <= 4 output channels that
+ * is the only reader of a 64-channel F(4x4) convolution is computed by that convolution's output stage and the
+ * 64-channel tensor is never written; 0: separate head kernel). */
 int ecseg_set_option(ecseg_ctx* h, const char* key, int value);
 
 /* ---- meta_preprocess (src/image_tools.py:86-101) ---------------------------------------------------------- */

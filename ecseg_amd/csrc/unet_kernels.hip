@@ -154,36 +154,53 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p, int tiles_
         __syncthreads();
     }
 
-    // ---- epilogue: bias + activation, 128-byte row segments per half wave ----
-    const int Hout = p.out.h, Wout = p.out.w;
+    // ---- epilogue: each wave turns its 32 pixel x 32 channel accumulator tile around through a private 4-KB LDS tile
+    //      (the K loop's last barrier has retired the staging buffers) so that a lane finishes 4 consecutive channels of
+    //      one pixel: bias + activation, one 16-byte store; a wave instruction writes 8 pixels x 128 B instead of 64 x 4 B ----
+    const int Hout = p.out.h, Wout = p.out.w, Cout = p.out.c;
     const int Ht = p.convt ? Hin : Hout, Wt = p.convt ? Win : Wout;   // extent the tiles walk over
-    int co_base = n0, oa = 0, ob = 0, Cout = p.out.c;
-    if (p.convt) {
-        const int ab = n0 / p.coutp;
-        co_base = n0 - ab * p.coutp;
-        oa = ab / p.kT; ob = ab - oa * p.kT;
-    }
+    float* Xs = reinterpret_cast<float*>(smem) + wave * 1024;
+    const bool vec_ok = (p.out.cs % 4 == 0) && (Cout % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.out.p) & 15) == 0);
+    const int quad = lane & 7;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int co = co_base + nt * 32 + li;
-        const bool co_ok = co < Cout;
-        const float bv = (p.bias != nullptr && co_ok) ? p.bias[co] : 0.f;
+        int co_base = n0 + nt * 32, oa = 0, ob = 0;
+        if (p.convt) {                                        // N index = (a * kT + b) * coutp + co
+            const int ab = co_base / p.coutp;
+            co_base -= ab * p.coutp;
+            oa = ab / p.kT; ob = ab - oa * p.kT;
+        }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;   // pixel index inside the wave's 32-pixel strip
+        for (int e = 0; e < 16; ++e) Xs[((e & 3) + 8 * (e >> 2) + 4 * lh) * 32 + li] = acc[nt][e];
+        const int co = co_base + 4 * quad;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (co + c < Cout) bv[c] = p.bias[co + c];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = (lane >> 3) + 8 * r;               // pixel index inside the wave's 32-pixel strip
+            f32x4 v = *reinterpret_cast<const f32x4*>(Xs + row * 32 + 4 * quad) + bv;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = apply_act(v[c], p.act, p.alpha);
             int py, px;
             if (TW == 32) { py = wave; px = row; } else { py = 2 * wave + (row >> 4); px = row & 15; }
-            const int tyy = ty0 + py, txx = tx0 + px;              // position in the tiled extent
+            const int tyy = ty0 + py, txx = tx0 + px;          // position in the tiled extent
             int oy = tyy, ox = txx;
-            bool ok = co_ok && tyy < Ht && txx < Wt;               // the tile may overhang the extent
+            bool ok = tyy < Ht && txx < Wt;                     // the tile may overhang the extent
             if (p.convt) {
                 oy = tyy * p.kT + oa - p.crop_top;
                 ox = txx * p.kT + ob - p.crop_left;
                 ok = ok && oy >= 0 && oy < Hout && ox >= 0 && ox < Wout;
             }
             if (ok) {
-                const size_t o = (((size_t)img * Hout + oy) * Wout + ox) * p.out.cs + co;
-                p.out.p[o] = apply_act(acc[nt][e] + bv, p.act, p.alpha);
+                float* o = p.out.p + (((size_t)img * Hout + oy) * Wout + ox) * p.out.cs + co;
+                if (vec_ok && co + 3 < Cout) *reinterpret_cast<f32x4*>(o) = v;
+                else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) if (co + c < Cout) o[c] = v[c];
+                }
             }
         }
     }
@@ -906,7 +923,8 @@ static hipError_t launch_conv_mfma_t(const ConvParams& p, hipStream_t s) {
     const int tiles_x = (ext_w + TW - 1) / TW, tiles_y = (ext_h + TH - 1) / TH;
     const int np_total = p.convt ? p.kT * p.kT * p.coutp : p.coutp;
     const int nblk_n = np_total / BN;
-    const size_t lds = (size_t)KCH * (2 * (TH + R - 1) * (TW + S - 1) + R * S * 2 * BN) * 16;
+    size_t lds = (size_t)KCH * (2 * (TH + R - 1) * (TW + S - 1) + R * S * 2 * BN) * 16;
+    if (lds < 4 * 4096) lds = 4 * 4096;                       // the output stage needs a 4-KB exchange tile per wave
     const size_t grid = (size_t)p.n * tiles_x * tiles_y * nblk_n;
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;

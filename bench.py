@@ -31,16 +31,18 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 PEAK_HBM_GBS = 8000.0
 
 
-def cpu_baseline(cfg, weights, n_images=1):
-    """The oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample."""
+def cpu_baseline(cfg, weights, n_images=1, hnd=None):
+    """The oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample.  The same
+    sample then serves as a full-size parity check of the device path (returned as the second value)."""
     import torch
     from ecseg_amd import synth
     from oracle import pipeline as op
+    from oracle import postproc, tiling, unet
     imgs = [synth.dapi_image(900 + i, H, W) for i in range(n_images)]
     t_unet = t_post = 0.0
+    ref = []
     t0 = time.perf_counter()
     for im in imgs:
-        from oracle import postproc, tiling, unet
         pos = tiling.patch_positions(H, W)
         patches = tiling.extract_patches(im[..., None], pos)
         a = time.perf_counter()
@@ -48,14 +50,31 @@ def cpu_baseline(cfg, weights, n_images=1):
         b = time.perf_counter()
         raw = op.raw_labels_from_probs(preds, pos)
         post = postproc.meta_inference(raw)
-        postproc.count_cc(post == 3)
+        nec = postproc.count_cc(post == 3)[0]
         c = time.perf_counter()
         t_unet += b - a
         t_post += c - b
+        ref.append((raw, post, nec))
     dt = time.perf_counter() - t0
-    return {'value': n_images / dt, 'unit': 'images/s', 'cores': int(torch.get_num_threads()), 'kind': 'port',
-            'sample': '%d synthetic 1040x1392 image(s), full path (U-Net via torch CPU fp32: %.1f s, stitch+argmax+'
-                      'meta_inference+count via numpy/scipy: %.1f s)' % (n_images, t_unet, t_post)}
+    res = {'value': n_images / dt, 'unit': 'images/s', 'cores': int(torch.get_num_threads()), 'kind': 'port',
+           'sample': '%d synthetic 1040x1392 image(s), full path (U-Net via torch CPU fp32: %.1f s, stitch+argmax+'
+                     'meta_inference+count via numpy/scipy: %.1f s)' % (n_images, t_unet, t_post)}
+    parity = None
+    if hnd is not None:
+        # device path on the same image(s): raw argmax labels may differ from the CPU's only where float rounding moves a
+        # quantised probability across a tie; everything after the raw labels is integer work and must be bit-exact
+        g_raw, g_post, g_nec = hnd.segment_images(np.stack(imgs), want_raw=True)
+        raw_mis = int(sum((np.asarray(r[0]) != g_raw[i]).sum() for i, r in enumerate(ref)))
+        post_mis = int(sum((np.asarray(r[1]) != g_post[i]).sum() for i, r in enumerate(ref)))
+        exact = all(np.array_equal(postproc.meta_inference(g_raw[i].astype(np.int64)), g_post[i]) and
+                    int(postproc.count_cc(g_post[i] == 3)[0]) == int(g_nec[i]) for i in range(n_images))
+        parity = {'sample': res['sample'].split(',')[0], 'pixels': int(n_images * H * W), 'raw_label_mismatch_px': raw_mis,
+                  'post_label_mismatch_px': post_mis, 'n_ec_device': [int(v) for v in g_nec],
+                  'n_ec_cpu': [int(r[2]) for r in ref], 'integer_stages_bit_exact_on_device_raw_labels': bool(exact),
+                  'note': 'raw labels differ only where fp32 summation order moves a uint8-quantised probability across an '
+                          'argmax tie (random-weight model = speckled, tie-rich output); clean-up and counting are '
+                          'bit-exact functions of the raw labels'}
+    return res, parity
 
 
 def main():
@@ -192,7 +211,7 @@ def main():
                                        'F(4x4,3x3) issues 36/144 (F(2x2): 16/36) of those multiplies, so frac can exceed 1',
                                'executed_tflops': round(exe, 2), 'executed_frac': round(exe / PEAK_FP32_MFMA_TFLOPS, 4)}
         if world == 1 and not args.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline(cfg, weights, 1)
+            res['cpu_baseline'], res['parity_vs_cpu'] = cpu_baseline(cfg, weights, 1, hnd)
         print(json.dumps(res), flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -207,8 +207,10 @@ def main():
                                'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
                                'avg_launch_ms': round(conv_ms / conv_launches, 4), 'launches': int(conv_launches),
                                'flop_per_launch_avg': conv_flops / conv_launches,
-                               'note': 'achieved = ALGORITHMIC (direct-convolution) FLOPs / measured kernel time; Winograd '
-                                       'F(4x4,3x3) issues 36/144 (F(2x2): 16/36) of those multiplies, so frac can exceed 1',
+                               'note': 'achieved = ALGORITHMIC (direct-convolution, whole 256x256 windows) FLOPs / measured kernel '
+                                       'time; Winograd F(4x4,3x3) issues 36/144 (F(2x2): 16/36) of those multiplies and the two last '
+                                       'full-resolution layers skip the 28 % of their 16x16 regions that the stitch never reads, so '
+                                       'frac can exceed 1; executed_tflops counts the multiplies really issued',
                                'executed_tflops': round(exe, 2), 'executed_frac': round(exe / PEAK_FP32_MFMA_TFLOPS, 4)}
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'], res['parity_vs_cpu'] = cpu_baseline(cfg, weights, 1, hnd)

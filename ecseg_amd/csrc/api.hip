@@ -28,6 +28,7 @@ struct OpRt {                 // run-time form of one plan operator
     float* bias = nullptr;
     float* head_w4 = nullptr; // PATH_HEAD with <= 4 classes: [cin][4] / [4] zero-padded copies for the fused output stage
     float* head_b4 = nullptr;
+    int crop_level = -1;      // >= 0: only the stitch's readers' regions (grown by crop_level pixels) of the output matter
     float* scale = nullptr;   // AFFINE
     float* shift = nullptr;
     int cin_chunks = 0, coutp = 0;
@@ -35,10 +36,15 @@ struct OpRt {                 // run-time form of one plan operator
 };
 enum { PATH_MFMA = 1, PATH_SMALL_CIN = 2, PATH_HEAD = 3, PATH_GENERIC = 4, PATH_OTHER = 5 };
 
+enum { CROP_LEVELS = 4 };
 struct StitchPlan {
     int n_pos = 0;
     int32_t* pos_dev = nullptr;   // (n_pos, 2) window origins (row, col), reference order
     int32_t* map_dev = nullptr;   // (H*W) source map
+    // demand-driven cropping: level k = 16x16 regions of every window that hold a pixel the stitch reads, grown by k
+    // pixels (the halo of k 3x3 convolutions); lut_len 0 = level unavailable
+    int32_t* lut_dev[CROP_LEVELS] = {nullptr, nullptr, nullptr, nullptr};
+    int lut_len[CROP_LEVELS] = {0, 0, 0, 0};
 };
 
 }  // namespace
@@ -80,6 +86,7 @@ struct ecseg_ctx {
     int post_chunk = 64;
     int overlap_post = 0;
     int fuse_pool = 1;        // 2x2 max-pool written by the producing F(4x4) convolution's output stage
+    int crop = 1;             // segment path: skip output regions of the last full-resolution convolutions that the stitch never reads
     int fuse_head = 1;        // 1x1 head (<= 4 classes) computed by the output stage of the last F(4x4) convolution
     int use_winograd = 2;     // 0 direct, 1 Winograd F(2x2,3x3), 2 F(4x4,3x3) where eligible (else F(2x2))
 
@@ -251,7 +258,8 @@ hipEvent_t* prof_pair(ecseg_ctx* h) {
 }
 
 // Run the whole plan on n patches whose input tensor has already been written.
-int run_plan(ecseg_ctx* h, int n) {
+// `crop`: the stitch that will read the model output (segment path), or null when every output pixel matters.
+int run_plan(ecseg_ctx* h, int n, const StitchPlan* crop = nullptr) {
     hipStream_t s = h->stream;
     for (size_t oi = 0; oi < h->ops.size(); ++oi) {
         const OpRt& o = h->ops[oi];
@@ -283,6 +291,10 @@ int run_plan(ecseg_ctx* h, int n) {
                     }
                     if (wino4) {
                         p.wt = o.wt_wino4; p.coutp = out.c;
+                        if (crop && h->crop && o.crop_level >= 0 && o.crop_level < CROP_LEVELS && crop->lut_len[o.crop_level] > 0 &&
+                            out.h == 256 && out.w == 256 && n % crop->n_pos == 0) {
+                            p.lut = crop->lut_dev[o.crop_level]; p.lut_len = crop->lut_len[o.crop_level]; p.per_image = crop->n_pos;
+                        }
                         // a MaxPooling2D(2x2, stride 2) that follows directly is written by the same output stage
                         if (oi + 1 < h->ops.size()) {
                             const ecseg_op_desc& nx = h->ops[oi + 1].d;
@@ -318,7 +330,8 @@ int run_plan(ecseg_ctx* h, int n) {
                     if (ev) {
                         (void)hipEventRecord(ev[1], s);
                         h->prof_flops += o.flops * n;
-                        h->prof_exec_flops += o.flops * n * (wino4 ? 0.25 : wino ? 16.0 / 36.0 : 1.0);   // multiplies actually issued
+                        const double computed = p.lut ? (double)p.lut_len / ((double)p.per_image * 256.0) : 1.0;   // cropped launch
+                        h->prof_exec_flops += o.flops * n * computed * (wino4 ? 0.25 : wino ? 16.0 / 36.0 : 1.0);   // multiplies actually issued
                     }
                 } else if (o.path == PATH_SMALL_CIN) {
                     e = launch_conv_small_cin(in, out, o.wt, o.bias, n, d.kh, d.kw, d.pad_top, d.pad_left, act, d.alpha, s);
@@ -417,6 +430,30 @@ int get_stitch(ecseg_ctx* h, int H, int W, StitchPlan** out) {
     for (int i = 0; i < n; ++i) put(i, pos[2 * i] + lo, pos[2 * i] + hi, pos[2 * i + 1] + lo, pos[2 * i + 1] + hi, lo, lo);
     StitchPlan sp;
     sp.n_pos = n;
+    {   // bounding box of the pixels the stitch takes from every window -> region lists per crop level
+        std::vector<int> box((size_t)n * 4);
+        for (int i = 0; i < n; ++i) { box[4 * i] = 256; box[4 * i + 1] = -1; box[4 * i + 2] = 256; box[4 * i + 3] = -1; }
+        for (int32_t v : map) {
+            if (v < 0) continue;
+            const int i = v >> 16, y = (v >> 8) & 255, x = v & 255;
+            box[4 * i] = std::min(box[4 * i], y); box[4 * i + 1] = std::max(box[4 * i + 1], y);
+            box[4 * i + 2] = std::min(box[4 * i + 2], x); box[4 * i + 3] = std::max(box[4 * i + 3], x);
+        }
+        for (int k = 0; k < CROP_LEVELS; ++k) {
+            std::vector<int32_t> lut;
+            for (int i = 0; i < n; ++i) {
+                if (box[4 * i + 1] < 0) continue;                       // nothing of this window is ever read
+                const int y0 = std::max(box[4 * i] - k, 0) / 16, y1 = std::min(box[4 * i + 1] + k, 255) / 16;
+                const int x0 = std::max(box[4 * i + 2] - k, 0) / 16, x1 = std::min(box[4 * i + 3] + k, 255) / 16;
+                for (int ry = y0; ry <= y1; ++ry)
+                    for (int rx = x0; rx <= x1; ++rx) lut.push_back((i << 16) | (ry << 8) | rx);
+            }
+            if (lut.empty() || lut.size() >= (size_t)n * 256) continue;  // nothing to gain
+            HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&sp.lut_dev[k]), lut.size() * sizeof(int32_t)));
+            HIP_TRY(h, hipMemcpy(sp.lut_dev[k], lut.data(), lut.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            sp.lut_len[k] = (int)lut.size();
+        }
+    }
     HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&sp.pos_dev), pos.size() * sizeof(int32_t)));
     HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&sp.map_dev), map.size() * sizeof(int32_t)));
     HIP_TRY(h, hipMemcpy(sp.pos_dev, pos.data(), pos.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -499,7 +536,7 @@ int segment_dev(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint
         HIP_TRY(h, launch_tile_patches(gray + (size_t)i0 * px, ni, H, W, sp->pos_dev, sp->n_pos,
                                        view_of(h, h->input_tensor).p, s));
         HIP_TRY(h, hipEventRecord(e6[1], s));
-        if ((rc = run_plan(h, ni * sp->n_pos))) return rc;
+        if ((rc = run_plan(h, ni * sp->n_pos, sp))) return rc;
         HIP_TRY(h, hipEventRecord(e6[2], s));
         const TView pv = view_of(h, h->output_tensor);
         HIP_TRY(h, launch_stitch_argmax(pv.p, pv.cs, sp->map_dev, ni, sp->n_pos, H, W, raw + (size_t)i0 * px, s));
@@ -601,6 +638,7 @@ int ecseg_set_option(ecseg_ctx* h, const char* key, int value) {
     if (k == "overlap_post") h->overlap_post = value != 0;
     else if (k == "fuse_pool") h->fuse_pool = value != 0;
     else if (k == "fuse_head") h->fuse_head = value != 0;
+    else if (k == "crop") h->crop = value != 0;
     else if (k == "winograd") h->use_winograd = value < 0 ? 0 : value > 2 ? 2 : (int)value;   // 0 direct, 1 F(2x2), 2 F(4x4)
     else if (k == "post_chunk" && value >= 1) h->post_chunk = value;
     else if (k == "images_per_group" && value >= 1) h->images_per_group = value;
@@ -743,6 +781,23 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
     for (const OpRt& o : h->ops) {
         if (o.d.in0 >= 0) ++h->consumers[o.d.in0];
         if (o.d.op == ECSEG_OP_ADD && o.d.in1 >= 0) ++h->consumers[o.d.in1];
+    }
+    {   // crop levels: walk back from the model output through a chain of single-reader convolutions.  A 1x1 convolution
+        // passes its reader's level on, a 3x3 'same' convolution's INPUT is needed one pixel further out
+        int t = output_tensor, level = 0;
+        for (;;) {
+            int prod = -1;
+            for (size_t k = 0; k < h->ops.size(); ++k) if (h->ops[k].d.out == t) { prod = prod < 0 ? (int)k : -2; }
+            if (prod < 0) break;                               // no (or no unique) producer: a concat view, the input ...
+            OpRt& o = h->ops[prod];
+            const ecseg_tensor_desc& ti = tensors[o.d.in0];
+            if (o.d.op != ECSEG_OP_CONV || level >= CROP_LEVELS) break;
+            o.crop_level = level;
+            if (o.d.kh == 3 && o.d.kw == 3 && o.d.pad_top == 1 && o.d.pad_left == 1) ++level;
+            else if (!(o.d.kh == 1 && o.d.kw == 1)) break;
+            if (h->consumers[o.d.in0] != 1 || ti.c_stride != ti.c || ti.c_offset != 0) break;
+            t = o.d.in0;
+        }
     }
     h->has_model = true;
     return ECSEG_OK;

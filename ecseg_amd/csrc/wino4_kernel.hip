@@ -87,8 +87,16 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int rid = 2 * pair + g;
-        const int rx = rid % regs_x, t = rid / regs_x;
-        const int ry = t % regs_y, img = t / regs_y;
+        int rx, ry, img;
+        if (p.lut != nullptr) {                              // cropped launch: the regions some later stage reads
+            const int i = rid / p.lut_len, v = p.lut[rid - i * p.lut_len];
+            img = i * p.per_image + (v >> 16); ry = (v >> 8) & 255; rx = v & 255;
+            if (i >= p.n / p.per_image) img = p.n;
+        } else {
+            rx = rid % regs_x;
+            const int t = rid / regs_x;
+            ry = t % regs_y; img = t / regs_y;
+        }
         r_img[g] = img < p.n ? img : -1;
         r_y0[g] = ry * 16; r_x0[g] = rx * 16;
     }
@@ -250,7 +258,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
     dma_filter_piece(0, 0, std::integral_constant<int, 0>{});
     dma_filter_piece(0, 0, std::integral_constant<int, 1>{});
     dma_filter_piece(0, 0, std::integral_constant<int, 2>{});
-    W4_WAIT(3);                                              // halo groups 0 and 1 have landed
+    if (ngroups > 1) W4_WAIT(5); else W4_WAIT(3);            // halo group 0 has landed (group 1: before barrier 1, below)
     if (cls == 0) {
         for (int grp = 0; grp < ngroups; ++grp) {
             WSTAMP(0);
@@ -472,7 +480,7 @@ bool conv_wino4_supported(const ConvParams& p) {
 
 hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s) {
     const int regs_x = p.out.w / 16, regs_y = p.out.h / 16;
-    const size_t nreg = (size_t)p.n * regs_x * regs_y;
+    const size_t nreg = p.lut != nullptr ? (size_t)(p.n / p.per_image) * p.lut_len : (size_t)p.n * regs_x * regs_y;
     const size_t npairs = (nreg + 1) / 2;
     const size_t grid = npairs * (size_t)(p.out.c / 64);
     if (grid == 0) return hipSuccess;

@@ -119,7 +119,9 @@ int ecseg_set_images_per_group(ecseg_ctx* h, int n);
  * (default): a MaxPooling2D(2x2, stride 2) that directly follows an F(4x4) convolution is written by that convolution's
  * output stage; 0: separate max-pool kernel), "fuse_head" (1 (default): a 1x1 convolution with <= 4 output channels that
  * is the only reader of a 64-channel F(4x4) convolution is computed by that convolution's output stage and the
- * 64-channel tensor is never written; 0: separate head kernel). */
+ * 64-channel tensor is never written; 0: separate head kernel), "crop" (1 (default): in ecseg_segment_images the last
+ * full-resolution F(4x4) convolutions compute only the 16x16 regions of every window that the stitch (or the halo of the
+ * convolutions behind them) reads - 72 % of them at 1040x1392; results are unchanged; 0: whole windows). */
 int ecseg_set_option(ecseg_ctx* h, const char* key, int value);
 
 /* ---- meta_preprocess (src/image_tools.py:86-101) ---------------------------------------------------------- */

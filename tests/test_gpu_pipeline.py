@@ -90,3 +90,26 @@ def test_overlay_full_size_batch_vs_oracle(gpu):
         got = csvio.overlay_cells(rec[i])
         assert csvio.csv_text(csvio.OVERLAY_COLUMNS, [['x.tif'] + got]) == \
             oracle_overlay.csv_text(oracle_overlay.OVERLAY_COLUMNS, [['x.tif'] + want]), i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('hw', [(300, 462), (600, 500), (1040, 1392)])
+def test_crop_of_unread_regions_changes_nothing(hw):
+    """Base-64 model (depth 1): the two last 3x3 convolutions run the F(4x4) kernel on the regions the stitch reads only
+    (option crop=1, default).  Raw labels, post-processed labels and counts must be identical to the uncropped run."""
+    from ecseg_amd import keras_plan
+    from ecseg_amd._lib import Handle
+    cfg = synth.unet_config(base=64, depth=1)
+    weights = synth.unet_weights(cfg, seed=9)
+    hnd = Handle(0)                                       # own handle: the module's model16 fixture keeps its plan
+    try:
+        hnd.load_plan(keras_plan.build_plan(cfg, weights, fuse=True))
+        imgs = np.stack([synth.dapi_image(40 + i, hw[0], hw[1]) for i in range(2)])
+        hnd.set_option('crop', 1)
+        a = hnd.segment_images(imgs, want_raw=True)
+        hnd.set_option('crop', 0)
+        b = hnd.segment_images(imgs, want_raw=True)
+    finally:
+        hnd.close()
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)

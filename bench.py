@@ -82,9 +82,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--images', type=int, default=8, help='images per GPU per step')
+    ap.add_argument('--images', type=int, default=16, help='images per GPU per step')
     ap.add_argument('--base', type=int, default=64, help='U-Net base width of the synthetic model')
-    ap.add_argument('--group', type=int, default=8, help='images per internal U-Net launch group')
+    ap.add_argument('--group', type=int, default=16, help='images per internal U-Net launch group')
     ap.add_argument('--overlap', action='store_true', help='run post-processing on a second stream')
     ap.add_argument('--direct', action='store_true', help='direct implicit-GEMM 3x3 kernel instead of Winograd')
     ap.add_argument('--wino', type=int, default=None, help='3x3 kernel: 0 direct, 1 Winograd F(2x2,3x3), 2 F(4x4,3x3) where eligible (default: library default)')

@@ -70,7 +70,7 @@ struct ecseg_ctx {
     double flops_per_patch = 0.0, mfma_flops_per_patch = 0.0;
 
     // image pipeline
-    int images_per_group = 8;
+    int images_per_group = 16;   // 560 windows per U-Net launch: ~46 GB of activations for the base-64 U-Net
     std::map<std::pair<int, int>, StitchPlan> stitch;
     uint8_t* d_gray = nullptr; size_t d_gray_cap = 0;
     uint8_t* d_raw = nullptr; size_t d_raw_cap = 0;

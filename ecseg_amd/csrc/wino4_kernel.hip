@@ -13,10 +13,16 @@
 // touches LDS or HBM.  After the K loop every wave folds its own row (R = M[xi][:] A) in registers, the six rows
 // meet through LDS, and Y = A^T R + bias, activation is written as 16-byte stores (128-B segments per pixel).
 //
-// Pipeline: the halo arrives 8 input channels at a time by LDS-DMA (double-buffered, ONE s_barrier per 8 channels);
-// the filter fragments are private to a wave (nobody else reads them), so every wave streams its own 3-KB stage
-// (6 points x 4 input channels x 32 output channels) by LDS-DMA into a private double buffer, ordered by its own
-// counted vmcnt only - no barrier on the filter path.
+// Pipeline: the halo arrives 8 input channels at a time by LDS-DMA into a 3-deep ring, two groups ahead of its use
+// (every wave issues two pieces per group, one at a time behind pinned MFMAs; nobody waits for a piece to land; ONE
+// s_barrier per 8 channels).  The filter fragments are private to a wave (nobody else reads them), so every wave
+// streams its own 3-KB stage (6 points x 4 input channels x 32 output channels) by LDS-DMA into a private double
+// buffer, ordered by its own counted vmcnt only - no barrier on the filter path.  All LDS-DMA goes through inline asm
+// (glds16): the compiler orders every ds_read behind a builtin LDS-DMA with vmcnt(0).  The barrier sits at a different
+// point of the phase sequence (transform, MFMA stage 0, MFMA stage 1) for the three waves of a SIMD (phase rotation).
+//
+// The output stage can also write the 2x2 max-pool of its result, finish a 1x1 head (<= 4 classes) and take its region
+// list from a look-up table (demand-driven cropping) - see ConvParams in common.h.
 //
 // LDS halo image, 16-byte slots (4 channels): slot(g, y, x, h) = (g * 18 + P(y)) * 36 + h * 18 + P(x), where
 // P(v) = {0, 5, 10, 14}[v % 4] + v / 4 regroups the 18 halo rows / columns by their phase modulo the tile stride 4.
@@ -61,8 +67,8 @@ __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {   
 
 }  // namespace
 
-// ABL: timing-only ablations for tools/layer_probe.py (ECSEG_W4_ABL): 1 no halo LDS reads, 2 no filter DMA, 4 no halo DMA,
-// 8 no MFMA
+// ABL: timing-only ablations for tools/w4_ablate.py (ECSEG_W4_ABL): 1 no halo LDS reads, 2 no filter DMA, 4 no halo DMA,
+// 8 no MFMA, 32 instruction mix of a (row, column-half) wave split; STAMP (ECSEG_W4_ABL=100): s_memtime stamps
 template <int ABL, bool STAMP = false, bool HEAD = false>
 __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_x, int regs_y, int npairs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -498,7 +504,6 @@ hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s) {
         case 6: kern = conv_wino4_kernel<6>; break;
         case 7: kern = conv_wino4_kernel<7>; break;
         case 8: kern = conv_wino4_kernel<8>; break;
-        case 16: kern = conv_wino4_kernel<16>; break;
         case 32: kern = conv_wino4_kernel<32>; break;
         case 100: kern = conv_wino4_kernel<0, true>; break;        // in-kernel cycle stamps (tools/w4_stamp_probe.py)
         default: break;

@@ -193,3 +193,24 @@ def test_base64_unet_f4x4_with_concat_views(gpu):
     assert np.abs(got - unfused).max() < 1e-5, np.abs(got - unfused).max()      # (the fused head sums in another order)
     assert np.abs(got - direct).max() < 1e-4, np.abs(got - direct).max()
     np.testing.assert_allclose(got.sum(-1), 1.0, atol=1e-5)
+
+
+@pytest.mark.parametrize('act,use_bias', [('linear', True), ('sigmoid', False), ('tanh', True), ('elu', True)])
+def test_winograd_f4x4_activations_and_no_bias(gpu, act, use_bias):
+    """The F(4x4) output stage applies the layer's own activation and tolerates a missing bias."""
+    rng = np.random.default_rng(17)
+    cin, cout, H, W, n = 16, 64, 32, 32, 2
+    cfg = {'class_name': 'Functional', 'config': {'name': 'm', 'layers': [
+        {'class_name': 'InputLayer', 'name': 'in', 'config': {'name': 'in', 'batch_input_shape': [None, H, W, cin]},
+         'inbound_nodes': []},
+        {'class_name': 'Conv2D', 'name': 'c', 'config': {'name': 'c', 'filters': cout, 'kernel_size': [3, 3],
+                                                         'strides': [1, 1], 'padding': 'same', 'activation': act,
+                                                         'use_bias': use_bias}, 'inbound_nodes': [[['in', 0, 0, {}]]]}],
+        'input_layers': [['in', 0, 0]], 'output_layers': [['c', 0, 0]]}}
+    w = [(rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin) / 64).astype(np.float32)]
+    if use_bias:
+        w.append(rng.normal(size=cout).astype(np.float32))
+    x = rng.integers(0, 256, size=(n, H, W, cin), dtype=np.uint8)
+    want = oracle_unet.forward(cfg, {'c': w}, x)
+    got, _ = _run(gpu, cfg, {'c': w}, x, fuse=True)
+    assert np.abs(got - want).max() < 5e-4 * max(1.0, float(np.abs(want).max())), np.abs(got - want).max()

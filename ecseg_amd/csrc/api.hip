@@ -28,7 +28,11 @@ struct OpRt {                 // run-time form of one plan operator
     float* bias = nullptr;
     float* head_w4 = nullptr; // PATH_HEAD with <= 4 classes: [cin][4] / [4] zero-padded copies for the fused output stage
     float* head_b4 = nullptr;
-    int crop_level = -1;      // >= 0: only the stitch's readers' regions (grown by crop_level pixels) of the output matter
+    // demand-driven cropping: which part of this op's OUTPUT somebody reads, as a recipe applied to the stitch's per-window
+    // bounding box: 'd' = grow by one pixel (a 3x3 convolution behind), 'h' = halve (a 2x2 / stride-2 up-convolution
+    // behind); crop_ok = false: everything is needed (or unknown)
+    bool crop_ok = false;
+    std::string crop_code;
     float* scale = nullptr;   // AFFINE
     float* shift = nullptr;
     int cin_chunks = 0, coutp = 0;
@@ -36,15 +40,15 @@ struct OpRt {                 // run-time form of one plan operator
 };
 enum { PATH_MFMA = 1, PATH_SMALL_CIN = 2, PATH_HEAD = 3, PATH_GENERIC = 4, PATH_OTHER = 5 };
 
-enum { CROP_LEVELS = 4 };
+struct CropLut { int32_t* dev = nullptr; int len = 0; int size = 0; };   // size: extent (pixels) of the tensors it applies to
 struct StitchPlan {
     int n_pos = 0;
     int32_t* pos_dev = nullptr;   // (n_pos, 2) window origins (row, col), reference order
     int32_t* map_dev = nullptr;   // (H*W) source map
-    // demand-driven cropping: level k = 16x16 regions of every window that hold a pixel the stitch reads, grown by k
-    // pixels (the halo of k 3x3 convolutions); lut_len 0 = level unavailable
-    int32_t* lut_dev[CROP_LEVELS] = {nullptr, nullptr, nullptr, nullptr};
-    int lut_len[CROP_LEVELS] = {0, 0, 0, 0};
+    // demand-driven cropping: per window the bounding box (y0, y1, x0, x1) of the pixels the stitch reads, and the region
+    // lists built from it on first use, keyed by the op's crop recipe (OpRt::crop_code)
+    std::vector<int> box;
+    std::map<std::string, CropLut> luts;
 };
 
 }  // namespace
@@ -258,8 +262,51 @@ hipEvent_t* prof_pair(ecseg_ctx* h) {
 }
 
 // Run the whole plan on n patches whose input tensor has already been written.
+// Region list of a crop recipe: per window the stitch's bounding box is grown / halved as the recipe says, then covered
+// by 16x16 regions whose origins are multiples of 4 pixels (the Winograd tile) and stay inside the tensor.  Entry =
+// window << 16 | (y origin / 4) << 8 | (x origin / 4).  len 0: nothing to gain (or an extent the kernel cannot take).
+const CropLut* get_crop_lut(StitchPlan* sp, const std::string& code) {
+    auto it = sp->luts.find(code);
+    if (it != sp->luts.end()) return &it->second;
+    CropLut cl;
+    int size = 256;
+    for (char c : code) if (c == 'h') size /= 2;
+    cl.size = size;
+    std::vector<int32_t> lut;
+    if (size >= 16 && size % 16 == 0) {
+        for (int i = 0; i < sp->n_pos; ++i) {
+            int b[4] = {sp->box[4 * i], sp->box[4 * i + 1], sp->box[4 * i + 2], sp->box[4 * i + 3]};
+            if (b[1] < 0) continue;                            // nothing of this window is ever read
+            int sz = 256;
+            for (char c : code) {
+                if (c == 'd') { b[0] = std::max(b[0] - 1, 0); b[1] = std::min(b[1] + 1, sz - 1); b[2] = std::max(b[2] - 1, 0); b[3] = std::min(b[3] + 1, sz - 1); }
+                else { sz /= 2; for (int& v : b) v /= 2; }
+            }
+            int o[2], nr[2];
+            for (int a = 0; a < 2; ++a) {
+                const int lo = b[2 * a], hi = b[2 * a + 1];
+                o[a] = lo & ~3;                                // tile-aligned start
+                nr[a] = (hi - o[a]) / 16 + 1;
+                if (16 * nr[a] >= size) { nr[a] = size / 16; o[a] = 0; }
+                else if (o[a] + 16 * nr[a] > size) o[a] = size - 16 * nr[a];
+            }
+            for (int ry = 0; ry < nr[0]; ++ry)
+                for (int rx = 0; rx < nr[1]; ++rx) lut.push_back((i << 16) | (((o[0] + 16 * ry) / 4) << 8) | ((o[1] + 16 * rx) / 4));
+        }
+        if (lut.size() >= (size_t)sp->n_pos * (size / 16) * (size / 16)) lut.clear();     // nothing to gain
+    }
+    if (!lut.empty()) {
+        if (hipMalloc(reinterpret_cast<void**>(&cl.dev), lut.size() * sizeof(int32_t)) != hipSuccess ||
+            hipMemcpy(cl.dev, lut.data(), lut.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
+            if (cl.dev) (void)hipFree(cl.dev);
+            cl.dev = nullptr;
+        } else cl.len = (int)lut.size();
+    }
+    return &sp->luts.emplace(code, cl).first->second;
+}
+
 // `crop`: the stitch that will read the model output (segment path), or null when every output pixel matters.
-int run_plan(ecseg_ctx* h, int n, const StitchPlan* crop = nullptr) {
+int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
     hipStream_t s = h->stream;
     for (size_t oi = 0; oi < h->ops.size(); ++oi) {
         const OpRt& o = h->ops[oi];
@@ -291,9 +338,11 @@ int run_plan(ecseg_ctx* h, int n, const StitchPlan* crop = nullptr) {
                     }
                     if (wino4) {
                         p.wt = o.wt_wino4; p.coutp = out.c;
-                        if (crop && h->crop && o.crop_level >= 0 && o.crop_level < CROP_LEVELS && crop->lut_len[o.crop_level] > 0 &&
-                            out.h == 256 && out.w == 256 && n % crop->n_pos == 0) {
-                            p.lut = crop->lut_dev[o.crop_level]; p.lut_len = crop->lut_len[o.crop_level]; p.per_image = crop->n_pos;
+                        if (crop && h->crop && o.crop_ok && n % crop->n_pos == 0) {
+                            const CropLut* cl = get_crop_lut(crop, o.crop_code);
+                            if (cl->len > 0 && out.h == cl->size && out.w == cl->size) {
+                                p.lut = cl->dev; p.lut_len = cl->len; p.per_image = crop->n_pos;
+                            }
                         }
                         // a MaxPooling2D(2x2, stride 2) that follows directly is written by the same output stage
                         if (oi + 1 < h->ops.size()) {
@@ -330,7 +379,7 @@ int run_plan(ecseg_ctx* h, int n, const StitchPlan* crop = nullptr) {
                     if (ev) {
                         (void)hipEventRecord(ev[1], s);
                         h->prof_flops += o.flops * n;
-                        const double computed = p.lut ? (double)p.lut_len / ((double)p.per_image * 256.0) : 1.0;   // cropped launch
+                        const double computed = p.lut ? (double)p.lut_len / ((double)p.per_image * (out.h / 16) * (out.w / 16)) : 1.0;   // cropped launch
                         h->prof_exec_flops += o.flops * n * computed * (wino4 ? 0.25 : wino ? 16.0 / 36.0 : 1.0);   // multiplies actually issued
                     }
                 } else if (o.path == PATH_SMALL_CIN) {
@@ -430,29 +479,13 @@ int get_stitch(ecseg_ctx* h, int H, int W, StitchPlan** out) {
     for (int i = 0; i < n; ++i) put(i, pos[2 * i] + lo, pos[2 * i] + hi, pos[2 * i + 1] + lo, pos[2 * i + 1] + hi, lo, lo);
     StitchPlan sp;
     sp.n_pos = n;
-    {   // bounding box of the pixels the stitch takes from every window -> region lists per crop level
-        std::vector<int> box((size_t)n * 4);
-        for (int i = 0; i < n; ++i) { box[4 * i] = 256; box[4 * i + 1] = -1; box[4 * i + 2] = 256; box[4 * i + 3] = -1; }
-        for (int32_t v : map) {
-            if (v < 0) continue;
-            const int i = v >> 16, y = (v >> 8) & 255, x = v & 255;
-            box[4 * i] = std::min(box[4 * i], y); box[4 * i + 1] = std::max(box[4 * i + 1], y);
-            box[4 * i + 2] = std::min(box[4 * i + 2], x); box[4 * i + 3] = std::max(box[4 * i + 3], x);
-        }
-        for (int k = 0; k < CROP_LEVELS; ++k) {
-            std::vector<int32_t> lut;
-            for (int i = 0; i < n; ++i) {
-                if (box[4 * i + 1] < 0) continue;                       // nothing of this window is ever read
-                const int y0 = std::max(box[4 * i] - k, 0) / 16, y1 = std::min(box[4 * i + 1] + k, 255) / 16;
-                const int x0 = std::max(box[4 * i + 2] - k, 0) / 16, x1 = std::min(box[4 * i + 3] + k, 255) / 16;
-                for (int ry = y0; ry <= y1; ++ry)
-                    for (int rx = x0; rx <= x1; ++rx) lut.push_back((i << 16) | (ry << 8) | rx);
-            }
-            if (lut.empty() || lut.size() >= (size_t)n * 256) continue;  // nothing to gain
-            HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&sp.lut_dev[k]), lut.size() * sizeof(int32_t)));
-            HIP_TRY(h, hipMemcpy(sp.lut_dev[k], lut.data(), lut.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-            sp.lut_len[k] = (int)lut.size();
-        }
+    sp.box.assign((size_t)n * 4, 0);
+    for (int i = 0; i < n; ++i) { sp.box[4 * i] = 256; sp.box[4 * i + 1] = -1; sp.box[4 * i + 2] = 256; sp.box[4 * i + 3] = -1; }
+    for (int32_t v : map) {
+        if (v < 0) continue;
+        const int i = v >> 16, y = (v >> 8) & 255, x = v & 255;
+        sp.box[4 * i] = std::min(sp.box[4 * i], y); sp.box[4 * i + 1] = std::max(sp.box[4 * i + 1], y);
+        sp.box[4 * i + 2] = std::min(sp.box[4 * i + 2], x); sp.box[4 * i + 3] = std::max(sp.box[4 * i + 3], x);
     }
     HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&sp.pos_dev), pos.size() * sizeof(int32_t)));
     HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&sp.map_dev), map.size() * sizeof(int32_t)));
@@ -604,7 +637,10 @@ void ecseg_destroy(ecseg_ctx* h) {
     (void)hipStreamSynchronize(h->stream);
     (void)hipStreamSynchronize(h->stream2);
     free_model(h);
-    for (auto& kv : h->stitch) { (void)hipFree(kv.second.pos_dev); (void)hipFree(kv.second.map_dev); }
+    for (auto& kv : h->stitch) {
+        (void)hipFree(kv.second.pos_dev); (void)hipFree(kv.second.map_dev);
+        for (auto& lk : kv.second.luts) if (lk.second.dev) (void)hipFree(lk.second.dev);
+    }
     if (h->zero_page) (void)hipFree(h->zero_page);
     void* ptrs[] = {h->d_gray, h->d_raw, h->d_post, h->d_aux8, h->d_u8in, h->d_i32, h->d_i64, h->d_probs_in, h->d_hist,
                     h->ws.L, h->ws.area, h->ws.sumy, h->ws.sumx, h->ws.flag, h->ws.tmpA, h->ws.tmpB, h->ws.list, h->ws.g};
@@ -782,21 +818,42 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
         if (o.d.in0 >= 0) ++h->consumers[o.d.in0];
         if (o.d.op == ECSEG_OP_ADD && o.d.in1 >= 0) ++h->consumers[o.d.in1];
     }
-    {   // crop levels: walk back from the model output through a chain of single-reader convolutions.  A 1x1 convolution
-        // passes its reader's level on, a 3x3 'same' convolution's INPUT is needed one pixel further out
-        int t = output_tensor, level = 0;
-        for (;;) {
-            int prod = -1;
-            for (size_t k = 0; k < h->ops.size(); ++k) if (h->ops[k].d.out == t) { prod = prod < 0 ? (int)k : -2; }
-            if (prod < 0) break;                               // no (or no unique) producer: a concat view, the input ...
+    {   // crop recipes: walk back from the model output.  A 1x1 convolution passes its reader's need on, a 3x3 'same'
+        // convolution needs its input one pixel further out ('d'); a concatenation is followed through the view written
+        // by a 2x2 / stride-2 transposed convolution (which itself computes everything, from an input needed at half the
+        // coordinates, 'h'); skip connections and anything with several readers keep their full extent and end the walk
+        int t = output_tensor, reader = (int)h->ops.size();
+        std::string code;
+        for (int guard = 0; guard < 32 && code.size() < 16; ++guard) {
+            int prod = -1, nprod = 0;
+            for (int k = 0; k < reader; ++k) if (h->ops[k].d.out == t) { prod = k; ++nprod; }
+            if (nprod == 0) {
+                const ecseg_tensor_desc& tt = tensors[t];
+                int up = -1;
+                for (int k = 0; k < reader; ++k) {
+                    const ecseg_op_desc& od = h->ops[k].d;
+                    const ecseg_tensor_desc& tv = tensors[od.out];
+                    if (od.op == ECSEG_OP_CONVT && tv.buffer == tt.buffer && tv.h == tt.h && tv.w == tt.w && tv.c_stride == tt.c_stride &&
+                        tv.c < tt.c && h->consumers[od.out] == 0) up = k;                  // the last such writer before the reader
+                }
+                if (up < 0) break;
+                const ecseg_op_desc& ud = h->ops[up].d;
+                const ecseg_tensor_desc& ui = tensors[ud.in0];
+                if (!(ud.kh == 2 && ud.kw == 2 && ud.stride == 2 && ud.pad_top == 0 && ud.pad_left == 0 && ui.h * 2 == tt.h && ui.w * 2 == tt.w)) break;
+                if (h->consumers[ud.in0] != 1 || ui.c_stride != ui.c || ui.c_offset != 0) break;
+                code += 'h';
+                t = ud.in0; reader = up;
+                continue;
+            }
+            if (nprod != 1) break;
             OpRt& o = h->ops[prod];
             const ecseg_tensor_desc& ti = tensors[o.d.in0];
-            if (o.d.op != ECSEG_OP_CONV || level >= CROP_LEVELS) break;
-            o.crop_level = level;
-            if (o.d.kh == 3 && o.d.kw == 3 && o.d.pad_top == 1 && o.d.pad_left == 1) ++level;
+            if (o.d.op != ECSEG_OP_CONV) break;
+            o.crop_ok = true; o.crop_code = code;
+            if (o.d.kh == 3 && o.d.kw == 3 && o.d.pad_top == 1 && o.d.pad_left == 1) code += 'd';
             else if (!(o.d.kh == 1 && o.d.kw == 1)) break;
             if (h->consumers[o.d.in0] != 1 || ti.c_stride != ti.c || ti.c_offset != 0) break;
-            t = o.d.in0;
+            t = o.d.in0; reader = prod;
         }
     }
     h->has_model = true;

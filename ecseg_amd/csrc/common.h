@@ -35,7 +35,7 @@ struct ConvParams {
     // is not written when head_only != 0
     const float* head_w; const float* head_b; TView head_out; int head_k, head_act, head_only;
     // demand-driven cropping (conv_wino4 only): lut != null: only the 16x16 regions listed are computed, the same list
-    // for every image of `per_image` consecutive patches; entry = patch-in-image << 16 | region row << 8 | region column
+    // for every image of `per_image` consecutive patches; entry = patch-in-image << 16 | (y origin / 4) << 8 | (x origin / 4)
     const int32_t* lut; int lut_len, per_image;
     // filter image strides in floats: [tap][chunk][half][N padded][4] with padded chunk / tap pitches (power-of-two
     // pitches put the 16 transform points of a K-chunk on the same L2 channel and set)

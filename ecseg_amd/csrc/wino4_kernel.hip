@@ -96,8 +96,11 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         int rx, ry, img;
         if (p.lut != nullptr) {                              // cropped launch: the regions some later stage reads
             const int i = rid / p.lut_len, v = p.lut[rid - i * p.lut_len];
-            img = i * p.per_image + (v >> 16); ry = (v >> 8) & 255; rx = v & 255;
+            img = i * p.per_image + (v >> 16); ry = (v >> 8) & 255; rx = v & 255;      // origins in 4-pixel tiles
             if (i >= p.n / p.per_image) img = p.n;
+            r_img[g] = img < p.n ? img : -1;
+            r_y0[g] = ry * 4; r_x0[g] = rx * 4;
+            continue;
         } else {
             rx = rid % regs_x;
             const int t = rid / regs_x;

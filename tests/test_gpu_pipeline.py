@@ -93,13 +93,14 @@ def test_overlay_full_size_batch_vs_oracle(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('hw', [(300, 462), (600, 500), (1040, 1392)])
-def test_crop_of_unread_regions_changes_nothing(hw):
-    """Base-64 model (depth 1): the two last 3x3 convolutions run the F(4x4) kernel on the regions the stitch reads only
-    (option crop=1, default).  Raw labels, post-processed labels and counts must be identical to the uncropped run."""
+@pytest.mark.parametrize('hw,depth', [((300, 462), 1), ((600, 500), 2), ((1040, 1392), 2), ((256, 256), 2)])
+def test_crop_of_unread_regions_changes_nothing(hw, depth):
+    """Base-64 model: the last 3x3 convolutions of the two highest decoder levels run the F(4x4) kernel only on the regions
+    that the stitch - or the halo of the layers behind them - reads (option crop=1, default).  Raw labels, post-processed
+    labels and counts must be identical to the uncropped run."""
     from ecseg_amd import keras_plan
     from ecseg_amd._lib import Handle
-    cfg = synth.unet_config(base=64, depth=1)
+    cfg = synth.unet_config(base=64, depth=depth)
     weights = synth.unet_weights(cfg, seed=9)
     hnd = Handle(0)                                       # own handle: the module's model16 fixture keeps its plan
     try:

@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libecseg_hip.so')
+# ECSEG_HIP_LIB: another build of the same library (A/B timing of two builds on one GPU box)
+LIB_PATH = os.environ.get('ECSEG_HIP_LIB') or os.path.join(HERE, 'libecseg_hip.so')
 
 EXPORTS = [
     'ecseg_abi_version', 'ecseg_create', 'ecseg_destroy', 'ecseg_last_error', 'ecseg_device_name', 'ecseg_stream',

@@ -35,6 +35,10 @@
 #include "common.h"
 #include "device_util.h"
 
+#ifndef W4_VARIANT
+#define W4_VARIANT 0
+#endif
+
 namespace ecseg {
 
 namespace {
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
                     if (v == 5) dma_filter_piece(next_stage, ss ^ 1, std::integral_constant<int, 2>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (ss == 0 && e == 1 && (v == 1 || v == 3) && halo_grp >= 0) {       // behind MFMAs 8 and 10
+                if (e == 1 && (v == 1 || v == 3) && halo_grp >= 0) {       // behind MFMAs 8 and 10
                     __builtin_amdgcn_sched_barrier(0);
                     if (v == 1) dma_halo_piece(halo_grp, std::integral_constant<int, 0>{});
                     if (v == 3) dma_halo_piece(halo_grp, std::integral_constant<int, 1>{});
@@ -251,7 +255,9 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
     // two feed the matrix pipe.  t[] lives in registers across the barrier; every class executes ngroups barriers and
     // reads halo group g only between barriers g and g+1.
 #define W4_SB() __builtin_amdgcn_sched_barrier(0)
-#define W4_T(g) do { __builtin_amdgcn_s_setprio(3); transform(g); __builtin_amdgcn_s_setprio(0); } while (0)
+// T(g): raised priority for the few long-latency instructions of the transform; afterwards the MFMA phases run at a
+// priority that orders the three waves of a SIMD (class 2 first): the wave that is latest in the rotation gets the pipe
+#define W4_T(g, PR) do { __builtin_amdgcn_s_setprio(3); transform(g); __builtin_amdgcn_s_setprio(W4_VARIANT == 12 ? (PR) + 1 : (PR)); } while (0)
     // S0(g): filter stage 2g has landed (it is the youngest thing this wave issued) -> vmcnt(0); streams stage 2g+1 and
     // the halo of group g+2.  S1(g): only the two halo pieces issued after stage 2g+1 may still fly -> vmcnt(2).
 #define W4_S0(g) do { W4_SB(); W4_WAIT(0); W4_SB(); mfma_stage(0, 2 * (g) + 1, (g) + 2 < ngroups ? (g) + 2 : -1); } while (0)
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             WSTAMP(0);
             W4_BARRIER();
             WSTAMP(1);
-            W4_T(grp);
+            W4_T(grp, 0);
             WSTAMP(2);
             W4_S0(grp);
             WSTAMP(3);
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         }
     } else if (cls == 1) {
         W4_BARRIER();
-        W4_T(0);
+        W4_T(0, 1);
         W4_S0(0);
         for (int grp = 1; grp < ngroups; ++grp) {
             WSTAMP(0);
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             WSTAMP(1);
             W4_S1(grp - 1);
             WSTAMP(2);
-            W4_T(grp);
+            W4_T(grp, 1);
             WSTAMP(3);
             W4_S0(grp);
             WSTAMP(4);
@@ -298,7 +304,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         W4_S1(ngroups - 1);
     } else {
         W4_BARRIER();
-        W4_T(0);
+        W4_T(0, 2);
         for (int grp = 1; grp < ngroups; ++grp) {
             W4_WAIT(3);                                      // own halo pieces of group grp + 0/1 landed (3 filter pieces may fly)
             WSTAMP(0);
@@ -308,7 +314,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             WSTAMP(2);
             W4_S1(grp - 1);
             WSTAMP(3);
-            W4_T(grp);
+            W4_T(grp, 2);
             WSTAMP(4);
         }
         W4_S0(ngroups - 1);

@@ -265,14 +265,16 @@ hipEvent_t* prof_pair(ecseg_ctx* h) {
 // Region list of a crop recipe: per window the stitch's bounding box is grown / halved as the recipe says, then covered
 // by 16x16 regions whose origins are multiples of 4 pixels (the Winograd tile) and stay inside the tensor.  Entry =
 // window << 16 | (y origin / 4) << 8 | (x origin / 4).  len 0: nothing to gain (or an extent the kernel cannot take).
-const CropLut* get_crop_lut(StitchPlan* sp, const std::string& code) {
-    auto it = sp->luts.find(code);
+const CropLut* get_crop_lut(StitchPlan* sp, const std::string& code, int rh = 16, int rw = 16) {
+    const std::string key = code + ":" + std::to_string(rh) + "x" + std::to_string(rw);
+    auto it = sp->luts.find(key);
     if (it != sp->luts.end()) return &it->second;
     CropLut cl;
     int size = 256;
     for (char c : code) if (c == 'h') size /= 2;
     cl.size = size;
     std::vector<int32_t> lut;
+    const int rdim[2] = {rh, rw};
     if (size >= 16 && size % 16 == 0) {
         for (int i = 0; i < sp->n_pos; ++i) {
             int b[4] = {sp->box[4 * i], sp->box[4 * i + 1], sp->box[4 * i + 2], sp->box[4 * i + 3]};
@@ -285,15 +287,16 @@ const CropLut* get_crop_lut(StitchPlan* sp, const std::string& code) {
             int o[2], nr[2];
             for (int a = 0; a < 2; ++a) {
                 const int lo = b[2 * a], hi = b[2 * a + 1];
+                const int R = rdim[a];
                 o[a] = lo & ~3;                                // tile-aligned start
-                nr[a] = (hi - o[a]) / 16 + 1;
-                if (16 * nr[a] >= size) { nr[a] = size / 16; o[a] = 0; }
-                else if (o[a] + 16 * nr[a] > size) o[a] = size - 16 * nr[a];
+                nr[a] = (hi - o[a]) / R + 1;
+                if (R * nr[a] >= size) { nr[a] = (size + R - 1) / R; o[a] = 0; }
+                else if (o[a] + R * nr[a] > size) o[a] = size - R * nr[a];
             }
             for (int ry = 0; ry < nr[0]; ++ry)
-                for (int rx = 0; rx < nr[1]; ++rx) lut.push_back((i << 16) | (((o[0] + 16 * ry) / 4) << 8) | ((o[1] + 16 * rx) / 4));
+                for (int rx = 0; rx < nr[1]; ++rx) lut.push_back((i << 16) | (((o[0] + rh * ry) / 4) << 8) | ((o[1] + rw * rx) / 4));
         }
-        if (lut.size() >= (size_t)sp->n_pos * (size / 16) * (size / 16)) lut.clear();     // nothing to gain
+        if (lut.size() >= (size_t)sp->n_pos * ((size + rh - 1) / rh) * ((size + rw - 1) / rw)) lut.clear();     // nothing to gain
     }
     if (!lut.empty()) {
         if (hipMalloc(reinterpret_cast<void**>(&cl.dev), lut.size() * sizeof(int32_t)) != hipSuccess ||
@@ -302,7 +305,7 @@ const CropLut* get_crop_lut(StitchPlan* sp, const std::string& code) {
             cl.dev = nullptr;
         } else cl.len = (int)lut.size();
     }
-    return &sp->luts.emplace(code, cl).first->second;
+    return &sp->luts.emplace(key, cl).first->second;
 }
 
 // `crop`: the stitch that will read the model output (segment path), or null when every output pixel matters.
@@ -330,6 +333,7 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                     }
                     hipEvent_t* ev = h->profile_kernels ? prof_pair(h) : nullptr;
                     if (ev) (void)hipEventRecord(ev[0], s);
+                    double computed = 1.0;                     // fraction of the layer a cropped launch really computes
                     const bool wino4 = h->use_winograd >= 2 && o.wt_wino4 && conv_wino4_supported(p);
                     const bool wino = !wino4 && h->use_winograd && o.wt_wino && out.h >= 4 && out.w >= 8;
                     {
@@ -342,6 +346,7 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                             const CropLut* cl = get_crop_lut(crop, o.crop_code);
                             if (cl->len > 0 && out.h == cl->size && out.w == cl->size) {
                                 p.lut = cl->dev; p.lut_len = cl->len; p.per_image = crop->n_pos;
+                                computed = (double)cl->len / ((double)crop->n_pos * (out.h / 16) * (out.w / 16));
                             }
                         }
                         // a MaxPooling2D(2x2, stride 2) that follows directly is written by the same output stage
@@ -374,12 +379,25 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                         p.wt_chunk_stride = wt_chunk_pitch(o.coutp_wino); p.wt_tap_stride = wt_tap_pitch(o.coutp_wino, o.cin_chunks);
                         e = launch_conv_wino(p, s);
                     } else {
+                        if (crop && h->crop && o.crop_ok && p.convt && n % crop->n_pos == 0 && in.h == in.w) {
+                            // cropped up-convolution: only the input tiles whose outputs somebody reads; of the two tile
+                            // shapes (4 x 32, 8 x 16) the one that needs fewer tiles
+                            const CropLut* a = get_crop_lut(crop, o.crop_code, 4, 32);
+                            const CropLut* b = get_crop_lut(crop, o.crop_code, 8, 16);
+                            const CropLut* cl = nullptr; int tw = 0;
+                            if (a->len > 0 && a->size == in.h && in.w >= 32 && (b->len == 0 || b->size != in.h || a->len <= b->len)) { cl = a; tw = 32; }
+                            else if (b->len > 0 && b->size == in.h) { cl = b; tw = 16; }
+                            if (cl) {
+                                p.lut = cl->dev; p.lut_len = cl->len; p.per_image = crop->n_pos; p.force_tw = tw;
+                                const int th = 128 / tw;
+                                computed = (double)cl->len / ((double)crop->n_pos * ((in.h + th - 1) / th) * ((in.w + tw - 1) / tw));
+                            }
+                        }
                         e = launch_conv_mfma(p, s);
                     }
                     if (ev) {
                         (void)hipEventRecord(ev[1], s);
                         h->prof_flops += o.flops * n;
-                        const double computed = p.lut ? (double)p.lut_len / ((double)p.per_image * (out.h / 16) * (out.w / 16)) : 1.0;   // cropped launch
                         h->prof_exec_flops += o.flops * n * computed * (wino4 ? 0.25 : wino ? 16.0 / 36.0 : 1.0);   // multiplies actually issued
                     }
                 } else if (o.path == PATH_SMALL_CIN) {
@@ -842,6 +860,7 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
                 if (!(ud.kh == 2 && ud.kw == 2 && ud.stride == 2 && ud.pad_top == 0 && ud.pad_left == 0 && ui.h * 2 == tt.h && ui.w * 2 == tt.w)) break;
                 if (h->consumers[ud.in0] != 1 || ui.c_stride != ui.c || ui.c_offset != 0) break;
                 code += 'h';
+                h->ops[up].crop_ok = true; h->ops[up].crop_code = code;      // the part of its INPUT that matters
                 t = ud.in0; reader = up;
                 continue;
             }

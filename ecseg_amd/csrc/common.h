@@ -37,6 +37,9 @@ struct ConvParams {
     // demand-driven cropping (conv_wino4 only): lut != null: only the 16x16 regions listed are computed, the same list
     // for every image of `per_image` consecutive patches; entry = patch-in-image << 16 | (y origin / 4) << 8 | (x origin / 4)
     const int32_t* lut; int lut_len, per_image;
+    // conv_mfma (transposed convolutions): the same list idea over its TH x TW tiles of the INPUT extent; force_tw = 16 | 32
+    // selects the tile shape the list was built for (0: the launcher's own choice)
+    int force_tw;
     // filter image strides in floats: [tap][chunk][half][N padded][4] with padded chunk / tap pitches (power-of-two
     // pitches put the 16 transform points of a K-chunk on the same L2 channel and set)
     long wt_chunk_stride, wt_tap_stride;

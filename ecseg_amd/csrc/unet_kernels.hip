@@ -42,9 +42,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p, int tiles_
     const int tid = threadIdx.x;
     unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
     const int nb = bid % nblk_n; bid /= nblk_n;
-    const int tx0 = (bid % tiles_x) * TW; bid /= tiles_x;
-    const int ty0 = (bid % tiles_y) * TH; bid /= tiles_y;
-    const int img = bid;
+    int tx0, ty0, img;
+    if (p.lut != nullptr) {                                  // cropped launch: tile origins (in 4-pixel units) from the list
+        const int i = bid / p.lut_len, v = p.lut[bid - i * p.lut_len];
+        img = i * p.per_image + (v >> 16); ty0 = ((v >> 8) & 255) * 4; tx0 = (v & 255) * 4;
+    } else {
+        tx0 = (bid % tiles_x) * TW; bid /= tiles_x;
+        ty0 = (bid % tiles_y) * TH; bid /= tiles_y;
+        img = bid;
+    }
     const int n0 = nb * BN;
 
     const int Hin = p.in.h, Win = p.in.w, Cin = p.in.c;
@@ -925,7 +931,7 @@ static hipError_t launch_conv_mfma_t(const ConvParams& p, hipStream_t s) {
     const int nblk_n = np_total / BN;
     size_t lds = (size_t)KCH * (2 * (TH + R - 1) * (TW + S - 1) + R * S * 2 * BN) * 16;
     if (lds < 4 * 4096) lds = 4 * 4096;                       // the output stage needs a 4-KB exchange tile per wave
-    const size_t grid = (size_t)p.n * tiles_x * tiles_y * nblk_n;
+    const size_t grid = (p.lut != nullptr ? (size_t)(p.n / p.per_image) * p.lut_len : (size_t)p.n * tiles_x * tiles_y) * nblk_n;
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     hipLaunchKernelGGL((conv_mfma_kernel<NT, TW, R, S, KCH>), dim3((unsigned)grid), dim3(256), lds, s, p, tiles_x, tiles_y,
@@ -942,7 +948,7 @@ static hipError_t launch_conv_mfma_rs(const ConvParams& p, hipStream_t s) {
 
 hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
     const int bn = conv_mfma_ntile(p.out.c);
-    const bool wide = (p.convt ? p.in.w : p.out.w) >= 32;
+    const bool wide = p.force_tw ? p.force_tw == 32 : (p.convt ? p.in.w : p.out.w) >= 32;
     if (bn == 128) return wide ? launch_conv_mfma_rs<4, 32>(p, s) : launch_conv_mfma_rs<4, 16>(p, s);
     if (bn == 64) return wide ? launch_conv_mfma_rs<2, 32>(p, s) : launch_conv_mfma_rs<2, 16>(p, s);
     return wide ? launch_conv_mfma_rs<1, 32>(p, s) : launch_conv_mfma_rs<1, 16>(p, s);

@@ -943,7 +943,7 @@ template <int NT, int TW>
 static hipError_t launch_conv_mfma_rs(const ConvParams& p, hipStream_t s) {
     if (p.R == 3) return launch_conv_mfma_t<NT, TW, 3, 3>(p, s);
     if (p.R == 2) return launch_conv_mfma_t<NT, TW, 2, 2>(p, s);
-    return launch_conv_mfma_t<NT, TW, 1, 1, 4>(p, s);
+    return launch_conv_mfma_t<NT, TW, 1, 1, 2>(p, s);      // K-chunks per barrier: 1 / 2 / 4 / 8 measured 0 / +0.2 / -0.2 / -1.5 % (A/B)
 }
 
 hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {

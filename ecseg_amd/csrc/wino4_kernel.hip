@@ -179,21 +179,40 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
 
     f32x4 t[6];
     // ---- row transform of group grp: t[j] for the six halo columns of the lane's tile, 4 channels each ----
+    // Rows 1-4 of B^T end in +1 (t = c0 d[r0] + c1 d[r1] + c2 d[r2] + d[r3]: three fmas), rows 0 and 5 have only three
+    // terms, the last with +1 (t = c0 d[r0] + c1 d[r1] + d[r2]: three reads, two fmas).
+    const bool inner_row = xi >= 1 && xi <= 4;
     auto transform = [&](int grp) {
         const f32x4* A = Hs + (grp % 3) * W4_HS + a_lane;
+        constexpr int cp[6] = {w4_cpos(0), w4_cpos(1), w4_cpos(2), w4_cpos(3), w4_cpos(4), w4_cpos(5)};
+        if (ABL & 1) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            constexpr int cp[6] = {w4_cpos(0), w4_cpos(1), w4_cpos(2), w4_cpos(3), w4_cpos(4), w4_cpos(5)};
-            if (ABL & 1) { t[j] = f32x4{c0, c1, c2, c3} * (float)(j + grp); continue; }
-            if ((ABL & 32) && j == 5) { t[5] = t[4]; continue; }      // timing model of the (row, column-half) wave split
-            const f32x4 d0 = A[ro0 + cp[j]], d1 = A[ro1 + cp[j]], d2 = A[ro2 + cp[j]], d3 = A[ro3 + cp[j]];
-            // scalar fmas on purpose (file is built with -fno-slp-vectorize): packed f32 VALU ops (v_pk_fma_f32) stall
-            // the SIMD beside MFMAs, single v_fma_f32 hide in the matrix pipe's shadow
+            for (int j = 0; j < 6; ++j) t[j] = f32x4{c0, c1, c2, c3} * (float)(j + grp);
+            return;
+        }
+        // scalar fmas on purpose (file is built with -fno-slp-vectorize): packed f32 VALU ops (v_pk_fma_f32) stall the
+        // SIMD beside MFMAs, single v_fma_f32 hide in the matrix pipe's shadow
+        if (inner_row) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                t[j][c] = __builtin_fmaf(c3, d3[c], __builtin_fmaf(c2, d2[c], __builtin_fmaf(c1, d1[c], c0 * d0[c])));
-            asm volatile("" : "+v"(t[j]));                   // finish this column here: 16 transient registers, not 96
-            __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < 6; ++j) {
+                if ((ABL & 32) && j == 5) { t[5] = t[4]; continue; }      // timing model of a (row, column-half) wave split
+                const f32x4 d0 = A[ro0 + cp[j]], d1 = A[ro1 + cp[j]], d2 = A[ro2 + cp[j]], d3 = A[ro3 + cp[j]];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    t[j][c] = __builtin_fmaf(c0, d0[c], __builtin_fmaf(c1, d1[c], __builtin_fmaf(c2, d2[c], d3[c])));
+                asm volatile("" : "+v"(t[j]));               // finish this column here: 16 transient registers, not 96
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                if ((ABL & 32) && j == 5) { t[5] = t[4]; continue; }
+                const f32x4 d0 = A[ro0 + cp[j]], d1 = A[ro1 + cp[j]], d2 = A[ro2 + cp[j]];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) t[j][c] = __builtin_fmaf(c0, d0[c], __builtin_fmaf(c1, d1[c], d2[c]));
+                asm volatile("" : "+v"(t[j]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
     // ---- one filter stage (2 of the group's 4 channel pairs; buffer ss): column transform + 12 MFMAs ----

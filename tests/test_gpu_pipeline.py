@@ -114,3 +114,27 @@ def test_crop_of_unread_regions_changes_nothing(hw, depth):
         hnd.close()
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.gpu
+def test_repeated_runs_are_bit_identical():
+    """Race screen (tools/stress_determinism.py runs the long version): the F(4x4) kernel orders its LDS-DMA traffic with
+    hand-counted vmcnt waits and one barrier per 8 channels; any mistake there shows up as run-to-run differences."""
+    from ecseg_amd import keras_plan
+    from ecseg_amd._lib import Handle
+    cfg = synth.unet_config(base=64, depth=2)
+    weights = synth.unet_weights(cfg, seed=5)
+    hnd = Handle(0)
+    try:
+        hnd.load_plan(keras_plan.build_plan(cfg, weights, fuse=True))
+        imgs = np.stack([synth.dapi_image(70 + i, 512, 640) for i in range(3)])
+        ref = hnd.segment_images(imgs, want_raw=True)
+        x = np.random.default_rng(3).integers(0, 256, size=(6, 256, 256, 1), dtype=np.uint8)
+        pref = hnd.forward_patches(x)
+        for _ in range(6):
+            out = hnd.segment_images(imgs, want_raw=True)
+            for a, b in zip(ref, out):
+                assert np.array_equal(a, b)
+            assert np.array_equal(pref, hnd.forward_patches(x))
+    finally:
+        hnd.close()

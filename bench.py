@@ -7,17 +7,25 @@ quantise + argmax -> meta_inference clean-up -> connected-component ecDNA count,
 rank runs - by the path's only exchange: an all-gather of the per-image result records (RCCL over xGMI).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--images B] [--base 64]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+
+``--gpus N`` with N > 1 starts the N ranks itself (one process per GPU, ``torch.distributed.run`` on 127.0.0.1) when
+it is not already running under a launcher; under ``torch.distributed.run`` (RANK / WORLD_SIZE set) it is one rank.
 
 Rank 0 prints ONE JSON line.  The workload is BASELINE.json configs[1] (single-GPU fp32 U-Net forward + argmax at
 1392x1040) extended with the post-processing and count that the metric's "CCL ms/image" names; weights are the
 canonical classic U-Net (base width 64, 23 conv layers, 96.2 GFLOP per 256x256 patch), random-initialised with a fixed
 seed because metaseg.h5 is not distributable.
+
+Order of work at N = 1: (1) the CPU baseline legs run FIRST, in worker processes, before this process touches the
+GPU (nothing competes with the timed GPU region and no process is started after HIP is initialised); (2) the timed GPU
+region; (3) a host-inclusive leg (host arrays in, labels + counts back on the host); (4) full-size parity of the device
+results against the CPU results of (1).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,52 +37,143 @@ sys.path.insert(0, ROOT)
 H, W = 1040, 1392
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
+CPU_SEED0 = 900                    # synthetic image indices of the CPU-baseline / parity sample
 
 
-def cpu_baseline(cfg, weights, n_images=1, hnd=None):
-    """The oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample.  The same
-    sample then serves as a full-size parity check of the device path (returned as the second value)."""
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle = CPU restatement of the reference path; the Keras original cannot run on this box)
+# ---------------------------------------------------------------------------------------------------------------------
+def _cpu_worker(job):
+    """One image (or a patch sample of one image) through the oracle with a fixed number of torch threads."""
+    base, idx, threads, n_patches = job
     import torch
+    torch.set_num_threads(threads)
     from ecseg_amd import synth
     from oracle import pipeline as op
     from oracle import postproc, tiling, unet
-    imgs = [synth.dapi_image(900 + i, H, W) for i in range(n_images)]
-    t_unet = t_post = 0.0
-    ref = []
+    cfg = synth.unet_config(base=base)
+    weights = synth.unet_weights(cfg, seed=0)
+    im = synth.dapi_image(idx, H, W)
+    pos = tiling.patch_positions(H, W)
+    patches = tiling.extract_patches(im[..., None], pos)
+    unet.forward(cfg, weights, patches[:1])                      # warm the thread pool / allocator (untimed)
     t0 = time.perf_counter()
-    for im in imgs:
-        pos = tiling.patch_positions(H, W)
-        patches = tiling.extract_patches(im[..., None], pos)
-        a = time.perf_counter()
+    if n_patches:                                                # bounded sample: a few windows only
+        preds = unet.forward(cfg, weights, patches[:n_patches])
+        t1 = time.perf_counter()
+        rng = np.random.default_rng(idx)
+        full = np.concatenate([preds] * (-(-len(patches) // n_patches)))[:len(patches)]
+        raw = op.raw_labels_from_probs(full[rng.permutation(len(patches))], pos)
+    else:
         preds = np.concatenate([unet.forward(cfg, weights, patches[i:i + 7]) for i in range(0, len(patches), 7)])
-        b = time.perf_counter()
+        t1 = time.perf_counter()
         raw = op.raw_labels_from_probs(preds, pos)
-        post = postproc.meta_inference(raw)
-        nec = postproc.count_cc(post == 3)[0]
-        c = time.perf_counter()
-        t_unet += b - a
-        t_post += c - b
-        ref.append((raw, post, nec))
-    dt = time.perf_counter() - t0
-    res = {'value': n_images / dt, 'unit': 'images/s', 'cores': int(torch.get_num_threads()), 'kind': 'port',
-           'sample': '%d synthetic 1040x1392 image(s), full path (U-Net via torch CPU fp32: %.1f s, stitch+argmax+'
-                     'meta_inference+count via numpy/scipy: %.1f s)' % (n_images, t_unet, t_post)}
-    parity = None
-    if hnd is not None:
-        # device path on the same image(s): raw argmax labels may differ from the CPU's only where float rounding moves a
-        # quantised probability across a tie; everything after the raw labels is integer work and must be bit-exact
-        g_raw, g_post, g_nec = hnd.segment_images(np.stack(imgs), want_raw=True)
-        raw_mis = int(sum((np.asarray(r[0]) != g_raw[i]).sum() for i, r in enumerate(ref)))
-        post_mis = int(sum((np.asarray(r[1]) != g_post[i]).sum() for i, r in enumerate(ref)))
-        exact = all(np.array_equal(postproc.meta_inference(g_raw[i].astype(np.int64)), g_post[i]) and
-                    int(postproc.count_cc(g_post[i] == 3)[0]) == int(g_nec[i]) for i in range(n_images))
-        parity = {'sample': res['sample'].split(',')[0], 'pixels': int(n_images * H * W), 'raw_label_mismatch_px': raw_mis,
-                  'post_label_mismatch_px': post_mis, 'n_ec_device': [int(v) for v in g_nec],
-                  'n_ec_cpu': [int(r[2]) for r in ref], 'integer_stages_bit_exact_on_device_raw_labels': bool(exact),
-                  'note': 'raw labels differ only where fp32 summation order moves a uint8-quantised probability across an '
-                          'argmax tie (random-weight model = speckled, tie-rich output); clean-up and counting are '
-                          'bit-exact functions of the raw labels'}
-    return res, parity
+    post = postproc.meta_inference(raw)
+    nec = postproc.count_cc(post == 3)[0]
+    t2 = time.perf_counter()
+    if n_patches:
+        return None, None, 0, t1 - t0, t2 - t1
+    return raw.astype(np.uint8), post.astype(np.uint8), int(nec), t1 - t0, t2 - t1
+
+
+def cpu_baseline(base):
+    """(i) image-parallel workers over all host cores, one full image each; (ii) one thread on a bounded patch sample.
+    Returns (cpu_baseline dict, single-thread dict, reference outputs for the parity check)."""
+    import multiprocessing as mp
+    ncpu = os.cpu_count() or 1
+    nproc = max(1, min(8, ncpu // 16))
+    threads = max(1, ncpu // nproc)
+    ctx = mp.get_context('spawn')
+    with ctx.Pool(nproc) as pool:
+        pool.map(_cpu_noop, range(nproc))                         # workers up, torch imported (untimed)
+        out = pool.map(_cpu_worker, [(base, CPU_SEED0 + i, threads, 0) for i in range(nproc)])
+        dt = max(o[3] + o[4] for o in out)                        # the workers run side by side; input synthesis is untimed
+    refs = [(o[0], o[1], o[2]) for o in out]
+    par = {'value': nproc / dt, 'unit': 'images/s', 'cores': nproc * threads, 'kind': 'port',
+           'sample': '%d synthetic 1040x1392 images, one per worker process (%d processes x %d torch threads), full path '
+                     '(U-Net via torch CPU fp32: %.1f s/image, stitch+argmax+meta_inference+count via numpy/scipy: %.2f '
+                     's/image), wall %.1f s' % (nproc, nproc, threads, float(np.mean([o[3] for o in out])),
+                                                float(np.mean([o[4] for o in out])), dt)}
+    n_sample = 2 if base >= 64 else 6 if base >= 32 else 18
+    with ctx.Pool(1) as pool:
+        pool.map(_cpu_noop, [0])
+        o = pool.map(_cpu_worker, [(base, CPU_SEED0, 1, n_sample)])[0]
+    t_img = o[3] * 35.0 / n_sample + o[4]
+    single = {'value': 1.0 / t_img, 'unit': 'images/s', 'cores': 1, 'kind': 'port',
+              'sample': 'one thread: U-Net on %d of the 35 windows of one image (%.1f s, scaled x35/%d) + stitch/argmax/'
+                        'meta_inference/count of one full image (%.2f s)' % (n_sample, o[3], n_sample, o[4])}
+    return par, single, refs
+
+
+def _cpu_noop(_):
+    import torch                                                   # noqa: F401
+    from oracle import pipeline, postproc, tiling, unet           # noqa: F401
+    return 0
+
+
+def parity_vs_cpu(hnd, refs):
+    """Device path on the CPU sample's images.  Raw argmax labels may differ from the CPU's only where float rounding moves
+    a quantised probability across a tie; everything after the raw labels is integer work and must be bit-exact."""
+    from ecseg_amd import synth
+    from oracle import postproc
+    n = len(refs)
+    imgs = np.stack([synth.dapi_image(CPU_SEED0 + i, H, W) for i in range(n)])
+    g_raw, g_post, g_nec = hnd.segment_images(imgs, want_raw=True)
+    raw_mis = [int((refs[i][0] != g_raw[i]).sum()) for i in range(n)]
+    post_mis = [int((refs[i][1] != g_post[i]).sum()) for i in range(n)]
+    k = min(n, 2)                                                  # the integer stages re-done on the CPU for two images
+    exact = all(np.array_equal(postproc.meta_inference(g_raw[i].astype(np.int64)), g_post[i]) and
+                int(postproc.count_cc(g_post[i] == 3)[0]) == int(g_nec[i]) for i in range(k))
+    return {'sample': '%d synthetic 1040x1392 image(s)' % n, 'pixels': int(n * H * W),
+            'raw_label_mismatch_px': int(sum(raw_mis)), 'post_label_mismatch_px': int(sum(post_mis)),
+            'raw_label_mismatch_px_per_image': raw_mis,
+            'n_ec_device': [int(v) for v in g_nec], 'n_ec_cpu': [int(r[2]) for r in refs],
+            'integer_stages_bit_exact_on_device_raw_labels': bool(exact),
+            'note': 'raw labels differ only where fp32 summation order moves a uint8-quantised probability across an '
+                    'argmax tie (random-weight model = speckled, tie-rich output; see profiles/*label_mismatch* for a '
+                    'smooth-output model); clean-up and counting are bit-exact functions of the raw labels'}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    """--gpus N > 1 outside a launcher: start one rank per GPU and relay rank 0's JSON line.  This parent never touches
+    the GPU (device_count() does not initialise HIP)."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit('bench.py: --gpus %d but only %d HIP device(s) visible' % (args.gpus, have))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def layer_table(model, recs, steps):
+    """Per-convolution table from the per-launch HIP-event records of the timed steps."""
+    plan = model.plan
+    agg = {}
+    for r in recs:
+        a = agg.setdefault(r['op'], dict(kind=r['kind'], launches=0, ms=0.0, flops=0.0, executed=0.0))
+        a['launches'] += 1; a['ms'] += r['ms']; a['flops'] += r['flops']; a['executed'] += r['executed_flops']
+    names = {v: k for k, v in plan.layer_tensor.items()}
+    rows = []
+    for op, a in sorted(agg.items()):
+        o = plan.ops[op]
+        ti, to = plan.tensors[o['in0']], plan.tensors[o['out']]
+        ms = a['ms'] / a['launches']
+        rows.append({'op': op, 'layer': names.get(o['out'], '?'), 'type': 'conv%dx%d' % (o['kh'], o['kw']) if o['op'] == 1 else 'convT%dx%d' % (o['kh'], o['kw']),
+                     'in': [ti['h'], ti['w'], ti['c']], 'out': [to['h'], to['w'], to['c']],
+                     'kernel': ('conv_mfma_kernel', 'conv_wino_kernel F(2x2)', 'conv_wino4_kernel F(4x4)')[a['kind']],
+                     'launches': a['launches'], 'avg_ms': round(ms, 4),
+                     'algorithmic_gflop_per_launch': round(a['flops'] / a['launches'] / 1e9, 2),
+                     'executed_gflop_per_launch': round(a['executed'] / a['launches'] / 1e9, 2),
+                     'algorithmic_tflops': round(a['flops'] / a['ms'] / 1e9, 1),
+                     'executed_tflops': round(a['executed'] / a['ms'] / 1e9, 1),
+                     'executed_frac_of_peak': round(a['executed'] / a['ms'] / 1e9 / PEAK_FP32_MFMA_TFLOPS, 3)})
+    return rows
 
 
 def main():
@@ -91,7 +190,18 @@ def main():
     ap.add_argument('--opt', action='append', default=[], help='library tuning knob key=value (ecseg_set_option), repeatable')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
+    ap.add_argument('--no-host-inclusive', action='store_true')
+    ap.add_argument('--layer-table', default=None, help='write the per-layer roofline table (JSON) to this path')
     args = ap.parse_args()
+
+    under_launcher = 'WORLD_SIZE' in os.environ and 'RANK' in os.environ
+    if args.gpus > 1 and not under_launcher:
+        self_launch(args)
+
+    want_cpu = args.gpus <= 1 and not under_launcher and not args.no_cpu_baseline
+    cpu_par = cpu_single = refs = None
+    if want_cpu:
+        cpu_par, cpu_single, refs = cpu_baseline(args.base)     # before this process initialises HIP
 
     import torch                      # first: libecseg_hip.so then binds to the HIP runtime torch already loaded
     import torch.distributed as dist
@@ -101,8 +211,8 @@ def main():
 
     rank, world = edist.init_process_group()
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != max(1, args.gpus) and rank == 0:
-        print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
+    if world != max(1, args.gpus):
+        raise SystemExit('bench.py: --gpus %d but the launcher started %d rank(s)' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no HIP device visible); there is no CPU fallback')
     torch.cuda.set_device(local)
@@ -150,6 +260,7 @@ def main():
     stage = {k: 0.0 for k in hnd.T_NAMES}
     conv_ms = conv_flops = conv_exec = 0.0
     conv_launches = 0
+    launch_recs = []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -159,6 +270,8 @@ def main():
         ms, nl, fl = hnd.conv_profile()
         conv_ms += ms; conv_launches += nl; conv_flops += fl
         conv_exec += hnd.conv_executed_flops()
+        if not args.no_kernel_profile:
+            launch_recs += hnd.conv_launch_profile()
     barrier()
     dt = time.perf_counter() - t0
     hnd.set_kernel_profiling(False)
@@ -187,33 +300,56 @@ def main():
             'ccl_ms_per_image': round(stage['post'] / (args.steps * B), 4),
         }
         if conv_launches:
-            traffic = None
+            traffic = traffic_src = None
             try:        # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
                 tag = {0: 'direct', 1: 'f2x2', 2: 'f4x4'}[wino_mode]
                 pmc = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_pmc_traffic.json')
                              and tag in f)
                 if pmc and args.base == 64:
                     traffic = json.load(open(os.path.join(ROOT, 'profiles', pmc[-1])))['conv_mfma_all']['hbm_bytes_per_launch']
+                    traffic_src = 'profiles/' + pmc[-1] + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, read from the committed summary, not measured in this run)'
             except Exception:
                 traffic = None
-            ach = conv_flops / (conv_ms * 1e-3) / 1e12
+            alg = conv_flops / (conv_ms * 1e-3) / 1e12
             exe = conv_exec / (conv_ms * 1e-3) / 1e12
             res['roofline'] = {'bound': 'mfma',
                                'kernel': {0: 'conv_mfma_kernel (direct implicit GEMM)',
                                           1: 'conv_wino_kernel (Winograd F(2x2,3x3)) + conv_mfma_kernel (2x2 up-convs)',
                                           2: 'conv_wino4_kernel (Winograd F(4x4,3x3)) + conv_mfma_kernel (2x2 up-convs)'}[wino_mode] +
                                          ', fp32 v_mfma_f32_32x32x2_f32',
-                               'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
+                               'achieved': round(exe, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': round(exe / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
                                'avg_launch_ms': round(conv_ms / conv_launches, 4), 'launches': int(conv_launches),
-                               'flop_per_launch_avg': conv_flops / conv_launches,
-                               'note': 'achieved = ALGORITHMIC (direct-convolution, whole 256x256 windows) FLOPs / measured kernel '
-                                       'time; Winograd F(4x4,3x3) issues 36/144 (F(2x2): 16/36) of those multiplies and the two last '
-                                       'full-resolution layers skip the 28 % of their 16x16 regions that the stitch never reads, so '
-                                       'frac can exceed 1; executed_tflops counts the multiplies really issued',
-                               'executed_tflops': round(exe, 2), 'executed_frac': round(exe / PEAK_FP32_MFMA_TFLOPS, 4)}
-        if world == 1 and not args.no_cpu_baseline:
-            res['cpu_baseline'], res['parity_vs_cpu'] = cpu_baseline(cfg, weights, 1, hnd)
+                               'executed_flop_per_launch_avg': conv_exec / conv_launches,
+                               'algorithmic_flop_per_launch_avg': conv_flops / conv_launches,
+                               'algorithmic_tflops': round(alg, 2),
+                               'algorithmic_over_direct_peak': round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
+                               'note': 'achieved / frac = FLOPs the matrix cores EXECUTED (multiplies really issued: Winograd '
+                                       'F(4x4,3x3) issues 36/144, F(2x2) 16/36 of a 3x3 convolution\'s multiplies; cropped decoder '
+                                       'layers count only the 16x16 regions computed) / HIP-event time of every MFMA-conv launch '
+                                       'on the handle\'s stream / fp32 MFMA peak, so frac <= 1 is matrix-pipe utilisation.  '
+                                       'algorithmic_tflops = direct-convolution FLOPs of whole 256x256 windows (SURVEY 8d) / the '
+                                       'same time; it exceeds the direct-convolution roof by the Winograd and cropping factors'}
+            if args.layer_table and launch_recs:
+                rows = layer_table(model, launch_recs, args.steps)
+                json.dump({'command': ' '.join(sys.argv), 'patches_per_launch': B * 35, 'peak_tflops': PEAK_FP32_MFMA_TFLOPS,
+                           'layers': rows}, open(args.layer_table, 'w'), indent=1)
+        if world == 1 and not args.no_host_inclusive:
+            # host arrays in (pageable numpy), labels + counts back on the host: H2D + device pipeline + D2H per call
+            n_hi = 2
+            hnd.segment_images(host, want_raw=False)
+            t1 = time.perf_counter()
+            for _ in range(n_hi):
+                hnd.segment_images(host, want_raw=False)
+            hi = (time.perf_counter() - t1) / n_hi
+            res['host_inclusive'] = {'value': round(B / hi, 3), 'unit': 'images/s', 'ms_per_image': round(hi / B * 1e3, 3),
+                                     'what': 'ecseg_segment_images: %d uint8 images from pageable host memory (H2D), device '
+                                             'pipeline, post-processed labels + counts back to host memory (D2H), synchronous'
+                                             % B}
+        if cpu_par is not None:
+            res['cpu_baseline'] = cpu_par
+            res['cpu_baseline_single_thread'] = cpu_single
+            res['parity_vs_cpu'] = parity_vs_cpu(hnd, refs)
         print(json.dumps(res), flush=True)
     if dist.is_initialized():
         dist.barrier()

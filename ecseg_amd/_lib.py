@@ -15,7 +15,7 @@ EXPORTS = [
     'ecseg_segment_images', 'ecseg_segment_images_dev', 'ecseg_set_images_per_group', 'ecseg_set_option', 'ecseg_preprocess', 'ecseg_u16_to_u8',
     'ecseg_stitch_argmax', 'ecseg_meta_inference', 'ecseg_meta_inference_dev', 'ecseg_count_cc', 'ecseg_ccl_labels',
     'ecseg_count_colocalization', 'ecseg_count_hsr', 'ecseg_overlay', 'ecseg_get_timings',
-    'ecseg_set_kernel_profiling', 'ecseg_get_conv_profile', 'ecseg_get_conv_executed_flops', 'ecseg_debug_peek', 'ecseg_lzw_decode', 'ecseg_lzw_encode',
+    'ecseg_set_kernel_profiling', 'ecseg_get_conv_profile', 'ecseg_get_conv_executed_flops', 'ecseg_get_conv_launch_profile', 'ecseg_debug_peek', 'ecseg_lzw_decode', 'ecseg_lzw_encode',
 ]
 
 
@@ -80,6 +80,7 @@ def load_library():
     lib.ecseg_get_conv_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     lib.ecseg_get_conv_executed_flops.argtypes = [vp, C.POINTER(C.c_double)]
     lib.ecseg_debug_peek.argtypes = [vp, vp, i32]
+    lib.ecseg_get_conv_launch_profile.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     for fn in (lib.ecseg_lzw_decode, lib.ecseg_lzw_encode):
         fn.argtypes = [vp, C.c_longlong, vp, C.c_longlong]
         fn.restype = C.c_longlong
@@ -316,6 +317,16 @@ class Handle:
         ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
         self._check(self.lib.ecseg_get_conv_profile(self.h, C.byref(ms), C.byref(n), C.byref(fl)), 'ecseg_get_conv_profile')
         return ms.value, n.value, fl.value
+
+    def conv_launch_profile(self, max_records=4096):
+        """Per-launch records of the last profiled call: list of dicts (op, kind, ms, flops, executed_flops)."""
+        op = np.zeros(max_records, np.int32); kind = np.zeros(max_records, np.int32)
+        ms = np.zeros(max_records, np.float32); fl = np.zeros(max_records, np.float64); ex = np.zeros(max_records, np.float64)
+        n = self.lib.ecseg_get_conv_launch_profile(self.h, max_records, _ptr(op), _ptr(kind), _ptr(ms), _ptr(fl), _ptr(ex))
+        if n < 0:
+            self._check(n, 'ecseg_get_conv_launch_profile')
+        return [dict(op=int(op[k]), kind=int(kind[k]), ms=float(ms[k]), flops=float(fl[k]), executed_flops=float(ex[k]))
+                for k in range(n)]
 
     def debug_peek(self, n=32):
         out = np.zeros(n, np.float32)

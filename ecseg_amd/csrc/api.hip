@@ -99,8 +99,11 @@ struct ecseg_ctx {
     float stage_ms[ECSEG_T_N] = {};
     bool profile_kernels = false;
     std::vector<hipEvent_t> prof_events;   // pairs
+    std::vector<hipEvent_t> grp_events;    // 6 per image group of segment_dev
     size_t prof_used = 0;
     double prof_flops = 0.0, prof_exec_flops = 0.0;
+    struct ProfRec { int op; int kind; double flops, exec_flops; float ms; };   // kind: 0 direct, 1 F(2x2), 2 F(4x4)
+    std::vector<ProfRec> prof_recs;        // one per profiled launch of the last segment / forward call
     double last_conv_ms = 0.0; long long last_conv_launches = 0; double last_conv_flops = 0.0, last_conv_exec_flops = 0.0;
 };
 
@@ -322,6 +325,7 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                 const bool softmax = d.act == ECSEG_ACT_SOFTMAX;
                 const int act = (softmax && o.path != PATH_HEAD) ? ECSEG_ACT_LINEAR : d.act;
                 if (o.path == PATH_MFMA) {
+                    const size_t oi_first = oi;                 // (fusions below advance oi)
                     ConvParams p{};
                     p.in = in; p.out = out; p.wt = o.wt; p.bias = o.bias; p.n = n;
                     p.act = act; p.alpha = d.alpha; p.cin_chunks = o.cin_chunks; p.coutp = o.coutp; p.zero = h->zero_page;
@@ -367,7 +371,10 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                             const OpRt& hx = h->ops[oi + 1];
                             const ecseg_tensor_desc& td = h->tensors[d.out];
                             if (hx.d.op == ECSEG_OP_CONV && hx.path == PATH_HEAD && hx.head_w4 && hx.d.in0 == d.out &&
-                                h->consumers[d.out] == 1 && d.out != h->output_tensor && td.c_stride == td.c && td.c_offset == 0) {
+                                h->consumers[d.out] == 1 && d.out != h->output_tensor && td.c_stride == td.c && td.c_offset == 0 &&
+                                // workgroups write head pixels while others still read the convolution's input halo
+                                h->tensors[hx.d.out].buffer != h->tensors[d.in0].buffer &&
+                                h->tensors[hx.d.out].buffer != td.buffer) {
                                 p.head_w = hx.head_w4; p.head_b = hx.head_b4; p.head_out = view_of(h, hx.d.out);
                                 p.head_k = p.head_out.c; p.head_act = hx.d.act; p.head_only = 1;
                                 ++oi;                          // the head op is done
@@ -398,7 +405,9 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                     if (ev) {
                         (void)hipEventRecord(ev[1], s);
                         h->prof_flops += o.flops * n;
-                        h->prof_exec_flops += o.flops * n * computed * (wino4 ? 0.25 : wino ? 16.0 / 36.0 : 1.0);   // multiplies actually issued
+                        const double ex = o.flops * n * computed * (wino4 ? 0.25 : wino ? 16.0 / 36.0 : 1.0);   // multiplies actually issued
+                        h->prof_exec_flops += ex;
+                        h->prof_recs.push_back({(int)oi_first, wino4 ? 2 : wino ? 1 : 0, o.flops * n, ex, 0.f});
                     }
                 } else if (o.path == PATH_SMALL_CIN) {
                     e = launch_conv_small_cin(in, out, o.wt, o.bias, n, d.kh, d.kw, d.pad_top, d.pad_left, act, d.alpha, s);
@@ -435,12 +444,13 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
     return ECSEG_OK;
 }
 
-void prof_begin(ecseg_ctx* h) { h->prof_used = 0; h->prof_flops = 0.0; h->prof_exec_flops = 0.0; }
+void prof_begin(ecseg_ctx* h) { h->prof_used = 0; h->prof_flops = 0.0; h->prof_exec_flops = 0.0; h->prof_recs.clear(); }
 void prof_end(ecseg_ctx* h) {   // stream must be idle
     double ms = 0.0;
     for (size_t k = 0; k + 1 < h->prof_used; k += 2) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, h->prof_events[k], h->prof_events[k + 1]) == hipSuccess) ms += t;
+        if (k / 2 < h->prof_recs.size()) h->prof_recs[k / 2].ms = t;
     }
     h->last_conv_ms = ms; h->last_conv_launches = (long long)(h->prof_used / 2); h->last_conv_flops = h->prof_flops;
     h->last_conv_exec_flops = h->prof_exec_flops;
@@ -578,11 +588,20 @@ int segment_dev(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint
     // Per group: tile -> U-Net -> stitch/argmax on the main stream; the group's clean-up + count then runs on the second
     // stream while the main stream already computes the next group's U-Net (MFMA-bound convs and latency-bound
     // integer kernels co-exist well).  6 events per group: tile start, unet start, tail start, tail end, post start/end.
-    std::vector<hipEvent_t> evs;
+    // events come from a pool owned by the handle (freed in ecseg_destroy): nothing to leak on an early return, and no
+    // event creation inside the timed loop
+    const size_t ngrp = ((size_t)n_img + grp - 1) / grp;
+    while (h->grp_events.size() < 6 * ngrp) {
+        hipEvent_t e;
+        HIP_TRY(h, hipEventCreate(&e));
+        h->grp_events.push_back(e);
+    }
+    const std::vector<hipEvent_t>& evs = h->grp_events;
+    size_t used = 0;
     for (int i0 = 0; i0 < n_img; i0 += grp) {
         const int ni = std::min(grp, n_img - i0);
-        hipEvent_t e6[6];
-        for (auto& e : e6) { HIP_TRY(h, hipEventCreate(&e)); evs.push_back(e); }
+        const hipEvent_t* e6 = &evs[used];
+        used += 6;
         HIP_TRY(h, hipEventRecord(e6[0], s));
         HIP_TRY(h, launch_tile_patches(gray + (size_t)i0 * px, ni, H, W, sp->pos_dev, sp->n_pos,
                                        view_of(h, h->input_tensor).p, s));
@@ -601,13 +620,12 @@ int segment_dev(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint
     }
     HIP_TRY(h, hipStreamSynchronize(s));
     HIP_TRY(h, hipStreamSynchronize(s2));
-    for (size_t k = 0; k + 5 < evs.size(); k += 6) {
+    for (size_t k = 0; k + 5 < used; k += 6) {
         h->stage_ms[ECSEG_T_TILE] += stage_elapsed(evs[k], evs[k + 1]);
         h->stage_ms[ECSEG_T_UNET] += stage_elapsed(evs[k + 1], evs[k + 2]);
         h->stage_ms[ECSEG_T_TAIL] += stage_elapsed(evs[k + 2], evs[k + 3]);
         h->stage_ms[ECSEG_T_POST] += stage_elapsed(evs[k + 4], evs[k + 5]);
     }
-    for (hipEvent_t e : evs) (void)hipEventDestroy(e);
     prof_end(h);
     return ECSEG_OK;
 }
@@ -665,6 +683,7 @@ void ecseg_destroy(ecseg_ctx* h) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->grp_events) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(h->stream2);
     (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1160,12 +1179,32 @@ int ecseg_get_conv_profile(ecseg_ctx* h, double* total_ms, int64_t* launches, do
     return ECSEG_OK;
 }
 
-// Diagnostics: floats 16.. of the zero page (in-kernel cycle stamps of the ECSEG_WINO_STAMP build).
+// Diagnostics: floats 16.. of the zero page (in-kernel cycle stamps); only in -DECSEG_DIAG builds (tools/build_variants.sh).
 int ecseg_debug_peek(ecseg_ctx* h, float* out, int n) {
+#ifdef ECSEG_DIAG
     if (!h || !out || n < 0 || n > 240 || !h->zero_page) return ECSEG_E_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipMemcpy(out, h->zero_page + 16, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     return ECSEG_OK;
+#else
+    (void)out; (void)n;
+    return fail(h, ECSEG_E_UNSUPPORTED, "ecseg_debug_peek: the shipped library carries no diagnostic kernels (build with -DECSEG_DIAG)");
+#endif
+}
+
+int ecseg_get_conv_launch_profile(ecseg_ctx* h, int max_records, int32_t* op_index, int32_t* kind, float* ms, double* flops,
+                                  double* executed_flops) {
+    if (!h || max_records < 0) return ECSEG_E_INVALID;
+    const int n = (int)std::min<size_t>(h->prof_recs.size(), (size_t)max_records);
+    for (int k = 0; k < n; ++k) {
+        const ecseg_ctx::ProfRec& r = h->prof_recs[k];
+        if (op_index) op_index[k] = r.op;
+        if (kind) kind[k] = r.kind;
+        if (ms) ms[k] = r.ms;
+        if (flops) flops[k] = r.flops;
+        if (executed_flops) executed_flops[k] = r.exec_flops;
+    }
+    return n;
 }
 
 int ecseg_get_conv_executed_flops(ecseg_ctx* h, double* flops) {

@@ -27,4 +27,18 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// Host side: "do this once per device" latch for per-device function attributes (hipFuncSetAttribute applies to the
+// current device only; one process may drive several handles on different GPUs).
+struct DeviceOnce {
+    unsigned long long done = 0;       // bit d: device d has been set up
+    int dev = 0;
+    bool first() {
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+        if (done >> dev & 1ull) return false;
+        done |= 1ull << dev;
+        return true;
+    }
+    void reset() { if (dev >= 0 && dev < 64) done &= ~(1ull << dev); }
+};
+
 }  // namespace ecseg

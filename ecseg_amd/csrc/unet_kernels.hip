@@ -277,7 +277,7 @@ __device__ __forceinline__ void wino_store_Y(const float* Rs, const ConvParams& 
     }
 }
 
-template <int NT, int MT, bool STAMP = false>
+template <int NT, int MT>
 __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void conv_wino_kernel(ConvParams p, int tiles_x, int tiles_y, int nblk_n) {
     constexpr int TTY = 4 * MT, TTX = 8;                     // MT MFMA row tiles of 4 x 8 Winograd tiles each
     constexpr int HR = 2 * TTY + 2, HC = 2 * TTX + 2;       // halo: (8 MT + 2) x 18 pixels
@@ -379,9 +379,6 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void conv_wino_kernel(ConvP
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[m][b][nt][e] = 0.f;
 
-    unsigned long long st[6] = {0, 0, 0, 0, 0, 0}, tk0 = 0, tk = 0;
-#define WSTAMP(i) do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); st[i] += now - tk; tk = now; __builtin_amdgcn_sched_barrier(0); } } while (0)
-    if (STAMP) { tk0 = tk = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
     load_a(0);
     dma_b(0, 0);
     store_a(0);
@@ -389,9 +386,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void conv_wino_kernel(ConvP
     for (int c = 0; c < p.cin_chunks; ++c) {
         const int cur = c & 1;
         const bool more = c + 1 < p.cin_chunks;
-        WSTAMP(0);                                             // [0] barrier exit -> here
         if (more) { load_a(c + 1); dma_b(c + 1, cur ^ 1); }   // next chunk streams in under this chunk's MFMAs
-        WSTAMP(1);                                             // [1] issue of next chunk's loads
         const f32x4* A0 = As + cur * A_SLOTS + a0_off;
         const f32x4* A1 = As + cur * A_SLOTS + a1_off;
         const f32x4* Bp = Bs + cur * B_PIECES + b_lane;
@@ -409,8 +404,6 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void conv_wino_kernel(ConvP
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) w[b][nt] = Bp[b * 2 * BN + nt * 32];
-        if (STAMP) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-        WSTAMP(2);                                             // [2] LDS reads issued + landed
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             // halo column j of the tile: plane (j & 1), slot + (j >> 1)
@@ -430,19 +423,8 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void conv_wino_kernel(ConvP
                 }
             }
         }
-        WSTAMP(3);                                             // [3] transform + MFMA issue
-        if (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-        WSTAMP(4);                                             // [4] wait for the next chunk's loads
         if (more) store_a(cur ^ 1);
         __syncthreads();
-        WSTAMP(5);                                             // [5] halo store + barrier
-    }
-#undef WSTAMP
-    if (STAMP && blockIdx.x == gridDim.x / 2 && (tid & 63) == 0) {
-        float* dbg = const_cast<float*>(p.zero) + 16 + (tid >> 6) * 8;
-        for (int i = 0; i < 6; ++i) dbg[i] = (float)st[i];
-        dbg[6] = (float)(__builtin_amdgcn_s_memtime() - tk0);
-        dbg[7] = (float)p.cin_chunks;
     }
 
     // ---- output stage, one row tile at a time (wino_write_R / wino_store_Y) ----
@@ -465,448 +447,23 @@ static hipError_t launch_conv_wino_t(const ConvParams& p, hipStream_t s) {
     size_t lds = (size_t)2 * (4 * (2 * TTY + 2) * 12 + 16 * 2 * BN) * 16;
     const size_t lds_epi = (size_t)4 * 2 * NT * 4 * 64 * 16;
     if (lds_epi > lds) lds = lds_epi;
-    if (const char* ev = getenv("ECSEG_WINO_LDS_KB")) { const size_t v = (size_t)atoi(ev) * 1024; if (v > lds) lds = v; }
     const size_t grid = (size_t)p.n * tiles_x * tiles_y * nblk_n;
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;                             // the attribute is per device
+    if (attr_set.first()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<NT, MT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    static const bool stamp = getenv("ECSEG_WINO_STAMP") != nullptr;
-    if (stamp && NT == 2 && MT == 1) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<2, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((conv_wino_kernel<2, 1, true>), dim3((unsigned)grid), dim3(256), lds, s, p, tiles_x, tiles_y, nblk_n);
-        return hipGetLastError();
+        if (e != hipSuccess) { attr_set.reset(); return e; }
     }
     hipLaunchKernelGGL((conv_wino_kernel<NT, MT>), dim3((unsigned)grid), dim3(256), lds, s, p, tiles_x, tiles_y, nblk_n);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// Winograd F(2x2,3x3), 8-wave "ping-pong" variant: 8 x 8 tiles (16 x 16 output pixels) x BN channels per workgroup.
-// Waves 0-3 (group A) and 4-7 (group B) own the upper / lower 4 x 8 tiles; inside a group the waves split the transform
-// rows exactly like conv_wino_kernel.  The filter slab (the dominant LDS fill traffic: 256 B per MFMA in the 4-wave
-// kernel) is shared by both groups -> 128 B per MFMA.  Each K-chunk has two phases separated by raw s_barriers:
-//     phase 1: group A issues its 32 MFMAs (operands already in registers)  | group B reads LDS + transforms chunk c
-//     phase 2: group A reads LDS + transforms chunk c+1                      | group B issues its 32 MFMAs
-// so every SIMD (one wave of each group) always has one wave feeding the matrix pipe.  Halo and filter slab both arrive
-// by LDS-DMA (global_load_lds, lane-linear LDS images, zero page for padding) two chunks ahead; the only waits are the
-// hand-placed vmcnt before phase 2 and lgkmcnt before each barrier.
-template <int NT, bool STAMP = false>
-__global__ __launch_bounds__(512, 2) void conv_wino8_kernel(ConvParams p, int tiles_x, int tiles_y, int nblk_n) {
-    constexpr int HR = 18, CS = 12;
-    constexpr int PLANE = HR * CS;                           // 216
-    constexpr int A_SLOTS = 1024;                            // 4 planes x 216 = 864 used, padded to 2 DMA per thread
-    constexpr int BN = NT * 32;
-    constexpr int B_PIECES = 16 * 2 * BN;
-    constexpr int A_PER_T = A_SLOTS / 256;                   // 4: the DMA of a chunk is issued by ONE group (256 threads)
-    constexpr int B_PER_T = B_PIECES / 256;
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4* As = reinterpret_cast<f32x4*>(smem);              // [2][A_SLOTS]   halo, double-buffered
-    f32x4* Bs = As + 2 * A_SLOTS;                            // [3][B_PIECES]  filter slab, triple-buffered
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-
-    const int tid = threadIdx.x;
-    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int bx = bid % tiles_x; bid /= tiles_x;
-    const int by = bid % tiles_y; bid /= tiles_y;
-    const int img = bid % p.n; bid /= p.n;
-    const int nb = bid;
-    const int ox0 = bx * 16, oy0 = by * 16;
-    const int n0 = nb * BN;
-    const int Hin = p.in.h, Win = p.in.w, Cin = p.in.c;
-    const float* in_base = p.in.p + (size_t)img * Hin * Win * p.in.cs;      // wave-uniform
-    const int nchunks = p.cin_chunks;
-
-    // ---- DMA source descriptors (32-bit offsets).  Thread t of the issuing group handles halo slots t + k * 256 and
-    //      filter pieces t + k * 256, t = tid & 255: the group that is NOT on the matrix pipe in a half-step issues the
-    //      whole chunk, so the MFMA group never spends issue slots on loads ----
-    const int t256 = tid & 255;
-    int a_off[A_PER_T];
-    bool a_hi[A_PER_T];
-#pragma unroll
-    for (int k = 0; k < A_PER_T; ++k) {
-        const int sl = t256 + k * 256;
-        a_off[k] = -1; a_hi[k] = false;
-        if (sl < 4 * PLANE) {
-            const int plane = sl / PLANE, rem = sl - plane * PLANE;
-            const int row = rem / CS, col = rem - row * CS;
-            const int h = plane >> 1, par = plane & 1;
-            const int iy = oy0 - 1 + row, ix = ox0 - 1 + 2 * col + par;
-            a_hi[k] = h != 0;
-            if (col < 9 && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) a_off[k] = (iy * Win + ix) * p.in.cs + h * 4;
-        }
-    }
-    const int chunk_stride = (int)p.wt_chunk_stride;         // floats between consecutive chunks of one transform point
-    const int tap_stride = (int)p.wt_tap_stride;
-    int b_off[B_PER_T];
-#pragma unroll
-    for (int k = 0; k < B_PER_T; ++k) {
-        const int q = t256 + k * 256;
-        const int tap = q / (2 * BN), rem = q - tap * 2 * BN;
-        const int h = rem / BN, j = rem - h * BN;
-        b_off[k] = tap * tap_stride + (h * p.coutp + n0 + j) * 4;
-    }
-    auto dma_halo = [&](int c, int abuf) {
-#pragma unroll
-        for (int k = 0; k < A_PER_T; ++k) {
-            const float* g = (a_off[k] >= 0 && c * 8 + (a_hi[k] ? 4 : 0) < Cin) ? in_base + a_off[k] + c * 8 : p.zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(As + abuf * A_SLOTS + t256 + k * 256), 16, 0, 0);
-        }
-    };
-    auto dma_filter = [&](int c, int bbuf, int k0, int k1) {    // k0, k1 compile-time at every call site
-#pragma unroll
-        for (int k = 0; k < B_PER_T; ++k) {
-            if (k < k0 || k >= k1) continue;
-            const float* g = p.wt + b_off[k] + (size_t)c * chunk_stride;
-            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Bs + bbuf * B_PIECES + t256 + k * 256), 16, 0, 0);
-        }
-    };
-    // Issue schedule (balanced: B_EVEN + (B_PER_T - B_EVEN + A_PER_T) pieces per chunk, never issued by the group that
-    // is on the matrix pipe): even half-step 2c, reader = group B: filter pieces [0, B_EVEN) of chunk c+2;
-    // odd half-step 2c+1, reader = group A: the remaining filter pieces and the halo of chunk c+2.
-    constexpr int B_EVEN = (B_PER_T + A_PER_T) / 2 < B_PER_T ? (B_PER_T + A_PER_T) / 2 : B_PER_T;
-
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, wa = wave & 3;               // group = tile-row half, wa = transform row a
-    const int li = lane & 31, lh = lane >> 5;
-    const int ti = li >> 3, tj = li & 7;
-    const int r0 = (wa == 0) ? 0 : 1, r1 = (wa == 3) ? 3 : 2;
-    const float s0 = (wa == 2) ? -1.f : 1.f, s1 = (wa == 0 || wa == 3) ? -1.f : 1.f;
-    const int a0_off = (lh * 2) * PLANE + (8 * grp + 2 * ti + r0) * CS + tj;
-    const int a1_off = (lh * 2) * PLANE + (8 * grp + 2 * ti + r1) * CS + tj;
-    const int b_lane = (wa * 4 * 2 + lh) * BN + li;
-
-    f32x16 acc[4][NT];
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[b][nt][e] = 0.f;
-    f32x4 V[4];
-
-    auto read_chunk = [&](int abuf) {                         // halo LDS -> registers, input transform
-        const f32x4* A0 = As + abuf * A_SLOTS + a0_off;
-        const f32x4* A1 = As + abuf * A_SLOTS + a1_off;
-        const f32x4 d00 = A0[0], d10 = A1[0], d01 = A0[PLANE], d11 = A1[PLANE];
-        const f32x4 d02 = A0[1], d12 = A1[1], d03 = A0[PLANE + 1], d13 = A1[PLANE + 1];
-        const f32x4 t0 = s0 * d00 + s1 * d10;
-        const f32x4 t1 = s0 * d01 + s1 * d11;
-        const f32x4 t2 = s0 * d02 + s1 * d12;
-        const f32x4 t3 = s0 * d03 + s1 * d13;
-        V[0] = t0 - t2; V[1] = t1 + t2; V[2] = t2 - t1; V[3] = t1 - t3;
-    };
-    auto mfma_chunk = [&](int bbuf) {                         // filter fragments stream from LDS beside the MFMAs
-        const f32x4* Bp = Bs + bbuf * B_PIECES + b_lane;
-        f32x4 wc[NT], wn[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wc[nt] = Bp[nt * 32];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            if (b < 3) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) wn[nt] = Bp[(b + 1) * 2 * BN + nt * 32];   // next point's fragments
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    acc[b][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b][e], wc[nt][e], acc[b][nt], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wc[nt] = wn[nt];
-        }
-    };
-#define WINO8_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-
-    // ---- prologue: chunks 0 and 1 complete in LDS (group A fetches chunk 0, group B chunk 1) ----
-    if (grp == 0) { dma_halo(0, 0); dma_filter(0, 0, 0, B_PER_T); }
-    else if (nchunks > 1) { dma_halo(1, 1); dma_filter(1, 1, 0, B_PER_T); }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    WINO8_BARRIER();
-    // Half-steps hs = -1 .. 2n-1, one barrier each.  Group A issues the MFMAs of chunk c at hs = 2c and transforms chunk
-    // c+1 at hs = 2c+1; group B transforms chunk c at hs = 2c and issues its MFMAs at hs = 2c+1: the same instruction
-    // stream for both groups, shifted by one half-step.  The group that is NOT on the matrix pipe issues its half of the
-    // LDS-DMA pieces of chunk c+2; buffers: halo c&1 (last read at hs = 2c by group B), filter (c+2)%3 (last read at
-    // hs = 2c-1 by group B's MFMAs of chunk c-1).
-    unsigned long long st[6] = {0, 0, 0, 0, 0, 0}, tk = 0, tk0 = 0;
-#define W8STAMP(i) do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); st[i] += now - tk; tk = now; __builtin_amdgcn_sched_barrier(0); } } while (0)
-    if (STAMP) { tk0 = tk = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
-    for (int hs = -1; hs < 2 * nchunks; ++hs) {
-        const int c = hs >> 1;                                 // chunk whose MFMAs run in this pair of half-steps
-        const bool issue = hs >= 0 && c + 2 < nchunks;
-        if (((hs ^ grp) & 1) == 0) {
-            if (c >= 0 && c < nchunks) mfma_chunk(c % 3);
-            W8STAMP(0);                                        // [0] MFMA role: filter reads + 32 MFMAs issued
-            // The MFMA group is the one whose earlier DMA shares are needed next:
-            //   group A (even hs): its pieces of chunk c+1 (issued at hs = 2c-1) feed its transform at hs = 2c+1;
-            //   group B (odd hs): its filter pieces of chunk c+1 (issued at hs = 2c-2) feed group A's MFMAs at hs = 2c+2,
-            //                     while its pieces of chunk c+2 (issued at hs = 2c) may keep flying.
-            if (grp == 0 || !issue) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_EVEN) : "memory");
-            W8STAMP(1);                                        // [1] MFMA role: vmcnt wait
-            WINO8_BARRIER();
-            W8STAMP(2);                                        // [2] MFMA role: barrier
-        } else {
-            const int rc = (hs + 1) >> 1;
-            // the transforming wave shares its SIMD with a wave that only needs one issue slot per 64 cycles (an MFMA):
-            // give the short VALU / LDS burst priority
-            __builtin_amdgcn_s_setprio(2);
-            if (rc < nchunks) read_chunk(rc & 1);
-            __builtin_amdgcn_s_setprio(0);
-            if (STAMP) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            W8STAMP(3);                                        // [3] reader role: LDS reads + transform
-            if (issue) {
-                if (hs & 1) { dma_filter(c + 2, (c + 2) % 3, B_EVEN, B_PER_T); dma_halo(c + 2, c & 1); }
-                else dma_filter(c + 2, (c + 2) % 3, 0, B_EVEN);
-            }
-            W8STAMP(4);                                        // [4] reader role: DMA issue
-            WINO8_BARRIER();
-            W8STAMP(5);                                        // [5] reader role: barrier
-        }
-    }
-#undef W8STAMP
-    if (STAMP && blockIdx.x == gridDim.x / 2 && (tid & 63) == 0) {
-        float* dbg = const_cast<float*>(p.zero) + 16 + (tid >> 6) * 8;
-        for (int i = 0; i < 6; ++i) dbg[i] = (float)st[i];
-        dbg[6] = (float)(__builtin_amdgcn_s_memtime() - tk0);
-        dbg[7] = (float)p.cin_chunks;
-    }
-#undef WINO8_BARRIER
-    __syncthreads();
-
-    // ---- output stage: each group of four waves finishes its own row tile ----
-    float* Rs = reinterpret_cast<float*>(smem) + grp * (4 * 2 * 32 * BN);
-    wino_write_R<NT>(Rs, acc, wa, lane);
-    __syncthreads();
-    wino_store_Y<NT>(Rs, p, img, oy0 + 8 * grp, ox0, n0, wa, lane);
-}
-
-template <int NT>
-static hipError_t launch_conv_wino8_t(const ConvParams& p, hipStream_t s) {
-    constexpr int BN = NT * 32;
-    const int tiles_x = (p.out.w + 15) / 16, tiles_y = (p.out.h + 15) / 16;
-    const int nblk_n = p.coutp / BN;
-    size_t lds = (size_t)(2 * 1024 + 3 * 16 * 2 * BN) * 16;
-    const size_t lds_epi = (size_t)2 * 4 * 2 * NT * 4 * 64 * 16;
-    if (lds_epi > lds) lds = lds_epi;
-    const size_t grid = (size_t)p.n * tiles_x * tiles_y * nblk_n;
-    if (grid == 0) return hipSuccess;
-    if (grid > 0x7fffffffull || p.zero == nullptr) return hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino8_kernel<NT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    static const bool stamp = getenv("ECSEG_WINO_STAMP") != nullptr;
-    if (stamp && NT == 2) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino8_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((conv_wino8_kernel<2, true>), dim3((unsigned)grid), dim3(512), lds, s, p, tiles_x, tiles_y, nblk_n);
-        return hipGetLastError();
-    }
-    hipLaunchKernelGGL((conv_wino8_kernel<NT>), dim3((unsigned)grid), dim3(512), lds, s, p, tiles_x, tiles_y, nblk_n);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// Winograd F(2x2,3x3), "whole transform per wave" variant.  Each wave owns a 4 x 8 block of tiles (8 x 16 output pixels)
-// x 32 output channels and ALL 16 transform points (256 accumulator registers, one wave per SIMD); the four waves of a
-// workgroup take four vertically stacked tile blocks (32 x 16 output pixels) and share one filter slab, so a slab
-// fragment is re-used by four MFMA row tiles (64 B of LDS fill per MFMA, like the direct kernel, instead of 256 B when
-// the waves split the transform points).  The 2-D input transform (128 packed adds) runs on the VALU beside the
-// matrix pipe, the next chunk's LDS-DMA pieces are issued one per transform point between the MFMAs, and the output
-// transform happens in registers - no cross-wave exchange at all.
-__global__ __launch_bounds__(256, 1) void conv_wino16_kernel(ConvParams p, int tiles_x, int tiles_y, int nblk_n) {
-    constexpr int HR = 34, CS = 12;
-    constexpr int PLANE = HR * CS;                           // 408
-    constexpr int A_USED = 4 * PLANE;                        // 1632 slots
-    constexpr int A_PER_T = 7;                               // 7 * 256 = 1792 slots (padding fed from the zero page)
-    constexpr int A_SLOTS = A_PER_T * 256;
-    constexpr int BN = 32;
-    constexpr int B_PIECES = 16 * 2 * BN;                    // 1024
-    constexpr int B_PER_T = B_PIECES / 256;                  // 4
-    constexpr int NDMA = A_PER_T + B_PER_T;                  // 11
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4* As = reinterpret_cast<f32x4*>(smem);              // [3][A_SLOTS]   three stages: chunk c in use, c+1 landed
-    f32x4* Bs = As + 3 * A_SLOTS;                            // [3][B_PIECES]  or landing, c+2 in flight
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-
-    const int tid = threadIdx.x;
-    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int bx = bid % tiles_x; bid /= tiles_x;
-    const int by = bid % tiles_y; bid /= tiles_y;
-    const int img = bid % p.n; bid /= p.n;
-    const int nb = bid;
-    const int ox0 = bx * 16, oy0 = by * 32;
-    const int n0 = nb * BN;
-    const int Hin = p.in.h, Win = p.in.w, Cin = p.in.c;
-    const float* in_base = p.in.p + (size_t)img * Hin * Win * p.in.cs;
-    const int nchunks = p.cin_chunks;
-
-    int a_off[A_PER_T];
-    unsigned a_himask = 0;
-#pragma unroll
-    for (int k = 0; k < A_PER_T; ++k) {
-        const int sl = tid + k * 256;
-        a_off[k] = -1;
-        if (sl < A_USED) {
-            const int plane = sl / PLANE, rem = sl - plane * PLANE;
-            const int row = rem / CS, col = rem - row * CS;
-            const int h = plane >> 1, par = plane & 1;
-            const int iy = oy0 - 1 + row, ix = ox0 - 1 + 2 * col + par;
-            if (h) a_himask |= 1u << k;
-            if (col < 9 && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) a_off[k] = (iy * Win + ix) * p.in.cs + h * 4;
-        }
-    }
-    const int chunk_stride = (int)p.wt_chunk_stride;
-    const int tap_stride = (int)p.wt_tap_stride;
-    int b_off[B_PER_T];
-#pragma unroll
-    for (int k = 0; k < B_PER_T; ++k) {
-        const int q = tid + k * 256;
-        const int tap = q / (2 * BN), rem = q - tap * 2 * BN;
-        const int h = rem / BN, j = rem - h * BN;
-        b_off[k] = tap * tap_stride + (h * p.coutp + n0 + j) * 4;
-    }
-    auto dma_piece = [&](int c, int buf, int k) {            // k is a compile-time constant at every call site
-        if (k < A_PER_T) {
-            const bool ok = a_off[k] >= 0 && c * 8 + (((a_himask >> k) & 1u) ? 4 : 0) < Cin;
-            const float* g = ok ? in_base + a_off[k] + c * 8 : p.zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(As + buf * A_SLOTS + tid + k * 256), 16, 0, 0);
-        } else {
-            const float* g = p.wt + b_off[k - A_PER_T] + (size_t)c * chunk_stride;
-            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Bs + buf * B_PIECES + tid + (k - A_PER_T) * 256), 16, 0, 0);
-        }
-    };
-
-    const int lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    const int ti = li >> 3, tj = li & 7;
-    const int a_lane = (lh * 2) * PLANE + (8 * wave + 2 * ti) * CS + tj;   // raw pixel (r, j): + (j & 1) * PLANE + r * CS + (j >> 1)
-    const int b_lane = lh * BN + li;
-
-    f32x16 acc[16];
-#pragma unroll
-    for (int x = 0; x < 16; ++x)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[x][e] = 0.f;
-
-#pragma unroll
-    for (int k = 0; k < NDMA; ++k) dma_piece(0, 0, k);
-    if (nchunks > 1) {
-#pragma unroll
-        for (int k = 0; k < NDMA; ++k) dma_piece(1, 1, k);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");      // chunk 0 landed, chunk 1 may still fly
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    asm volatile("s_barrier" ::: "memory");
-    int cur = 0, nxt2 = 2;                                   // stage of chunk c, stage that chunk c+2 goes to
-    for (int c = 0; c < nchunks; ++c) {
-        const bool more2 = c + 2 < nchunks;
-        const f32x4* Ap = As + cur * A_SLOTS + a_lane;
-        const f32x4* Bp = Bs + cur * B_PIECES + b_lane;
-        // every LDS read of the chunk is issued up front (16 raw pixels + 16 filter fragments per lane): one exposed
-        // LDS latency per chunk; the transform of row a+1 then overlaps the MFMAs of row a
-        f32x4 V[16], w[16];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int o = (j & 1) * PLANE + (j >> 1);
-            V[0 * 4 + j] = Ap[o]; V[1 * 4 + j] = Ap[o + CS]; V[2 * 4 + j] = Ap[o + 2 * CS]; V[3 * 4 + j] = Ap[o + 3 * CS];
-        }
-#pragma unroll
-        for (int x = 0; x < 16; ++x) w[x] = Bp[x * 2 * BN];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {                        // row transform (over the tile's rows), in place
-            const f32x4 d0 = V[0 * 4 + j], d1 = V[1 * 4 + j], d2 = V[2 * 4 + j], d3 = V[3 * 4 + j];
-            V[0 * 4 + j] = d0 - d2; V[1 * 4 + j] = d1 + d2; V[2 * 4 + j] = d2 - d1; V[3 * 4 + j] = d1 - d3;
-        }
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const f32x4 t0 = V[a * 4 + 0], t1 = V[a * 4 + 1], t2 = V[a * 4 + 2], t3 = V[a * 4 + 3];
-            V[a * 4 + 0] = t0 - t2; V[a * 4 + 1] = t1 + t2; V[a * 4 + 2] = t2 - t1; V[a * 4 + 3] = t1 - t3;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int x = a * 4 + b;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[x][e], w[x][e], acc[x], 0, 0, 0);
-                if (x < NDMA && more2) dma_piece(c + 2, nxt2, x);    // one LDS-DMA piece per transform point
-            }
-        }
-        // chunk c+1 must have landed; chunk c+2 (just issued) keeps flying across the barrier
-        if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        cur = (cur == 2) ? 0 : cur + 1;
-        nxt2 = (nxt2 == 2) ? 0 : nxt2 + 1;
-    }
-
-    // ---- output transform in registers: Y = A^T M A per (tile, channel), bias, activation, 128-byte row segments ----
-    const int Hout = p.out.h, Wout = p.out.w, Cout = p.out.c;
-    const int co = n0 + li;
-    const bool co_ok = co < Cout;
-    const float bv = (p.bias != nullptr && co_ok) ? p.bias[co] : 0.f;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        float R[4][2];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            R[a][0] = acc[a * 4 + 0][e] + acc[a * 4 + 1][e] + acc[a * 4 + 2][e];
-            R[a][1] = acc[a * 4 + 1][e] - acc[a * 4 + 2][e] - acc[a * 4 + 3][e];
-        }
-        const int t = (e & 3) + 8 * (e >> 2) + 4 * lh;
-        const int oy = oy0 + 8 * wave + 2 * (t >> 3), ox = ox0 + 2 * (t & 7);
-#pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {
-            const float y0 = R[0][jp] + R[1][jp] + R[2][jp] + bv;
-            const float y1 = R[1][jp] - R[2][jp] - R[3][jp] + bv;
-            if (co_ok && ox + jp < Wout) {
-                if (oy < Hout) p.out.p[(((size_t)img * Hout + oy) * Wout + ox + jp) * p.out.cs + co] = apply_act(y0, p.act, p.alpha);
-                if (oy + 1 < Hout) p.out.p[(((size_t)img * Hout + oy + 1) * Wout + ox + jp) * p.out.cs + co] = apply_act(y1, p.act, p.alpha);
-            }
-        }
-    }
-}
-
-static hipError_t launch_conv_wino16(const ConvParams& p, hipStream_t s) {
-    const int tiles_x = (p.out.w + 15) / 16, tiles_y = (p.out.h + 31) / 32;
-    const int nblk_n = p.coutp / 32;
-    const size_t lds = (size_t)3 * (7 * 256 + 1024) * 16;     // 135168 bytes
-    const size_t grid = (size_t)p.n * tiles_x * tiles_y * nblk_n;
-    if (grid == 0) return hipSuccess;
-    if (grid > 0x7fffffffull || p.zero == nullptr) return hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino16_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(conv_wino16_kernel, dim3((unsigned)grid), dim3(256), lds, s, p, tiles_x, tiles_y, nblk_n);
     return hipGetLastError();
 }
 
 int conv_wino_ntile(int cout) { return (cout % 64 == 0 || cout > 64) ? 64 : 32; }
 
 hipError_t launch_conv_wino(const ConvParams& p, hipStream_t s) {
-    // ECSEG_WINO_VARIANT: 4 (default) = 4-wave kernel, 8 = 8-wave ping-pong kernel (measured slower), 42 = 4-wave kernel with two row tiles
-    static const int variant = getenv("ECSEG_WINO_VARIANT") ? atoi(getenv("ECSEG_WINO_VARIANT")) : 4;
-    const bool n64 = conv_wino_ntile(p.out.c) == 64;
-    if (variant == 16 && p.out.h >= 32 && p.zero != nullptr && p.coutp % 32 == 0) return launch_conv_wino16(p, s);
-    if (variant == 8 && p.out.h >= 16 && p.zero != nullptr) return n64 ? launch_conv_wino8_t<2>(p, s) : launch_conv_wino8_t<1>(p, s);
-    if (variant == 42 && p.out.h >= 16) return n64 ? launch_conv_wino_t<2, 2>(p, s) : launch_conv_wino_t<1, 2>(p, s);
-    return n64 ? launch_conv_wino_t<2, 1>(p, s) : launch_conv_wino_t<1, 1>(p, s);
+    return conv_wino_ntile(p.out.c) == 64 ? launch_conv_wino_t<2, 1>(p, s) : launch_conv_wino_t<1, 1>(p, s);
 }
 
 int conv_mfma_ntile(int cout) {

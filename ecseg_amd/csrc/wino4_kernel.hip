@@ -522,10 +522,13 @@ hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s) {
     size_t lds = (size_t)(3 * W4_HS + 12 * 2 * W4_BWS) * 16 + 2 * 768 * 8;
     const size_t lds_epi = (size_t)24 * W4_RPLANE * 4;
     if (lds_epi > lds) lds = lds_epi;
-    static const int abl = getenv("ECSEG_W4_ABL") ? atoi(getenv("ECSEG_W4_ABL")) : 0;
     void (*kern)(ConvParams, int, int, int) = conv_wino4_kernel<0>;
     if (p.head_w != nullptr) kern = conv_wino4_kernel<0, false, true>;
-    else switch (abl) {
+#ifdef ECSEG_DIAG
+    // timing-only ablations / in-kernel cycle stamps: diagnostic builds only (tools/build_variants.sh -DECSEG_DIAG);
+    // the shipped library has none of these kernels
+    static const int abl = getenv("ECSEG_W4_ABL") ? atoi(getenv("ECSEG_W4_ABL")) : 0;
+    if (p.head_w == nullptr) switch (abl) {
         case 1: kern = conv_wino4_kernel<1>; break;
         case 2: kern = conv_wino4_kernel<2>; break;
         case 3: kern = conv_wino4_kernel<3>; break;
@@ -536,12 +539,13 @@ hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s) {
         case 100: kern = conv_wino4_kernel<0, true>; break;        // in-kernel cycle stamps (tools/w4_stamp_probe.py)
         default: break;
     }
-    static bool attr_set[2] = {false, false};
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#endif
+    static DeviceOnce attr_set[2];                          // the attribute is per device
     const int which = p.head_w != nullptr ? 1 : 0;
-    if (!attr_set[which]) {
+    if (attr_set[which].first()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set[which] = true;
+        if (e != hipSuccess) { attr_set[which].reset(); return e; }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(768), lds, s, p, regs_x, regs_y, (int)npairs);
     return hipGetLastError();

@@ -349,8 +349,13 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
 
     # a 2x2 max-pool that directly follows its producing convolution may be written by that convolution's output stage
     # (csrc/api.hip run_plan): the convolution's input must then still be alive when the pool's buffer is chosen
+    # ... and likewise a 1x1 convolution (the head) that directly follows a convolution may be finished by that
+    # convolution's output stage: its output buffer must differ from the producing convolution's INPUT buffer, which other
+    # workgroups are still reading
     for a, b in zip(order, order[1:]):
-        if nodes[b]['kind'] == 'maxpool' and nodes[a]['kind'] == 'conv' and nodes[b]['inputs'] == [a]:
+        fused_pool = nodes[b]['kind'] == 'maxpool'
+        fused_head = nodes[b]['kind'] == 'conv' and nodes[b]['kh'] == 1 and nodes[b]['kw'] == 1
+        if (fused_pool or fused_head) and nodes[a]['kind'] == 'conv' and nodes[b]['inputs'] == [a]:
             for i in nodes[a]['inputs']:
                 last_use[i] = max(last_use.get(i, i), b)
 

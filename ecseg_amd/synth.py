@@ -58,6 +58,23 @@ def unet_config(base=64, depth=4, in_ch=1, n_classes=4, up='transpose', batchnor
                        'output_layers': [[out, 0, 0]]}}
 
 
+def conv_stack_config(n_convs=3, ch=64, n_classes=4, in_ch=1):
+    """Plain stack: input -> (conv3-relu) x n_convs -> 1x1 softmax head (no pooling, no skips)."""
+    def L(cls, name, inb, **c):
+        return {'class_name': cls, 'name': name, 'config': dict(c, name=name),
+                'inbound_nodes': [[[i, 0, 0, {}] for i in inb]] if inb else []}
+    layers = [L('InputLayer', 'in', [], batch_input_shape=[None, 256, 256, in_ch])]
+    prev = 'in'
+    for k in range(n_convs):
+        layers.append(L('Conv2D', 'c%d' % k, [prev], filters=ch, kernel_size=[3, 3], strides=[1, 1], padding='same',
+                        activation='relu', use_bias=True))
+        prev = 'c%d' % k
+    layers.append(L('Conv2D', 'head', [prev], filters=n_classes, kernel_size=[1, 1], strides=[1, 1], padding='same',
+                    activation='softmax', use_bias=True))
+    return {'class_name': 'Functional', 'config': {'name': 'stack', 'layers': layers, 'input_layers': [['in', 0, 0]],
+                                                   'output_layers': [['head', 0, 0]]}}
+
+
 def unet_weights(config, seed=0, input_scale=1.0 / 255.0, head_gain=6.0):
     """Seeded He-normal kernels.  The first convolution is scaled by ``input_scale`` because the reference feeds raw
     0..255 pixel values (no normalisation anywhere in src/utils.py:109-120); the head is scaled up so that the
@@ -110,18 +127,22 @@ def _blur(img, sigma):
     return sum(k[i] * tmp[:, i:i + img.shape[1]] for i in range(2 * r + 1))
 
 
-def dapi_image(idx, H=1040, W=1392, rgb=False):
+def dapi_image(idx, H=1040, W=1392, rgb=False, with_labels=False):
     """Seeded synthetic DAPI metaphase image (uint8): dim noisy background, a few nuclei discs, a cluster of
     chromosome ellipses, ecDNA dots; blurred with sigma 1.5.  ``rgb=True`` puts it in channel 2 and adds red /
-    green FISH spot fields in channels 0 / 1."""
+    green FISH spot fields in channels 0 / 1.  ``with_labels=True`` also returns the scene's class map
+    (uint8: 0 background, 1 nucleus, 2 chromosome, 3 ecDNA; later objects cover earlier ones) - the pixel image is the
+    same either way."""
     rng = np.random.default_rng(1234 + idx)
     img = np.clip(rng.normal(6, 4, size=(H, W)), 0, 255)
+    lab = np.zeros((H, W), np.uint8)
     yy, xx = np.ogrid[:H, :W]
     for _ in range(int(rng.integers(2, 5))):
         r = rng.integers(60, 121)
         cy, cx = rng.integers(0, H), rng.integers(0, W)
         m = (yy - cy) ** 2 + (xx - cx) ** 2 <= r * r
         img[m] = np.clip(rng.normal(160, 25), 60, 255)
+        lab[m] = 1
     cy0, cx0 = rng.integers(H // 4, 3 * H // 4), rng.integers(W // 4, 3 * W // 4)
     for _ in range(int(rng.integers(40, 71))):
         a, b = rng.uniform(8, 25), rng.uniform(4, 9)
@@ -136,15 +157,17 @@ def dapi_image(idx, H=1040, W=1392, rgb=False):
         v = -(sx - cx) * np.sin(th) + (sy - cy) * np.cos(th)
         m = (u / a) ** 2 + (v / b) ** 2 <= 1
         img[y0:y1, x0:x1][m] = np.clip(rng.normal(200, 30), 80, 255)
+        lab[y0:y1, x0:x1][m] = 2
     for _ in range(int(rng.integers(50, 201))):
         r = rng.integers(2, 5)
         cy, cx = rng.integers(r, H - r), rng.integers(r, W - r)
         sy, sx = np.ogrid[cy - r:cy + r + 1, cx - r:cx + r + 1]
         m = (sy - cy) ** 2 + (sx - cx) ** 2 <= r * r
         img[cy - r:cy + r + 1, cx - r:cx + r + 1][m] = np.clip(rng.normal(180, 40), 60, 255)
+        lab[cy - r:cy + r + 1, cx - r:cx + r + 1][m] = 3
     gray = np.clip(np.rint(_blur(img, 1.5)), 0, 255).astype(np.uint8)
     if not rgb:
-        return gray
+        return (gray, lab) if with_labels else gray
     out = np.zeros((H, W, 3), np.uint8)
     out[..., 2] = gray
     for ch in (0, 1):
@@ -156,7 +179,7 @@ def dapi_image(idx, H=1040, W=1392, rgb=False):
             m = (sy - cy) ** 2 + (sx - cx) ** 2 <= r * r
             f[cy - r:cy + r + 1, cx - r:cx + r + 1][m] = rng.integers(120, 256)
         out[..., ch] = f.astype(np.uint8)
-    return out
+    return (out, lab) if with_labels else out
 
 
 def label_map(idx, H=1040, W=1392, salt=0.002):

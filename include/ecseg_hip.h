@@ -183,7 +183,12 @@ int ecseg_get_conv_profile(ecseg_ctx* h, double* total_ms, int64_t* launches, do
 /* FLOPs the matrix cores actually executed in those launches (Winograd F(2x2,3x3) issues 16/36 of the algorithmic
  * multiplies of a 3x3 convolution; the direct kernel issues all of them). */
 int ecseg_get_conv_executed_flops(ecseg_ctx* h, double* flops);
-/* Diagnostics only: up to 240 floats of in-kernel cycle stamps written by the ECSEG_WINO_STAMP build of the conv kernel. */
+/* Per-launch records of the same profile, in launch order: plan operator index, kernel family (0 direct implicit GEMM,
+ * 1 Winograd F(2x2,3x3), 2 Winograd F(4x4,3x3)), duration, algorithmic and executed FLOPs.  Returns the number of
+ * records written (<= max_records) or a negative error. */
+int ecseg_get_conv_launch_profile(ecseg_ctx* h, int max_records, int32_t* op_index, int32_t* kind, float* ms,
+                                  double* flops, double* executed_flops);
+/* Diagnostics only (-DECSEG_DIAG builds; ECSEG_E_UNSUPPORTED otherwise): up to 240 floats of in-kernel cycle stamps written by the ECSEG_WINO_STAMP build of the conv kernel. */
 int ecseg_debug_peek(ecseg_ctx* h, float* out, int n);
 
 /* ---- host-side byte codecs for the file I/O around the path (no GPU work) ---------------------------------- */

@@ -207,3 +207,78 @@ def conv_numpy(x_nhwc, kernel_hwio, bias, padding='same'):
         for j in range(kw):
             y += np.einsum('nhwc,co->nhwo', x[:, i:i + Ho, j:j + Wo, :], kernel_hwio[i, j]).astype(np.float32)
     return y + np.asarray(bias, np.float32)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Independent numpy restatements of the other Keras layer types (no torch), written from the layers' published
+# definitions; tests/test_oracle_layers.py checks them against hand-computed known answers AND against the torch path
+# above, so that every layer type of ``forward`` rests on two independent implementations.
+# ---------------------------------------------------------------------------------------------------------------------
+def conv_transpose_numpy(x_nhwc, kernel_hwoi, bias, stride, padding='same'):
+    """Conv2DTranspose: every input pixel stamps ``in[c] * w[kh, kw, o, c]`` at output rows ``i * s + kh``; 'same' crops
+    the full ((n - 1) s + k) result to n * s, dropping ``max(k - s, 0) // 2`` rows/columns in front (the padding TF's
+    forward 'same' convolution of that stride would have put in front)."""
+    x = np.asarray(x_nhwc, np.float32)
+    kh, kw, co, ci = kernel_hwoi.shape
+    N, Hi, Wi, _ = x.shape
+    s = int(stride)
+    full = np.zeros((N, (Hi - 1) * s + max(kh, s), (Wi - 1) * s + max(kw, s), co), np.float32)
+    for a in range(kh):
+        for b in range(kw):
+            contrib = np.einsum('nhwc,oc->nhwo', x, kernel_hwoi[a, b]).astype(np.float32)
+            full[:, a:a + (Hi - 1) * s + 1:s, b:b + (Wi - 1) * s + 1:s, :] += contrib
+    if padding == 'same':
+        ct, cl = max(kh - s, 0) // 2, max(kw - s, 0) // 2
+        full = full[:, ct:ct + Hi * s, cl:cl + Wi * s, :]
+    if bias is not None:
+        full = full + np.asarray(bias, np.float32)
+    return full
+
+
+def upsample_numpy(x_nhwc, factor, interpolation='nearest'):
+    """UpSampling2D.  nearest: repeat.  bilinear: tf.image.resize semantics with half-pixel centres, no antialiasing:
+    source coordinate ``(dst + 0.5) / f - 0.5``, neighbours clamped to the image, weights from the fractional part."""
+    x = np.asarray(x_nhwc, np.float32)
+    f = int(factor)
+    if interpolation == 'nearest':
+        return x.repeat(f, axis=1).repeat(f, axis=2)
+
+    def axis_weights(n):
+        src = (np.arange(n * f) + 0.5) / f - 0.5
+        lo = np.floor(src)
+        frac = (src - lo).astype(np.float32)
+        i0 = np.clip(lo, 0, n - 1).astype(int)
+        i1 = np.clip(lo + 1, 0, n - 1).astype(int)
+        return i0, i1, frac
+
+    N, Hh, Ww, C = x.shape
+    r0, r1, rf = axis_weights(Hh)
+    c0, c1, cf = axis_weights(Ww)
+    rows = x[:, r0] * (1 - rf)[None, :, None, None] + x[:, r1] * rf[None, :, None, None]
+    return (rows[:, :, c0] * (1 - cf)[None, None, :, None] + rows[:, :, c1] * cf[None, None, :, None]).astype(np.float32)
+
+
+def batchnorm_numpy(x_nhwc, gamma, beta, mean, var, eps=1e-3):
+    """BatchNormalization at inference: ``gamma * (x - mean) / sqrt(var + eps) + beta`` per channel."""
+    x = np.asarray(x_nhwc, np.float64)
+    g = np.ones(x.shape[-1]) if gamma is None else np.asarray(gamma, np.float64)
+    b = np.zeros(x.shape[-1]) if beta is None else np.asarray(beta, np.float64)
+    return (g * (x - np.asarray(mean, np.float64)) / np.sqrt(np.asarray(var, np.float64) + eps) + b).astype(np.float32)
+
+
+def maxpool_numpy(x_nhwc, k=2, s=2):
+    """MaxPooling2D, 'valid' (floor)."""
+    x = np.asarray(x_nhwc, np.float32)
+    N, Hh, Ww, C = x.shape
+    Ho, Wo = (Hh - k) // s + 1, (Ww - k) // s + 1
+    out = np.full((N, Ho, Wo, C), -np.inf, np.float32)
+    for a in range(k):
+        for b in range(k):
+            out = np.maximum(out, x[:, a:a + (Ho - 1) * s + 1:s, b:b + (Wo - 1) * s + 1:s, :])
+    return out
+
+
+def softmax_numpy(x_nhwc):
+    x = np.asarray(x_nhwc, np.float64)
+    e = np.exp(x - x.max(-1, keepdims=True))
+    return (e / e.sum(-1, keepdims=True)).astype(np.float32)

@@ -214,3 +214,23 @@ def test_winograd_f4x4_activations_and_no_bias(gpu, act, use_bias):
     want = oracle_unet.forward(cfg, {'c': w}, x)
     got, _ = _run(gpu, cfg, {'c': w}, x, fuse=True)
     assert np.abs(got - want).max() < 5e-4 * max(1.0, float(np.abs(want).max())), np.abs(got - want).max()
+
+
+@pytest.mark.parametrize('n_convs', [3, 4])
+def test_fused_head_on_plain_conv_stack(gpu, n_convs):
+    """in -> conv64 x n -> 1x1 softmax head.  The liveness allocator used to hand the head the buffer the last
+    3x3 convolution READS; with the head fused into that convolution's output stage this was a race.  Fused and unfused
+    runs must agree (and match the oracle)."""
+    cfg = synth.conv_stack_config(n_convs)
+    weights = synth.unet_weights(cfg, seed=11)
+    x = _patches(3, seed=2)
+    want = oracle_unet.forward(cfg, weights, x)
+    try:
+        gpu.set_option('fuse_head', 1)
+        fused, plan = _run(gpu, cfg, weights, x, fuse=True)
+        gpu.set_option('fuse_head', 0)
+        unfused = gpu.forward_patches(x)
+    finally:
+        gpu.set_option('fuse_head', 1)
+    assert np.abs(fused - want).max() < TOL
+    assert np.abs(fused - unfused).max() < 1e-5

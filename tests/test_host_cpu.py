@@ -175,3 +175,34 @@ def test_allgather_records_gloo_world2(n_images):
     for rank, idx, nec in res:
         assert idx == list(range(n_images))
         assert nec == [1000 + i for i in range(n_images)]
+
+
+@pytest.mark.parametrize('n_convs', [2, 3, 4, 5])
+def test_fusable_head_never_shares_a_buffer_with_the_fused_convs_input(n_convs):
+    """the 1x1 head may be finished by the output stage of the 3x3 convolution in front of it; workgroups
+    then write head pixels while others still read that convolution's input halo, so the two must not share a buffer
+    (same rule as the fused 2x2 max-pool).  Plain conv stacks used to re-use the freed input buffer for the head."""
+    cfg = synth.conv_stack_config(n_convs)
+    plan = keras_plan.build_plan(cfg, synth.unet_weights(cfg))
+    head, conv = plan.ops[-1], plan.ops[-2]
+    assert head['kh'] == 1 and conv['kh'] == 3 and head['in0'] == conv['out']
+    bufs = [plan.tensors[t]['buffer'] for t in (conv['in0'], conv['out'], head['out'])]
+    assert len(set(bufs)) == 3, bufs
+    for base in (16, 64):                                   # ... and the canonical U-Nets keep the property
+        p = keras_plan.build_plan(synth.unet_config(base=base), synth.unet_weights(synth.unet_config(base=base)))
+        head, conv = p.ops[-1], p.ops[-2]
+        assert len({p.tensors[t]['buffer'] for t in (conv['in0'], conv['out'], head['out'])}) == 3
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`bench.py --gpus N` starts its own ranks; with fewer than N devices visible it must fail loudly (never run one
+    rank and report it as N)."""
+    import subprocess
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('2 GPUs present')
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1'], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert 'HIP device' in (out.stderr + out.stdout)

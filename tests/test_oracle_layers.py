@@ -1,0 +1,187 @@
+"""Every Keras layer type the U-Net oracle (oracle/unet.py ``forward``, torch CPU) evaluates is checked here against
+(a) known answers written out by hand from the layers' published definitions and (b) an independent numpy restatement
+(``*_numpy`` in oracle/unet.py).  TensorFlow itself is not available (PARITY UNPINNED vs TF 2.8); this pins the oracle
+on two implementations that share no code."""
+import numpy as np
+import pytest
+
+from oracle import unet
+
+
+def _model(layer_cls, shape, **cfg):
+    cfg = dict(cfg, name='L')
+    return {'class_name': 'Functional', 'config': {'name': 'm', 'layers': [
+        {'class_name': 'InputLayer', 'name': 'in', 'config': {'name': 'in', 'batch_input_shape': [None] + list(shape)},
+         'inbound_nodes': []},
+        {'class_name': layer_cls, 'name': 'L', 'config': cfg, 'inbound_nodes': [[['in', 0, 0, {}]]]}],
+        'input_layers': [['in', 0, 0]], 'output_layers': [['L', 0, 0]]}}
+
+
+def test_conv2d_same_padding_even_kernel_known_answer():
+    """TF 'same' with a 2x2 kernel at stride 1 pads ONE row/column, at the bottom/right only."""
+    x = np.array([[1, 2], [3, 4]], np.float32).reshape(1, 2, 2, 1)
+    k = np.array([[1, 10], [100, 1000]], np.float32).reshape(2, 2, 1, 1)
+    cfg = _model('Conv2D', (2, 2, 1), filters=1, kernel_size=[2, 2], strides=[1, 1], padding='same', activation='linear',
+                 use_bias=False)
+    got = unet.forward(cfg, {'L': [k]}, x)[0, :, :, 0]
+    # out[i,j] = x[i,j] + 10 x[i,j+1] + 100 x[i+1,j] + 1000 x[i+1,j+1], zeros beyond the bottom/right edge
+    want = np.array([[1 + 20 + 300 + 4000, 2 + 400], [3 + 40, 4]], np.float32)
+    assert np.array_equal(got, want)
+    assert np.array_equal(unet.conv_numpy(x, k, np.zeros(1))[0, :, :, 0], want)
+
+
+def test_conv2d_3x3_same_known_answer():
+    x = np.arange(1, 10, dtype=np.float32).reshape(1, 3, 3, 1)
+    k = np.zeros((3, 3, 1, 1), np.float32)
+    k[0, 0] = 1; k[2, 2] = 2; k[1, 1] = 3              # top-left, bottom-right, centre taps (cross-correlation)
+    cfg = _model('Conv2D', (3, 3, 1), filters=1, kernel_size=[3, 3], strides=[1, 1], padding='same', activation='linear',
+                 use_bias=True)
+    got = unet.forward(cfg, {'L': [k, np.array([0.5], np.float32)]}, x)[0, :, :, 0]
+    X = np.pad(x[0, :, :, 0], 1)
+    want = X[:-2, :-2] * 1 + X[2:, 2:] * 2 + X[1:-1, 1:-1] * 3 + 0.5
+    assert np.array_equal(got, want)
+    assert got[1, 1] == 1 * 1 + 9 * 2 + 5 * 3 + 0.5
+
+
+def test_conv2d_transpose_2x2_stride2_known_answer():
+    """kernel (kh, kw, out, in): out[2i + a, 2j + b, o] = sum_c in[i, j, c] * w[a, b, o, c] (+ bias): no overlap."""
+    x = np.array([[1, 2], [3, 4]], np.float32).reshape(1, 2, 2, 1)
+    k = np.array([[1, 10], [100, 1000]], np.float32).reshape(2, 2, 1, 1)
+    cfg = _model('Conv2DTranspose', (2, 2, 1), filters=1, kernel_size=[2, 2], strides=[2, 2], padding='same',
+                 activation='linear', use_bias=True, output_padding=None)
+    got = unet.forward(cfg, {'L': [k, np.array([0.25], np.float32)]}, x)[0, :, :, 0]
+    want = np.kron(x[0, :, :, 0], k[:, :, 0, 0]) + 0.25
+    assert np.array_equal(got, want)
+    assert np.array_equal(unet.conv_transpose_numpy(x, k, [0.25], 2)[0, :, :, 0], want)
+
+
+def test_conv2d_transpose_3x3_stride2_same_and_valid_known_answer():
+    """1-D-like case by hand: in = [1, 2], w = [1, 10, 100], stride 2: full = [1, 10, 100 + 2, 20, 200]; 'valid' keeps all
+    5, 'same' (output 4) drops max(k - s, 0) // 2 = 0 in front and the last one."""
+    x = np.array([1, 2], np.float32).reshape(1, 1, 2, 1)
+    k = np.zeros((3, 3, 1, 1), np.float32)
+    k[0, :, 0, 0] = [1, 10, 100]                          # only the first kernel row: output row 0 carries the 1-D case
+    for pad, want in (('valid', [1, 10, 102, 20, 200]), ('same', [1, 10, 102, 20])):
+        cfg = _model('Conv2DTranspose', (1, 2, 1), filters=1, kernel_size=[3, 3], strides=[2, 2], padding=pad,
+                     activation='linear', use_bias=False, output_padding=None)
+        got = unet.forward(cfg, {'L': [k]}, x)
+        assert got.shape == ((1, 3, 5, 1) if pad == 'valid' else (1, 2, 4, 1))
+        assert np.array_equal(got[0, 0, :, 0], np.array(want, np.float32))
+        assert np.array_equal(unet.conv_transpose_numpy(x, k, None, 2, pad), got)
+
+
+def test_conv2d_transpose_4x4_stride2_same_crops_one_in_front():
+    x = np.array([1, 2, 3], np.float32).reshape(1, 1, 3, 1)
+    k = np.zeros((4, 4, 1, 1), np.float32)
+    k[1, :, 0, 0] = [1, 10, 100, 1000]                    # kernel row 1 lands on output row 0 after the 1-row crop
+    cfg = _model('Conv2DTranspose', (1, 3, 1), filters=1, kernel_size=[4, 4], strides=[2, 2], padding='same',
+                 activation='linear', use_bias=False, output_padding=None)
+    got = unet.forward(cfg, {'L': [k]}, x)
+    full = np.array([1, 10, 100 + 2, 1000 + 20, 200 + 3, 2000 + 30, 300, 3000], np.float32)
+    assert np.array_equal(got[0, 0, :, 0], full[1:7])
+    assert np.array_equal(unet.conv_transpose_numpy(x, k, None, 2, 'same'), got)
+
+
+def test_upsampling_known_answers():
+    x = np.array([1, 2], np.float32).reshape(1, 1, 2, 1)
+    near = unet.forward(_model('UpSampling2D', (1, 2, 1), size=[2, 2], interpolation='nearest'), {}, x)
+    assert np.array_equal(near[0, :, :, 0], [[1, 1, 2, 2], [1, 1, 2, 2]])
+    bil = unet.forward(_model('UpSampling2D', (1, 2, 1), size=[2, 2], interpolation='bilinear'), {}, x)
+    # half-pixel centres: sources -0.25, 0.25, 0.75, 1.25 -> clamp, 0.75/0.25, 0.25/0.75, clamp
+    assert np.allclose(bil[0, 0, :, 0], [1, 1.25, 1.75, 2], atol=1e-7)
+    x3 = np.array([0, 4, 8], np.float32).reshape(1, 3, 1, 1)
+    bil3 = unet.forward(_model('UpSampling2D', (3, 1, 1), size=[2, 2], interpolation='bilinear'), {}, x3)
+    assert np.allclose(bil3[0, :, 0, 0], [0, 1, 3, 5, 7, 8], atol=1e-6)
+
+
+def test_batchnorm_maxpool_softmax_known_answers():
+    x = np.array([[2.0, -1.0]], np.float32).reshape(1, 1, 1, 2)
+    w = [np.array([2, 3], np.float32), np.array([1, -1], np.float32), np.array([1, 1], np.float32), np.array([3, 8], np.float32)]
+    cfg = _model('BatchNormalization', (1, 1, 2), axis=[3], epsilon=1.0, center=True, scale=True)
+    got = unet.forward(cfg, {'L': w}, x)[0, 0, 0]
+    # gamma (x - mean) / sqrt(var + eps) + beta = 2 * 1 / 2 + 1, 3 * (-2) / 3 - 1
+    assert np.allclose(got, [2.0, -3.0], atol=1e-6)
+    nocenter = unet.forward(_model('BatchNormalization', (1, 1, 2), axis=[3], epsilon=1.0, center=False, scale=True),
+                            {'L': [w[0], w[2], w[3]]}, x)[0, 0, 0]
+    assert np.allclose(nocenter, [1.0, -2.0], atol=1e-6)
+    p = np.arange(25, dtype=np.float32).reshape(1, 5, 5, 1)
+    mp = unet.forward(_model('MaxPooling2D', (5, 5, 1), pool_size=[2, 2], strides=[2, 2], padding='valid'), {}, p)
+    assert np.array_equal(mp[0, :, :, 0], [[6, 8], [16, 18]])           # floor: the fifth row / column is dropped
+    z = np.log(np.array([1, 2, 3, 4], np.float32)).reshape(1, 1, 1, 4)
+    sm = unet.forward(_model('Softmax', (1, 1, 4), axis=-1), {}, z)[0, 0, 0]
+    assert np.allclose(sm, [0.1, 0.2, 0.3, 0.4], atol=1e-6)
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_numpy_restatements_match_torch_path_on_random_tensors(seed):
+    rng = np.random.default_rng(seed)
+    x = rng.normal(size=(2, 7, 9, 5)).astype(np.float32)
+    for k, s, pad in ((2, 2, 'same'), (3, 2, 'same'), (4, 2, 'same'), (3, 2, 'valid'), (2, 2, 'valid'), (3, 3, 'same')):
+        w = rng.normal(size=(k, k, 6, 5)).astype(np.float32)
+        b = rng.normal(size=6).astype(np.float32)
+        cfg = _model('Conv2DTranspose', (7, 9, 5), filters=6, kernel_size=[k, k], strides=[s, s], padding=pad,
+                     activation='linear', use_bias=True, output_padding=None)
+        got = unet.forward(cfg, {'L': [w, b]}, x)
+        want = unet.conv_transpose_numpy(x, w, b, s, pad)
+        assert got.shape == want.shape, (k, s, pad)
+        assert np.abs(got - want).max() < 1e-4, (k, s, pad)
+    for k in (1, 2, 3, 4, 5):
+        w = rng.normal(size=(k, k, 5, 4)).astype(np.float32)
+        b = rng.normal(size=4).astype(np.float32)
+        for pad in ('same', 'valid'):
+            cfg = _model('Conv2D', (7, 9, 5), filters=4, kernel_size=[k, k], strides=[1, 1], padding=pad,
+                         activation='linear', use_bias=True)
+            assert np.abs(unet.forward(cfg, {'L': [w, b]}, x) - unet.conv_numpy(x, w, b, pad)).max() < 1e-4, (k, pad)
+    for interp in ('nearest', 'bilinear'):
+        for f in (2, 3):
+            got = unet.forward(_model('UpSampling2D', (7, 9, 5), size=[f, f], interpolation=interp), {}, x)
+            assert np.abs(got - unet.upsample_numpy(x, f, interp)).max() < 1e-5, (interp, f)
+    bn = [rng.uniform(0.5, 2, 5).astype(np.float32), rng.normal(size=5).astype(np.float32),
+          rng.normal(size=5).astype(np.float32), rng.uniform(0.5, 2, 5).astype(np.float32)]
+    got = unet.forward(_model('BatchNormalization', (7, 9, 5), axis=[3], epsilon=1e-3, center=True, scale=True), {'L': bn}, x)
+    assert np.abs(got - unet.batchnorm_numpy(x, *bn, eps=1e-3)).max() < 1e-5
+    got = unet.forward(_model('MaxPooling2D', (7, 9, 5), pool_size=[2, 2], strides=[2, 2], padding='valid'), {}, x)
+    assert np.array_equal(got, unet.maxpool_numpy(x))
+    got = unet.forward(_model('Softmax', (7, 9, 5), axis=-1), {}, x)
+    assert np.abs(got - unet.softmax_numpy(x)).max() < 1e-6
+
+
+def test_whole_unet_numpy_chain_matches_torch_path():
+    """The canonical U-Net (depth 2, base 8, both up-sampling styles, with and without BatchNormalization) evaluated layer
+    by layer with the numpy restatements only == the torch path."""
+    from ecseg_amd import synth
+    rng = np.random.default_rng(4)
+    x = rng.integers(0, 256, size=(1, 32, 32, 1), dtype=np.uint8)
+    for up, bn in (('transpose', False), ('upsample', True)):
+        cfg = synth.unet_config(base=8, depth=2, up=up, batchnorm=bn)
+        cfg['config']['layers'][0]['config']['batch_input_shape'] = [None, 32, 32, 1]
+        w = synth.unet_weights(cfg, seed=2)
+        want = unet.forward(cfg, w, x)
+        vals = {}
+        for L in cfg['config']['layers']:
+            cls, lc, name = L['class_name'], L['config'], L['config']['name']
+            if cls == 'InputLayer':
+                vals[name] = x.astype(np.float32)
+                continue
+            ins = [vals[r[0]] for r in L['inbound_nodes'][0]]
+            a = ins[0]
+            if cls == 'Conv2D':
+                y = unet.conv_numpy(a, w[name][0], w[name][1], lc['padding'])
+                y = np.maximum(y, 0) if lc['activation'] == 'relu' else unet.softmax_numpy(y) if lc['activation'] == 'softmax' else y
+            elif cls == 'Conv2DTranspose':
+                y = unet.conv_transpose_numpy(a, w[name][0], w[name][1], lc['strides'][0], lc['padding'])
+            elif cls == 'MaxPooling2D':
+                y = unet.maxpool_numpy(a)
+            elif cls == 'UpSampling2D':
+                y = unet.upsample_numpy(a, lc['size'][0], lc['interpolation'])
+            elif cls == 'Concatenate':
+                y = np.concatenate(ins, -1)
+            elif cls == 'BatchNormalization':
+                y = unet.batchnorm_numpy(a, *w[name], eps=lc['epsilon'])
+            elif cls == 'Activation':
+                y = np.maximum(a, 0)
+            else:
+                raise AssertionError(cls)
+            vals[name] = y
+        got = vals[cfg['config']['output_layers'][0][0]]
+        assert np.abs(got - want).max() < 1e-5, (up, bn)

@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""How often does fp32 summation order flip a uint8-quantised argmax label?  ("measure and commit the
+label-mismatch rate ... on a smooth-output model".)
+
+Fits the canonical U-Net for a few hundred steps on synthetic scenes (tools/fit_smooth_model.py; torch CPU), runs the CPU
+oracle on N full-size 1040x1392 synthetic images (worker processes, BEFORE this process touches the GPU), then the device
+pipeline with each of the three 3x3 kernels (direct / Winograd F(2x2) / F(4x4)) and reports, per mode: raw-label
+mismatch pixels, post-processed-label mismatch pixels and |delta n_ec| - per image, in total and scaled to 100 images.
+Also reports the same for the seeded RANDOM-weight model (speckled output, the bench model).
+
+    python tools/label_mismatch.py [--base 64] [--fit-steps 150] [--images 16] [--out profiles/r02_label_mismatch.json]
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+H, W = 1040, 1392
+SEED0 = 5000
+
+
+def _load(path):
+    z = np.load(path)
+    w = {}
+    for k in z.files:
+        name, i = k.rsplit('/', 1)
+        w.setdefault(name, {})[int(i)] = z[k]
+    return {n: [d[i] for i in sorted(d)] for n, d in w.items()}
+
+
+def _worker(job):
+    base, wpath, idx, threads = job
+    import torch
+    torch.set_num_threads(threads)
+    from ecseg_amd import synth
+    from oracle import pipeline, postproc
+    cfg = synth.unet_config(base=base)
+    w = _load(wpath)
+    img = synth.dapi_image(idx, H, W)
+    post, raw, _, _ = pipeline.segment_gray(cfg, w, img, batch=7, return_intermediate=True)
+    return raw.astype(np.uint8), post.astype(np.uint8), int(postproc.count_cc(post == 3)[0])
+
+
+def cpu_refs(base, wpath, n):
+    import multiprocessing as mp
+    ncpu = os.cpu_count() or 1
+    nproc = max(1, min(8, ncpu // 16, n))
+    with mp.get_context('spawn').Pool(nproc) as pool:
+        return pool.map(_worker, [(base, wpath, SEED0 + i, max(1, ncpu // nproc)) for i in range(n)], chunksize=1)
+
+
+def device_modes(base, weights, n, refs):
+    from ecseg_amd import synth
+    from ecseg_amd.model import MetasegModel
+    from oracle import postproc
+    cfg = synth.unet_config(base=base)
+    model = MetasegModel(cfg, weights, device=0)
+    imgs = np.stack([synth.dapi_image(SEED0 + i, H, W) for i in range(n)])
+    out = {}
+    for mode, tag in ((0, 'direct'), (1, 'winograd_f2x2'), (2, 'winograd_f4x4')):
+        model.handle.set_option('winograd', mode)
+        raw, post, nec = model.handle.segment_images(imgs, want_raw=True)
+        raw_mis = [int((raw[i] != refs[i][0]).sum()) for i in range(n)]
+        post_mis = [int((post[i] != refs[i][1]).sum()) for i in range(n)]
+        dn = [int(nec[i]) - refs[i][2] for i in range(n)]
+        exact = all(np.array_equal(postproc.meta_inference(raw[i].astype(np.int64)), post[i]) for i in range(min(n, 2)))
+        out[tag] = {'raw_mismatch_px': raw_mis, 'post_mismatch_px': post_mis, 'delta_n_ec': dn,
+                    'images_with_any_raw_mismatch': int(sum(v > 0 for v in raw_mis)),
+                    'images_with_csv_difference': int(sum(v != 0 for v in dn)),
+                    'raw_mismatch_px_per_100_images': round(100.0 * sum(raw_mis) / n, 1),
+                    'post_mismatch_px_per_100_images': round(100.0 * sum(post_mis) / n, 1),
+                    'abs_delta_n_ec_per_100_images': round(100.0 * sum(abs(v) for v in dn) / n, 1),
+                    'integer_stages_bit_exact_on_device_raw_labels': bool(exact)}
+    model.handle.set_option('winograd', 2)
+    model.handle.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--base', type=int, default=64)
+    ap.add_argument('--fit-steps', type=int, default=150)
+    ap.add_argument('--images', type=int, default=16)
+    ap.add_argument('--out', default=None)
+    ap.add_argument('--skip-random', action='store_true')
+    a = ap.parse_args()
+    from ecseg_amd import synth
+    from tools import fit_smooth_model
+    res = {'image_size': [H, W], 'pixels_per_image': H * W, 'images': a.images, 'unet_base': a.base, 'models': {}}
+    tmp = tempfile.mkdtemp()
+    jobs = []
+    t0 = time.time()
+    cfg, w_fit = fit_smooth_model.fit(a.base, steps=a.fit_steps, log=lambda s: print(s, file=sys.stderr))
+    jobs.append(('fitted_%d_steps' % a.fit_steps, w_fit))
+    if not a.skip_random:
+        jobs.append(('random_seed0', synth.unet_weights(cfg, seed=0)))
+    staged = []
+    for tag, w in jobs:                                          # all CPU work first: no process is started after HIP init
+        path = os.path.join(tmp, tag + '.npz')
+        np.savez(path, **{'%s/%d' % (k, i): arr for k, v in w.items() for i, arr in enumerate(v)})
+        refs = cpu_refs(a.base, path, a.images)
+        staged.append((tag, w, refs))
+        print('%s: CPU oracle done (%.0f s)' % (tag, time.time() - t0), file=sys.stderr)
+    for tag, w, refs in staged:
+        r = device_modes(a.base, w, a.images, refs)
+        r['n_ec_cpu'] = [x[2] for x in refs]
+        r['class_fractions_cpu_raw'] = [round(float(v), 4) for v in
+                                        np.bincount(np.concatenate([x[0].ravel() for x in refs]), minlength=4) / (a.images * H * W)]
+        res['models'][tag] = r
+    text = json.dumps(res, indent=1)
+    if a.out:
+        open(a.out, 'w').write(text)
+    print(text)
+
+
+if __name__ == '__main__':
+    main()

@@ -81,8 +81,8 @@ def cpu_baseline(base):
     Returns (cpu_baseline dict, single-thread dict, reference outputs for the parity check)."""
     import multiprocessing as mp
     ncpu = os.cpu_count() or 1
-    nproc = max(1, min(8, ncpu // 16))
-    threads = max(1, ncpu // nproc)
+    nproc = max(1, min(64, ncpu // 4))                            # many small workers: torch's CPU convolutions scale poorly
+    threads = max(1, ncpu // nproc)                               # beyond a few threads, images are independent
     ctx = mp.get_context('spawn')
     with ctx.Pool(nproc) as pool:
         pool.map(_cpu_noop, range(nproc))                         # workers up, torch imported (untimed)

@@ -21,6 +21,20 @@ __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
     }
 }
 
+// Four values at once with ONE uniform branch on the activation code: the per-element switch of apply_act costs a scalar
+// compare / branch chain per value, which dominated the output stages of the MFMA kernels (ReLU and linear are the
+// activations of every convolution of a U-Net).
+__device__ __forceinline__ f32x4 apply_act4(f32x4 v, int act, float alpha) {
+    if (act == ECSEG_ACT_RELU) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+    } else if (act != ECSEG_ACT_LINEAR) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = apply_act(v[c], act, alpha);
+    }
+    return v;
+}
+
 // T1: give every XCD (blocks with equal blockIdx % 8 share one L2) a contiguous range of logical block ids.
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
     const unsigned q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u;

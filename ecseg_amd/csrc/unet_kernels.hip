@@ -188,8 +188,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p, int tiles_
         for (int r = 0; r < 4; ++r) {
             const int row = (lane >> 3) + 8 * r;               // pixel index inside the wave's 32-pixel strip
             f32x4 v = *reinterpret_cast<const f32x4*>(Xs + row * 32 + 4 * quad) + bv;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = apply_act(v[c], p.act, p.alpha);
+            v = apply_act4(v, p.act, p.alpha);
             int py, px;
             if (TW == 32) { py = wave; px = row; } else { py = 2 * wave + (row >> 4); px = row & 15; }
             const int tyy = ty0 + py, txx = tx0 + px;          // position in the tiled extent
@@ -266,8 +265,7 @@ __device__ __forceinline__ void wino_store_Y(const float* Rs, const ConvParams& 
         const f32x4 q2 = *reinterpret_cast<const f32x4*>(Rs + ((2 * 2 + jp) * 32 + t) * BN + 4 * q);
         const f32x4 q3 = *reinterpret_cast<const f32x4*>(Rs + ((3 * 2 + jp) * 32 + t) * BN + 4 * q);
         f32x4 y0 = q0 + q1 + q2 + bv, y1 = q1 - q2 - q3 + bv;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { y0[k] = apply_act(y0[k], p.act, p.alpha); y1[k] = apply_act(y1[k], p.act, p.alpha); }
+        y0 = apply_act4(y0, p.act, p.alpha); y1 = apply_act4(y1, p.act, p.alpha);
         const int oy = oy0 + 2 * (t >> 3), ox = ox0 + 2 * (t & 7) + jp;
         if (co + 3 < Cout && ox < Wout) {
             float* o = p.out.p + (((size_t)img * Hout + oy) * Wout + ox) * p.out.cs + co;
@@ -545,8 +543,8 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(TView in, TView out
         }
         float* op = out.p + ((img * out.h + oy) * out.w + ox) * out.cs + q * 4;
         f32x4 o;
-        o[0] = apply_act(acc[0], act, alpha); o[1] = apply_act(acc[1], act, alpha);
-        o[2] = apply_act(acc[2], act, alpha); o[3] = apply_act(acc[3], act, alpha);
+        o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+        o = apply_act4(o, act, alpha);
         *reinterpret_cast<f32x4*>(op) = o;
     }
 }
@@ -595,8 +593,8 @@ __global__ __launch_bounds__(256) void conv_first_kernel(TView in, TView out, co
         for (int i = 0; i < PX; ++i) {
             if (x0 + i < out.w) {
                 f32x4 o;
-                o[0] = apply_act(acc[i][0], act, alpha); o[1] = apply_act(acc[i][1], act, alpha);
-                o[2] = apply_act(acc[i][2], act, alpha); o[3] = apply_act(acc[i][3], act, alpha);
+                o[0] = acc[i][0]; o[1] = acc[i][1]; o[2] = acc[i][2]; o[3] = acc[i][3];
+                o = apply_act4(o, act, alpha);
                 *reinterpret_cast<f32x4*>(out.p + ((img * out.h + oy) * out.w + x0 + i) * out.cs + q * 4) = o;
             }
         }

@@ -72,7 +72,8 @@ __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {   
 }  // namespace
 
 // ABL: timing-only ablations for tools/w4_ablate.py (ECSEG_W4_ABL): 1 no halo LDS reads, 2 no filter DMA, 4 no halo DMA,
-// 8 no MFMA, 32 instruction mix of a (row, column-half) wave split; STAMP (ECSEG_W4_ABL=100): s_memtime stamps
+// 8 no MFMA, 32 instruction mix of a (row, column-half) wave split, 64 instruction mix of a transform shared between
+// the two channel-half waves of a row through LDS; STAMP (ECSEG_W4_ABL=100): s_memtime stamps
 template <int ABL, bool STAMP = false, bool HEAD = false>
 __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_x, int regs_y, int npairs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -192,6 +193,24 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         }
         // scalar fmas on purpose (file is built with -fno-slp-vectorize): packed f32 VALU ops (v_pk_fma_f32) stall the
         // SIMD beside MFMAs, single v_fma_f32 hide in the matrix pipe's shadow
+        if (ABL & 64) {
+            // timing model of a transform shared by the two channel-half waves of a row: each wave transforms 2 of the 4
+            // channels per lane (b64 halo reads, half the fmas), the column transform of ONE stage, and hands its 12
+            // values to the partner through LDS (3 b128 writes here, 3 + 3 b128 reads in the MFMA stages)
+            const f32x2* A2 = reinterpret_cast<const f32x2*>(A) + ch;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const f32x2 d0 = A2[2 * (ro0 + cp[j])], d1 = A2[2 * (ro1 + cp[j])], d2 = A2[2 * (ro2 + cp[j])], d3 = A2[2 * (ro3 + cp[j])];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    t[j][c] = inner_row ? __builtin_fmaf(c0, d0[c], __builtin_fmaf(c1, d1[c], __builtin_fmaf(c2, d2[c], d3[c])))
+                                        : __builtin_fmaf(c0, d0[c], __builtin_fmaf(c1, d1[c], d2[c]));
+                t[j][2] = t[j][0]; t[j][3] = t[j][1];
+                asm volatile("" : "+v"(t[j]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
         if (inner_row) {
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
@@ -218,6 +237,14 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
     // ---- one filter stage (2 of the group's 4 channel pairs; buffer ss): column transform + 12 MFMAs ----
     auto mfma_stage = [&](int ss, int next_stage, int halo_grp) {     // halo_grp: group to prefetch (stage 0), < 0: none
         float V[6][2];
+        if ((ABL & 64) && ss == 1) {
+            // stage 1 of the shared-transform model: the 12 values come from the partner through LDS
+            f32x4* X = Hs + 3 * W4_HS + (wave * 2 + 1) * W4_BWS + 3 * 64 + lane;     // (scratch behind the wave's own filter stage)
+            const f32x4 x0 = X[0], x1 = X[1], x2 = X[2];
+            asm volatile("" :: "v"(x0), "v"(x1), "v"(x2));
+#pragma unroll
+            for (int v = 0; v < 6; ++v) { V[v][0] = t[v][0]; V[v][1] = t[v][1]; }
+        } else
 #pragma unroll
         for (int e = 0; e < 2; ++e) {   // V[nu] = sum_j B^T[nu][j] t[j], scalar ops (see transform)
             const int c = 2 * ss + e;
@@ -231,6 +258,14 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             V[3][e] = b42 + b31;
             V[4][e] = b42 - b31;
             V[5][e] = __builtin_fmaf(4.f, u1, __builtin_fmaf(-5.f, u3, u5));
+        }
+        if ((ABL & 64) && ss == 0) {
+            f32x4* X = Hs + (halo_grp >= 0 ? 0 : 0) + 3 * W4_HS + 12 * 2 * W4_BWS - 3 * 64 * 12 + wave * 3 * 64 + lane;   // scratch: tail of the filter area (timing only)
+            X[0] = f32x4{V[0][0], V[0][1], V[1][0], V[1][1]};
+            X[64] = f32x4{V[2][0], V[2][1], V[3][0], V[3][1]};
+            X[128] = f32x4{V[4][0], V[4][1], V[5][0], V[5][1]};
+            const f32x4 x0 = X[0], x1 = X[64], x2 = X[128];
+            asm volatile("" :: "v"(x0), "v"(x1), "v"(x2));
         }
         const f32x2* Bp = reinterpret_cast<const f32x2*>(Bw + ss * W4_BWS) + lane;
         f32x2 w2[6];
@@ -360,13 +395,23 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
     const int Cout = p.out.c;
     unsigned long long et[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ek = STAMP ? __builtin_amdgcn_s_memtime() : 0;
 #define ESTAMP(i) do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); et[i] += now - ek; ek = now; __builtin_amdgcn_sched_barrier(0); } } while (0)
-    float hl[2][4][4];                                       // fused 1x1 head: partial logits [item][row][class]
+    // Work split of the combine step: per pass 2048 "half items" (channel quad q, column x, tile n, row pair yh) over the
+    // 768 threads in three rounds (the last one 2/3 full) - with whole items (1024 over 768 threads) the first four
+    // waves did two rounds of 4 rows while the others idled behind them.
+    float hl[3][2][4];                                       // fused 1x1 head: partial logits [round][row of the pair][class]
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int c = 0; c < 4; ++c) hl[a][b][c] = 0.f;
+    // the bias quads of both passes are fetched here, under the K loop's drain and the first barrier: a global load inside
+    // the combine step would queue behind the previous pass's output stores (one in-order vmcnt)
+    f32x4 bvp[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (p.bias != nullptr) {
+        bvp[0] = *reinterpret_cast<const f32x4*>(p.bias + nb * 64 + 4 * (tid & 7));
+        bvp[1] = *reinterpret_cast<const f32x4*>(p.bias + nb * 64 + 32 + 4 * (tid & 7));
+    }
     for (int pass = 0; pass < 2; ++pass) {
         __syncthreads();                                     // main-loop LDS reads / previous pass's combine are done
         ESTAMP(0);                                           // [0] barrier (K-loop skew / previous combine)
@@ -387,75 +432,73 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         __syncthreads();
         ESTAMP(2);                                           // [2] barrier
         const int n0 = nb * 64 + pass * 32;
+        const f32x4 bv = pass ? bvp[1] : bvp[0];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < 3; ++k) {
             const int item = tid + k * 768;
-            if (item >= 1024) break;
-            const int q = item & 7, x = (item >> 3) & 3, n = item >> 5;
+            if (item >= 2048) break;
+            const int q = item & 7, x = (item >> 3) & 3, n = (item >> 5) & 31, yh = item >> 10;
             const int nq8 = n >> 2, ntx = n & 3;
             const int g = (0x96 >> nq8) & 1;
             const int nty = nq8 < 2 ? 0 : nq8 < 4 ? 1 : nq8 < 6 ? 2 : 3;
             const int img = g ? r_img[1] : r_img[0];
             if (img < 0) continue;
             const float* r = Rs + x * W4_RPLANE + n * 32 + 4 * q;
-            const f32x4 q0 = *reinterpret_cast<const f32x4*>(r + 0 * 4 * W4_RPLANE);
+            // rows 0 / 1 need transform rows 0..4, rows 2 / 3 need 1..5
             const f32x4 q1 = *reinterpret_cast<const f32x4*>(r + 1 * 4 * W4_RPLANE);
             const f32x4 q2 = *reinterpret_cast<const f32x4*>(r + 2 * 4 * W4_RPLANE);
             const f32x4 q3 = *reinterpret_cast<const f32x4*>(r + 3 * 4 * W4_RPLANE);
             const f32x4 q4 = *reinterpret_cast<const f32x4*>(r + 4 * 4 * W4_RPLANE);
-            const f32x4 q5 = *reinterpret_cast<const f32x4*>(r + 5 * 4 * W4_RPLANE);
+            const f32x4 qe = *reinterpret_cast<const f32x4*>(r + (yh ? 5 : 0) * 4 * W4_RPLANE);
             const int co = n0 + 4 * q;
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(p.bias + co);
             const f32x4 s12 = q1 + q2, d12 = q1 - q2, s34 = q3 + q4, d34 = q3 - q4;
-            f32x4 y[4];
-            y[0] = q0 + s12 + s34 + bv;
-            y[1] = d12 + 2.f * d34 + bv;
-            y[2] = s12 + 4.f * s34 + bv;
-            y[3] = d12 + 8.f * d34 + q5 + bv;
-            const int oy = (g ? r_y0[1] : r_y0[0]) + 4 * nty, ox = (g ? r_x0[1] : r_x0[0]) + 4 * ntx + x;
+            f32x4 y[2];
+            if (yh == 0) {
+                y[0] = qe + s12 + s34 + bv;
+                y[1] = d12 + 2.f * d34 + bv;
+            } else {
+                y[0] = s12 + 4.f * s34 + bv;
+                y[1] = d12 + 8.f * d34 + qe + bv;
+            }
+            const int oy = (g ? r_y0[1] : r_y0[0]) + 4 * nty + 2 * yh, ox = (g ? r_x0[1] : r_x0[0]) + 4 * ntx + x;
             float* o = p.out.p + (((size_t)img * H + oy) * W + ox) * p.out.cs + co;
 #pragma unroll
-            for (int yy = 0; yy < 4; ++yy) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) y[yy][c] = apply_act(y[yy][c], p.act, p.alpha);
+            for (int yy = 0; yy < 2; ++yy) {
+                y[yy] = apply_act4(y[yy], p.act, p.alpha);
                 if (co + 3 < Cout && !(HEAD && p.head_only)) *reinterpret_cast<f32x4*>(o + (size_t)yy * W * p.out.cs) = y[yy];
             }
             if (HEAD) {                                      // this lane's 4 channels x 4 classes of the 1x1 head
                 const f32x4* hw = reinterpret_cast<const f32x4*>(p.head_w) + co;
                 const f32x4 w0 = hw[0], w1 = hw[1], w2 = hw[2], w3 = hw[3];
 #pragma unroll
-                for (int yy = 0; yy < 4; ++yy)
+                for (int yy = 0; yy < 2; ++yy)
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                         hl[k][yy][c] += y[yy][0] * w0[c] + y[yy][1] * w1[c] + y[yy][2] * w2[c] + y[yy][3] * w3[c];
             }
             if (p.pool.p != nullptr) {
-                // fused MaxPooling2D(2x2, stride 2): rows pair up in registers, the column partner (x ^ 1) is lane ^ 8 of
+                // fused MaxPooling2D(2x2, stride 2): the row pair is in registers, the column partner (x ^ 1) is lane ^ 8 of
                 // the same tile, hence of the same region: it is active whenever this lane is
+                f32x4 m;
 #pragma unroll
-                for (int yp = 0; yp < 2; ++yp) {
-                    f32x4 m;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float a = fmaxf(y[2 * yp][c], y[2 * yp + 1][c]);
-                        m[c] = fmaxf(a, __shfl_xor(a, 8));
-                    }
-                    if (!(x & 1) && co + 3 < Cout)
-                        *reinterpret_cast<f32x4*>(p.pool.p + (((size_t)img * p.pool.h + (oy >> 1) + yp) * p.pool.w + (ox >> 1)) * p.pool.cs + co) = m;
+                for (int c = 0; c < 4; ++c) {
+                    const float a = fmaxf(y[0][c], y[1][c]);
+                    m[c] = fmaxf(a, __shfl_xor(a, 8));
                 }
+                if (!(x & 1) && co + 3 < Cout)
+                    *reinterpret_cast<f32x4*>(p.pool.p + (((size_t)img * p.pool.h + (oy >> 1)) * p.pool.w + (ox >> 1)) * p.pool.cs + co) = m;
             }
         }
         ESTAMP(3);                                           // [3] combine + output stores issued
     }
     if (HEAD) {
         // the eight lanes q = 0..7 of a pixel column hold partial logits of 8 output channels each: butterfly over q,
-        // then lane q < 4 finishes row q (bias, softmax / activation over head_k classes) and stores it
+        // then lane q < 2 finishes row q of the pair (bias, softmax / activation over head_k classes) and stores it
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < 3; ++k) {
             const int item = tid + k * 768;
-            if (item >= 1024) break;
-            const int q = item & 7, x = (item >> 3) & 3, n = item >> 5;
+            if (item >= 2048) break;
+            const int q = item & 7, x = (item >> 3) & 3, n = (item >> 5) & 31, yh = item >> 10;
             const int nq8 = n >> 2, ntx = n & 3;
             const int g = (0x96 >> nq8) & 1;
             const int nty = nq8 < 2 ? 0 : nq8 < 4 ? 1 : nq8 < 6 ? 2 : 3;
@@ -463,14 +506,14 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             if (img < 0) continue;
             f32x4 mine = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int yy = 0; yy < 4; ++yy)
+            for (int yy = 0; yy < 2; ++yy)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float v = hl[k][yy][c];
                     v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
                     if (q == yy) mine[c] = v;
                 }
-            if (q < 4) {
+            if (q < 2) {
                 const f32x4 hb = *reinterpret_cast<const f32x4*>(p.head_b);
                 float l[4];
 #pragma unroll
@@ -488,7 +531,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
 #pragma unroll
                     for (int c = 0; c < 4; ++c) l[c] = apply_act(l[c], p.head_act, p.alpha);
                 }
-                const int oy = (g ? r_y0[1] : r_y0[0]) + 4 * nty + q, ox = (g ? r_x0[1] : r_x0[0]) + 4 * ntx + x;
+                const int oy = (g ? r_y0[1] : r_y0[0]) + 4 * nty + 2 * yh + q, ox = (g ? r_x0[1] : r_x0[0]) + 4 * ntx + x;
                 float* ho = p.head_out.p + (((size_t)img * H + oy) * W + ox) * p.head_out.cs;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) if (c < p.head_k) ho[c] = l[c];
@@ -536,6 +579,7 @@ hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s) {
         case 7: kern = conv_wino4_kernel<7>; break;
         case 8: kern = conv_wino4_kernel<8>; break;
         case 32: kern = conv_wino4_kernel<32>; break;
+        case 64: kern = conv_wino4_kernel<64>; break;
         case 100: kern = conv_wino4_kernel<0, true>; break;        // in-kernel cycle stamps (tools/w4_stamp_probe.py)
         default: break;
     }

@@ -51,9 +51,9 @@ def _worker(job):
 def cpu_refs(base, wpath, n):
     import multiprocessing as mp
     ncpu = os.cpu_count() or 1
-    nproc = max(1, min(8, ncpu // 16, n))
+    nproc = max(1, min(64, ncpu // 4, n))
     with mp.get_context('spawn').Pool(nproc) as pool:
-        return pool.map(_worker, [(base, wpath, SEED0 + i, max(1, ncpu // nproc)) for i in range(n)], chunksize=1)
+        return pool.map(_worker, [(base, wpath, SEED0 + i, max(1, min(8, ncpu // nproc))) for i in range(n)], chunksize=1)
 
 
 def device_modes(base, weights, n, refs):

@@ -20,7 +20,11 @@ EXPORTS = [
 
 
 class EcsegError(RuntimeError):
-    pass
+    """``code`` carries the ECSEG_E_* status of the failed call (None for binding-level errors)."""
+    code = None
+
+
+E_NOMEM = -4
 
 
 class TensorDesc(C.Structure):
@@ -134,7 +138,9 @@ class Handle:
 
     def _check(self, rc, what):
         if rc != 0:
-            raise EcsegError('%s failed (%d): %s' % (what, rc, self.lib.ecseg_last_error(self.h).decode()))
+            e = EcsegError('%s failed (%d): %s' % (what, rc, self.lib.ecseg_last_error(self.h).decode()))
+            e.code = rc
+            raise e
 
     @property
     def device_name(self):

@@ -580,7 +580,9 @@ int segment_dev(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint
     if ((rc = get_stitch(h, H, W, &sp))) return rc;
     const size_t px = (size_t)H * W;
     hipStream_t s = h->stream, s2 = h->overlap_post ? h->stream2 : h->stream;
-    const int grp = std::max(1, h->images_per_group);
+    // images per U-Net launch: images_per_group is calibrated for 35-window images (1040 x 1392); larger images have more
+    // windows each, so the group shrinks to keep the activation memory (~82 MB per window for a base-64 U-Net) bounded
+    const int grp = std::max(1, std::min(h->images_per_group, std::max(1, h->images_per_group * 35 / sp->n_pos)));
     if ((rc = ensure_patches(h, std::min(grp, n_img) * sp->n_pos))) return rc;
     if ((rc = ensure_post(h, std::min(n_img, grp), px))) return rc;
     for (float& v : h->stage_ms) v = 0.f;

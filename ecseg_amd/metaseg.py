@@ -3,71 +3,135 @@
 output files), running on MI355X.
 
 Differences that do not change results: images are processed in batches on the GPU instead of one by one, in sorted
-order; under ``torchrun`` the images are sharded across the GPUs of the node, every rank writes the outputs of its
-own images and rank 0 writes ``ec_quantification.csv`` after one all-gather of the per-image records.
+order; TIFF decoding and the output encoders (dapi TIFF, label PNG, int64 .npy) run on worker threads around the GPU
+batches with a bounded number of images in flight (the reference's loop at src/metaseg.py:42-54 is serial); with
+``device_ids: [0, 1, ...]`` in the config section (or under ``torchrun``) the images are sharded across the GPUs of the
+node, every rank writes the outputs of its own images and rank 0 writes ``ec_quantification.csv`` after one all-gather
+of the per-image records (the reference's analogue is the implicit all-device MirroredStrategy, src/metaseg.py:33-36).
+
+Optional config keys (defaults keep the reference's behaviour): ``batch_images`` (8), ``io_threads``, ``device_ids``.
 """
+import concurrent.futures as cf
 import os
+import socket
+import subprocess
 import sys
+import threading
+import time
 
 import numpy as np
 import yaml
 
 from . import csvio, dist, image_io
+from ._lib import E_NOMEM, EcsegError
 from .utils import get_imgs, load_model, save_img
 
 MODEL_NAME = 'metaseg.h5'
 
 
-def _batches(items, key, max_batch):
-    """Consecutive runs of items with equal key, cut at max_batch."""
-    out, cur, cur_key = [], [], None
-    for it in items:
-        k = key(it)
-        if cur and (k != cur_key or len(cur) >= max_batch):
-            out.append(cur)
-            cur = []
-        cur.append(it)
-        cur_key = k
-    if cur:
-        out.append(cur)
-    return out
+def _read(p):
+    img = image_io.imread(p)
+    if img.dtype not in (np.uint8, np.uint16) or img.ndim not in (2, 3):
+        raise ValueError('unsupported image array %s %s' % (img.dtype, img.shape))
+    return img
 
 
-def run(inpath, model, image_paths, rank=0, world=1, batch_images=8, log=print):
+def _write_outputs(p, gray_inv, post, log):
+    path_split = os.path.split(p)
+    save_img(gray_inv, path_split, 'dapi')                               # cv2.bitwise_not(I) (src/utils.py:112)
+    outpath = os.path.join(path_split[0], 'labels', path_split[1][:-4])
+    log("Saving labels: ", p, " to ", outpath)
+    image_io.write_label_png(outpath + '.png', post)
+    np.save(outpath, post.astype(np.int64))                               # int64 .npy (src/metaseg.py:53)
+
+
+def _segment_with_retry(model, imgs, log):
+    """GPU part of one batch; on an out-of-memory status the internal launch group is halved (down to one image)."""
+    h = model.handle
+    group = None
+    while True:
+        try:
+            gray, _ = h.preprocess(imgs)
+            post, nec = model.segment(gray)
+            return gray, post, nec
+        except EcsegError as e:
+            if e.code != E_NOMEM:
+                raise
+            group = 8 if group is None else group // 2
+            if group < 1:
+                raise
+            log("Out of device memory for a batch of shape %s: retrying with %d image(s) per launch group" % (imgs.shape, group))
+            h.set_images_per_group(group)
+
+
+def run(inpath, model, image_paths, rank=0, world=1, batch_images=8, io_threads=None, log=print, stats=None):
     """Segment this rank's shard; returns records (one row per image of the WHOLE job after the all-gather)."""
     start, stop, per = dist.shard_bounds(len(image_paths), rank, world)
     mine = image_paths[start:stop]
     n_ec = np.zeros(len(mine), np.int64)
     status = np.zeros(len(mine), np.int64)
-    loaded = []
-    for k, p in enumerate(mine):
-        log("Processing image: ", p)
-        try:
-            img = image_io.imread(p)
-            if img.dtype not in (np.uint8, np.uint16) or img.ndim not in (2, 3):
-                raise ValueError('unsupported image array %s %s' % (img.dtype, img.shape))
-            loaded.append((k, p, img))
-        except Exception as e:                     # a corrupt image must not take the shard down
-            log("Skipping %s: %s" % (p, e))
-            status[k] = 1
-    for group in _batches(loaded, lambda t: (t[2].shape, t[2].dtype.str), batch_images):
-        imgs = np.stack([g[2] for g in group])
-        try:
-            gray, _ = model.handle.preprocess(imgs)
-            post, nec = model.segment(gray)
-        except Exception as e:
-            log("Skipping %d image(s) of shape %s: %s" % (len(group), imgs.shape[1:], e))
-            for k, _, _ in group:
-                status[k] = 2
-            continue
-        for j, (k, p, _) in enumerate(group):
-            path_split = os.path.split(p)
-            save_img(~gray[j], path_split, 'dapi')                       # cv2.bitwise_not(I) (src/utils.py:112)
-            outpath = os.path.join(path_split[0], 'labels', path_split[1][:-4])
-            log("Saving labels: ", p, " to ", outpath)
-            image_io.write_label_png(outpath + '.png', post[j])
-            np.save(outpath, post[j].astype(np.int64))                     # int64 .npy (src/metaseg.py:53)
-            n_ec[k] = int(nec[j])
+    io_threads = io_threads or max(2, min(32, (os.cpu_count() or 4) // max(world, 1)))
+    window = max(2 * batch_images, io_threads)                             # images decoded ahead of the GPU
+    pending_writes = threading.BoundedSemaphore(4 * batch_images + io_threads)   # bounds the outputs held in memory
+    t_gpu = 0.0
+    with cf.ThreadPoolExecutor(io_threads) as readers, cf.ThreadPoolExecutor(io_threads) as writers:
+        reads = {}
+        next_submit = 0
+
+        def top_up(upto):
+            nonlocal next_submit
+            while next_submit < min(len(mine), upto):
+                log("Processing image: ", mine[next_submit])
+                reads[next_submit] = readers.submit(_read, mine[next_submit])
+                next_submit += 1
+
+        write_futs = []
+
+        def flush(group):
+            nonlocal t_gpu
+            if not group:
+                return
+            imgs = np.stack([g[1] for g in group])
+            try:
+                t0 = time.perf_counter()
+                gray, post, nec = _segment_with_retry(model, imgs, log)
+                t_gpu += time.perf_counter() - t0
+            except Exception as e:                         # a failing batch must not take the shard down
+                log("Skipping %d image(s) of shape %s: %s" % (len(group), imgs.shape[1:], e))
+                for k, _ in group:
+                    status[k] = 2
+                return
+            for j, (k, _) in enumerate(group):
+                n_ec[k] = int(nec[j])
+                pending_writes.acquire()
+                f = writers.submit(_write_outputs, mine[k], ~gray[j], post[j], log)
+                f.add_done_callback(lambda _f: pending_writes.release())
+                write_futs.append((k, f))
+
+        group, key = [], None
+        for k in range(len(mine)):
+            top_up(k + window)
+            try:
+                img = reads.pop(k).result()
+            except Exception as e:                         # a corrupt image must not take the shard down
+                log("Skipping %s: %s" % (mine[k], e))
+                status[k] = 1
+                continue
+            kk = (img.shape, img.dtype.str)
+            if group and (kk != key or len(group) >= batch_images):
+                flush(group)
+                group = []
+            group.append((k, img))
+            key = kk
+        flush(group)
+        for k, f in write_futs:
+            try:
+                f.result()
+            except Exception as e:
+                log("Could not write the outputs of %s: %s" % (mine[k], e))
+                status[k] = 3
+    if stats is not None:
+        stats['gpu_seconds'] = t_gpu
     rec = dist.make_records(start, len(mine), per, n_ec=n_ec, status=status)
     if world > 1:
         import torch
@@ -76,6 +140,18 @@ def run(inpath, model, image_paths, rank=0, world=1, batch_images=8, log=print):
     else:
         rec = dist.compact_records(rec)
     return rec
+
+
+def _self_launch(device_ids):
+    """``device_ids`` with more than one GPU outside a launcher: one rank per listed GPU (this parent never touches HIP)."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, ECSEG_DEVICE_IDS=','.join(str(int(d)) for d in device_ids),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(len(device_ids)),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), '-m', 'ecseg_amd.metaseg']
+    sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
 def main(argv=None):
@@ -89,12 +165,25 @@ def main(argv=None):
     for sub in ('dapi', 'labels'):
         os.makedirs(os.path.join(inpath, sub), exist_ok=True)
 
-    rank, world = dist.init_process_group() if int(os.environ.get('WORLD_SIZE', '1')) > 1 else (0, 1)
-    model = load_model(MODEL_NAME)
+    under_launcher = int(os.environ.get('WORLD_SIZE', '1')) > 1
+    device_ids = var.get('device_ids')
+    if device_ids and len(device_ids) > 1 and not under_launcher:
+        _self_launch(device_ids)
+    rank, world = dist.init_process_group() if under_launcher else (0, 1)
+    device = None
+    if os.environ.get('ECSEG_DEVICE_IDS'):
+        device = int(os.environ['ECSEG_DEVICE_IDS'].split(',')[int(os.environ.get('LOCAL_RANK', '0'))])
+    elif device_ids:
+        device = int(device_ids[0])
+    model = load_model(MODEL_NAME, device=device)
     print(model.handle.device_name)
     image_paths = get_imgs(inpath)
     print("Reading from: ", inpath)
-    rec = run(inpath, model, image_paths, rank, world, batch_images=int(var.get('batch_images', 8)))
+    t0 = time.perf_counter()
+    stats = {}
+    rec = run(inpath, model, image_paths, rank, world, batch_images=int(var.get('batch_images', 8)),
+              io_threads=var.get('io_threads'), stats=stats)
+    failed = [r for r in rec if r[dist.F_STATUS] != 0]
     if rank == 0:
         rows = [[os.path.split(image_paths[int(r[dist.F_INDEX])])[1], int(r[dist.F_NEC])]
                 for r in rec if r[dist.F_STATUS] == 0]
@@ -105,10 +194,21 @@ def main(argv=None):
             f.write(text)
         with open(os.path.join(inpath, 'ec_quantifications.csv'), 'w') as f:   # the name README.md:86 uses
             f.write(text)
+        dt = time.perf_counter() - t0
+        if image_paths:
+            print("%d image(s) in %.2f s (%.1f images/s; device calls %.2f s on rank 0)"
+                  % (len(image_paths), dt, len(image_paths) / dt, stats.get('gpu_seconds', 0.0)))
+        if failed:
+            why = {1: 'could not be read', 2: 'failed on the device', 3: 'outputs could not be written'}
+            print("%d image(s) were NOT processed and are missing from the CSV:" % len(failed))
+            for r in failed:
+                print("  ", image_paths[int(r[dist.F_INDEX])], "-", why.get(int(r[dist.F_STATUS]), 'failed'))
     if world > 1:
         import torch.distributed as td
         td.barrier()
         td.destroy_process_group()
+    if failed:
+        sys.exit(1)             # the reference would have crashed on the first such image (src/metaseg.py:42-54)
 
 
 if __name__ == "__main__":

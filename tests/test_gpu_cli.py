@@ -14,6 +14,7 @@ from oracle import pipeline as oracle_pipeline
 from oracle import postproc, preprocess
 
 pytestmark = pytest.mark.gpu
+MPL_RGBA = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'io_label_png.npz'))['class_rgba']
 
 
 @pytest.fixture()
@@ -44,9 +45,10 @@ def test_metaseg_then_overlay_cli(workdir):
     assert tifs == ['gray.tif', 'img0.tif', 'img1.tif', 'img2.tif']
     rows = []
     for n in tifs:
-        img = image_io.imread(str(inp / n))
+        img = np.array(Image.open(str(inp / n)))                   # the oracle side decodes with PIL, not with the product's reader
+        assert np.array_equal(img, image_io.imread(str(inp / n)))
         gray = preprocess.meta_preprocess(img)
-        assert np.array_equal(image_io.read_tiff(str(inp / 'dapi' / n)), 255 - gray), n     # cv2.bitwise_not(I)
+        assert np.array_equal(np.array(Image.open(str(inp / 'dapi' / n))), 255 - gray), n     # cv2.bitwise_not(I); PIL = independent decoder
         lab = np.load(str(inp / 'labels' / (n[:-4] + '.npy')))
         assert lab.dtype == np.int64 and lab.shape == gray.shape
         want = oracle_pipeline.segment_gray(cfg, weights, gray)
@@ -55,7 +57,7 @@ def test_metaseg_then_overlay_cli(workdir):
             # must still be exact, which test_gpu_pipeline checks.  Report it loudly here.
             pytest.fail('%s: %d label pixels differ from the oracle' % (n, int((lab != want).sum())))
         png = np.array(Image.open(str(inp / 'labels' / (n[:-4] + '.png'))))
-        assert np.array_equal(png, image_io.LABEL_COLORS[lab])
+        assert np.array_equal(png, MPL_RGBA[lab])                   # colours pinned by matplotlib's own imsave output
         rows.append([n, postproc.count_cc(want == 3)[0]])
     text = open(str(inp / 'ec_quantification.csv')).read()
     assert text == oracle_overlay.csv_text(oracle_overlay.METASEG_COLUMNS, rows)
@@ -72,6 +74,21 @@ def test_metaseg_then_overlay_cli(workdir):
         assert np.array_equal(np.array(Image.open(str(inp / 'red' / (n + '.png')))), 255 - img[..., 0])
         assert np.array_equal(np.array(Image.open(str(inp / 'green' / (n + '.png')))), 255 - img[..., 1])
     assert open(str(inp / 'fish_quantification.csv')).read() == oracle_overlay.csv_text(oracle_overlay.OVERLAY_COLUMNS, rows)
+
+
+def test_corrupt_image_is_reported_and_exit_code_is_nonzero(workdir):
+    """A file that cannot be decoded must not take the run down (per-image status), but it must not pass
+    silently either: the others are processed, it is absent from the CSV, a summary is printed and the exit code is 1."""
+    from ecseg_amd import metaseg
+    tmp, inp = workdir
+    with open(str(inp / 'broken.tif'), 'wb') as f:
+        f.write(b'II*\x00\x08\x00\x00\x00' + b'\xff' * 40)
+    with pytest.raises(SystemExit) as e:
+        metaseg.main([])
+    assert e.value.code == 1
+    text = open(str(inp / 'ec_quantification.csv')).read()
+    assert 'broken.tif' not in text and text.count('\n') == 1 + 4
+    assert os.path.exists(str(inp / 'labels' / 'img2.npy')) and not os.path.exists(str(inp / 'labels' / 'broken.npy'))
 
 
 def test_metaseg_cli_exit_codes(tmp_path, monkeypatch):

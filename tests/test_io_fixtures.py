@@ -1,0 +1,155 @@
+"""The file I/O layer around the hot path (A2 imread, A5 dapi/<name>.tif, A18 labels/<stem>.png) pinned on
+fixtures produced by the libraries the reference itself uses (tools/make_golden.py gen_io, run under the container's
+conda Python): TIFF files written by tifffile / libtiff with the pixels ``skimage.io.imread`` returned for them, and the
+RGBA that ``plt.imsave(cmap=4 colours, vmin=0, vmax=4)`` writes.  Files the product writes are read back with
+independent decoders (PIL/libtiff always; tifffile when the conda Python is present).  No GPU needed: the LZW codec is
+host code in libecseg_hip.so."""
+import base64
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from ecseg_amd import image_io
+
+CONDA = '/opt/conda/bin/python3.9'
+EXAMPLE = '/root/reference/example_ecSeg/dapi.jpeg'
+
+
+def _fixtures(golden_dir):
+    files = json.load(open(os.path.join(golden_dir, 'io_tiff_files.json')))['files']
+    px = np.load(os.path.join(golden_dir, 'io_tiff_pixels.npz'))
+    return files, px
+
+
+def test_imread_matches_skimage_on_tifffile_written_files(golden_dir, tmp_path):
+    files, px = _fixtures(golden_dir)
+    assert len(files) >= 12
+    kinds = set()
+    for name, b64 in files.items():
+        path = str(tmp_path / (name + '.tif'))
+        open(path, 'wb').write(base64.b64decode(b64))
+        got = image_io.imread(path)
+        want = px[name]
+        assert got.shape == want.shape and got.dtype == want.dtype, name
+        assert np.array_equal(got, want), name
+        kinds.add((want.dtype.itemsize, want.ndim))
+    assert kinds == {(1, 2), (1, 3), (2, 2), (2, 3)}            # 8/16-bit, gray/RGB all covered
+
+
+def test_label_png_matches_matplotlib_imsave(golden_dir, tmp_path):
+    z = np.load(os.path.join(golden_dir, 'io_label_png.npz'))
+    assert np.array_equal(image_io.LABEL_COLORS, z['class_rgba'])
+    path = str(tmp_path / 'lab.png')
+    image_io.write_label_png(path, z['labels'].astype(np.int64))
+    img = Image.open(path)
+    assert img.mode == 'RGBA'
+    assert np.array_equal(np.array(img), z['rgba'])
+
+
+@pytest.mark.parametrize('hw', [(1040, 1392), (37, 52), (5, 9000), (64, 1)])
+def test_written_dapi_tiff_decodes_with_libtiff_and_has_opencv_tags(tmp_path, hw):
+    rng = np.random.default_rng(hw[0])
+    H, W = hw
+    yy, xx = np.mgrid[:H, :W]
+    img = ((yy * 3 + xx * 7) % 200 + rng.integers(0, 40, (H, W))).astype(np.uint8)
+    path = str(tmp_path / 'x.tif')
+    image_io.write_tiff_gray8(path, img)
+    im = Image.open(path)
+    assert np.array_equal(np.array(im), img)
+    tags = im.tag_v2
+    assert tags[259] == 5 and tags[317] == 2 and tags[258] == (8,) and tags[262] == 1       # LZW, predictor 2, 8-bit gray
+    assert tags[278] == max(1, min(H, 8192 // W))                 # rows per strip of cv2.imwrite (5 at width 1392)
+    assert np.array_equal(image_io.imread(path), img)
+
+
+@pytest.mark.skipif(not os.path.exists(CONDA), reason='conda Python with tifffile not present (GPU box)')
+def test_written_files_decode_with_tifffile(tmp_path):
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (300, 462)).astype(np.uint8)
+    img[:, :200] = 7                                              # long runs: exercises LZW table growth / resets
+    tif, png = str(tmp_path / 'a.tif'), str(tmp_path / 'b.png')
+    image_io.write_tiff_gray8(tif, img)
+    lab = rng.integers(0, 4, (50, 60))
+    image_io.write_label_png(png, lab)
+    np.save(str(tmp_path / 'img.npy'), img)
+    np.save(str(tmp_path / 'rgba.npy'), image_io.LABEL_COLORS[lab])
+    code = ("import sys, numpy as np\n"
+            "from skimage.io import imread\n"
+            "import matplotlib.pyplot as plt\n"
+            "d = sys.argv[1]\n"
+            "assert np.array_equal(imread(d + '/a.tif'), np.load(d + '/img.npy'))\n"
+            "p = (plt.imread(d + '/b.png') * 255 + 0.5).astype(np.uint8)\n"
+            "assert np.array_equal(p, np.load(d + '/rgba.npy'))\n"
+            "print('ok')\n")
+    out = subprocess.run([CONDA, '-W', 'ignore', '-c', code, str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-1500:]
+
+
+@pytest.mark.skipif(not os.path.exists(EXAMPLE), reason='reference tree not present (GPU box)')
+def test_reference_example_file_decodes_to_the_stored_pixels(golden_dir):
+    """example_ecSeg/dapi.jpeg is an OpenCV-written TIFF (LZW, predictor 2, 5 rows per strip): the real thing the reader
+    must handle; its pixels as decoded by skimage.io.imread are in dapi_example.npz."""
+    want = np.load(os.path.join(golden_dir, 'dapi_example.npz'))['dapi']
+    assert np.array_equal(image_io.imread(EXAMPLE), want)
+
+
+def test_lzw_roundtrip_and_corrupt_streams_do_not_crash():
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 2, 255, 4096, 70000):
+        for kind in range(3):
+            raw = (np.zeros(n, np.uint8) if kind == 0 else rng.integers(0, 256, n).astype(np.uint8) if kind == 1
+                   else np.repeat(rng.integers(0, 4, n // 16 + 1).astype(np.uint8), 16)[:n])
+            enc = image_io._lzw_encode(raw.tobytes())
+            assert np.array_equal(image_io._lzw_decode(enc, n), raw)
+    raw = np.repeat(np.arange(64, dtype=np.uint8), 200)
+    enc = bytearray(image_io._lzw_encode(raw.tobytes()))
+    for trial in range(200):                                      # truncated / bit-flipped streams: error or garbage, never a crash
+        bad = bytearray(enc[:rng.integers(1, len(enc) + 1)])
+        for _ in range(int(rng.integers(0, 4))):
+            bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        try:
+            out = image_io._lzw_decode(bytes(bad), len(raw))
+            assert out.shape == (len(raw),)
+        except image_io.TiffError:
+            pass
+    with pytest.raises(image_io.TiffError):
+        image_io._lzw_decode(b'\xff\xff\xff\xff\xff\xff', 100)
+
+
+def test_host_codec_under_address_sanitizer():
+    """`make asan`: ASan + UBSan build of csrc/host_codec.cpp driven over a corrupt-stream corpus (tools/asan)."""
+    import shutil
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not shutil.which('g++') or not shutil.which('make'):
+        pytest.skip('no g++ / make')
+    out = subprocess.run(['make', '-C', root, 'asan'], capture_output=True, text=True, timeout=600)
+    if 'cannot find' in out.stderr and 'asan' in out.stderr:
+        pytest.skip('libasan not installed')
+    assert out.returncode == 0, (out.stdout + out.stderr)[-2000:]
+    assert 'codec_fuzz ok' in out.stdout
+
+
+def test_truncated_and_corrupt_h5_files_raise_cleanly(golden_dir, tmp_path):
+    """hdf5_min parses the weights file (untrusted bytes): damaged files must raise, not hang or return garbage silently."""
+    from ecseg_amd import hdf5_min
+    data = open(os.path.join(golden_dir, 'keras_tiny.h5'), 'rb').read()
+    rng = np.random.default_rng(1)
+    for cut in (0, 7, 8, 100, len(data) // 3, len(data) - 1000):
+        p = str(tmp_path / ('cut%d.h5' % cut))
+        open(p, 'wb').write(data[:cut])
+        with pytest.raises(Exception):
+            hdf5_min.load_keras_h5(p)
+    for trial in range(20):                                # byte noise in the metadata region: raise or load, never hang
+        bad = bytearray(data)
+        for _ in range(8):
+            bad[int(rng.integers(0, min(len(bad), 4096)))] = int(rng.integers(0, 256))
+        p = str(tmp_path / ('noise%d.h5' % trial))
+        open(p, 'wb').write(bytes(bad))
+        try:
+            hdf5_min.load_keras_h5(p)
+        except Exception:
+            pass

@@ -1,0 +1,52 @@
+// AddressSanitizer / UBSan driver for the host-side byte codecs of libecseg_hip (csrc/host_codec.cpp): the TIFF LZW
+// decoder parses untrusted files (inputs globbed by get_imgs).  CPU build only (`make asan`); GPU sanitizers are not
+// available on the target pool.  Corpus: round trips of structured / random buffers, then truncated, bit-flipped and
+// random streams decoded into exact, short and oversized destinations.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+extern "C" long long ecseg_lzw_decode(const uint8_t* src, long long n, uint8_t* dst, long long dst_cap);
+extern "C" long long ecseg_lzw_encode(const uint8_t* src, long long n, uint8_t* dst, long long dst_cap);
+
+static uint64_t s = 0x9e3779b97f4a7c15ull;
+static uint32_t rnd() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (uint32_t)(s >> 11); }
+
+int main() {
+    long long checked = 0;
+    for (int round = 0; round < 400; ++round) {
+        const int n = round < 8 ? round : (int)(rnd() % 20000);
+        std::vector<uint8_t> raw(n + 1);       // (+1: data() of an empty vector is null, which the ABI rejects)
+        const int kind = round % 4;
+        for (int i = 0; i < n; ++i)
+            raw[i] = kind == 0 ? 0 : kind == 1 ? (uint8_t)rnd() : kind == 2 ? (uint8_t)((i / 37) & 3) : (uint8_t)(i * 7);
+        std::vector<uint8_t> enc(2 * n + 64);
+        const long long m = ecseg_lzw_encode(raw.data(), n, enc.data(), (long long)enc.size());
+        if (m < 0) { std::printf("encode failed at round %d\n", round); return 1; }
+        std::vector<uint8_t> dec(n + 1);
+        const long long k = ecseg_lzw_decode(enc.data(), m, dec.data(), n);
+        if (k != n || std::memcmp(dec.data(), raw.data(), n) != 0) { std::printf("round trip mismatch at round %d\n", round); return 1; }
+        // encoder with a destination that is too small must fail cleanly
+        if (m > 2) { std::vector<uint8_t> small(m / 2); (void)ecseg_lzw_encode(raw.data(), n, small.data(), (long long)small.size()); }
+        for (int t = 0; t < 24; ++t) {
+            std::vector<uint8_t> bad(enc.begin(), enc.begin() + (m ? 1 + rnd() % m : 0)); bad.push_back(0); bad.pop_back();
+            const int flips = rnd() % 6;
+            for (int f = 0; f < flips && !bad.empty(); ++f) bad[rnd() % bad.size()] ^= (uint8_t)(1u << (rnd() % 8));
+            const long long cap = t % 3 == 0 ? n : t % 3 == 1 ? (long long)(rnd() % (n + 1)) : n + (long long)(rnd() % 4096);
+            std::vector<uint8_t> out((size_t)cap + 1, 0xAB);
+            const long long r = ecseg_lzw_decode(bad.data(), (long long)bad.size(), out.data(), cap);
+            if (r > cap) { std::printf("decoder reported %lld bytes for a %lld-byte destination\n", r, cap); return 1; }
+            if (out[(size_t)cap] != 0xAB) { std::printf("decoder wrote past its destination\n"); return 1; }
+            ++checked;
+        }
+        std::vector<uint8_t> junk(rnd() % 4096);
+        for (auto& b : junk) b = (uint8_t)rnd();
+        std::vector<uint8_t> out(5000);
+        (void)ecseg_lzw_decode(junk.data(), (long long)junk.size(), out.data(), (long long)out.size());
+    }
+    (void)ecseg_lzw_decode(nullptr, 0, nullptr, 0);
+    std::printf("codec_fuzz ok: %lld corrupt streams\n", checked);
+    return 0;
+}

@@ -20,8 +20,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def fit(base=64, depth=4, steps=150, crop=128, batch=2, seed=0, lr=2e-3, threads=None, log=None):
-    """-> (model_config, weights) in the same form as synth.unet_config / synth.unet_weights."""
+def fit(base=64, depth=4, steps=150, crop=128, batch=2, seed=0, lr=2e-3, threads=None, log=None, device='cpu'):
+    """-> (model_config, weights) in the same form as synth.unet_config / synth.unet_weights.  ``device='cuda'`` runs the
+    autograd steps with torch on the GPU (test infrastructure; the product never uses torch for arithmetic)."""
     import torch
     import torch.nn.functional as F
     from ecseg_amd import synth
@@ -33,7 +34,7 @@ def fit(base=64, depth=4, steps=150, crop=128, batch=2, seed=0, lr=2e-3, threads
     layers = cfg['config']['layers']
     params = {}
     for name, arrs in w0.items():
-        params[name] = [torch.tensor(a, requires_grad=True) for a in arrs]
+        params[name] = [torch.tensor(a, requires_grad=True, device=device) for a in arrs]
 
     def forward(x):                                              # x: (N, 1, h, w) float 0..255 -> logits (N, 4, h, w)
         vals = {}
@@ -65,7 +66,7 @@ def fit(base=64, depth=4, steps=150, crop=128, batch=2, seed=0, lr=2e-3, threads
     scenes = [synth.dapi_image(7000 + i, 512, 640, with_labels=True) for i in range(12)]
     flat = [t for ps in params.values() for t in ps]
     opt = torch.optim.Adam(flat, lr=lr)
-    cw = torch.tensor([0.3, 1.0, 1.5, 3.0])
+    cw = torch.tensor([0.3, 1.0, 1.5, 3.0], device=device)
     t0 = time.time()
     for step in range(steps):
         xs, ys = [], []
@@ -76,15 +77,15 @@ def fit(base=64, depth=4, steps=150, crop=128, batch=2, seed=0, lr=2e-3, threads
                 if (lab[y0:y0 + crop, x0:x0 + crop] > 0).mean() > 0.03:
                     break
             xs.append(g[y0:y0 + crop, x0:x0 + crop]); ys.append(lab[y0:y0 + crop, x0:x0 + crop])
-        x = torch.from_numpy(np.stack(xs).astype(np.float32))[:, None]
-        y = torch.from_numpy(np.stack(ys).astype(np.int64))
+        x = torch.from_numpy(np.stack(xs).astype(np.float32))[:, None].to(device)
+        y = torch.from_numpy(np.stack(ys).astype(np.int64)).to(device)
         loss = F.cross_entropy(forward(x), y, weight=cw)
         opt.zero_grad()
         loss.backward()
         opt.step()
         if log and (step % 25 == 0 or step == steps - 1):
             log('step %d loss %.4f (%.1f s)' % (step, float(loss.detach()), time.time() - t0))
-    weights = {name: [p.detach().numpy().copy() for p in ps] for name, ps in params.items()}
+    weights = {name: [p.detach().cpu().numpy().copy() for p in ps] for name, ps in params.items()}
     return cfg, weights
 
 
@@ -94,8 +95,10 @@ def main():
     ap.add_argument('--steps', type=int, default=150)
     ap.add_argument('--crop', type=int, default=128)
     ap.add_argument('--out', default=None)
+    ap.add_argument('--device', default='cpu')
+    ap.add_argument('--batch', type=int, default=2)
     a = ap.parse_args()
-    cfg, w = fit(a.base, steps=a.steps, crop=a.crop, log=print)
+    cfg, w = fit(a.base, steps=a.steps, crop=a.crop, batch=a.batch, log=print, device=a.device)
     if a.out:
         np.savez(a.out, **{'%s/%d' % (k, i): arr for k, v in w.items() for i, arr in enumerate(v)})
         print('saved', a.out)

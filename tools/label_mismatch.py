@@ -90,6 +90,8 @@ def main():
     ap.add_argument('--images', type=int, default=16)
     ap.add_argument('--out', default=None)
     ap.add_argument('--skip-random', action='store_true')
+    ap.add_argument('--fit-device', default='cpu', help="'cuda': fit in a child process with torch on the GPU")
+    ap.add_argument('--fit-batch', type=int, default=2)
     a = ap.parse_args()
     from ecseg_amd import synth
     from tools import fit_smooth_model
@@ -97,7 +99,15 @@ def main():
     tmp = tempfile.mkdtemp()
     jobs = []
     t0 = time.time()
-    cfg, w_fit = fit_smooth_model.fit(a.base, steps=a.fit_steps, log=lambda s: print(s, file=sys.stderr))
+    if a.fit_device == 'cpu':
+        cfg, w_fit = fit_smooth_model.fit(a.base, steps=a.fit_steps, batch=a.fit_batch, log=lambda s: print(s, file=sys.stderr))
+    else:                                                        # child process: this one stays off the GPU until the CPU legs are done
+        import subprocess
+        fpath = os.path.join(tmp, 'fit.npz')
+        subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'fit_smooth_model.py'), '--base', str(a.base), '--steps',
+                        str(a.fit_steps), '--device', a.fit_device, '--batch', str(a.fit_batch), '--out', fpath], check=True,
+                       stdout=sys.stderr)
+        cfg, w_fit = synth.unet_config(base=a.base), _load(fpath)
     jobs.append(('fitted_%d_steps' % a.fit_steps, w_fit))
     if not a.skip_random:
         jobs.append(('random_seed0', synth.unet_weights(cfg, seed=0)))

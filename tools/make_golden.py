@@ -17,6 +17,8 @@ compressed ``.npz`` / ``.json`` fixtures under ``tests/golden/``:
   csv_text.json     A18/A23 exact CSV text produced by pandas for both tasks
   keras_tiny.h5     a tiny Keras-layout HDF5 file written by h5py (reader fixture)
   dapi_example.npz  pixels of example_ecSeg/dapi.jpeg (data file held by the reference)
+  io_tiff_files.json / io_tiff_pixels.npz   tifffile-written TIFF variants + the pixels skimage.io.imread returns
+  io_label_png.npz  RGBA that plt.imsave(cmap=4 colours, vmin=0, vmax=4) writes for a label image
 
 Only data (inputs and the reference's outputs) is stored; no reference source text.
 """
@@ -492,8 +494,97 @@ def gen_metaseg_h5():
     print('metaseg_synth_b8.h5', os.path.getsize(path), 'bytes')
 
 
+def gen_io():
+    """I/O-layer fixtures written / decoded by the libraries the reference itself uses: TIFF files written by tifffile
+    (the decoder behind ``skimage.io.imread``, src/utils.py:110) in the variants microscopes and OpenCV produce, with the
+    pixels skimage.io.imread returns for them; and the RGBA pixels ``plt.imsave(..., cmap=ListedColormap(4 colours),
+    vmin=0, vmax=4)`` writes for a label image (src/metaseg.py:47-52), decoded back with matplotlib."""
+    import base64
+    import tempfile
+    import tifffile
+    from skimage.io import imread
+    import matplotlib
+    matplotlib.use('Agg')
+    import matplotlib.pyplot as plt
+    from matplotlib.colors import ListedColormap
+    rng = np.random.default_rng(11)
+    H, W = 37, 52
+    yy, xx = np.mgrid[:H, :W]
+    smooth = (yy * 5 + xx * 3) % 256
+    g8 = (smooth + rng.integers(0, 8, (H, W))).astype(np.uint8)
+    g16 = (smooth.astype(np.uint16) * 251 + rng.integers(0, 300, (H, W))).astype(np.uint16)
+    rgb8 = np.stack([g8, g8[::-1], rng.integers(0, 256, (H, W)).astype(np.uint8)], -1)
+    rgb16 = np.stack([g16, g16[:, ::-1], rng.integers(0, 65536, (H, W)).astype(np.uint16)], -1)
+    cases = [
+        ('gray8_raw', g8, dict()),
+        ('gray8_lzw_pred_strips5', g8, dict(compression='lzw', predictor=True, rowsperstrip=5)),      # OpenCV imwrite style
+        ('rgb8_lzw_pred_strips7', rgb8, dict(compression='lzw', predictor=True, rowsperstrip=7, photometric='rgb')),
+        ('rgb8_deflate', rgb8, dict(compression='zlib', photometric='rgb')),
+        ('gray16_lzw_pred', g16, dict(compression='lzw', predictor=True, rowsperstrip=8)),
+        ('rgb16_lzw_pred', rgb16, dict(compression='lzw', predictor=True, rowsperstrip=4, photometric='rgb')),
+        ('rgb16_deflate_pred', rgb16, dict(compression='zlib', predictor=True, photometric='rgb')),
+        ('gray16_bigendian', g16, dict(byteorder='>')),
+        ('rgb8_tiled16', rgb8, dict(tile=(16, 16), compression='zlib', photometric='rgb')),
+        ('gray16_tiled32_pred', g16, dict(tile=(32, 32), compression='zlib', predictor=True)),
+        ('gray8_packbits', g8, dict(compression='packbits')),
+        ('rgb8_bigtiff', rgb8, dict(bigtiff=True, photometric='rgb', compression='zlib', predictor=True)),
+        ('gray8_strips5_deflate_pred', g8, dict(compression='zlib', predictor=True, rowsperstrip=5)),
+    ]
+    files, pixels = {}, {}
+    tmp = tempfile.mkdtemp()
+    for name, arr, kw in cases:
+        path = os.path.join(tmp, name + '.tif')
+        try:
+            tifffile.imwrite(path, arr, **kw)
+        except Exception as e:                                  # codec missing in this tifffile / imagecodecs build
+            print('  skipped', name, e)
+            continue
+        dec = imread(path)                                       # what the reference's imread returns
+        assert dec.shape == arr.shape and dec.dtype == arr.dtype and np.array_equal(dec, arr), name
+        files[name] = base64.b64encode(open(path, 'rb').read()).decode()
+        pixels[name] = dec
+    # LZW (this imagecodecs build only decodes it): written by libtiff through PIL, decoded by tifffile like every other
+    # case; + the reference's own example file (OpenCV-written: LZW, predictor 2, 5 rows per strip)
+    from PIL import Image
+    lzw_cases = [('pil_gray8_lzw', g8, {}), ('pil_rgb8_lzw', rgb8, {}), ('pil_gray16_lzw', g16, {}),
+                 ('pil_gray8_lzw_pred2', g8, {'tiffinfo': {317: 2}}), ('pil_rgb8_lzw_pred2', rgb8, {'tiffinfo': {317: 2}})]
+    for name, arr, kw in lzw_cases:
+        path = os.path.join(tmp, name + '.tif')
+        try:
+            Image.fromarray(arr).save(path, compression='tiff_lzw', **kw)
+            dec = imread(path)
+        except Exception as e:
+            print('  skipped', name, e)
+            continue
+        assert dec.shape == arr.shape and dec.dtype == arr.dtype and np.array_equal(dec, arr), name
+        files[name] = base64.b64encode(open(path, 'rb').read()).decode()
+        pixels[name] = dec
+    ex = '/root/reference/example_ecSeg/dapi.jpeg'
+    crop = imread(ex)[400:440, 600:660]                          # a 40x60 window re-encoded the way OpenCV wrote the file
+    tf = tifffile.TiffFile(ex).pages[0]
+    print('  example_ecSeg/dapi.jpeg tags: compression', tf.compression, 'predictor', tf.predictor, 'rowsperstrip', tf.rowsperstrip)
+    json.dump({'note': 'TIFF files written by tifffile %s (imagecodecs) or libtiff via PIL (pil_*), base64; pixels in io_tiff_pixels.npz are what '
+                       'skimage.io.imread returned for each' % tifffile.__version__, 'files': files},
+              open(os.path.join(OUT, 'io_tiff_files.json'), 'w'))
+    np.savez_compressed(os.path.join(OUT, 'io_tiff_pixels.npz'), **pixels)
+    print('io: %d tifffile-written TIFF fixtures' % len(files))
+
+    # labels/<stem>.png exactly as src/metaseg.py:47-52 writes it
+    cmap = ListedColormap(["#386cb0", "#ffff99", "#7fc97f", '#f0027f'])
+    lab = rng.integers(0, 4, (23, 31)).astype(np.int64)
+    lab[0, :4] = [0, 1, 2, 3]
+    path = os.path.join(tmp, 'lab.png')
+    plt.imsave(path, lab.astype('uint8'), cmap=cmap, vmin=0, vmax=4)
+    rgba = (plt.imread(path) * 255.0 + 0.5).astype(np.uint8)
+    assert rgba.shape == (23, 31, 4)
+    np.savez_compressed(os.path.join(OUT, 'io_label_png.npz'), labels=lab.astype(np.uint8), rgba=rgba,
+                        class_rgba=rgba[0, :4])
+    print('io: label PNG colours', rgba[0, :4].tolist())
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['tiling', 'quant', 'meta', 'counting', 'overlay', 'h5', 'metaseg_h5']
+    which = sys.argv[1:] or ['tiling', 'quant', 'meta', 'counting', 'overlay', 'h5', 'metaseg_h5', 'io']
+    if 'io' in which: gen_io()
     if 'metaseg_h5' in which: gen_metaseg_h5()
     if 'tiling' in which: gen_tiling()
     if 'quant' in which: gen_quant()

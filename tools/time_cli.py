@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""User-visible rate of `make metaseg`: N generated 1040x1392 RGB LZW TIFF files in, labels/*.npy + *.png, dapi/*.tif and
+ec_quantification.csv out ("time `make metaseg` on 256 generated files").  Prints one JSON line.
+
+    python tools/time_cli.py [--n 256] [--base 64] [--batch 16] [--io-threads 32] [--keep DIR]
+"""
+import argparse
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--n', type=int, default=256)
+    ap.add_argument('--base', type=int, default=64)
+    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--io-threads', type=int, default=None)
+    ap.add_argument('--keep', default=None)
+    a = ap.parse_args()
+    from PIL import Image
+    import yaml
+    from ecseg_amd import metaseg, synth, utils
+    from ecseg_amd.model import MetasegModel
+    work = a.keep or tempfile.mkdtemp(prefix='ecseg_cli_')
+    inp = os.path.join(work, 'images')
+    os.makedirs(inp, exist_ok=True)
+    base = [synth.dapi_image(600 + i, rgb=True) for i in range(8)]
+    t0 = time.perf_counter()
+    for i in range(a.n):
+        img = np.roll(base[i % 8], (31 * (i // 8), 17 * (i // 8)), axis=(0, 1))
+        Image.fromarray(img).save(os.path.join(inp, 'img%04d.tif' % i), compression='tiff_lzw')
+    t_gen = time.perf_counter() - t0
+    in_bytes = sum(os.path.getsize(os.path.join(inp, f)) for f in os.listdir(inp))
+    cfg = synth.unet_config(base=a.base)
+    model = MetasegModel(cfg, synth.unet_weights(cfg, seed=0), device=0)
+    model.handle.set_images_per_group(16)
+    with open(os.path.join(work, 'config.yaml'), 'w') as f:
+        yaml.safe_dump({'metaseg': {'inpath': inp, 'batch_images': a.batch, **({'io_threads': a.io_threads} if a.io_threads else {})}}, f)
+    os.chdir(work)
+    real_load = metaseg.load_model
+    metaseg.load_model = lambda name, device=None: model           # random-weight canonical model instead of models/metaseg.h5
+    try:
+        warm = os.path.join(work, 'warm')
+        os.makedirs(warm, exist_ok=True)
+        shutil.copy(os.path.join(inp, 'img0000.tif'), warm)
+        stats = {}
+        metaseg.run(warm, model, utils.get_imgs(warm), batch_images=a.batch, log=lambda *x: None, stats=stats)   # first-use allocations
+        t0 = time.perf_counter()
+        rec = metaseg.run(inp, model, utils.get_imgs(inp), batch_images=a.batch, io_threads=a.io_threads, log=lambda *x: None, stats=stats)
+        dt = time.perf_counter() - t0
+    finally:
+        metaseg.load_model = real_load
+    out_bytes = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(inp) for f in fs) - in_bytes
+    print(json.dumps({'what': '`make metaseg` loop: %d RGB LZW TIFF files (1040x1392) -> dapi/*.tif, labels/*.png, labels/*.npy (int64), '
+                              'records' % a.n, 'images': a.n, 'unet_base': a.base, 'batch_images': a.batch,
+                      'io_threads': a.io_threads or 'default', 'cpu_count': os.cpu_count(),
+                      'seconds': round(dt, 3), 'images_per_s': round(a.n / dt, 2),
+                      'device_call_seconds': round(stats.get('gpu_seconds', 0.0), 3),
+                      'input_MB': round(in_bytes / 1e6, 1), 'output_MB': round(out_bytes / 1e6, 1),
+                      'ok_images': int((rec[:, 1] == 0).sum()), 'generate_seconds': round(t_gen, 1)}))
+    if not a.keep:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+if __name__ == '__main__':
+    main()

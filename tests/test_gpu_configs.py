@@ -24,9 +24,12 @@ from oracle import unet as oracle_unet
 
 pytestmark = pytest.mark.gpu
 H, W = 1040, 1392
-# Measured on MI355X (profiles/r02_label_mismatch.json): raw argmax labels of the device vs the CPU oracle differ in at
-# most a handful of pixels per full-size image, all of them ties of the uint8-quantised probabilities.
-MAX_RAW_MISMATCH_PX_PER_IMAGE = 12
+# Measured on MI355X over 32 full-size images per model and kernel (profiles/r02_label_mismatch.json, tools/label_mismatch.py):
+# random-weight bench model (speckled output, 16-17 k components per image): 2.4 - 5.3 raw-label pixels per image differ
+# from the CPU oracle (max 12 in one image), all of them ties of the uint8-quantised probabilities; a fitted,
+# smooth-output model: 1 pixel in 1 - 2 images of 32, ec_quantification.csv rows differing in 0 - 1 image of 32.
+MAX_RAW_MISMATCH_PX_PER_IMAGE = 24              # 2 x the worst image measured for the random-weight model
+MAX_RAW_MISMATCH_PX_PER_IMAGE_SMOOTH = 3
 
 
 @pytest.fixture(scope='module')
@@ -105,6 +108,35 @@ def test_bench_model_full_size_labels_vs_cpu_oracle(bench_model):
     assert nec == postproc.count_cc(want_post == 3)[0]
     if not diff.any():
         assert np.array_equal(post, o_post)
+
+
+def test_smooth_output_model_labels_vs_cpu_oracle():
+    """The label-mismatch bound on a realistic (smooth-output) model: a base-16 U-Net fitted for 120 steps on synthetic
+    scenes (tools/fit_smooth_model.py, torch CPU), two full-size images, all three 3x3 kernels.  At most a few raw pixels
+    per image may differ, only at quantised ties; the clean-up is an exact function of the device's raw labels."""
+    from ecseg_amd._lib import Handle
+    from tools import fit_smooth_model
+    cfg, weights = fit_smooth_model.fit(base=16, steps=120, threads=8)
+    imgs = np.stack([synth.dapi_image(950 + i) for i in range(2)])
+    refs = [oracle_pipeline.segment_gray(cfg, weights, im, return_intermediate=True) for im in imgs]
+    assert all(50 < int((r[1] == 3).sum()) for r in refs)          # the fitted model does find ecDNA-like blobs
+    hnd = Handle(0)
+    try:
+        hnd.load_plan(keras_plan.build_plan(cfg, weights))
+        for mode in (2, 1, 0):
+            hnd.set_option('winograd', mode)
+            raw, post, nec = hnd.segment_images(imgs, want_raw=True)
+            for i, (o_post, o_raw, o_probs, pos) in enumerate(refs):
+                diff = raw[i] != o_raw
+                assert int(diff.sum()) <= MAX_RAW_MISMATCH_PX_PER_IMAGE_SMOOTH, (mode, i, int(diff.sum()))
+                if diff.any():
+                    q = np.sort(quant.quantise_u8(tiling.stitch(o_probs, pos))[diff].astype(int), axis=-1)
+                    assert (q[:, -1] - q[:, -2] <= 1).all()
+                else:
+                    assert np.array_equal(post[i], o_post) and nec[i] == postproc.count_cc(o_post == 3)[0]
+                assert np.array_equal(post[i], postproc.meta_inference(raw[i]))
+    finally:
+        hnd.close()
 
 
 def test_config0_example_image_plumbing(tmp_path, golden_dir, monkeypatch):

@@ -33,6 +33,8 @@ def main():
     work = a.keep or tempfile.mkdtemp(prefix='ecseg_cli_')
     inp = os.path.join(work, 'images')
     os.makedirs(inp, exist_ok=True)
+    for sub in ('dapi', 'labels'):
+        os.makedirs(os.path.join(inp, sub), exist_ok=True)
     base = [synth.dapi_image(600 + i, rgb=True) for i in range(8)]
     t0 = time.perf_counter()
     for i in range(a.n):
@@ -50,7 +52,8 @@ def main():
     metaseg.load_model = lambda name, device=None: model           # random-weight canonical model instead of models/metaseg.h5
     try:
         warm = os.path.join(work, 'warm')
-        os.makedirs(warm, exist_ok=True)
+        for sub in ('', 'dapi', 'labels'):
+            os.makedirs(os.path.join(warm, sub), exist_ok=True)
         shutil.copy(os.path.join(inp, 'img0000.tif'), warm)
         stats = {}
         metaseg.run(warm, model, utils.get_imgs(warm), batch_images=a.batch, log=lambda *x: None, stats=stats)   # first-use allocations

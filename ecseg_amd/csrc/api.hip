@@ -199,7 +199,9 @@ std::vector<float> winograd_filter(const float* w, int cin, int cout) {
 std::vector<float> winograd4_filter(const float* w, int cin, int cout) {
     static const double G[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                                    {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
-    const int nblk = cout / 64, nstages = cin / 4;
+    // zero padded to whole 64-channel output blocks and whole 8-channel input groups (Cout % 64 == 32: the second
+    // channel-half waves of the last block multiply zeros; Cin % 8 == 4: the second half of the last group is zero)
+    const int nblk = (cout + 63) / 64, nstages = 2 * ((cin + 7) / 8);
     std::vector<float> o((size_t)nblk * nstages * 12 * 768, 0.f);
     for (int ci = 0; ci < cin; ++ci) {
         const int grp = ci / 8, r8 = ci % 8;
@@ -802,12 +804,14 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
                     o.cin_chunks = (cin + 7) / 8;
                     if ((rc = upload(h, relayout_conv(kw, d.kh, d.kw, cin, cout, o.cin_chunks, o.coutp), &o.wt))) return rc;
                     h->mfma_flops_per_patch += o.flops;
-                    if (d.kh == 3 && d.pad_top == 1 && d.pad_left == 1 && to.h == ti.h && to.w == ti.w && cout >= 32 && cout % 4 == 0 && out_al) {
+                    if (d.kh == 3 && d.pad_top == 1 && d.pad_left == 1 && to.h == ti.h && to.w == ti.w && cout >= 16 && cout % 4 == 0 && out_al) {
                         const int bnw = conv_wino_ntile(cout);
                         o.coutp_wino = (cout + bnw - 1) / bnw * bnw;
                         const std::vector<float> u = winograd_filter(kw, cin, cout);
                         if ((rc = upload(h, relayout_conv(u.data(), 4, 4, cin, cout, o.cin_chunks, o.coutp_wino), &o.wt_wino))) return rc;
-                        if (cin % 8 == 0 && cout % 64 == 0 && to.h % 16 == 0 && to.w % 16 == 0)
+                        // F(4x4): a lone 32-channel block wastes its second channel-half waves on zeros; measured on
+                        // MI355X (profiles/r02_kernel_map.json) that still beats F(2x2) once the K loop is long enough
+                        if (cin % 4 == 0 && cin >= 8 && cout % 32 == 0 && (cout != 32 || cin >= 64) && to.h % 16 == 0 && to.w % 16 == 0)
                             if ((rc = upload(h, winograd4_filter(kw, cin, cout), &o.wt_wino4))) return rc;
                     }
                 } else {

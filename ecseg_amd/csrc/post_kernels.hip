@@ -389,6 +389,45 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8
     else if (tid == 8) { if (red[8]) atomicMax(G + G_LAST_ROOT, red[8]); }
 }
 
+// count_cc needs no flatten: after ccl_local + ccl_border a component's root is the one pixel that still points at itself,
+// so components and pixels per key are counted straight from (image, parents).
+__global__ __launch_bounds__(256) void count_roots_kernel(CclGeom g, const uint8_t* __restrict__ img_all, uint32_t lut,
+                                                          const int32_t* __restrict__ L_all, int32_t* __restrict__ G_all) {
+    __shared__ int red[8];
+    int img, y0, cx;
+    if (!decode_block(g, img, y0, cx)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < 8) red[tid] = 0;
+    __syncthreads();
+    const size_t base = (size_t)img * g.H * g.W;
+    const int x = cx * 64 + lane;
+    int nc[4] = {0, 0, 0, 0}, np[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < CCL_ROWS; ++r) {
+        const int y = y0 + r;
+        int key = 0;
+        bool root = false;
+        if (y < g.H && x < g.W) {
+            const int p = y * g.W + x;
+            key = key_of(img_all[base + p], lut);
+            root = key != 0 && L_all[base + p] == p;
+        }
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            np[k] += __popcll(__ballot(key == k));
+            nc[k] += __popcll(__ballot(root && key == k));
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 1; k < 4; ++k) { if (nc[k]) atomicAdd(&red[k - 1], nc[k]); if (np[k]) atomicAdd(&red[3 + k - 1], np[k]); }
+    }
+    __syncthreads();
+    int32_t* G = G_all + (size_t)img * G_IMG + (size_t)((blockIdx.x >> 3) % G_SHARDS) * G_STRIDE;
+    if (tid < 3) { if (red[tid]) atomicAdd(G + G_NCOMP + 1 + tid, red[tid]); }
+    else if (tid < 6) { if (red[tid]) atomicAdd(G + G_NPX + 1 + (tid - 3), red[tid]); }
+}
+
 // fold the G_SHARDS replicas of every image's counter block into replica 0
 __global__ void reduce_g_kernel(int32_t* __restrict__ G_all, int n_img) {
     const int im = blockIdx.x, t = threadIdx.x;          // blockDim = G_STRIDE
@@ -415,6 +454,7 @@ struct CclPass {
     int aux_mode, aux_c;
     const uint8_t* aux_img;
     int need;      // NEED_* counters this pass has to produce
+    bool count_only = false;   // only NEED_NCOMP | NEED_NPX are wanted: count roots instead of flattening
 };
 
 static hipError_t run_ccl_pass(PostWorkspace& ws, const CclGeom& g, const CclPass& c, hipStream_t s) {
@@ -429,6 +469,11 @@ static hipError_t run_ccl_pass(PostWorkspace& ws, const CclGeom& g, const CclPas
         hipLaunchKernelGGL(ccl_local_kernel<4>, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy,
                            ws.sumx, ws.flag, c.stat);
         hipLaunchKernelGGL(ccl_border_kernel<4>, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L);
+    }
+    if (c.count_only) {        // counts per key only: no per-pixel roots, no statistics
+        hipLaunchKernelGGL(count_roots_kernel, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L, ws.g);
+        hipLaunchKernelGGL(reduce_g_kernel, dim3(g.n_img), dim3(G_STRIDE), 0, s, ws.g, g.n_img);
+        return hipGetLastError();
     }
     const size_t dyn = (c.stat & STAT_SUMS) ? (size_t)CCL_BLOCK_ROWS * 64 * 16 : 0;
     hipLaunchKernelGGL(ccl_flatten_kernel, dim3(grid), dim3(256), dyn, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy,
@@ -471,13 +516,14 @@ __global__ __launch_bounds__(256) void apply_size_thresh_kernel(uint8_t* __restr
         if (r < 0) continue;
         const size_t im = t / px;
         const int32_t* G = G_all + im * G_IMG;
-        const double avg_chrom = G[G_NCOMP + 2] ? (double)G[G_NPX + 2] / (double)G[G_NCOMP + 2] : __longlong_as_double(0x7ff8000000000000LL);
-        const double avg_ec = G[G_NCOMP + 3] ? (double)G[G_NPX + 3] / (double)G[G_NCOMP + 3] : __longlong_as_double(0x7ff8000000000000LL);
-        const double a = (double)area[im * px + r];
+        // area < mean(areas) = S / n, evaluated exactly in integers: area * n < S.  (The reference compares in float64;
+        // S / n is either an integer or at least 1 / n away from one, far more than a rounding error, so both orders
+        // agree.  n == 0: the reference's mean is NaN and every comparison false; here S == 0 gives the same.)
+        const long long a = (long long)area[im * px + r];
         const uint8_t v = img[t];
-        if (v == 1) { if (a < avg_chrom) img[t] = 0; }
-        else if (v == 2) { if (a < avg_ec) img[t] = 3; }
-        else if (v == 3) { if (a < (double)ec_thresh) img[t] = 0; }
+        if (v == 1) { if (a * (long long)G[G_NCOMP + 2] < (long long)G[G_NPX + 2]) img[t] = 0; }
+        else if (v == 2) { if (a * (long long)G[G_NCOMP + 3] < (long long)G[G_NPX + 3]) img[t] = 3; }
+        else if (v == 3) { if (a < (long long)ec_thresh) img[t] = 0; }
     }
 }
 
@@ -515,7 +561,63 @@ __global__ __launch_bounds__(256) void ec_dilate_kernel(const uint8_t* __restric
     }
 }
 
-// Roots of class-1 and class-2 components -> compact per-image lists (nucleus root indices; chromosome centroids).
+// The four 3x3-cross stencils above, four pixels per thread (W % 4 == 0: one aligned 32-bit load per row instead of four
+// byte loads; the scalar kernels remain for other widths).  OP: 0 band removal, 1 ecDNA dilation, 2 grey erosion,
+// 3 opening + combine (A = eroded image; B = label image, updated in place; C = merge_comp's working image).
+template <int OP>
+__global__ __launch_bounds__(256) void stencil4_kernel(const uint8_t* __restrict__ A, const uint8_t* B,
+                                                       const uint8_t* __restrict__ C, uint8_t* out, size_t total4,
+                                                       int H, int W, int c, int m) {
+    const int W4 = W >> 2;
+    const size_t px4 = (size_t)H * W4;
+    PX_LOOP(total4) {
+        const size_t q = t % px4;
+        const int y = (int)(q / W4), x4 = (int)(q % W4);
+        const size_t p = t * 4;
+        const uint32_t cw = *reinterpret_cast<const uint32_t*>(A + p);
+        const bool hn = y > 0, hs = y < H - 1, hw = x4 > 0, he = x4 < W4 - 1;
+        const uint32_t nw = hn ? *reinterpret_cast<const uint32_t*>(A + p - W) : 0u;
+        const uint32_t sw = hs ? *reinterpret_cast<const uint32_t*>(A + p + W) : 0u;
+        const uint32_t wb = hw ? A[p - 1] : 0u, eb = he ? A[p + 4] : 0u;
+        uint32_t bw = 0, tw = 0;
+        if (OP == 3) { bw = *reinterpret_cast<const uint32_t*>(B + p); tw = *reinterpret_cast<const uint32_t*>(C + p); }
+        uint32_t res = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t v = (cw >> (8 * k)) & 0xffu;
+            const uint32_t n = (nw >> (8 * k)) & 0xffu, sv = (sw >> (8 * k)) & 0xffu;
+            const uint32_t wv = k ? (cw >> (8 * (k - 1))) & 0xffu : wb, ev = k < 3 ? (cw >> (8 * (k + 1))) & 0xffu : eb;
+            const bool bwst = k ? true : hw, best = k < 3 ? true : he;     // west / east neighbour exists
+            uint32_t o;
+            if (OP == 0) {
+                const bool cc = v == 3, nn = hn && n == 3, ss = hs && sv == 3, ww = bwst && wv == 3, ee = best && ev == 3;
+                const bool dil = cc | nn | ss | ww | ee;
+                const bool ero = cc & (hn ? nn : true) & (hs ? ss : true) & (bwst ? ww : true) & (best ? ee : true);
+                o = (dil != ero) ? 0u : v;
+            } else if (OP == 1) {
+                const bool d = v == 3 || (hn && n == 3) || (hs && sv == 3) || (bwst && wv == 3) || (best && ev == 3);
+                o = d ? 3u : v;
+            } else if (OP == 2) {
+                o = v;
+                if (hn) o = min(o, n);
+                if (hs) o = min(o, sv);
+                if (bwst) o = min(o, wv);
+                if (best) o = min(o, ev);
+            } else {
+                uint32_t mx = v;
+                if (hn) mx = max(mx, n);
+                if (hs) mx = max(mx, sv);
+                if (bwst) mx = max(mx, wv);
+                if (best) mx = max(mx, ev);
+                const uint32_t orig = (bw >> (8 * k)) & 0xffu;
+                o = (orig == (uint32_t)m) ? (uint32_t)m : (mx == (uint32_t)c ? (uint32_t)c : (tw >> (8 * k)) & 0xffu);
+            }
+            res |= o << (8 * k);
+        }
+        *reinterpret_cast<uint32_t*>(out + p) = res;
+    }
+}
+
 // Roots of class-1 and class-2 components -> compact per-image lists (nucleus root indices; chromosome centroids).
 __global__ __launch_bounds__(256) void compact_roots_kernel(const uint8_t* __restrict__ img, const int32_t* __restrict__ L,
                                                             const uint32_t* __restrict__ area, const u64* __restrict__ sumy,
@@ -692,38 +794,52 @@ hipError_t run_meta_inference(PostWorkspace& ws, uint8_t* img, int n_img, int H,
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
         hipLaunchKernelGGL(apply_size_thresh_kernel, dim3(pg), dim3(256), 0, s, img, ws.L, ws.area, ws.g, total, px, 15);
     }
-    // 5. ecDNA band removal (img -> tmpA -> img)
-    hipLaunchKernelGGL(band_removal_kernel, dim3(pg), dim3(256), 0, s, img, ws.tmpA, total, H, W);
-    if ((e = hipMemcpyAsync(img, ws.tmpA, total, hipMemcpyDeviceToDevice, s)) != hipSuccess) return e;
+    // From here on the working image is ws.tmpA and the caller's buffer is a scratch image (no copies back and forth);
+    // the last stencil writes the result into the caller's buffer.  W % 4 == 0: four pixels per thread.
+    const bool v4 = (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(img) | reinterpret_cast<uintptr_t>(ws.tmpA) |
+                                      reinterpret_cast<uintptr_t>(ws.tmpB)) & 3) == 0;
+    const size_t total4 = total / 4;
+    const unsigned pg4 = px_grid(total4);
+    uint8_t* cur = ws.tmpA;
+    uint8_t* t1 = img;
+    uint8_t* t2 = ws.tmpB;
+    // 5. ecDNA band removal
+    if (v4) hipLaunchKernelGGL(stencil4_kernel<0>, dim3(pg4), dim3(256), 0, s, img, nullptr, nullptr, cur, total4, H, W, 0, 0);
+    else hipLaunchKernelGGL(band_removal_kernel, dim3(pg), dim3(256), 0, s, img, cur, total, H, W);
     // 6. nucleus-in-metaphase test
     {
-        CclPass p{img, LUT_MULTI, 8, STAT_AREA | STAT_SUMS, AUX_NONE, 0, nullptr, 0};
+        CclPass p{cur, LUT_MULTI, 8, STAT_AREA | STAT_SUMS, AUX_NONE, 0, nullptr, 0};
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
         const size_t cap = px / 4 + (size_t)(H + W) / 2 + 4;
         int32_t* list1 = ws.list;
         double2* list2 = reinterpret_cast<double2*>(ws.list + (((size_t)n_img * cap + 3) & ~(size_t)3));
-        hipLaunchKernelGGL(compact_roots_kernel, dim3(pg), dim3(256), 0, s, img, ws.L, ws.area, ws.sumy, ws.sumx, ws.g,
+        hipLaunchKernelGGL(compact_roots_kernel, dim3(pg), dim3(256), 0, s, cur, ws.L, ws.area, ws.sumy, ws.sumx, ws.g,
                            list1, list2, total, px, cap);
         const int bpi = 32;
         hipLaunchKernelGGL(nucleus_test_kernel, dim3(n_img * bpi), dim3(256), 0, s, ws.area, ws.sumy, ws.sumx, ws.g, list1,
                            list2, ws.flag, px, cap, bpi, 70.0, 5);
-        hipLaunchKernelGGL(apply_nucleus_kill_kernel, dim3(pg), dim3(256), 0, s, img, ws.L, ws.flag, total, px);
+        hipLaunchKernelGGL(apply_nucleus_kill_kernel, dim3(pg), dim3(256), 0, s, cur, ws.L, ws.flag, total, px);
     }
     // 7-8. merge_comp(1), merge_comp(2)
     for (int c = 1; c <= 2; ++c) {
         const int m = (c == 1) ? 2 : 1;
-        CclPass p{img, lut_nonzero_except(m), 8, 0, AUX_VALUE_EQ, c, nullptr, NEED_LAST};
+        CclPass p{cur, lut_nonzero_except(m), 8, 0, AUX_VALUE_EQ, c, nullptr, NEED_LAST};
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
-        hipLaunchKernelGGL(apply_merge_kernel, dim3(pg), dim3(256), 0, s, img, ws.tmpA, ws.L, ws.flag, ws.g, total, px, c, m);
-        hipLaunchKernelGGL(grey_erode_kernel, dim3(pg), dim3(256), 0, s, ws.tmpA, ws.tmpB, total, H, W);
-        hipLaunchKernelGGL(open_combine_kernel, dim3(pg), dim3(256), 0, s, img, ws.tmpA, ws.tmpB, total, H, W, c, m);
+        hipLaunchKernelGGL(apply_merge_kernel, dim3(pg), dim3(256), 0, s, cur, t1, ws.L, ws.flag, ws.g, total, px, c, m);
+        if (v4) {
+            hipLaunchKernelGGL(stencil4_kernel<2>, dim3(pg4), dim3(256), 0, s, t1, nullptr, nullptr, t2, total4, H, W, 0, 0);
+            hipLaunchKernelGGL(stencil4_kernel<3>, dim3(pg4), dim3(256), 0, s, t2, cur, t1, cur, total4, H, W, c, m);
+        } else {
+            hipLaunchKernelGGL(grey_erode_kernel, dim3(pg), dim3(256), 0, s, t1, t2, total, H, W);
+            hipLaunchKernelGGL(open_combine_kernel, dim3(pg), dim3(256), 0, s, cur, t1, t2, total, H, W, c, m);
+        }
     }
-    // 9. final ecDNA dilation
-    hipLaunchKernelGGL(ec_dilate_kernel, dim3(pg), dim3(256), 0, s, img, ws.tmpA, total, H, W);
-    if ((e = hipMemcpyAsync(img, ws.tmpA, total, hipMemcpyDeviceToDevice, s)) != hipSuccess) return e;
+    // 9. final ecDNA dilation, back into the caller's buffer
+    if (v4) hipLaunchKernelGGL(stencil4_kernel<1>, dim3(pg4), dim3(256), 0, s, cur, nullptr, nullptr, img, total4, H, W, 0, 0);
+    else hipLaunchKernelGGL(ec_dilate_kernel, dim3(pg), dim3(256), 0, s, cur, img, total, H, W);
     // 10. count_cc(img == 3)[0]
     if (n_ec_dev) {
-        CclPass p{img, lut_eq(3), 8, 0, AUX_NONE, 0, nullptr, NEED_NCOMP | NEED_NPX};
+        CclPass p{img, lut_eq(3), 8, 0, AUX_NONE, 0, nullptr, NEED_NCOMP | NEED_NPX, true};
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
         hipLaunchKernelGGL(gather_counts_kernel, dim3((n_img + 63) / 64), dim3(64), 0, s, ws.g, n_img, 1, n_ec_dev,
                            (long long*)nullptr, (long long)px);
@@ -738,7 +854,7 @@ hipError_t run_count_cc(PostWorkspace& ws, const uint8_t* mask, int n_img, int H
                         hipStream_t s) {
     if (n_img <= 0) return hipSuccess;
     const CclGeom g = make_geom(n_img, H, W);
-    CclPass p{mask, LUT_NONZERO, 8, 0, AUX_NONE, 0, nullptr, NEED_NCOMP | NEED_NPX};
+    CclPass p{mask, LUT_NONZERO, 8, 0, AUX_NONE, 0, nullptr, NEED_NCOMP | NEED_NPX, true};
     hipError_t e = run_ccl_pass(ws, g, p, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(gather_counts_kernel, dim3((n_img + 63) / 64), dim3(64), 0, s, ws.g, n_img, 1, n_dev, px_dev,

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
     const int H = p.in.h, W = p.in.w;                        // output extent == input extent
     const int ngroups = p.cin_chunks;                        // 8 input channels each
     const int nstages = 2 * ngroups;
+    const bool tail4 = (p.in.c & 7) != 0;                    // (pointers are 16-byte aligned: bits 0 / 1 carry lane flags)
 
     // the two 16 x 16 regions of this workgroup: consecutive in (patch, region row, region column) order
     int r_img[2], r_y0[2], r_x0[2];
@@ -131,15 +132,17 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             const int img = g ? r_img[1] : r_img[0];
             const int iy = (g ? r_y0[1] : r_y0[0]) - 1 + w4_inv(r), ix = (g ? r_x0[1] : r_x0[0]) - 1 + w4_inv(c);
             if (img >= 0 && iy >= 0 && iy < H && ix >= 0 && ix < W)
-                d = (unsigned long long)(size_t)(p.in.p + (((size_t)img * H + iy) * W + ix) * p.in.cs + 4 * h) | 1ull;
+                d = (unsigned long long)(size_t)(p.in.p + (((size_t)img * H + iy) * W + ix) * p.in.cs + 4 * h) | 1ull | (h ? 2ull : 0ull);
         }
         Hd[i * 768] = d;
     }
     auto dma_halo_piece = [&](int grp, auto ii) {            // piece ii (0 | 1) of halo group grp (< ngroups)
         if (ABL & 4) return;
         constexpr int i = decltype(ii)::value;
-        const unsigned long long d = Hd[i * 768];
-        const float* src = reinterpret_cast<const float*>((size_t)(d & ~1ull)) + (d & 1ull ? grp * 8 : 0);
+        unsigned long long d = Hd[i * 768];
+        // Cin % 8 == 4: the upper channel half of the last group does not exist - its lanes (bit 1) read the zero page
+        if (tail4 && grp == ngroups - 1 && (d & 2ull)) d = (unsigned long long)(size_t)p.zero;
+        const float* src = reinterpret_cast<const float*>((size_t)(d & ~3ull)) + (d & 1ull ? grp * 8 : 0);
         glds16<0>(src, lds_base + (unsigned)((grp % 3) * W4_HS + 64 * (wave + 12 * i)) * 16u);
     };
     // ---- filter DMA: wt4[nb][stage][wave][point nu][h][cout 32][k 2], 768 floats per wave and stage ----
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
     f32x4 bvp[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     if (p.bias != nullptr) {
         bvp[0] = *reinterpret_cast<const f32x4*>(p.bias + nb * 64 + 4 * (tid & 7));
-        bvp[1] = *reinterpret_cast<const f32x4*>(p.bias + nb * 64 + 32 + 4 * (tid & 7));
+        if (nb * 64 + 32 < Cout) bvp[1] = *reinterpret_cast<const f32x4*>(p.bias + nb * 64 + 32 + 4 * (tid & 7));
     }
     for (int pass = 0; pass < 2; ++pass) {
         __syncthreads();                                     // main-loop LDS reads / previous pass's combine are done
@@ -548,18 +551,18 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
 #undef ESTAMP
 }
 
-// Eligibility beyond "3x3, stride 1, pad 1, same size" (checked by the caller): extents multiples of 16, channels
-// multiples of 8 / 64, 16-byte aligned views.
+// Eligibility beyond "3x3, stride 1, pad 1, same size" (checked by the caller): extents multiples of 16, input channels
+// a multiple of 4 (>= 8), output channels a multiple of 32 (the filter image is zero padded to 8 / 64), 16-byte aligned views.
 bool conv_wino4_supported(const ConvParams& p) {
-    return p.in.h == p.out.h && p.in.w == p.out.w && p.out.h % 16 == 0 && p.out.w % 16 == 0 && p.in.c % 8 == 0 &&
-           p.in.c >= 8 && p.out.c % 64 == 0 && p.in.cs % 4 == 0 && p.out.cs % 4 == 0 && p.zero != nullptr;
+    return p.in.h == p.out.h && p.in.w == p.out.w && p.out.h % 16 == 0 && p.out.w % 16 == 0 && p.in.c % 4 == 0 &&
+           p.in.c >= 8 && p.out.c % 32 == 0 && p.in.cs % 4 == 0 && p.out.cs % 4 == 0 && p.zero != nullptr;
 }
 
 hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s) {
     const int regs_x = p.out.w / 16, regs_y = p.out.h / 16;
     const size_t nreg = p.lut != nullptr ? (size_t)(p.n / p.per_image) * p.lut_len : (size_t)p.n * regs_x * regs_y;
     const size_t npairs = (nreg + 1) / 2;
-    const size_t grid = npairs * (size_t)(p.out.c / 64);
+    const size_t grid = npairs * (size_t)((p.out.c + 63) / 64);
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     size_t lds = (size_t)(3 * W4_HS + 12 * 2 * W4_BWS) * 16 + 2 * 768 * 8;

@@ -13,6 +13,7 @@ Optional config keys (defaults keep the reference's behaviour): ``batch_images``
 """
 import concurrent.futures as cf
 import os
+import queue
 import socket
 import subprocess
 import sys
@@ -108,22 +109,40 @@ def run(inpath, model, image_paths, rank=0, world=1, batch_images=8, io_threads=
                 f.add_done_callback(lambda _f: pending_writes.release())
                 write_futs.append((k, f))
 
-        group, key = [], None
-        for k in range(len(mine)):
-            top_up(k + window)
-            try:
-                img = reads.pop(k).result()
-            except Exception as e:                         # a corrupt image must not take the shard down
-                log("Skipping %s: %s" % (mine[k], e))
-                status[k] = 1
-                continue
-            kk = (img.shape, img.dtype.str)
-            if group and (kk != key or len(group) >= batch_images):
-                flush(group)
-                group = []
-            group.append((k, img))
-            key = kk
-        flush(group)
+        # the device calls run on their own thread (one batch in the queue, one on the GPU) so that collecting decoded
+        # images and handing results to the writers overlaps the U-Net
+        batches = queue.Queue(maxsize=2)
+
+        def gpu_loop():
+            while True:
+                g = batches.get()
+                if g is None:
+                    return
+                flush(g)
+
+        gpu_thread = threading.Thread(target=gpu_loop, name='ecseg-gpu')
+        gpu_thread.start()
+        try:
+            group, key = [], None
+            for k in range(len(mine)):
+                top_up(k + window)
+                try:
+                    img = reads.pop(k).result()
+                except Exception as e:                     # a corrupt image must not take the shard down
+                    log("Skipping %s: %s" % (mine[k], e))
+                    status[k] = 1
+                    continue
+                kk = (img.shape, img.dtype.str)
+                if group and (kk != key or len(group) >= batch_images):
+                    batches.put(group)
+                    group = []
+                group.append((k, img))
+                key = kk
+            if group:
+                batches.put(group)
+        finally:
+            batches.put(None)
+            gpu_thread.join()
         for k, f in write_futs:
             try:
                 f.result()

@@ -109,7 +109,8 @@ def test_conv_numpy_crosscheck_of_oracle():
     assert np.abs(got - want).max() < 1e-4
 
 
-@pytest.mark.parametrize('cin,cout,hw', [(64, 64, (64, 96)), (16, 32, (20, 40)), (128, 192, (16, 16)), (40, 72, (37, 53))])
+@pytest.mark.parametrize('cin,cout,hw', [(64, 64, (64, 96)), (16, 32, (20, 40)), (128, 192, (16, 16)), (40, 72, (37, 53)),
+                                         (32, 16, (32, 48)), (16, 16, (24, 24)), (24, 20, (16, 40))])
 def test_winograd_matches_direct_and_oracle(gpu, cin, cout, hw):
     """The Winograd F(2x2,3x3) kernel and the direct implicit-GEMM kernel are both fp32; they must agree with each other
     and with the oracle well inside the 1e-3 tolerance (incl. image sizes that are not multiples of the 8x16 tile)."""
@@ -139,7 +140,10 @@ def test_winograd_matches_direct_and_oracle(gpu, cin, cout, hw):
 
 
 @pytest.mark.parametrize('cin,cout,hw,n', [(64, 64, (64, 96), 3), (8, 64, (16, 16), 3), (128, 192, (16, 16), 4),
-                                           (72, 128, (32, 48), 2), (24, 64, (48, 16), 1)])
+                                           (72, 128, (32, 48), 2), (24, 64, (48, 16), 1),
+                                           # relaxed eligibility (r02): Cout % 64 == 32 (zero-padded channel half), Cin % 8 == 4
+                                           (64, 32, (32, 32), 3), (16, 96, (16, 48), 2), (12, 64, (32, 16), 2),
+                                           (68, 32, (16, 16), 5), (36, 160, (16, 32), 1)])
 def test_winograd_f4x4_matches_direct_and_oracle(gpu, cin, cout, hw, n):
     """Winograd F(4x4,3x3) (option winograd=2; extents multiples of 16, Cin % 8 == 0, Cout % 64 == 0) is still an fp32
     kernel: it must agree with the direct kernel and the oracle well inside the 1e-3 tolerance.  Covers an odd number of

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get('ECSEG_HIP_LIB') or os.path.join(HERE, 'libecseg_hip.s
 
 EXPORTS = [
     'ecseg_abi_version', 'ecseg_create', 'ecseg_destroy', 'ecseg_last_error', 'ecseg_device_name', 'ecseg_stream',
-    'ecseg_model_load', 'ecseg_model_flops_per_patch', 'ecseg_forward_patches', 'ecseg_read_tensor',
+    'ecseg_model_load', 'ecseg_model_flops_per_patch', 'ecseg_forward_patches', 'ecseg_forward_patches_f32', 'ecseg_read_tensor',
     'ecseg_segment_images', 'ecseg_segment_images_dev', 'ecseg_set_images_per_group', 'ecseg_set_option', 'ecseg_preprocess', 'ecseg_u16_to_u8',
     'ecseg_stitch_argmax', 'ecseg_meta_inference', 'ecseg_meta_inference_dev', 'ecseg_count_cc', 'ecseg_ccl_labels',
     'ecseg_count_colocalization', 'ecseg_count_hsr', 'ecseg_overlay', 'ecseg_get_timings',
@@ -64,6 +64,7 @@ def load_library():
                                      C.POINTER(C.c_void_p), C.POINTER(C.c_int64), i32, i32, i32]
     lib.ecseg_model_flops_per_patch.argtypes = [vp, C.POINTER(C.c_double)]
     lib.ecseg_forward_patches.argtypes = [vp, u8p, i32, vp]
+    lib.ecseg_forward_patches_f32.argtypes = [vp, vp, i32, vp]
     lib.ecseg_read_tensor.argtypes = [vp, i32, i32, vp]
     lib.ecseg_segment_images.argtypes = [vp, u8p, i32, i32, i32, vp, vp, vp]
     lib.ecseg_segment_images_dev.argtypes = [vp, u8p, i32, i32, i32, vp, vp, vp]
@@ -179,17 +180,23 @@ class Handle:
         self._check(self.lib.ecseg_set_option(self.h, key.encode(), int(value)), 'ecseg_set_option(%s)' % key)
 
     def forward_patches(self, patches):
-        """uint8 (N, H, W, C) -> float32 (N, H, W, K): ``model.predict_on_batch`` (reference src/utils.py:115)."""
+        """uint8 (or float32) (N, H, W, C) -> float32 (N, H', W', K): ``model.predict_on_batch`` (reference
+        src/utils.py:115; the interSeg classifiers of src/interseg.py:155,168 return (N, K))."""
         if self.plan is None:
             raise EcsegError('no model loaded')
-        p = _u8(patches)
+        p = np.ascontiguousarray(patches)
+        is_f32 = p.dtype.kind == 'f'
+        p = np.ascontiguousarray(p, np.float32) if is_f32 else _u8(p)
         ti, to = self.plan.tensors[self.plan.input_tensor], self.plan.tensors[self.plan.output_tensor]
         if p.ndim == 3:
             p = p[..., None]
         if p.shape[1:] != (ti['h'], ti['w'], ti['c']):
             raise ValueError('expected patches of shape (N, %d, %d, %d), got %s' % (ti['h'], ti['w'], ti['c'], p.shape))
         out = np.empty((p.shape[0], to['h'], to['w'], to['c']), np.float32)
-        self._check(self.lib.ecseg_forward_patches(self.h, _ptr(p), p.shape[0], _ptr(out)), 'ecseg_forward_patches')
+        fn = self.lib.ecseg_forward_patches_f32 if is_f32 else self.lib.ecseg_forward_patches
+        self._check(fn(self.h, _ptr(p), p.shape[0], _ptr(out)), 'ecseg_forward_patches')
+        if getattr(self.plan, 'output_rank', 4) == 2:
+            out = out.reshape(p.shape[0], to['c'])
         return out
 
     def read_tensor(self, tensor, n):

@@ -330,6 +330,10 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                     const size_t oi_first = oi;                 // (fusions below advance oi)
                     ConvParams p{};
                     p.in = in; p.out = out; p.wt = o.wt; p.bias = o.bias; p.n = n;
+                    if (d.op == ECSEG_OP_CONV && d.kh == 1 && d.kw == 1 && in.h == 1 && in.w == 1 && out.h == 1 && out.w == 1) {
+                        // Dense layer: the batch is the GEMM's M dimension - one "patch" whose pixels are the samples
+                        p.in.w = n; p.out.w = n; p.n = 1;
+                    }
                     p.act = act; p.alpha = d.alpha; p.cin_chunks = o.cin_chunks; p.coutp = o.coutp; p.zero = h->zero_page;
                     if (d.op == ECSEG_OP_CONV) {
                         p.R = d.kh; p.S = d.kw; p.pad_top = d.pad_top; p.pad_left = d.pad_left; p.convt = 0;
@@ -416,14 +420,15 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                 } else if (o.path == PATH_HEAD) {
                     e = launch_conv_head(in, out, o.wt, o.bias, n, d.act, d.alpha, s);
                 } else if (d.op == ECSEG_OP_CONV) {
-                    e = launch_conv_generic(in, out, o.wt, o.bias, n, d.kh, d.kw, d.pad_top, d.pad_left, act, d.alpha, s);
+                    e = launch_conv_generic(in, out, o.wt, o.bias, n, d.kh, d.kw, d.stride, d.pad_top, d.pad_left, act, d.alpha, s);
                 } else {
                     e = launch_convt_generic(in, out, o.wt, o.bias, n, d.kh, d.kw, d.stride, d.pad_top, d.pad_left, act, d.alpha, s);
                 }
                 if (e == hipSuccess && softmax && o.path != PATH_HEAD) e = launch_softmax(out, out, n, s);
                 break;
             }
-            case ECSEG_OP_MAXPOOL: e = launch_maxpool(in, out, n, d.kh, d.kw, d.stride, s); break;
+            case ECSEG_OP_MAXPOOL: e = launch_maxpool(in, out, n, d.kh, d.kw, d.stride, d.mode, s); break;
+            case ECSEG_OP_GLOBALPOOL: e = launch_global_pool(in, out, n, d.mode, s); break;
             case ECSEG_OP_UPSAMPLE: e = launch_upsample(in, out, n, d.stride, d.mode, s); break;
             case ECSEG_OP_AFFINE:
                 if (d.act == ECSEG_ACT_SOFTMAX) {
@@ -778,12 +783,15 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
             const bool in_al = (ti.c_stride % 4 == 0) && (ti.c_offset % 4 == 0) && (cin % 4 == 0);
             const bool out_al = (to.c_stride % 4 == 0) && (to.c_offset % 4 == 0);
             if (d.op == ECSEG_OP_CONV) {
-                if (d.stride != 1) return fail(h, ECSEG_E_UNSUPPORTED, "strided Conv2D is not supported");
-                if (to.h + d.kh - 1 > ti.h + d.kh - 1 || to.w + d.kw - 1 > ti.w + d.kw - 1)
+                if ((to.h - 1) * d.stride + 1 > ti.h + d.kh - 1 || (to.w - 1) * d.stride + 1 > ti.w + d.kw - 1)
                     return fail(h, ECSEG_E_INVALID, "conv output larger than its input in op " + std::to_string(k));
                 o.flops = 2.0 * d.kh * d.kw * cin * cout * (double)to.h * to.w;
                 const bool taps_ok = d.kh == d.kw && (d.kh == 1 || d.kh == 2 || d.kh == 3);
-                if (cin <= 4 && cout % 4 == 0 && out_al) {
+                if (d.stride != 1) {
+                    // strided convolutions (classifier stems) take the generic kernel; the MFMA kernels are stride 1
+                    o.path = PATH_GENERIC;
+                    if ((rc = upload(h, std::vector<float>(kw, kw + (size_t)d.kh * d.kw * cin * cout), &o.wt))) return rc;
+                } else if (cin <= 4 && cout % 4 == 0 && out_al) {
                     o.path = PATH_SMALL_CIN;
                     if ((rc = upload(h, std::vector<float>(kw, kw + (size_t)d.kh * d.kw * cin * cout), &o.wt))) return rc;
                 } else if (d.kh == 1 && d.kw == 1 && cout <= 8 && in_al) {
@@ -846,13 +854,15 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
                 return fail(h, ECSEG_E_INVALID, "max-pool window leaves the input in op " + std::to_string(k));
             if (d.op == ECSEG_OP_UPSAMPLE && (to.h != ti.h * d.stride || to.w != ti.w * d.stride))
                 return fail(h, ECSEG_E_INVALID, "bad upsample shape in op " + std::to_string(k));
+        } else if (d.op == ECSEG_OP_GLOBALPOOL) {
+            if (to.h != 1 || to.w != 1 || to.c != ti.c) return fail(h, ECSEG_E_INVALID, "bad global-pool shape in op " + std::to_string(k));
         } else if (d.op == ECSEG_OP_ACT || d.op == ECSEG_OP_ADD || d.op == ECSEG_OP_COPY) {
             // nothing to prepare
         } else {
             return fail(h, ECSEG_E_INVALID, "unknown op code in op " + std::to_string(k));
         }
         if (d.op != ECSEG_OP_CONV && d.op != ECSEG_OP_CONVT && d.op != ECSEG_OP_MAXPOOL && d.op != ECSEG_OP_UPSAMPLE &&
-            d.op != ECSEG_OP_COPY && (ti.h != to.h || ti.w != to.w || ti.c != to.c))
+            d.op != ECSEG_OP_COPY && d.op != ECSEG_OP_GLOBALPOOL && (ti.h != to.h || ti.w != to.w || ti.c != to.c))
             return fail(h, ECSEG_E_INVALID, "shape mismatch in element-wise op " + std::to_string(k));
         h->ops.push_back(o);
     }
@@ -911,7 +921,7 @@ int ecseg_model_flops_per_patch(ecseg_ctx* h, double* flops) {
     return ECSEG_OK;
 }
 
-int ecseg_forward_patches(ecseg_ctx* h, const uint8_t* patches, int n, float* out) {
+static int forward_host(ecseg_ctx* h, const void* patches, bool is_f32, int n, float* out) {
     int rc = check_model(h);
     if (rc) return rc;
     if (n < 0 || (n > 0 && (!patches || !out))) return fail(h, ECSEG_E_INVALID, "forward_patches: bad arguments");
@@ -923,13 +933,18 @@ int ecseg_forward_patches(ecseg_ctx* h, const uint8_t* patches, int n, float* ou
     const size_t in_per = (size_t)ti.h * ti.w * ti.c, out_per = (size_t)to.h * to.w * to.c;
     const int chunk = std::max(1, h->images_per_group * 35);
     if ((rc = ensure_patches(h, std::min(n, chunk)))) return rc;
-    if ((rc = ensure(h, h->d_u8in, h->d_u8in_cap, in_per * std::min(n, chunk)))) return rc;
+    if (!is_f32 && (rc = ensure(h, h->d_u8in, h->d_u8in_cap, in_per * std::min(n, chunk)))) return rc;
     hipStream_t s = h->stream;
     prof_begin(h);
     for (int i0 = 0; i0 < n; i0 += chunk) {
         const int ni = std::min(chunk, n - i0);
-        HIP_TRY(h, hipMemcpyAsync(h->d_u8in, patches + (size_t)i0 * in_per, in_per * ni, hipMemcpyHostToDevice, s));
-        HIP_TRY(h, launch_u8_to_f32(h->d_u8in, view_of(h, h->input_tensor).p, in_per * ni, s));
+        if (is_f32) {
+            HIP_TRY(h, hipMemcpyAsync(view_of(h, h->input_tensor).p, static_cast<const float*>(patches) + (size_t)i0 * in_per,
+                                      in_per * ni * sizeof(float), hipMemcpyHostToDevice, s));
+        } else {
+            HIP_TRY(h, hipMemcpyAsync(h->d_u8in, static_cast<const uint8_t*>(patches) + (size_t)i0 * in_per, in_per * ni, hipMemcpyHostToDevice, s));
+            HIP_TRY(h, launch_u8_to_f32(h->d_u8in, view_of(h, h->input_tensor).p, in_per * ni, s));
+        }
         if ((rc = run_plan(h, ni))) return rc;
         const TView ov = view_of(h, h->output_tensor);
         HIP_TRY(h, hipMemcpy2DAsync(out + (size_t)i0 * out_per, (size_t)to.c * sizeof(float), ov.p, (size_t)ov.cs * sizeof(float),
@@ -939,6 +954,9 @@ int ecseg_forward_patches(ecseg_ctx* h, const uint8_t* patches, int n, float* ou
     prof_end(h);
     return ECSEG_OK;
 }
+
+int ecseg_forward_patches(ecseg_ctx* h, const uint8_t* patches, int n, float* out) { return forward_host(h, patches, false, n, out); }
+int ecseg_forward_patches_f32(ecseg_ctx* h, const float* patches, int n, float* out) { return forward_host(h, patches, true, n, out); }
 
 int ecseg_read_tensor(ecseg_ctx* h, int tensor, int n, float* out) {
     int rc = check_model(h);

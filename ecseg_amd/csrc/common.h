@@ -66,11 +66,12 @@ hipError_t launch_conv_small_cin(const TView& in, const TView& out, const float*
 hipError_t launch_conv_head(const TView& in, const TView& out, const float* w_io, const float* bias, int n, int act,
                             float alpha, hipStream_t s);
 hipError_t launch_conv_generic(const TView& in, const TView& out, const float* w_hwio, const float* bias, int n,
-                               int R, int S, int pad_top, int pad_left, int act, float alpha, hipStream_t s);
+                               int R, int S, int stride, int pad_top, int pad_left, int act, float alpha, hipStream_t s);
 hipError_t launch_convt_generic(const TView& in, const TView& out, const float* w_hwoi, const float* bias, int n,
                                 int R, int S, int stride, int crop_top, int crop_left, int act, float alpha,
                                 hipStream_t s);
-hipError_t launch_maxpool(const TView& in, const TView& out, int n, int kh, int kw, int stride, hipStream_t s);
+hipError_t launch_maxpool(const TView& in, const TView& out, int n, int kh, int kw, int stride, int mode, hipStream_t s);
+hipError_t launch_global_pool(const TView& in, const TView& out, int n, int mode, hipStream_t s);
 hipError_t launch_upsample(const TView& in, const TView& out, int n, int factor, int mode, hipStream_t s);
 hipError_t launch_affine(const TView& in, const TView& out, const float* scale, const float* shift, int n, int act,
                          float alpha, hipStream_t s);

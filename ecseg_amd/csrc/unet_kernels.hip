@@ -696,7 +696,7 @@ hipError_t launch_conv_head(const TView& in, const TView& out, const float* w, c
 // does not take (odd channel counts, large taps).
 __global__ __launch_bounds__(256) void conv_generic_kernel(TView in, TView out, const float* __restrict__ w,
                                                            const float* __restrict__ bias, size_t total, int R, int S,
-                                                           int pad_top, int pad_left, int act, float alpha) {
+                                                           int stride, int pad_top, int pad_left, int act, float alpha) {
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
         const int co = (int)(t % out.c);
         size_t pix = t / out.c;
@@ -705,10 +705,10 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(TView in, TView out, 
         const size_t img = pix / out.h;
         float acc = bias ? bias[co] : 0.f;
         for (int r = 0; r < R; ++r) {
-            const int iy = oy - pad_top + r;
+            const int iy = oy * stride - pad_top + r;
             if (iy < 0 || iy >= in.h) continue;
             for (int s = 0; s < S; ++s) {
-                const int ix = ox - pad_left + s;
+                const int ix = ox * stride - pad_left + s;
                 if (ix < 0 || ix >= in.w) continue;
                 const float* ip = in.p + ((img * in.h + iy) * in.w + ix) * in.cs;
                 const float* wp = w + (size_t)(r * S + s) * in.c * out.c + co;
@@ -720,13 +720,13 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(TView in, TView out, 
 }
 
 hipError_t launch_conv_generic(const TView& in, const TView& out, const float* w, const float* bias, int n, int R, int S,
-                               int pad_top, int pad_left, int act, float alpha, hipStream_t s) {
+                               int stride, int pad_top, int pad_left, int act, float alpha, hipStream_t s) {
     const size_t total = (size_t)n * out.h * out.w * out.c;
     if (!total) return hipSuccess;
     size_t blocks = (total + 255) / 256;
     if (blocks > 65536 * 16) blocks = 65536 * 16;
-    hipLaunchKernelGGL(conv_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, out, w, bias, total, R, S, pad_top,
-                       pad_left, act, alpha);
+    hipLaunchKernelGGL(conv_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, out, w, bias, total, R, S, stride,
+                       pad_top, pad_left, act, alpha);
     return hipGetLastError();
 }
 
@@ -780,8 +780,9 @@ __device__ __forceinline__ bool view_vec4(const TView& v) {
     return (v.c % 4 == 0) && (v.cs % 4 == 0) && ((((uintptr_t)v.p) & 15) == 0);
 }
 
+// MaxPooling2D (mode 0) / AveragePooling2D (mode 1), 'valid'
 template <bool VEC>
-__global__ __launch_bounds__(256) void maxpool_kernel(TView in, TView out, size_t total, int kh, int kw, int stride) {
+__global__ __launch_bounds__(256) void maxpool_kernel(TView in, TView out, size_t total, int kh, int kw, int stride, int mode) {
     constexpr int V = VEC ? 4 : 1;
     const int cq = out.c / V;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
@@ -792,18 +793,23 @@ __global__ __launch_bounds__(256) void maxpool_kernel(TView in, TView out, size_
         const size_t img = pix / out.h;
         float m[V];
 #pragma unroll
-        for (int e = 0; e < V; ++e) m[e] = -INFINITY;
+        for (int e = 0; e < V; ++e) m[e] = mode ? 0.f : -INFINITY;
         for (int r = 0; r < kh; ++r)
             for (int s = 0; s < kw; ++s) {
                 const float* ip = in.p + ((img * in.h + (oy * stride + r)) * in.w + (ox * stride + s)) * in.cs + c;
                 if (VEC) {
                     const f32x4 v = *reinterpret_cast<const f32x4*>(ip);
 #pragma unroll
-                    for (int e = 0; e < V; ++e) m[e] = fmaxf(m[e], v[e]);
+                    for (int e = 0; e < V; ++e) m[e] = mode ? m[e] + v[e] : fmaxf(m[e], v[e]);
                 } else {
-                    m[0] = fmaxf(m[0], ip[0]);
+                    m[0] = mode ? m[0] + ip[0] : fmaxf(m[0], ip[0]);
                 }
             }
+        if (mode) {
+            const float inv = 1.f / (float)(kh * kw);
+#pragma unroll
+            for (int e = 0; e < V; ++e) m[e] *= inv;
+        }
         float* op = out.p + ((img * out.h + oy) * out.w + ox) * out.cs + c;
         if (VEC) {
             f32x4 o; o[0] = m[0]; o[1] = m[V > 1 ? 1 : 0]; o[2] = m[V > 2 ? 2 : 0]; o[3] = m[V > 3 ? 3 : 0];
@@ -820,12 +826,45 @@ static unsigned grid_for(size_t total) {
     return (unsigned)(b ? b : 1);
 }
 
-hipError_t launch_maxpool(const TView& in, const TView& out, int n, int kh, int kw, int stride, hipStream_t s) {
+hipError_t launch_maxpool(const TView& in, const TView& out, int n, int kh, int kw, int stride, int mode, hipStream_t s) {
     const bool vec = (in.c % 4 == 0) && (in.cs % 4 == 0) && (out.cs % 4 == 0) && ((((uintptr_t)in.p) | ((uintptr_t)out.p)) & 15) == 0;
     const size_t total = (size_t)n * out.h * out.w * (vec ? out.c / 4 : out.c);
     if (!total) return hipSuccess;
-    if (vec) hipLaunchKernelGGL(maxpool_kernel<true>, dim3(grid_for(total)), dim3(256), 0, s, in, out, total, kh, kw, stride);
-    else hipLaunchKernelGGL(maxpool_kernel<false>, dim3(grid_for(total)), dim3(256), 0, s, in, out, total, kh, kw, stride);
+    if (vec) hipLaunchKernelGGL(maxpool_kernel<true>, dim3(grid_for(total)), dim3(256), 0, s, in, out, total, kh, kw, stride, mode);
+    else hipLaunchKernelGGL(maxpool_kernel<false>, dim3(grid_for(total)), dim3(256), 0, s, in, out, total, kh, kw, stride, mode);
+    return hipGetLastError();
+}
+
+// GlobalAveragePooling2D (mode 1) / GlobalMaxPooling2D (mode 0): workgroup = (patch, 64 channels); lane = channel
+// (coalesced 256-B rows), the four waves split the pixels and meet in LDS.  Fixed summation order: run-to-run identical.
+__global__ __launch_bounds__(256) void global_pool_kernel(TView in, TView out, int mode) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const size_t img = blockIdx.y;
+    const int npx = in.h * in.w;
+    float acc = mode ? 0.f : -INFINITY;
+    if (c < in.c) {
+        const float* ip = in.p + img * (size_t)npx * in.cs + c;
+        for (int q = wave; q < npx; q += 4) {
+            const float v = ip[(size_t)q * in.cs];
+            acc = mode ? acc + v : fmaxf(acc, v);
+        }
+    }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && c < in.c) {
+        float r = part[0][lane];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) r = mode ? r + part[k][lane] : fmaxf(r, part[k][lane]);
+        if (mode) r *= 1.f / (float)npx;
+        out.p[img * (size_t)out.cs + c] = r;
+    }
+}
+
+hipError_t launch_global_pool(const TView& in, const TView& out, int n, int mode, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(global_pool_kernel, dim3((unsigned)((in.c + 63) / 64), (unsigned)n), dim3(256), 0, s, in, out, mode);
     return hipGetLastError();
 }
 

@@ -17,7 +17,7 @@ import json
 import numpy as np
 
 # op / activation codes mirror include/ecseg_hip.h
-OP_CONV, OP_CONVT, OP_MAXPOOL, OP_UPSAMPLE, OP_AFFINE, OP_ACT, OP_ADD, OP_COPY = 1, 2, 3, 4, 5, 6, 7, 8
+OP_CONV, OP_CONVT, OP_MAXPOOL, OP_UPSAMPLE, OP_AFFINE, OP_ACT, OP_ADD, OP_COPY, OP_GLOBALPOOL = 1, 2, 3, 4, 5, 6, 7, 8, 9
 ACT = {'linear': 0, None: 0, 'relu': 1, 'softmax': 2, 'sigmoid': 3, 'leaky_relu': 4, 'tanh': 5, 'elu': 6}
 IDENTITY_LAYERS = ('Dropout', 'SpatialDropout2D', 'GaussianNoise', 'GaussianDropout', 'AlphaDropout',
                    'ActivityRegularization')
@@ -37,6 +37,7 @@ class Plan:
         self.buffer_floats = []
         self.input_tensor = self.output_tensor = -1
         self.layer_tensor = {}     # Keras layer name -> tensor index of its output
+        self.output_rank = 4       # 2: the Keras model returns (N, K) (classifier heads: Flatten / global pooling / Dense)
 
     def flops_per_patch(self):
         f = 0.0
@@ -118,6 +119,8 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
     by_name = {}
 
     def add(name, kind, inputs, shape, **params):
+        if 'rank' not in params:           # rank of the Keras tensor (4: (N, H, W, C); 2: (N, K)), inherited by default
+            params['rank'] = nodes[inputs[0]].get('rank', 4) if inputs else 4
         nodes.append(dict(name=name, kind=kind, inputs=list(inputs), shape=tuple(int(v) for v in shape), **params))
         by_name[name] = len(nodes) - 1
         return len(nodes) - 1
@@ -132,10 +135,10 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
                 raise PlanError('cannot determine the input shape')
             h = bis[1] or input_hw[0]
             w = bis[2] or input_hw[1]
-            c = bis[3]
+            c = bis[3] if len(bis) > 3 else 1      # (None, H, W): a single-channel image without a channel axis
             if c is None:
                 raise PlanError('input channel count is undefined')
-            idx = add(name if cls == 'InputLayer' else '__input__', 'input', [], (h, w, c))
+            idx = add(name if cls == 'InputLayer' else '__input__', 'input', [], (h, w, c), rank=len(bis))
             prev = idx
             if cls == 'InputLayer':
                 continue
@@ -160,21 +163,21 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
         if cls == 'Conv2D':
             kh, kw = lc['kernel_size']
             sh, sw = lc.get('strides', [1, 1])
-            if list(lc.get('dilation_rate', [1, 1])) != [1, 1] or lc.get('groups', 1) != 1 or (sh, sw) != (1, 1):
-                raise PlanError('Conv2D %s: dilation / groups / strides are not supported' % name)
+            if list(lc.get('dilation_rate', [1, 1])) != [1, 1] or lc.get('groups', 1) != 1 or sh != sw:
+                raise PlanError('Conv2D %s: dilation / groups / anisotropic strides are not supported' % name)
             if lc.get('data_format', 'channels_last') != 'channels_last':
                 raise PlanError('channels_first is not supported')
             if lc['padding'] == 'same':
-                pt, pl = _same_pad(kh, 1, h)[0], _same_pad(kw, 1, w)[0]
-                oh, ow = h, w
+                pt, pl = _same_pad(kh, sh, h)[0], _same_pad(kw, sw, w)[0]
+                oh, ow = -(-h // sh), -(-w // sw)
             else:
                 pt = pl = 0
-                oh, ow = h - kh + 1, w - kw + 1
+                oh, ow = (h - kh) // sh + 1, (w - kw) // sw + 1
             kernel = np.ascontiguousarray(ws[0], np.float32)
             if kernel.shape != (kh, kw, c, lc['filters']):
                 raise PlanError('Conv2D %s: kernel shape %s does not match config' % (name, kernel.shape))
             bias = np.ascontiguousarray(ws[1], np.float32) if lc.get('use_bias', True) else None
-            idx = add(name, 'conv', ins, (oh, ow, lc['filters']), kh=kh, kw=kw, pad_top=pt, pad_left=pl,
+            idx = add(name, 'conv', ins, (oh, ow, lc['filters']), kh=kh, kw=kw, stride=sh, pad_top=pt, pad_left=pl,
                       kernel=kernel, bias=bias, act=_act_code(lc.get('activation')), alpha=0.0)
         elif cls == 'Conv2DTranspose':
             kh, kw = lc['kernel_size']
@@ -193,12 +196,39 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
                 ct = cl = 0
             idx = add(name, 'convt', ins, (oh, ow, lc['filters']), kh=kh, kw=kw, stride=sh, pad_top=ct, pad_left=cl,
                       kernel=kernel, bias=bias, act=_act_code(lc.get('activation')), alpha=0.0)
-        elif cls == 'MaxPooling2D':
+        elif cls in ('MaxPooling2D', 'AveragePooling2D'):
             kh, kw = lc['pool_size']
             st = lc.get('strides') or lc['pool_size']
             if st[0] != st[1] or lc.get('padding', 'valid') != 'valid':
-                raise PlanError('MaxPooling2D %s: unsupported geometry' % name)
-            idx = add(name, 'maxpool', ins, ((h - kh) // st[0] + 1, (w - kw) // st[0] + 1, c), kh=kh, kw=kw, stride=st[0])
+                raise PlanError('%s %s: unsupported geometry' % (cls, name))
+            idx = add(name, 'maxpool', ins, ((h - kh) // st[0] + 1, (w - kw) // st[0] + 1, c), kh=kh, kw=kw, stride=st[0],
+                      mode=int(cls == 'AveragePooling2D'))
+        elif cls in ('GlobalAveragePooling2D', 'GlobalMaxPooling2D'):
+            idx = add(name, 'globalpool', ins, (1, 1, c), mode=int(cls == 'GlobalAveragePooling2D'),
+                      rank=4 if lc.get('keepdims') else 2)
+        elif cls == 'Flatten':
+            idx = add(name, 'reshape', ins, (1, 1, h * w * c), rank=2)
+        elif cls == 'Reshape':
+            ts = [int(v) for v in lc['target_shape']]
+            if len(ts) == 3:
+                shp = tuple(ts)
+            elif len(ts) == 2:
+                shp = (ts[0], ts[1], 1)
+            elif len(ts) == 1:
+                shp = (1, 1, ts[0])
+            else:
+                raise PlanError('Reshape %s: target_shape %s is not supported' % (name, ts))
+            if -1 in shp or shp[0] * shp[1] * shp[2] != h * w * c:
+                raise PlanError('Reshape %s: %s does not match the input (%d, %d, %d)' % (name, ts, h, w, c))
+            idx = add(name, 'reshape', ins, shp, rank=len(ts) + 1)
+        elif cls == 'Dense':
+            kernel = np.ascontiguousarray(ws[0], np.float32)     # (features, units)
+            if kernel.shape != (c, lc['units']):
+                raise PlanError('Dense %s: kernel shape %s does not match its input (%d features)' % (name, kernel.shape, c))
+            bias = np.ascontiguousarray(ws[1], np.float32) if lc.get('use_bias', True) else None
+            # a Dense layer acts on the last axis: a 1x1 convolution (on a (1, 1, F) tensor after Flatten / global pooling)
+            idx = add(name, 'conv', ins, (h, w, lc['units']), kh=1, kw=1, stride=1, pad_top=0, pad_left=0,
+                      kernel=kernel.reshape(1, 1, c, lc['units']), bias=bias, act=_act_code(lc.get('activation')), alpha=0.0)
         elif cls == 'UpSampling2D':
             sz = lc['size']
             if sz[0] != sz[1]:
@@ -341,6 +371,15 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
         for i in nodes[j]['inputs']:
             last_use[i] = j
     last_use[out_node] = len(nodes) + 1
+    # Flatten / Reshape are views of their input's buffer: the owner lives as long as the view is read
+    def owner(i):
+        while nodes[i]['kind'] == 'reshape':
+            i = nodes[i]['inputs'][0]
+        return i
+    for j in reversed(order):
+        if nodes[j]['kind'] == 'reshape':
+            o_ = nodes[j]['inputs'][0]
+            last_use[o_] = max(last_use.get(o_, o_), last_use.get(j, j))
     # a concat buffer lives from its first producer to the concat's last use
     first_touch = {}
     for i, (j, _) in view.items():
@@ -411,6 +450,7 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
         plan.ops.append(d)
 
     released = set()
+    plan_input_node = [in_nodes[0]]
 
     def release_after(step):
         for i in list(node_buf.keys()):
@@ -428,6 +468,17 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
         k = n['kind']
         if k == 'input':
             plan.input_tensor = new_tensor(j)
+        elif k == 'reshape':
+            i = n['inputs'][0]
+            ti_ = plan.tensors[tensor_of[i]]
+            if i in view or nodes[i]['kind'] == 'concat' or ti_['c_stride'] != ti_['c'] or ti_['c_offset'] != 0:
+                raise PlanError('%s: reshaping a strided view is not supported' % n['name'])
+            h_, w_, c_ = n['shape']
+            plan.tensors.append(dict(buffer=ti_['buffer'], h=h_, w=w_, c=c_, c_stride=c_, c_offset=0))
+            tensor_of[j] = len(plan.tensors) - 1
+            plan.layer_tensor[n['name']] = tensor_of[j]
+            if i == plan_input_node[0]:
+                pass
         elif k == 'concat':
             t = new_tensor(j)
             off = 0
@@ -442,13 +493,15 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
             ins = [tensor_of[i] for i in n['inputs']]
             t = new_tensor(j)
             if k == 'conv':
-                op(op=OP_CONV, in0=ins[0], out=t, kh=n['kh'], kw=n['kw'], pad_top=n['pad_top'], pad_left=n['pad_left'],
+                op(op=OP_CONV, in0=ins[0], out=t, kh=n['kh'], kw=n['kw'], stride=n.get('stride', 1), pad_top=n['pad_top'], pad_left=n['pad_left'],
                    act=n['act'], alpha=n['alpha'], w0=add_weight(n['kernel']), w1=add_weight(n['bias']))
             elif k == 'convt':
                 op(op=OP_CONVT, in0=ins[0], out=t, kh=n['kh'], kw=n['kw'], stride=n['stride'], pad_top=n['pad_top'],
                    pad_left=n['pad_left'], act=n['act'], alpha=n['alpha'], w0=add_weight(n['kernel']), w1=add_weight(n['bias']))
             elif k == 'maxpool':
-                op(op=OP_MAXPOOL, in0=ins[0], out=t, kh=n['kh'], kw=n['kw'], stride=n['stride'])
+                op(op=OP_MAXPOOL, in0=ins[0], out=t, kh=n['kh'], kw=n['kw'], stride=n['stride'], mode=n.get('mode', 0))
+            elif k == 'globalpool':
+                op(op=OP_GLOBALPOOL, in0=ins[0], out=t, mode=n['mode'])
             elif k == 'upsample':
                 op(op=OP_UPSAMPLE, in0=ins[0], out=t, stride=n['stride'], mode=n['mode'])
             elif k == 'affine':
@@ -467,5 +520,6 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
                 raise PlanError('internal: unknown node kind %s' % k)
         release_after(j)
     plan.output_tensor = tensor_of[out_node]
+    plan.output_rank = 2 if nodes[out_node].get('rank', 4) == 2 else 4
     # the model output must be readable as a compact tensor for predict_on_batch; views are fine for the C side
     return plan

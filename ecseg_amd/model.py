@@ -28,6 +28,9 @@ class MetasegModel:
     def from_h5(cls, path, device=0, fuse=True, lambda_overrides=None):
         if not os.path.exists(path):
             raise FileNotFoundError(path)
+        if os.path.isdir(path):
+            raise ValueError('%s is a TensorFlow SavedModel directory; only the Keras HDF5 format is read here - '
+                             're-save it with model.save("<name>.h5") where TensorFlow is available' % path)
         cfg, weights = hdf5_min.load_keras_h5(path)
         return cls(cfg, weights, device=device, fuse=fuse, lambda_overrides=lambda_overrides)
 

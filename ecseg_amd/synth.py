@@ -75,6 +75,96 @@ def conv_stack_config(n_convs=3, ch=64, n_classes=4, in_ch=1):
                                                    'output_layers': [['head', 0, 0]]}}
 
 
+def classifier_config(kind='interseg'):
+    """Keras-2 functional ``model_config`` of a small per-nucleus classifier in the two call shapes of the reference's
+    interSeg step: ``'interseg'``: input (256, 256) uint8 without a channel axis -> 3-way softmax (src/interseg.py:155,
+    ``ecseg_i_model.predict(p[..., 0])``); ``'ecseg_c'``: input (256, 256, 3) float32 in [0, 1] (preprocess_ecseg_c,
+    src/utils.py:166-173) -> one sigmoid unit (src/interseg.py:168-170).  The real architectures live only in
+    interseg_models/*.h5 (not distributable); these cover the layer vocabulary such Keras classifiers are written in."""
+    layers = []
+
+    def L(cls, name, inb, **c):
+        layers.append({'class_name': cls, 'name': name, 'config': dict(c, name=name),
+                       'inbound_nodes': [[[i, 0, 0, {}] for i in inb]] if inb else []})
+        return name
+
+    def conv(name, x, f, k, s=1, pad='same', act='relu'):
+        return L('Conv2D', name, [x], filters=f, kernel_size=[k, k], strides=[s, s], padding=pad, data_format='channels_last',
+                 dilation_rate=[1, 1], groups=1, activation=act, use_bias=True)
+
+    if kind == 'interseg':
+        x = L('InputLayer', 'input_1', [], batch_input_shape=[None, 256, 256], dtype='float32')
+        x = L('Reshape', 'reshape', [x], target_shape=[256, 256, 1])
+        x = L('Rescaling', 'rescaling', [x], scale=1.0 / 255.0, offset=0.0)
+        x = conv('conv_a', x, 16, 3, s=2)
+        x = conv('conv_b', x, 32, 3)
+        x = L('MaxPooling2D', 'pool_a', [x], pool_size=[2, 2], strides=[2, 2], padding='valid')
+        x = conv('conv_c', x, 64, 3, act='linear')
+        x = L('BatchNormalization', 'bn_c', [x], axis=[3], momentum=0.99, epsilon=1e-3, center=True, scale=True)
+        x = L('Activation', 'act_c', [x], activation='relu')
+        x = L('MaxPooling2D', 'pool_b', [x], pool_size=[2, 2], strides=[2, 2], padding='valid')
+        x = conv('conv_d', x, 128, 3)
+        x = L('GlobalAveragePooling2D', 'gap', [x], data_format='channels_last', keepdims=False)
+        x = L('Dense', 'dense_a', [x], units=64, activation='relu', use_bias=True)
+        x = L('Dropout', 'dropout', [x], rate=0.3)
+        out = L('Dense', 'dense_out', [x], units=3, activation='softmax', use_bias=True)
+    elif kind == 'ecseg_c':
+        x = L('InputLayer', 'input_1', [], batch_input_shape=[None, 256, 256, 3], dtype='float32')
+        x = conv('conv_a', x, 16, 5, s=2)
+        x = L('AveragePooling2D', 'avg_a', [x], pool_size=[2, 2], strides=[2, 2], padding='valid')
+        x = conv('conv_b', x, 32, 3, pad='valid')
+        x = L('MaxPooling2D', 'pool_b', [x], pool_size=[2, 2], strides=[2, 2], padding='valid')
+        x = conv('conv_c', x, 64, 3)
+        x = L('MaxPooling2D', 'pool_c', [x], pool_size=[4, 4], strides=[4, 4], padding='valid')
+        x = L('Flatten', 'flatten', [x], data_format='channels_last')
+        x = L('Dense', 'dense_a', [x], units=32, activation='relu', use_bias=True)
+        out = L('Dense', 'dense_out', [x], units=1, activation='sigmoid', use_bias=True)
+    else:
+        raise ValueError(kind)
+    return {'class_name': 'Functional', 'config': {'name': kind + '_synth', 'layers': layers,
+                                                   'input_layers': [['input_1', 0, 0]], 'output_layers': [[out, 0, 0]]}}
+
+
+def classifier_weights(config, seed=0):
+    """Seeded He-normal weights for ``classifier_config`` (Conv2D / Dense / BatchNormalization)."""
+    rng = np.random.default_rng(seed)
+    weights = {}
+    shape = {}
+    for Ld in config['config']['layers']:
+        cls, lc, name = Ld['class_name'], Ld['config'], Ld['config']['name']
+        if cls == 'InputLayer':
+            bis = lc['batch_input_shape']
+            shape[name] = (bis[1], bis[2], bis[3] if len(bis) > 3 else 1)
+            continue
+        h, w, c = shape[Ld['inbound_nodes'][0][0][0]]
+        if cls == 'Conv2D':
+            k, st, f = lc['kernel_size'][0], lc['strides'][0], lc['filters']
+            weights[name] = [(rng.normal(size=(k, k, c, f)) * np.sqrt(2.0 / (k * k * c))).astype(np.float32),
+                             (rng.normal(size=f) * 0.05).astype(np.float32)]
+            shape[name] = (-(-h // st), -(-w // st), f) if lc['padding'] == 'same' else ((h - k) // st + 1, (w - k) // st + 1, f)
+        elif cls in ('MaxPooling2D', 'AveragePooling2D'):
+            k, st = lc['pool_size'][0], lc['strides'][0]
+            shape[name] = ((h - k) // st + 1, (w - k) // st + 1, c)
+        elif cls == 'BatchNormalization':
+            weights[name] = [rng.uniform(0.8, 1.2, c).astype(np.float32), (rng.normal(size=c) * 0.05).astype(np.float32),
+                             (rng.normal(size=c) * 0.05).astype(np.float32), rng.uniform(0.8, 1.2, c).astype(np.float32)]
+            shape[name] = (h, w, c)
+        elif cls in ('GlobalAveragePooling2D', 'GlobalMaxPooling2D'):
+            shape[name] = (1, 1, c)
+        elif cls == 'Flatten':
+            shape[name] = (1, 1, h * w * c)
+        elif cls == 'Reshape':
+            ts = lc['target_shape']
+            shape[name] = tuple(ts) if len(ts) == 3 else (1, 1, ts[0])
+        elif cls == 'Dense':
+            u = lc['units']
+            weights[name] = [(rng.normal(size=(c, u)) * np.sqrt(2.0 / c)).astype(np.float32), (rng.normal(size=u) * 0.05).astype(np.float32)]
+            shape[name] = (h, w, u)
+        else:
+            shape[name] = (h, w, c)
+    return weights
+
+
 def unet_weights(config, seed=0, input_scale=1.0 / 255.0, head_gain=6.0):
     """Seeded He-normal kernels.  The first convolution is scaled by ``input_scale`` because the reference feeds raw
     0..255 pixel values (no normalisation anywhere in src/utils.py:109-120); the head is scaled up so that the

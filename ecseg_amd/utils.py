@@ -13,6 +13,8 @@ def load_model(model_name, device=None):
     """src/utils.py:27-33: ``models/<name>`` (``interseg_models/`` for the interSeg classifiers), relative to the CWD."""
     folder = 'interseg_models' if model_name in ('interseg', 'ecseg_c') else 'models'
     path = os.path.join(folder, model_name)
+    if not os.path.exists(path) and os.path.exists(path + '.h5'):      # interseg_models/interseg -> interseg.h5
+        path += '.h5'
     dev = int(os.environ.get('ECSEG_DEVICE', os.environ.get('LOCAL_RANK', '0'))) if device is None else device
     model = MetasegModel.from_h5(path, device=dev)
     image_tools.set_default_handle(model.handle)

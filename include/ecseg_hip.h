@@ -52,14 +52,16 @@ void*       ecseg_stream(ecseg_ctx* h);
  * found in metaseg.h5 to this list; tensors are NHWC float32 "views" into device buffers so that Concatenate
  * costs nothing (producers write straight into the concatenated buffer). */
 enum {
-    ECSEG_OP_CONV      = 1,  /* Conv2D kh x kw, stride 1, zero padding (pad_top, pad_left), bias, activation */
+    ECSEG_OP_CONV      = 1,  /* Conv2D kh x kw, stride s, zero padding (pad_top, pad_left), bias, activation; a Dense
+                                layer is the 1x1 case on a (1, 1, features) tensor */
     ECSEG_OP_CONVT     = 2,  /* Conv2DTranspose kh x kw, stride s, crop (pad_top, pad_left), bias, activation */
-    ECSEG_OP_MAXPOOL   = 3,  /* MaxPooling2D kh x kw stride s (valid) */
+    ECSEG_OP_MAXPOOL   = 3,  /* MaxPooling2D (mode 0) / AveragePooling2D (mode 1) kh x kw stride s (valid) */
     ECSEG_OP_UPSAMPLE  = 4,  /* UpSampling2D x s, mode: 0 nearest, 1 bilinear (half-pixel centres) */
     ECSEG_OP_AFFINE    = 5,  /* y = act(x * scale[c] + shift[c]): BatchNormalization (inference), Rescaling */
     ECSEG_OP_ACT       = 6,  /* y = act(x) */
     ECSEG_OP_ADD       = 7,  /* y = act(a + b) */
-    ECSEG_OP_COPY      = 8   /* y = x (materialise a view, ZeroPadding2D / Cropping2D via offsets) */
+    ECSEG_OP_COPY      = 8,  /* y = x (materialise a view, ZeroPadding2D / Cropping2D via offsets) */
+    ECSEG_OP_GLOBALPOOL = 9  /* GlobalMaxPooling2D (mode 0) / GlobalAveragePooling2D (mode 1): (h, w, c) -> (1, 1, c) */
 };
 enum { ECSEG_ACT_LINEAR = 0, ECSEG_ACT_RELU = 1, ECSEG_ACT_SOFTMAX = 2, ECSEG_ACT_SIGMOID = 3,
        ECSEG_ACT_LEAKY = 4, ECSEG_ACT_TANH = 5, ECSEG_ACT_ELU = 6 };
@@ -79,7 +81,7 @@ typedef struct ecseg_op_desc {
     int32_t pad_top, pad_left;  /* CONV: zero padding before; CONVT: rows/cols cropped from the full output;
                                    COPY: offset of the input inside the output (>0) or crop (<0) */
     int32_t act;
-    int32_t mode;               /* UPSAMPLE interpolation */
+    int32_t mode;               /* UPSAMPLE interpolation; MAXPOOL / GLOBALPOOL: 0 max, 1 average */
     int32_t w0, w1;             /* weight array indices: CONV/CONVT kernel + bias (-1 none); AFFINE scale + shift */
     float   alpha;              /* LEAKY slope */
 } ecseg_op_desc;
@@ -96,6 +98,9 @@ int ecseg_model_flops_per_patch(ecseg_ctx* h, double* flops);   /* algorithmic 2
 
 /* ---- model.predict_on_batch(uint8[N,256,256,C]) -> float32[N,256,256,K] (src/utils.py:115) --------------- */
 int ecseg_forward_patches(ecseg_ctx* h, const uint8_t* patches_nhwc, int n, float* out_nhwc);
+/* Same with float32 inputs (N, H, W, C): the interSeg classifier ecseg_c is fed normalised floats
+ * (preprocess_ecseg_c, src/utils.py:166-173; src/interseg.py:167-168). */
+int ecseg_forward_patches_f32(ecseg_ctx* h, const float* patches_nhwc, int n, float* out_nhwc);
 /* Debug/parity: copy any plan tensor (compact NHWC float32) after the last forward of n patches. */
 int ecseg_read_tensor(ecseg_ctx* h, int tensor, int n, float* out_nhwc);
 

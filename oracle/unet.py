@@ -13,7 +13,8 @@ definitions and evaluated with torch CPU float32 ops (``conv_numpy`` is an indep
 * MaxPooling2D (valid, floor), UpSampling2D (nearest | bilinear with half-pixel centres), Concatenate(axis=-1),
   BatchNormalization (inference; weight order gamma, beta, moving_mean, moving_variance, honouring center/scale),
   Dropout-like layers = identity, Activation / ReLU / LeakyReLU / Softmax, Add, ZeroPadding2D, Cropping2D,
-  Rescaling.
+  Rescaling; for the interSeg classifiers (src/interseg.py:96-98,155,168): strided Conv2D, AveragePooling2D,
+  GlobalAveragePooling2D / GlobalMaxPooling2D, Flatten (NHWC order), Reshape, Dense (last axis).
 The uint8 patch batch is cast to float32 without scaling (Keras casts inputs to the InputLayer dtype).
 """
 import json
@@ -112,7 +113,10 @@ def forward(model_config, weights, x_nhwc, lambda_fns=None):
     layers = cfg['layers'] if isinstance(cfg, dict) else cfg
     seq = model_config['class_name'] == 'Sequential'
     vals = {}
-    x = torch.from_numpy(np.ascontiguousarray(x_nhwc).astype(np.float32)).permute(0, 3, 1, 2).contiguous()
+    x_nhwc = np.ascontiguousarray(x_nhwc)
+    if x_nhwc.ndim == 3:                      # (N, H, W): a model whose InputLayer has no channel axis
+        x_nhwc = x_nhwc[..., None]
+    x = torch.from_numpy(x_nhwc.astype(np.float32)).permute(0, 3, 1, 2).contiguous()
     prev = None
     with torch.no_grad():
         for L in layers:
@@ -143,6 +147,41 @@ def forward(model_config, weights, x_nhwc, lambda_fns=None):
             elif cls == 'MaxPooling2D':
                 assert lc.get('padding', 'valid') == 'valid'
                 y = F.max_pool2d(a, tuple(lc['pool_size']), tuple(lc.get('strides') or lc['pool_size']))
+            elif cls == 'AveragePooling2D':
+                assert lc.get('padding', 'valid') == 'valid'
+                y = F.avg_pool2d(a, tuple(lc['pool_size']), tuple(lc.get('strides') or lc['pool_size']))
+            elif cls == 'GlobalAveragePooling2D':
+                y = a.mean(dim=(2, 3))
+                if lc.get('keepdims'):
+                    y = y[:, :, None, None]
+            elif cls == 'GlobalMaxPooling2D':
+                y = a.amax(dim=(2, 3))
+                if lc.get('keepdims'):
+                    y = y[:, :, None, None]
+            elif cls == 'Flatten':
+                y = a.permute(0, 2, 3, 1).reshape(a.shape[0], -1) if a.dim() == 4 else a.reshape(a.shape[0], -1)
+            elif cls == 'Reshape':
+                ts = [int(v) for v in lc['target_shape']]
+                flat = a.permute(0, 2, 3, 1).reshape(a.shape[0], -1) if a.dim() == 4 else a.reshape(a.shape[0], -1)
+                if len(ts) == 1:
+                    y = flat
+                else:
+                    if len(ts) == 2:
+                        ts = ts + [1]
+                    y = flat.reshape(a.shape[0], ts[0], ts[1], ts[2]).permute(0, 3, 1, 2).contiguous()
+            elif cls == 'Dense':
+                kernel = torch.from_numpy(np.ascontiguousarray(w[0]))            # (features, units), acts on the last axis
+                bias = torch.from_numpy(np.ascontiguousarray(w[1])) if lc.get('use_bias', True) else None
+                if a.dim() == 4:
+                    y = torch.einsum('nchw,cu->nuhw', a, kernel)
+                    if bias is not None:
+                        y = y + bias.view(1, -1, 1, 1)
+                    y = _act(lc.get('activation'), y)
+                else:
+                    y = a @ kernel
+                    if bias is not None:
+                        y = y + bias
+                    y = _act(lc.get('activation'), y)
             elif cls == 'UpSampling2D':
                 sz = tuple(lc['size'])
                 if lc.get('interpolation', 'nearest') == 'nearest':
@@ -189,23 +228,27 @@ def forward(model_config, weights, x_nhwc, lambda_fns=None):
             out = vals[prev]
         else:
             out = vals[cfg['output_layers'][0][0]]
+    if out.dim() == 2:
+        return out.contiguous().numpy()
     return out.permute(0, 2, 3, 1).contiguous().numpy()
 
 
-def conv_numpy(x_nhwc, kernel_hwio, bias, padding='same'):
-    """Independent numpy float32 Conv2D (stride 1) used to cross-check the torch path on small inputs."""
+def conv_numpy(x_nhwc, kernel_hwio, bias, padding='same', stride=1):
+    """Independent numpy float32 Conv2D used to cross-check the torch path on small inputs.  'same' at stride s pads a
+    total of max((ceil(n / s) - 1) s + k - n, 0), the smaller half in front (TensorFlow's rule)."""
     x = np.asarray(x_nhwc, np.float32)
     kh, kw, ci, co = kernel_hwio.shape
+    s = int(stride)
     if padding == 'same':
-        pt, pb = _same_pad(kh, 1, x.shape[1])
-        pl, pr = _same_pad(kw, 1, x.shape[2])
+        pt, pb = _same_pad(kh, s, x.shape[1])
+        pl, pr = _same_pad(kw, s, x.shape[2])
         x = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
     N, H, W, _ = x.shape
-    Ho, Wo = H - kh + 1, W - kw + 1
+    Ho, Wo = (H - kh) // s + 1, (W - kw) // s + 1
     y = np.zeros((N, Ho, Wo, co), np.float32)
     for i in range(kh):
         for j in range(kw):
-            y += np.einsum('nhwc,co->nhwo', x[:, i:i + Ho, j:j + Wo, :], kernel_hwio[i, j]).astype(np.float32)
+            y += np.einsum('nhwc,co->nhwo', x[:, i:i + (Ho - 1) * s + 1:s, j:j + (Wo - 1) * s + 1:s, :], kernel_hwio[i, j]).astype(np.float32)
     return y + np.asarray(bias, np.float32)
 
 
@@ -276,6 +319,24 @@ def maxpool_numpy(x_nhwc, k=2, s=2):
         for b in range(k):
             out = np.maximum(out, x[:, a:a + (Ho - 1) * s + 1:s, b:b + (Wo - 1) * s + 1:s, :])
     return out
+
+
+def avgpool_numpy(x_nhwc, k=2, s=2):
+    """AveragePooling2D, 'valid' (floor)."""
+    x = np.asarray(x_nhwc, np.float32)
+    N, Hh, Ww, C = x.shape
+    Ho, Wo = (Hh - k) // s + 1, (Ww - k) // s + 1
+    out = np.zeros((N, Ho, Wo, C), np.float64)
+    for a in range(k):
+        for b in range(k):
+            out += x[:, a:a + (Ho - 1) * s + 1:s, b:b + (Wo - 1) * s + 1:s, :]
+    return (out / (k * k)).astype(np.float32)
+
+
+def dense_numpy(x, kernel, bias):
+    """Dense: acts on the last axis."""
+    y = np.asarray(x, np.float64) @ np.asarray(kernel, np.float64)
+    return (y + (0 if bias is None else np.asarray(bias, np.float64))).astype(np.float32)
 
 
 def softmax_numpy(x_nhwc):

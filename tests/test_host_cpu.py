@@ -117,7 +117,11 @@ def test_plan_rejects_what_it_cannot_lower():
     with pytest.raises(keras_plan.PlanError):
         keras_plan.build_plan(bad, w)
     bad = json.loads(json.dumps(cfg))
-    bad['config']['layers'][1]['config']['strides'] = [2, 2]
+    bad['config']['layers'][1]['config']['strides'] = [2, 1]              # (isotropic strides are lowered since r02)
+    with pytest.raises(keras_plan.PlanError):
+        keras_plan.build_plan(bad, w)
+    bad = json.loads(json.dumps(cfg))
+    bad['config']['layers'][1]['config']['dilation_rate'] = [2, 2]
     with pytest.raises(keras_plan.PlanError):
         keras_plan.build_plan(bad, w)
 
@@ -206,3 +210,19 @@ def test_bench_refuses_more_ranks_than_gpus():
                          capture_output=True, text=True, timeout=300)
     assert out.returncode != 0
     assert 'HIP device' in (out.stderr + out.stdout)
+
+
+@pytest.mark.parametrize('kind', ['interseg', 'ecseg_c'])
+def test_plan_of_classifier_graphs(kind, golden_dir):
+    """interSeg classifier call shapes (src/interseg.py:96-98): the fixtures written by h5py load through hdf5_min and
+    lower to a plan whose output is (N, K)."""
+    cfg, w = hdf5_min.load_keras_h5(os.path.join(golden_dir, '%s_synth.h5' % kind))
+    ref_cfg = synth.classifier_config(kind)
+    assert (json.loads(cfg) if isinstance(cfg, (str, bytes)) else cfg) == ref_cfg
+    plan = keras_plan.build_plan(cfg, w)
+    to, ti = plan.tensors[plan.output_tensor], plan.tensors[plan.input_tensor]
+    assert plan.output_rank == 2 and (to['h'], to['w']) == (1, 1) and to['c'] == (3 if kind == 'interseg' else 1)
+    assert (ti['h'], ti['w'], ti['c']) == ((256, 256, 1) if kind == 'interseg' else (256, 256, 3))
+    ops = [o['op'] for o in plan.ops]
+    assert keras_plan.OP_GLOBALPOOL in ops if kind == 'interseg' else keras_plan.OP_GLOBALPOOL not in ops
+    assert any(o['op'] == keras_plan.OP_CONV and o['stride'] == 2 for o in plan.ops)

@@ -185,3 +185,62 @@ def test_whole_unet_numpy_chain_matches_torch_path():
             vals[name] = y
         got = vals[cfg['config']['output_layers'][0][0]]
         assert np.abs(got - want).max() < 1e-5, (up, bn)
+
+
+def test_classifier_layers_known_answers_and_numpy_restatements():
+    """Strided Conv2D ('same' pads the smaller half in front), AveragePooling2D, global pooling, Flatten (NHWC order),
+    Reshape, Dense - the layer types of the interSeg classifiers (src/interseg.py:96-98)."""
+    # stride 2, 'same', 3x3 on 4 pixels: total pad = (2 - 1) * 2 + 3 - 4 = 1 -> 0 in front, 1 behind
+    x = np.array([1, 2, 3, 4], np.float32).reshape(1, 1, 4, 1)
+    k = np.zeros((3, 3, 1, 1), np.float32)
+    k[0, :, 0, 0] = [1, 10, 100]                      # with 1 row: pad_top = 0 (total (1-1)*2+3-1 = 2 -> 1 front?)
+    cfg = _model('Conv2D', (1, 4, 1), filters=1, kernel_size=[3, 3], strides=[2, 2], padding='same', activation='linear', use_bias=False)
+    got = unet.forward(cfg, {'L': [k]}, x)
+    assert got.shape == (1, 1, 2, 1)
+    # rows: H = 1, total pad 2 -> 1 in front: kernel row 1 sits on the data row, row 0 on padding -> all zero output
+    assert np.array_equal(got[0, 0, :, 0], [0, 0])
+    k2 = np.zeros((3, 3, 1, 1), np.float32)
+    k2[1, :, 0, 0] = [1, 10, 100]
+    got = unet.forward(cfg, {'L': [k2]}, x)
+    assert np.array_equal(got[0, 0, :, 0], [1 + 20 + 300, 3 + 40 + 0])       # windows [1,2,3] and [3,4,pad]
+    assert np.array_equal(unet.conv_numpy(x, k2, np.zeros(1), 'same', 2), got)
+    rng = np.random.default_rng(5)
+    xr = rng.normal(size=(2, 9, 11, 3)).astype(np.float32)
+    for kk, st, pad in ((3, 2, 'same'), (5, 2, 'valid'), (2, 3, 'same'), (4, 2, 'same')):
+        w = rng.normal(size=(kk, kk, 3, 4)).astype(np.float32)
+        b = rng.normal(size=4).astype(np.float32)
+        c = _model('Conv2D', (9, 11, 3), filters=4, kernel_size=[kk, kk], strides=[st, st], padding=pad, activation='linear', use_bias=True)
+        assert np.abs(unet.forward(c, {'L': [w, b]}, xr) - unet.conv_numpy(xr, w, b, pad, st)).max() < 1e-4, (kk, st, pad)
+    p = np.arange(16, dtype=np.float32).reshape(1, 4, 4, 1)
+    ap = unet.forward(_model('AveragePooling2D', (4, 4, 1), pool_size=[2, 2], strides=[2, 2], padding='valid'), {}, p)
+    assert np.array_equal(ap[0, :, :, 0], [[2.5, 4.5], [10.5, 12.5]])
+    assert np.array_equal(unet.avgpool_numpy(p), ap)
+    g = unet.forward(_model('GlobalAveragePooling2D', (4, 4, 1)), {}, p)
+    assert g.shape == (1, 1) and g[0, 0] == 7.5
+    g = unet.forward(_model('GlobalMaxPooling2D', (4, 4, 1)), {}, p)
+    assert g.shape == (1, 1) and g[0, 0] == 15
+    q = np.arange(12, dtype=np.float32).reshape(1, 2, 3, 2)                  # NHWC
+    fl = unet.forward(_model('Flatten', (2, 3, 2)), {}, q)
+    assert np.array_equal(fl, q.reshape(1, 12))                              # Keras flattens in (h, w, c) order
+    rs = unet.forward(_model('Reshape', (2, 3, 2), target_shape=[3, 2, 2]), {}, q)
+    assert np.array_equal(rs, q.reshape(1, 3, 2, 2))
+    W = np.array([[1, 10], [100, 1000]], np.float32)
+    d = unet.forward(_model('Dense', (1, 1, 2), units=2, activation='linear', use_bias=True), {'L': [W, np.array([0.5, -0.5], np.float32)]},
+                     np.array([2, 3], np.float32).reshape(1, 1, 1, 2))
+    assert np.array_equal(d.reshape(-1), [2 + 300 + 0.5, 20 + 3000 - 0.5])
+    assert np.array_equal(unet.dense_numpy([[2, 3]], W, [0.5, -0.5]).reshape(-1), d.reshape(-1))
+
+
+def test_preprocess_ecseg_c_known_answer():
+    """src/utils.py:166-173: per-channel max normalisation, quantised to 1/255 with round-half-to-even."""
+    from ecseg_amd import interseg
+    x = np.zeros((2, 2, 3), np.uint8)
+    x[..., 0] = [[0, 50], [100, 200]]
+    x[..., 1] = [[10, 10], [10, 10]]
+    x[..., 2] = [[1, 2], [3, 4]]
+    y = interseg.preprocess_ecseg_c(x)
+    assert y.dtype == np.float32
+    assert np.allclose(y[..., 0], np.rint(np.array([[0, 50], [100, 200]]) / 200 * 255) / 255)
+    assert np.allclose(y[..., 1], 1.0)
+    assert np.allclose(y[..., 2], np.rint(np.array([[1, 2], [3, 4]]) / 4 * 255) / 255)
+    assert y[0, 1, 0] == np.float32(64 / 255)                               # 63.75 -> 64

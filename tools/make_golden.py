@@ -465,33 +465,43 @@ def gen_keras_h5():
     print('keras_tiny.h5', os.path.getsize(path), 'bytes')
 
 
-def gen_metaseg_h5():
-    """A small but complete Keras-layout ``metaseg.h5`` (U-Net base 8, depth 3) written by h5py from the repo's own
-    seeded synthetic weights, so that ``make metaseg`` can be exercised end to end where h5py does not exist."""
+def write_keras_h5(path, cfg, weights):
+    """Keras-2 layout: root attr model_config (JSON), model_weights/<layer>/<layer>/<weight>:0 datasets."""
     import h5py
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
-    from ecseg_amd import synth
-    cfg = synth.unet_config(base=8, depth=3)
-    weights = synth.unet_weights(cfg, seed=11)
-    path = os.path.join(OUT, 'metaseg_synth_b8.h5')
+    wnames = {'BatchNormalization': ['gamma:0', 'beta:0', 'moving_mean:0', 'moving_variance:0']}
     with h5py.File(path, 'w') as f:
         f.attrs['keras_version'] = '2.8.0'
         f.attrs['backend'] = 'tensorflow'
         f.attrs['model_config'] = json.dumps(cfg)
         g = f.create_group('model_weights')
-        names = [l['config']['name'] for l in cfg['config']['layers']]
+        layers = cfg['config']['layers']
+        names = [l['config']['name'] for l in layers]
         g.attrs['layer_names'] = np.array([n.encode() for n in names])
         g.attrs['backend'] = 'tensorflow'; g.attrs['keras_version'] = '2.8.0'
-        for n in names:
+        for l in layers:
+            n = l['config']['name']
             lg = g.create_group(n)
             ws = weights.get(n, [])
-            wn = ['kernel:0', 'bias:0'][:len(ws)]
+            wn = wnames.get(l['class_name'], ['kernel:0', 'bias:0'])[:len(ws)]
             lg.attrs['weight_names'] = np.array([('%s/%s' % (n, w)).encode() for w in wn]) if ws else np.zeros((0,), 'S1')
             if ws:
                 sub = lg.create_group(n)
                 for w, arr in zip(wn, ws):
                     sub.create_dataset(w, data=arr)
-    print('metaseg_synth_b8.h5', os.path.getsize(path), 'bytes')
+    print(os.path.basename(path), os.path.getsize(path), 'bytes')
+
+
+def gen_metaseg_h5():
+    """A small but complete Keras-layout ``metaseg.h5`` (U-Net base 8, depth 3) written by h5py from the repo's own
+    seeded synthetic weights, so that ``make metaseg`` can be exercised end to end where h5py does not exist; and the two
+    interSeg classifier call shapes (``interseg_models/interseg``, ``interseg_models/ecseg_c``) the same way."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    from ecseg_amd import synth
+    cfg = synth.unet_config(base=8, depth=3)
+    write_keras_h5(os.path.join(OUT, 'metaseg_synth_b8.h5'), cfg, synth.unet_weights(cfg, seed=11))
+    for kind, seed in (('interseg', 21), ('ecseg_c', 22)):
+        cfg = synth.classifier_config(kind)
+        write_keras_h5(os.path.join(OUT, '%s_synth.h5' % kind), cfg, synth.classifier_weights(cfg, seed=seed))
 
 
 def gen_io():

@@ -76,26 +76,44 @@ def _cpu_worker(job):
     return raw.astype(np.uint8), post.astype(np.uint8), int(nec), t1 - t0, t2 - t1
 
 
+def _cpu_init(counter, threads):
+    """Pool initializer: give every worker its own block of cores BEFORE torch creates its thread pool (64 workers x 4
+    OpenMP threads otherwise end up bound to the same few cores and run 10x slower than one thread alone)."""
+    with counter.get_lock():
+        idx = counter.value
+        counter.value += 1
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+        mine = avail[(idx * threads) % len(avail):][:threads] or avail[:threads]
+        os.sched_setaffinity(0, set(mine))
+    except (AttributeError, OSError):
+        pass
+    os.environ['OMP_NUM_THREADS'] = str(threads)
+    os.environ['MKL_NUM_THREADS'] = str(threads)
+    import torch
+    torch.set_num_threads(threads)
+
+
 def cpu_baseline(base):
-    """(i) image-parallel workers over all host cores, one full image each; (ii) one thread on a bounded patch sample.
+    """(i) image-parallel workers over the host cores, one full image each; (ii) one thread on a bounded patch sample.
     Returns (cpu_baseline dict, single-thread dict, reference outputs for the parity check)."""
     import multiprocessing as mp
-    ncpu = os.cpu_count() or 1
-    nproc = max(1, min(64, ncpu // 4))                            # many small workers: torch's CPU convolutions scale poorly
-    threads = max(1, ncpu // nproc)                               # beyond a few threads, images are independent
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    threads = 8 if ncpu >= 16 else max(1, ncpu)
+    nproc = max(1, min(16, ncpu // threads))                       # bounded sample: at most 16 images
     ctx = mp.get_context('spawn')
-    with ctx.Pool(nproc) as pool:
+    with ctx.Pool(nproc, initializer=_cpu_init, initargs=(ctx.Value('i', 0), threads)) as pool:
         pool.map(_cpu_noop, range(nproc))                         # workers up, torch imported (untimed)
-        out = pool.map(_cpu_worker, [(base, CPU_SEED0 + i, threads, 0) for i in range(nproc)])
+        out = pool.map(_cpu_worker, [(base, CPU_SEED0 + i, threads, 0) for i in range(nproc)], chunksize=1)
         dt = max(o[3] + o[4] for o in out)                        # the workers run side by side; input synthesis is untimed
     refs = [(o[0], o[1], o[2]) for o in out]
     par = {'value': nproc / dt, 'unit': 'images/s', 'cores': nproc * threads, 'kind': 'port',
-           'sample': '%d synthetic 1040x1392 images, one per worker process (%d processes x %d torch threads), full path '
-                     '(U-Net via torch CPU fp32: %.1f s/image, stitch+argmax+meta_inference+count via numpy/scipy: %.2f '
-                     's/image), wall %.1f s' % (nproc, nproc, threads, float(np.mean([o[3] for o in out])),
-                                                float(np.mean([o[4] for o in out])), dt)}
+           'sample': '%d synthetic 1040x1392 images, one per worker process (%d processes x %d torch threads, each pinned to '
+                     'its own cores; %d host cores visible), full path (U-Net via torch CPU fp32: %.1f s/image, stitch+argmax+'
+                     'meta_inference+count via numpy/scipy: %.2f s/image), wall %.1f s'
+                     % (nproc, nproc, threads, ncpu, float(np.mean([o[3] for o in out])), float(np.mean([o[4] for o in out])), dt)}
     n_sample = 2 if base >= 64 else 6 if base >= 32 else 18
-    with ctx.Pool(1) as pool:
+    with ctx.Pool(1, initializer=_cpu_init, initargs=(ctx.Value('i', 0), 1)) as pool:
         pool.map(_cpu_noop, [0])
         o = pool.map(_cpu_worker, [(base, CPU_SEED0, 1, n_sample)])[0]
     t_img = o[3] * 35.0 / n_sample + o[4]

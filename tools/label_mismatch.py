@@ -50,10 +50,13 @@ def _worker(job):
 
 def cpu_refs(base, wpath, n):
     import multiprocessing as mp
-    ncpu = os.cpu_count() or 1
-    nproc = max(1, min(64, ncpu // 4, n))
-    with mp.get_context('spawn').Pool(nproc) as pool:
-        return pool.map(_worker, [(base, wpath, SEED0 + i, max(1, min(8, ncpu // nproc))) for i in range(n)], chunksize=1)
+    import bench
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    threads = 8 if ncpu >= 16 else max(1, ncpu)
+    nproc = max(1, min(32, ncpu // threads, n))
+    ctx = mp.get_context('spawn')
+    with ctx.Pool(nproc, initializer=bench._cpu_init, initargs=(ctx.Value('i', 0), threads)) as pool:
+        return pool.map(_worker, [(base, wpath, SEED0 + i, threads) for i in range(n)], chunksize=1)
 
 
 def device_modes(base, weights, n, refs):

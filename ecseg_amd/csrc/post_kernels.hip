@@ -41,7 +41,7 @@ __device__ __forceinline__ int key_of(uint8_t v, uint32_t lut) {
 // reduce_g_kernel folds the replicas into replica 0, which is what every consumer reads.
 enum { G_NCOMP = 0 /*[4]*/, G_NPX = 4 /*[4]*/, G_LAST_ROOT = 8, G_NLIST1 = 9, G_NLIST2 = 10,
        G_CNT0 = 12 /* [8] generic root counters */, G_OTSU_INV = 20 };
-enum { NEED_NCOMP = 1, NEED_NPX = 2, NEED_LAST = 4 };
+enum { NEED_NCOMP = 1, NEED_NPX = 2, NEED_LAST = 4, NEED_LISTS = 8 };
 static constexpr int G_IMG = G_STRIDE * G_SHARDS;     // ints per image
 
 // aux modes of ccl_flatten: which per-pixel bits are OR-ed into the root's flag word
@@ -259,9 +259,10 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8
                                                           u64* __restrict__ sumy_all, u64* __restrict__ sumx_all,
                                                           uint32_t* __restrict__ flag_all, int32_t* __restrict__ G_all,
                                                           int stat, int aux_mode, int aux_c,
-                                                          const uint8_t* __restrict__ aux_img, int need) {
+                                                          const uint8_t* __restrict__ aux_img, int need,
+                                                          int32_t* __restrict__ list1, int32_t* __restrict__ list2, size_t list_cap) {
     constexpr int TP = CCL_BLOCK_ROWS * 64;                    // pixels per tile
-    __shared__ int red[16];                                    // ncomp[1..3], npx[1..3], -, -, last root (64 B keeps the dynamic LDS base 16-B aligned)
+    __shared__ int red[16];                                    // ncomp[1..3], npx[1..3], -, -, last root, list counts [9..10], list bases [11..12] (64 B keeps the dynamic LDS base 16-B aligned)
     __shared__ int groot_s[TP];                                // tile root -> global root
     __shared__ uint32_t area_s[TP];
     __shared__ uint32_t flag_s[TP];
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8
     int img, y0, cx;
     if (!decode_block(g, img, y0, cx)) return;                 // block-uniform
     const int tid = threadIdx.x;
-    if (tid < 9) red[tid] = 0;
+    if (tid < 16) red[tid] = 0;
     if (tid < TP / 32) used_s[tid] = 0u;
     for (int i = tid; i < TP; i += 256) {
         area_s[i] = 0u; flag_s[i] = 0u;
@@ -351,6 +352,9 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8
     // ---- B: slot owners (tile roots) resolve their global root and forward the slot's sums ----
     int ncomp[4] = {0, 0, 0, 0};
     int last_root = 0;
+    int16_t lslot[CCL_ROWS];                                   // (class << 12 | index inside the block's range), -1 = none
+#pragma unroll
+    for (int r = 0; r < CCL_ROWS; ++r) lslot[r] = -1;
 #pragma unroll
     for (int r = 0; r < CCL_ROWS; ++r) {
         const int li = (wave * CCL_ROWS + r) * 64 + lane;
@@ -364,9 +368,26 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8
         if (gr == p) {                                         // a global root lives in this tile
             if (need & NEED_NCOMP) ncomp[key_of(im[p], lut) & 3] += 1;
             last_root = max(last_root, p + 1);
+            if (need & NEED_LISTS) {                           // roots of class 1 / 2 go to the per-image lists (nucleus test)
+                const uint8_t v = im[p];
+                if (v == 1 || v == 2) lslot[r] = (int16_t)((v << 12) | atomicAdd(&red[8 + v], 1));
+            }
         }
     }
     __syncthreads();
+    if (need & NEED_LISTS) {
+        // one global atomic per workgroup and class reserves the block's range in the image's list
+        if (tid < 2 && red[9 + tid]) red[11 + tid] = atomicAdd(G_all + (size_t)img * G_IMG + (tid == 0 ? G_NLIST1 : G_NLIST2), red[9 + tid]);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < CCL_ROWS; ++r) {
+            if (lslot[r] < 0) continue;
+            const int v = lslot[r] >> 12, k = lslot[r] & 0xfff;
+            const int p = (y0 + r) * W + x;
+            if (v == 1) list1[(size_t)img * list_cap + red[11] + k] = p;
+            else list2[((size_t)img * list_cap + red[12] + k) * 4] = p;      // first word of the chromosome's centroid slot
+        }
+    }
     // ---- C: every pixel takes its component's global root ----
 #pragma unroll
     for (int r = 0; r < CCL_ROWS; ++r) {
@@ -455,6 +476,9 @@ struct CclPass {
     const uint8_t* aux_img;
     int need;      // NEED_* counters this pass has to produce
     bool count_only = false;   // only NEED_NCOMP | NEED_NPX are wanted: count roots instead of flattening
+    int32_t* list1 = nullptr;  // NEED_LISTS: per-image lists of class-1 roots / class-2 roots (first word of 16-byte slots)
+    int32_t* list2 = nullptr;
+    size_t list_cap = 0;
 };
 
 static hipError_t run_ccl_pass(PostWorkspace& ws, const CclGeom& g, const CclPass& c, hipStream_t s) {
@@ -477,7 +501,7 @@ static hipError_t run_ccl_pass(PostWorkspace& ws, const CclGeom& g, const CclPas
     }
     const size_t dyn = (c.stat & STAT_SUMS) ? (size_t)CCL_BLOCK_ROWS * 64 * 16 : 0;
     hipLaunchKernelGGL(ccl_flatten_kernel, dim3(grid), dim3(256), dyn, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy,
-                       ws.sumx, ws.flag, ws.g, c.stat, c.aux_mode, c.aux_c, c.aux_img, c.need);
+                       ws.sumx, ws.flag, ws.g, c.stat, c.aux_mode, c.aux_c, c.aux_img, c.need, c.list1, c.list2, c.list_cap);
     if (c.need) hipLaunchKernelGGL(reduce_g_kernel, dim3(g.n_img), dim3(G_STRIDE), 0, s, ws.g, g.n_img);
     return hipGetLastError();
 }
@@ -618,48 +642,19 @@ __global__ __launch_bounds__(256) void stencil4_kernel(const uint8_t* __restrict
     }
 }
 
-// Roots of class-1 and class-2 components -> compact per-image lists (nucleus root indices; chromosome centroids).
-__global__ __launch_bounds__(256) void compact_roots_kernel(const uint8_t* __restrict__ img, const int32_t* __restrict__ L,
-                                                            const uint32_t* __restrict__ area, const u64* __restrict__ sumy,
-                                                            const u64* __restrict__ sumx, int32_t* __restrict__ G_all,
-                                                            int32_t* __restrict__ list1, double2* __restrict__ list2,
-                                                            size_t total, size_t px, size_t cap) {
-    // grid-stride in whole waves so that the ballots below see full wavefronts; one atomic per wave and class
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const int lane = threadIdx.x & 63;
-    for (size_t t0 = (size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); t0 < total; t0 += stride) {
-        const size_t t = t0 + lane;
-        int cls = 0;
-        size_t im = 0;
-        int p = 0;
-        if (t < total) {
-            im = t / px;
-            p = (int)(t - im * px);
-            if (L[t] == p) { const uint8_t v = img[t]; cls = (v == 1) ? 1 : (v == 2 ? 2 : 0); }
-        }
-        const size_t im0 = t0 / px;                              // image of lane 0; a wave may straddle two images
-#pragma unroll
-        for (int c = 1; c <= 2; ++c) {
-#pragma unroll
-            for (int side = 0; side < 2; ++side) {
-                const bool mine = cls == c && ((im == im0) == (side == 0));
-                const u64 m = __ballot(mine);
-                if (!m) continue;
-                const int leader = __ffsll((long long)m) - 1;
-                int basek = 0;
-                if (lane == leader)
-                    basek = atomicAdd(G_all + im * G_IMG + (c == 1 ? G_NLIST1 : G_NLIST2), __popcll(m));
-                basek = __shfl(basek, leader, 64);
-                if (mine) {
-                    const int k = basek + __popcll(m & ((1ull << lane) - 1ull));
-                    if (c == 1) list1[im * cap + k] = p;
-                    else {
-                        const double a = (double)area[t];
-                        list2[im * cap + k] = make_double2((double)sumy[t] / a, (double)sumx[t] / a);   // regionprops centroid
-                    }
-                }
-            }
-        }
+// The class-2 root indices that ccl_flatten appended (first word of every 16-byte slot) become regionprops centroids
+// (mean of the pixel coordinates, float64) in place.
+__global__ __launch_bounds__(256) void centroids_kernel(const uint32_t* __restrict__ area, const u64* __restrict__ sumy,
+                                                        const u64* __restrict__ sumx, const int32_t* __restrict__ G_all,
+                                                        double2* __restrict__ list2, size_t px, size_t cap) {
+    const int im = blockIdx.y;
+    const int n2 = G_all[(size_t)im * G_IMG + G_NLIST2];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n2; k += gridDim.x * blockDim.x) {
+        double2* slot = list2 + (size_t)im * cap + k;
+        const int root = *reinterpret_cast<const int32_t*>(slot);
+        const size_t t = (size_t)im * px + root;
+        const double a = (double)area[t];
+        *slot = make_double2((double)sumy[t] / a, (double)sumx[t] / a);
     }
 }
 
@@ -808,13 +803,13 @@ hipError_t run_meta_inference(PostWorkspace& ws, uint8_t* img, int n_img, int H,
     else hipLaunchKernelGGL(band_removal_kernel, dim3(pg), dim3(256), 0, s, img, cur, total, H, W);
     // 6. nucleus-in-metaphase test
     {
-        CclPass p{cur, LUT_MULTI, 8, STAT_AREA | STAT_SUMS, AUX_NONE, 0, nullptr, 0};
-        if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
         const size_t cap = px / 4 + (size_t)(H + W) / 2 + 4;
         int32_t* list1 = ws.list;
         double2* list2 = reinterpret_cast<double2*>(ws.list + (((size_t)n_img * cap + 3) & ~(size_t)3));
-        hipLaunchKernelGGL(compact_roots_kernel, dim3(pg), dim3(256), 0, s, cur, ws.L, ws.area, ws.sumy, ws.sumx, ws.g,
-                           list1, list2, total, px, cap);
+        CclPass p{cur, LUT_MULTI, 8, STAT_AREA | STAT_SUMS, AUX_NONE, 0, nullptr, NEED_LISTS};
+        p.list1 = list1; p.list2 = reinterpret_cast<int32_t*>(list2); p.list_cap = cap;
+        if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(centroids_kernel, dim3(8, n_img), dim3(256), 0, s, ws.area, ws.sumy, ws.sumx, ws.g, list2, px, cap);
         const int bpi = 32;
         hipLaunchKernelGGL(nucleus_test_kernel, dim3(n_img * bpi), dim3(256), 0, s, ws.area, ws.sumy, ws.sumx, ws.g, list1,
                            list2, ws.flag, px, cap, bpi, 70.0, 5);

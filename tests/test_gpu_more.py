@@ -129,3 +129,45 @@ def test_input_normalisation_lambdas(gpu):
         gpu.load_plan(keras_plan.build_plan(cfg, weights, lambda_overrides={'lambda': (1 / 255.0, 0.0)}))
         got = gpu.forward_patches(x)
         assert np.abs(got - want).max() < 1e-5, kind
+
+
+def test_preprocess_on_second_source_otsu_fixtures(gpu, golden_dir):
+    """Device meta_preprocess on the skimage-pinned Otsu fixtures (tests/golden/otsu_skimage.npz) and the hand-computed
+    convertScaleAbs answers: same result as the oracle, image by image."""
+    import os
+    from oracle import preprocess
+    z = np.load(os.path.join(golden_dir, 'otsu_skimage.npz'))
+    n = len([k for k in z.files if k.startswith('img_')])
+    for k in range(n):
+        im = z['img_%02d' % k]
+        gray, inv = gpu.preprocess(im[None])
+        want = preprocess.meta_preprocess(im)
+        assert np.array_equal(gray[0], want), k
+        assert bool(inv[0]) == (not np.array_equal(want, im))
+    x = np.array([0, 1, 128, 129, 257, 32767, 32768, 32896, 65534, 65535], np.uint16)
+    assert gpu.u16_to_u8(x).tolist() == [0, 0, 0, 1, 1, 127, 128, 128, 255, 255]
+
+
+def test_edge_cases_empty_small_and_large_images(gpu):
+    """Empty batches are no-ops, images smaller than one 256x256 window are rejected as by the reference (which crashes on
+    them), and a 2304x2304 image (121 windows: the launch group shrinks to keep the activation memory bounded) goes through
+    with the same invariants as any other size."""
+    from ecseg_amd import keras_plan
+    from ecseg_amd._lib import EcsegError
+    from oracle import postproc
+    cfg = synth.unet_config(base=16, depth=2)
+    gpu.load_plan(keras_plan.build_plan(cfg, synth.unet_weights(cfg, seed=4)))
+    raw, post, nec = gpu.segment_images(np.zeros((0, 300, 300), np.uint8))
+    assert post.shape == (0, 300, 300) and nec.shape == (0,)
+    assert gpu.forward_patches(np.zeros((0, 256, 256, 1), np.uint8)).shape[0] == 0
+    assert gpu.count_cc(np.zeros((0, 8, 8), np.uint8))[0].shape == (0,)
+    with pytest.raises(EcsegError):
+        gpu.segment_images(np.zeros((1, 200, 300), np.uint8))
+    big = np.stack([synth.dapi_image(70 + i, 2304, 2304) for i in range(2)])
+    raw, post, nec = gpu.segment_images(big, want_raw=True)
+    for i in range(2):
+        want = postproc.meta_inference(raw[i])
+        assert np.array_equal(post[i], want)
+        assert nec[i] == postproc.count_cc(want == 3)[0]
+    one = gpu.segment_images(big[1:2], want_raw=True)
+    assert np.array_equal(one[0][0], raw[1]) and np.array_equal(one[1][0], post[1])

@@ -97,3 +97,40 @@ def test_overlay_rows_and_csv(golden_dir):
         assert overlay.csv_text(overlay.OVERLAY_COLUMNS, [['img%02d.tif' % k] + got]) == want['csv'], k
     c = json.load(open(os.path.join(golden_dir, 'csv_text.json')))
     assert overlay.csv_text(overlay.METASEG_COLUMNS, c['metaseg_rows']) == c['metaseg']
+
+
+def test_otsu_against_skimage_second_source(golden_dir):
+    """A3/A4 (OpenCV, PARITY UNPINNED): the Otsu restatement agrees with scikit-image's independent implementation of the
+    same criterion - threshold within one grey level (the two break flat maxima differently), identical '> 50 % white'
+    decision wherever that decision does not hinge on the one ambiguous level."""
+    from oracle import preprocess
+    z = np.load(os.path.join(golden_dir, 'otsu_skimage.npz'))
+    n = len([k for k in z.files if k.startswith('img_')])
+    assert n >= 26
+    for k in range(n):
+        im = z['img_%02d' % k]
+        t = preprocess.otsu_threshold_u8(im)
+        assert abs(t - int(z['thr_%02d' % k])) <= 1, (k, t, int(z['thr_%02d' % k]))
+        white = int(np.count_nonzero(im > t))
+        half = im.size * 0.5
+        if (white > half) != (int(z['white_%02d' % k]) > half):
+            lo, hi = sorted((white, int(z['white_%02d' % k])))
+            assert lo <= half <= hi                                    # only possible when the two thresholds differ
+        inv = preprocess.meta_preprocess(im)
+        assert np.array_equal(inv, ~im if white > half else im)
+
+
+def test_convert_scale_abs_known_answers():
+    """cv2.convertScaleAbs(u16, alpha = 255/65535): |x * alpha| in float32, cvRound (half to even), saturate to uint8 -
+    values worked out by hand from that definition."""
+    from oracle import preprocess
+    x = np.array([0, 1, 128, 129, 257, 32767, 32768, 32896, 65534, 65535], np.uint16)
+    a = np.float32(255.0 / 65535.0)
+    want = [0, 0, 0, 1, 1, 127, 128, 128, 255, 255]
+    # 128 * a = 0.49805 -> 0; 129 * a = 0.50194 -> 1; 257 * a = 1.0000 -> 1; 32767 * a = 127.498 -> 127;
+    # 32768 * a = 127.502 -> 128; 32896 * a = 128.0 -> 128
+    got = preprocess.u16_to_u8(x)
+    assert got.dtype == np.uint8 and got.tolist() == want
+    assert [int(np.rint(np.float32(v) * a)) for v in x.tolist()] == want
+    u8 = np.arange(256, dtype=np.uint8)
+    assert preprocess.u16_to_u8(u8) is u8                              # non-uint16 passes through (src/image_tools.py:99)

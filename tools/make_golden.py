@@ -592,9 +592,36 @@ def gen_io():
     print('io: label PNG colours', rgba[0, :4].tolist())
 
 
+def gen_otsu():
+    """meta_preprocess's only data-dependent decision is ``sum(otsu(img)) > 0.5 H W`` (src/image_tools.py:91-95).  OpenCV
+    is not installed anywhere; scikit-image's ``threshold_otsu`` (an independent implementation of the same published
+    criterion, 256 bins on uint8) gives second-source thresholds + decisions for seeded images, stored as data."""
+    from skimage.filters import threshold_otsu
+    rng = np.random.default_rng(21)
+    imgs = []
+    for k in range(24):
+        H, W = int(rng.integers(40, 90)), int(rng.integers(40, 90))
+        bg, fg = int(rng.integers(0, 120)), int(rng.integers(130, 256))
+        frac = [0.1, 0.3, 0.45, 0.55, 0.7, 0.9][k % 6]
+        m = rng.random((H, W)) < frac
+        img = np.where(m, rng.normal(fg, 12, (H, W)), rng.normal(bg, 8, (H, W)))
+        imgs.append(np.clip(np.rint(img), 0, 255).astype(np.uint8))
+    d = np.load(os.path.join(OUT, 'dapi_example.npz'))['dapi']
+    imgs += [d[::4, ::4].copy(), (255 - d)[::4, ::4].copy()]
+    pack = {}
+    for k, im in enumerate(imgs):
+        t = int(threshold_otsu(im))                               # foreground = img > t, as cv2.THRESH_BINARY
+        pack['img_%02d' % k] = im
+        pack['thr_%02d' % k] = np.int64(t)
+        pack['white_%02d' % k] = np.int64(np.count_nonzero(im > t))
+    np.savez_compressed(os.path.join(OUT, 'otsu_skimage.npz'), **pack)
+    print('otsu: %d images' % len(imgs))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['tiling', 'quant', 'meta', 'counting', 'overlay', 'h5', 'metaseg_h5', 'io']
+    which = sys.argv[1:] or ['tiling', 'quant', 'meta', 'counting', 'overlay', 'h5', 'metaseg_h5', 'io', 'otsu']
     if 'io' in which: gen_io()
+    if 'otsu' in which: gen_otsu()
     if 'metaseg_h5' in which: gen_metaseg_h5()
     if 'tiling' in which: gen_tiling()
     if 'quant' in which: gen_quant()

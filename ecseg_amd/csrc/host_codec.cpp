@@ -10,36 +10,24 @@
 extern "C" {
 
 // Decodes one LZW strip.  Returns the number of bytes written (<= dst_cap) or -1 on a corrupt stream.
+// Every table entry is remembered as (offset, length) of an occurrence of its string in the OUTPUT written so far: the
+// string of a new entry (previous string + first byte of the current one) starts where the previous code was emitted,
+// so emitting a code is one forward copy from earlier output instead of a backward walk along a prefix chain.
 long long ecseg_lzw_decode(const uint8_t* src, long long n, uint8_t* dst, long long dst_cap) {
     if (!src || !dst || n < 0 || dst_cap < 0) return -1;
-    struct Entry { int32_t prefix; uint16_t len; uint8_t first, last; };
-    std::vector<Entry> tab(4096);
-    for (int i = 0; i < 256; ++i) tab[i] = Entry{-1, 1, (uint8_t)i, (uint8_t)i};
+    struct Entry { long long pos; int32_t len; };      // pos < 0: a literal byte (codes 0..255)
+    Entry tab[4096];
+    for (int i = 0; i < 256; ++i) tab[i] = Entry{-1, 1};
     int next = 258, width = 9;
     long long out = 0;
     uint64_t acc = 0;
     int nbits = 0;
     long long pos = 0;
     int old = -1;
-    auto emit = [&](int code) -> bool {
-        const int len = tab[code].len;
-        if (out + len > dst_cap) {               // truncated output buffer: write what fits
-            // walk and write the tail-limited part
-            int c = code;
-            long long p = out + len - 1;
-            while (c >= 0) { if (p < dst_cap) dst[p] = tab[c].last; --p; c = tab[c].prefix; }
-            out = dst_cap;
-            return false;
-        }
-        int c = code;
-        long long p = out + len - 1;
-        while (c >= 0) { dst[p--] = tab[c].last; c = tab[c].prefix; }
-        out += len;
-        return true;
-    };
+    long long old_pos = 0;                              // where the previous code's string starts in dst
     for (;;) {
         while (nbits < width) {
-            if (pos >= n) return out;            // stream ended without EOI: accept what we have
+            if (pos >= n) return out;                   // stream ended without EOI: accept what we have
             acc = (acc << 8) | src[pos++];
             nbits += 8;
         }
@@ -49,22 +37,31 @@ long long ecseg_lzw_decode(const uint8_t* src, long long n, uint8_t* dst, long l
         if (code == 256) { next = 258; width = 9; old = -1; continue; }
         if (old < 0) {
             if (code >= 256) return -1;
-            if (!emit(code)) return out;
+            if (out >= dst_cap) return out;             // truncated output buffer: write what fits
+            old_pos = out;
+            dst[out++] = (uint8_t)code;
             old = code;
             continue;
         }
+        const int old_len = tab[old].len;
+        long long cpos; int clen;                       // the string of `code`
         if (code < next) {
             if (code >= 256 && code < 258) return -1;
-            if (next < 4096) { tab[next] = Entry{old, (uint16_t)(tab[old].len + 1), tab[old].first, tab[code].first}; ++next; }
-            if (!emit(code)) return out;
-        } else if (code == next && next < 4096) {
-            tab[next] = Entry{old, (uint16_t)(tab[old].len + 1), tab[old].first, tab[old].first};
-            ++next;
-            if (!emit(code)) return out;
+            cpos = tab[code].pos; clen = tab[code].len;
+        } else if (code == next && next < 4096) {      // KwKwK: previous string + its own first byte
+            cpos = old_pos; clen = old_len + 1;
         } else {
             return -1;
         }
-        old = code;
+        const long long start = out;
+        const long long room = dst_cap - out;
+        const int ncopy = (long long)clen <= room ? clen : (int)room;
+        if (cpos < 0) { if (ncopy > 0) dst[out] = (uint8_t)code; }
+        else for (int k = 0; k < ncopy; ++k) dst[out + k] = dst[cpos + k];     // may overlap forward (KwKwK): byte by byte
+        out += ncopy;
+        if (next < 4096) { tab[next] = Entry{old_pos, old_len + 1}; ++next; }   // previous string + first byte of this one
+        if (ncopy < clen) return out;                   // destination full
+        old = code; old_pos = start;
         if (next >= (1 << width) - 1 && width < 12) ++width;   // early change
     }
     return out;

@@ -243,7 +243,7 @@ def write_tiff_gray8(path, img):
         f.write(struct.pack('<H', len(entries)) + b''.join(entries) + struct.pack('<I', 0))
 
 
-def write_png(path, img):
+def write_png(path, img, level=6):
     """8-bit PNG: (H, W) gray, (H, W, 3) RGB or (H, W, 4) RGBA."""
     img = np.ascontiguousarray(img, np.uint8)
     if img.ndim == 2:
@@ -255,21 +255,32 @@ def write_png(path, img):
     else:
         raise ValueError('unsupported PNG shape %s' % (img.shape,))
     H, W = img.shape[:2]
-    rows = np.zeros((H, 1 + W * ch), np.uint8)           # filter type 0 on every scan line
+    rows = np.empty((H, 1 + W * ch), np.uint8)           # filter type 0 on every scan line
+    rows[:, 0] = 0
     rows[:, 1:] = img.reshape(H, W * ch)
 
     def chunk(tag, data):
-        return struct.pack('>I', len(data)) + tag + data + struct.pack('>I', zlib.crc32(tag + data) & 0xffffffff)
+        return struct.pack('>I', len(data)) + tag + data + struct.pack('>I', zlib.crc32(data, zlib.crc32(tag)) & 0xffffffff)
 
     with open(path, 'wb') as f:
         f.write(b'\x89PNG\r\n\x1a\n')
         f.write(chunk(b'IHDR', struct.pack('>IIBBBBB', W, H, 8, ctype, 0, 0, 0)))
-        f.write(chunk(b'IDAT', zlib.compress(rows.tobytes(), 6)))
+        f.write(chunk(b'IDAT', zlib.compress(rows, level)))          # (zlib takes the buffer directly: no tobytes copy)
         f.write(chunk(b'IEND', b''))
+
+
+_LABEL_COLORS_U32 = None
 
 
 def write_label_png(path, labels):
     """``plt.imsave(path, I.astype('uint8'), cmap=ListedColormap([...4 colours...]), vmin=0, vmax=4)``
-    (src/metaseg.py:47-52): class k -> colour k, RGBA."""
+    (src/metaseg.py:47-52): class k -> colour k, RGBA.  The four colours compress to almost nothing at any zlib level;
+    level 1 keeps the encoder off the critical path of `make metaseg` (pixels, not bytes, are the contract)."""
+    global _LABEL_COLORS_U32
+    if _LABEL_COLORS_U32 is None:
+        _LABEL_COLORS_U32 = np.ascontiguousarray(LABEL_COLORS).view('<u4').ravel().copy()
     lab = np.asarray(labels)
-    write_png(path, LABEL_COLORS[np.clip(lab, 0, 3).astype(np.intp)])
+    if lab.dtype != np.uint8:
+        lab = np.clip(lab, 0, 3).astype(np.uint8)
+    rgba = np.take(_LABEL_COLORS_U32, lab, mode='clip')              # one 32-bit gather per pixel
+    write_png(path, rgba.view(np.uint8).reshape(lab.shape[0], lab.shape[1], 4), level=1)

@@ -1,4 +1,6 @@
-"""Timing of conv_wino4_kernel on a few layer shapes; run once per ECSEG_W4_ABL value (timing-only ablations)."""
+"""Timing of conv_wino4_kernel on a few layer shapes; run once per ECSEG_W4_ABL value (timing-only ablations).
+Needs the diagnostic build: `bash tools/build_variants.sh diag` and `ECSEG_HIP_LIB=.../ecseg_amd/libecseg_diag.so` (the
+shipped library contains no ablation kernels and ignores ECSEG_W4_ABL)."""
 import os
 import sys
 

@@ -1,4 +1,5 @@
-"""In-kernel cycle stamps of conv_wino4_kernel (run with ECSEG_W4_ABL=100): per wave and 8-channel group, the cycles
+"""In-kernel cycle stamps of conv_wino4_kernel (run with ECSEG_W4_ABL=100 on the diagnostic build: `bash
+tools/build_variants.sh diag`, `ECSEG_HIP_LIB=.../ecseg_amd/libecseg_diag.so`): per wave and 8-channel group, the cycles
 spent in each phase of the main loop, for one workgroup in the middle of the grid."""
 import os
 import sys

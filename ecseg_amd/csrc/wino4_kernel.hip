@@ -88,7 +88,19 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
     const int li = lane & 31, lh = lane >> 5;
 
     unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int pair = (int)(bid % (unsigned)npairs), nb = (int)(bid / (unsigned)npairs);
+    // Block order: output-channel blocks in groups of G = 4 (2) next to each other, region pairs next, groups slowest.  The
+    // workgroups running together on an XCD then share each input halo in L2 between G of them and keep only G filter
+    // slabs streaming (spatial position fastest alone re-read the input Cout / 64 times from the Infinity Cache: 11-13x
+    // the algorithmic bytes on the Cin = 1024 layers; channel block fastest alone streams Cout / 64 slabs at once): +1.4 %.
+#if W4_VARIANT == 44
+    const unsigned G = 1u;
+#else
+    const unsigned nblk_all = gridDim.x / (unsigned)npairs;
+    const unsigned G = (nblk_all & 3u) == 0 ? 4u : (nblk_all & 1u) == 0 ? 2u : 1u;
+#endif
+    const unsigned lo = bid % G, rest = bid / G;
+    const int pair = (int)(rest % (unsigned)npairs);
+    const int nb = (int)((rest / (unsigned)npairs) * G + lo);
     const int H = p.in.h, W = p.in.w;                        // output extent == input extent
     const int ngroups = p.cin_chunks;                        // 8 input channels each
     const int nstages = 2 * ngroups;

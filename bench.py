@@ -76,6 +76,25 @@ def _cpu_worker(job):
     return raw.astype(np.uint8), post.astype(np.uint8), int(nec), t1 - t0, t2 - t1
 
 
+def host_cpu_budget():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (a 256-core box inside a
+    16-CPU quota runs 16 busy processes at full speed and 64 at a quarter of it)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        q = open('/sys/fs/cgroup/cpu.max').read().split()                  # cgroup v2: "<quota|max> <period>"
+        if q[0] != 'max':
+            n = min(n, max(1, int(int(q[0]) / int(q[1]))))
+    except (OSError, ValueError, IndexError):
+        try:
+            quota = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def _cpu_init(counter, threads):
     """Pool initializer: give every worker its own block of cores BEFORE torch creates its thread pool (64 workers x 4
     OpenMP threads otherwise end up bound to the same few cores and run 10x slower than one thread alone)."""
@@ -98,9 +117,12 @@ def cpu_baseline(base):
     """(i) image-parallel workers over the host cores, one full image each; (ii) one thread on a bounded patch sample.
     Returns (cpu_baseline dict, single-thread dict, reference outputs for the parity check)."""
     import multiprocessing as mp
-    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    threads = 8 if ncpu >= 16 else max(1, ncpu)
-    nproc = max(1, min(16, ncpu // threads))                       # bounded sample: at most 16 images
+    ncpu = host_cpu_budget()
+    # one single-threaded worker per usable core, one image each: measured on the MI355X boxes of this pool
+    # (tools/cpu_scale_probe.py) torch's CPU convolutions lose throughput with more threads per worker (16 x 8 threads:
+    # 0.38 images/s, 16 x 1: 0.74) and the container's CPU quota ends the scaling near 16 busy workers (64 x 1: 0.52)
+    threads = 1
+    nproc = max(1, min(16, ncpu))                                 # bounded sample: at most 16 images
     ctx = mp.get_context('spawn')
     with ctx.Pool(nproc, initializer=_cpu_init, initargs=(ctx.Value('i', 0), threads)) as pool:
         pool.map(_cpu_noop, range(nproc))                         # workers up, torch imported (untimed)
@@ -109,7 +131,7 @@ def cpu_baseline(base):
     refs = [(o[0], o[1], o[2]) for o in out]
     par = {'value': nproc / dt, 'unit': 'images/s', 'cores': nproc * threads, 'kind': 'port',
            'sample': '%d synthetic 1040x1392 images, one per worker process (%d processes x %d torch threads, each pinned to '
-                     'its own cores; %d host cores visible), full path (U-Net via torch CPU fp32: %.1f s/image, stitch+argmax+'
+                     'its own cores; CPU budget of this container: %d), full path (U-Net via torch CPU fp32: %.1f s/image, stitch+argmax+'
                      'meta_inference+count via numpy/scipy: %.2f s/image), wall %.1f s'
                      % (nproc, nproc, threads, ncpu, float(np.mean([o[3] for o in out])), float(np.mean([o[4] for o in out])), dt)}
     n_sample = 2 if base >= 64 else 6 if base >= 32 else 18

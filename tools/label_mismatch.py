@@ -51,9 +51,8 @@ def _worker(job):
 def cpu_refs(base, wpath, n):
     import multiprocessing as mp
     import bench
-    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    threads = 8 if ncpu >= 16 else max(1, ncpu)
-    nproc = max(1, min(32, ncpu // threads, n))
+    threads = 1
+    nproc = max(1, min(16, bench.host_cpu_budget(), n))
     ctx = mp.get_context('spawn')
     with ctx.Pool(nproc, initializer=bench._cpu_init, initargs=(ctx.Value('i', 0), threads)) as pool:
         return pool.map(_worker, [(base, wpath, SEED0 + i, threads) for i in range(n)], chunksize=1)

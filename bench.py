@@ -16,10 +16,11 @@ Rank 0 prints ONE JSON line.  The workload is BASELINE.json configs[1] (single-G
 canonical classic U-Net (base width 64, 23 conv layers, 96.2 GFLOP per 256x256 patch), random-initialised with a fixed
 seed because metaseg.h5 is not distributable.
 
-Order of work at N = 1: (1) the CPU baseline legs run FIRST, in worker processes, before this process touches the
-GPU (nothing competes with the timed GPU region and no process is started after HIP is initialised); (2) the timed GPU
-region; (3) a host-inclusive leg (host arrays in, labels + counts back on the host); (4) full-size parity of the device
-results against the CPU results of (1).
+Order of work at N = 1: (1) the CPU-baseline worker processes are STARTED (idle) before this process touches the GPU - no
+process is ever created after HIP is initialised; (2) the timed GPU region; (3) a host-inclusive leg (host arrays in,
+labels + counts back on the host); (4) the CPU baseline legs on the waiting workers (after the GPU timing: 20 s of
+all-core CPU load right before it cost 1.5 - 3 % of the GPU number); (5) full-size parity of the device results against
+the CPU results of (4).
 """
 import argparse
 import json
@@ -113,9 +114,10 @@ def _cpu_init(counter, threads):
     torch.set_num_threads(threads)
 
 
-def cpu_baseline(base):
-    """(i) image-parallel workers over the host cores, one full image each; (ii) one thread on a bounded patch sample.
-    Returns (cpu_baseline dict, single-thread dict, reference outputs for the parity check)."""
+def cpu_pools_start():
+    """Start the CPU-baseline worker processes (idle until used).  Called BEFORE this process initialises HIP: no process
+    is ever created from a process that has touched the GPU; the CPU legs themselves run after the timed GPU region so
+    that 20 s of all-core CPU load do not precede it (measured: -1.5 ... -3 % on the GPU number otherwise)."""
     import multiprocessing as mp
     ncpu = host_cpu_budget()
     # one single-threaded worker per usable core, one image each: measured on the MI355X boxes of this pool
@@ -124,10 +126,17 @@ def cpu_baseline(base):
     threads = 1
     nproc = max(1, min(16, ncpu))                                 # bounded sample: at most 16 images
     ctx = mp.get_context('spawn')
-    with ctx.Pool(nproc, initializer=_cpu_init, initargs=(ctx.Value('i', 0), threads)) as pool:
-        pool.map(_cpu_noop, range(nproc))                         # workers up, torch imported (untimed)
-        out = pool.map(_cpu_worker, [(base, CPU_SEED0 + i, threads, 0) for i in range(nproc)], chunksize=1)
-        dt = max(o[3] + o[4] for o in out)                        # the workers run side by side; input synthesis is untimed
+    pool = ctx.Pool(nproc, initializer=_cpu_init, initargs=(ctx.Value('i', 0), threads))
+    pool.map(_cpu_noop, range(nproc))                             # workers up, torch imported (untimed)
+    return {'pool': pool, 'nproc': nproc, 'threads': threads, 'ncpu': ncpu}
+
+
+def cpu_baseline(base, pools):
+    """(i) image-parallel workers over the host cores, one full image each; (ii) one thread on a bounded patch sample.
+    Returns (cpu_baseline dict, single-thread dict, reference outputs for the parity check)."""
+    pool, nproc, threads, ncpu = pools['pool'], pools['nproc'], pools['threads'], pools['ncpu']
+    out = pool.map(_cpu_worker, [(base, CPU_SEED0 + i, threads, 0) for i in range(nproc)], chunksize=1)
+    dt = max(o[3] + o[4] for o in out)                            # the workers run side by side; input synthesis is untimed
     refs = [(o[0], o[1], o[2]) for o in out]
     par = {'value': nproc / dt, 'unit': 'images/s', 'cores': nproc * threads, 'kind': 'port',
            'sample': '%d synthetic 1040x1392 images, one per worker process (%d processes x %d torch threads, each pinned to '
@@ -135,13 +144,13 @@ def cpu_baseline(base):
                      'meta_inference+count via numpy/scipy: %.2f s/image), wall %.1f s'
                      % (nproc, nproc, threads, ncpu, float(np.mean([o[3] for o in out])), float(np.mean([o[4] for o in out])), dt)}
     n_sample = 2 if base >= 64 else 6 if base >= 32 else 18
-    with ctx.Pool(1, initializer=_cpu_init, initargs=(ctx.Value('i', 0), 1)) as pool:
-        pool.map(_cpu_noop, [0])
-        o = pool.map(_cpu_worker, [(base, CPU_SEED0, 1, n_sample)])[0]
+    o = pool.map(_cpu_worker, [(base, CPU_SEED0, 1, n_sample)])[0]       # one worker busy, the others idle
     t_img = o[3] * 35.0 / n_sample + o[4]
     single = {'value': 1.0 / t_img, 'unit': 'images/s', 'cores': 1, 'kind': 'port',
               'sample': 'one thread: U-Net on %d of the 35 windows of one image (%.1f s, scaled x35/%d) + stitch/argmax/'
                         'meta_inference/count of one full image (%.2f s)' % (n_sample, o[3], n_sample, o[4])}
+    pool.close()
+    pool.join()
     return par, single, refs
 
 
@@ -240,8 +249,7 @@ def main():
 
     want_cpu = args.gpus <= 1 and not under_launcher and not args.no_cpu_baseline
     cpu_par = cpu_single = refs = None
-    if want_cpu:
-        cpu_par, cpu_single, refs = cpu_baseline(args.base)     # before this process initialises HIP
+    pools = cpu_pools_start() if want_cpu else None              # worker processes exist before this process initialises HIP
 
     import torch                      # first: libecseg_hip.so then binds to the HIP runtime torch already loaded
     import torch.distributed as dist
@@ -386,7 +394,8 @@ def main():
                                      'what': 'ecseg_segment_images: %d uint8 images from pageable host memory (H2D), device '
                                              'pipeline, post-processed labels + counts back to host memory (D2H), synchronous'
                                              % B}
-        if cpu_par is not None:
+        if pools is not None:
+            cpu_par, cpu_single, refs = cpu_baseline(args.base, pools)    # after the timed region, on the idle workers
             res['cpu_baseline'] = cpu_par
             res['cpu_baseline_single_thread'] = cpu_single
             res['parity_vs_cpu'] = parity_vs_cpu(hnd, refs)

@@ -118,7 +118,12 @@ def run(inpath, model, image_paths, rank=0, world=1, batch_images=8, io_threads=
                 g = batches.get()
                 if g is None:
                     return
-                flush(g)
+                try:
+                    flush(g)
+                except BaseException as e:                 # never leave the feeding loop blocked on a dead consumer
+                    log("Skipping %d image(s): %r" % (len(g), e))
+                    for k, _ in g:
+                        status[k] = 2
 
         gpu_thread = threading.Thread(target=gpu_loop, name='ecseg-gpu')
         gpu_thread.start()

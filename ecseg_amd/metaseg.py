@@ -171,8 +171,10 @@ def _self_launch(device_ids):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))          # the ranks import ecseg_amd from here
     env = dict(os.environ, ECSEG_DEVICE_IDS=','.join(str(int(d)) for d in device_ids),
-               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'),
+               PYTHONPATH=root + (os.pathsep + os.environ['PYTHONPATH'] if os.environ.get('PYTHONPATH') else ''))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(len(device_ids)),
            '--master-addr', '127.0.0.1', '--master-port', str(port), '-m', 'ecseg_amd.metaseg']
     sys.exit(subprocess.run(cmd, env=env).returncode)

@@ -38,24 +38,71 @@ def main(argv=None):
         os.makedirs(os.path.join(inpath, sub), exist_ok=True)
 
     handle = image_tools.default_handle()
-    rows = []
-    for p in get_imgs(inpath):
-        path_split = os.path.split(p)
-        print("Processing image: ", p)
-        I = image_io.imread(p)
-        if I.ndim < 3:
-            # the reference prints this and then crashes on the tuple unpack (src/meta_overlay.py:60); skipping is the
-            # evident intent
-            print(p, " isn't an RGB image. Therefore, no FISH signals could be identified. Skipping...")
-            continue
-        I8 = image_tools.u16_to_u8(I, handle=handle)   # src/image_tools.py:142
-        image_io.write_png(os.path.join(path_split[0], 'red', path_split[1] + '.png'), ~np.uint8(I8[..., 0]))
-        image_io.write_png(os.path.join(path_split[0], 'green', path_split[1] + '.png'), ~np.uint8(I8[..., 1]))
-        seg = np.load(os.path.join(path_split[0], 'labels', path_split[1][:-4] + '.npy'))
-        rec = handle.overlay(seg.astype(np.uint8), np.ascontiguousarray(I8), int(sensitivity), HSR_SIZE_THRESHOLD)
-        rows.append([path_split[1]] + csvio.overlay_cells(rec))
+    rows = run(inpath, handle, get_imgs(inpath), int(sensitivity), batch_images=int(var.get('batch_images', 8)),
+               io_threads=var.get('io_threads'))
     with open(os.path.join(inpath, 'fish_quantification.csv'), 'w') as f:
         f.write(csvio.csv_text(csvio.OVERLAY_COLUMNS, rows))
+
+
+def _load(p):
+    """Decode one input image and the labels metaseg wrote for it (reader thread)."""
+    path_split = os.path.split(p)
+    I = image_io.imread(p)
+    if I.ndim < 3:
+        return I, None
+    seg = np.load(os.path.join(path_split[0], 'labels', path_split[1][:-4] + '.npy'))
+    return I, np.ascontiguousarray(seg.astype(np.uint8))
+
+
+def _write_channels(p, I8):
+    path_split = os.path.split(p)
+    image_io.write_png(os.path.join(path_split[0], 'red', path_split[1] + '.png'), ~np.uint8(I8[..., 0]))
+    image_io.write_png(os.path.join(path_split[0], 'green', path_split[1] + '.png'), ~np.uint8(I8[..., 1]))
+
+
+def run(inpath, handle, image_paths, sensitivity, batch_images=8, io_threads=None, log=print):
+    """The per-image loop of src/meta_overlay.py:56-95 with the decoding (TIFF + labels/*.npy) and the red / green PNG
+    encoders on worker threads and the nine counts of consecutive same-shaped images computed in one device call.  Rows
+    come back in the order of ``image_paths``."""
+    import concurrent.futures as cf
+    io_threads = io_threads or max(2, min(32, os.cpu_count() or 4))
+    window = max(2 * batch_images, io_threads)
+    rows = [None] * len(image_paths)
+    with cf.ThreadPoolExecutor(io_threads) as readers, cf.ThreadPoolExecutor(io_threads) as writers:
+        reads, next_submit, writes = {}, 0, []
+
+        def flush(group):
+            if not group:
+                return
+            rgb = np.stack([g[1] for g in group])
+            I8 = image_tools.u16_to_u8(rgb, handle=handle)   # src/image_tools.py:142
+            rec = handle.overlay(np.stack([g[2] for g in group]), np.ascontiguousarray(I8), sensitivity, HSR_SIZE_THRESHOLD)
+            for j, (k, _, _) in enumerate(group):
+                writes.append(writers.submit(_write_channels, image_paths[k], I8[j]))
+                rows[k] = [os.path.split(image_paths[k])[1]] + csvio.overlay_cells(rec[j])
+
+        group, key = [], None
+        for k, p in enumerate(image_paths):
+            while next_submit < min(len(image_paths), k + window):
+                log("Processing image: ", image_paths[next_submit])
+                reads[next_submit] = readers.submit(_load, image_paths[next_submit])
+                next_submit += 1
+            I, seg = reads.pop(k).result()
+            if seg is None:
+                # the reference prints this and then crashes on the tuple unpack (src/meta_overlay.py:60); skipping is the
+                # evident intent
+                log(p, " isn't an RGB image. Therefore, no FISH signals could be identified. Skipping...")
+                continue
+            kk = (I.shape, I.dtype.str, seg.shape)
+            if group and (kk != key or len(group) >= batch_images):
+                flush(group)
+                group = []
+            group.append((k, I, seg))
+            key = kk
+        flush(group)
+        for f in writes:
+            f.result()
+    return [r for r in rows if r is not None]
 
 
 if __name__ == "__main__":

@@ -62,6 +62,14 @@ def main():
         dt = time.perf_counter() - t0
     finally:
         metaseg.load_model = real_load
+    # `make meta_overlay` over the same files (labels/*.npy from the run above): decode + labels in, red / green PNGs +
+    # nine counts per image out
+    from ecseg_amd import meta_overlay
+    for sub in ('red', 'green'):
+        os.makedirs(os.path.join(inp, sub), exist_ok=True)
+    t0 = time.perf_counter()
+    rows = meta_overlay.run(inp, model.handle, utils.get_imgs(inp), 85, batch_images=a.batch, io_threads=a.io_threads, log=lambda *x: None)
+    dt_ov = time.perf_counter() - t0
     out_bytes = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(inp) for f in fs) - in_bytes
     print(json.dumps({'what': '`make metaseg` loop: %d RGB LZW TIFF files (1040x1392) -> dapi/*.tif, labels/*.png, labels/*.npy (int64), '
                               'records' % a.n, 'images': a.n, 'unet_base': a.base, 'batch_images': a.batch,
@@ -69,7 +77,8 @@ def main():
                       'seconds': round(dt, 3), 'images_per_s': round(a.n / dt, 2),
                       'device_call_seconds': round(stats.get('gpu_seconds', 0.0), 3),
                       'input_MB': round(in_bytes / 1e6, 1), 'output_MB': round(out_bytes / 1e6, 1),
-                      'ok_images': int((rec[:, 1] == 0).sum()), 'generate_seconds': round(t_gen, 1)}))
+                      'ok_images': int((rec[:, 1] == 0).sum()), 'generate_seconds': round(t_gen, 1),
+                      'meta_overlay_seconds': round(dt_ov, 3), 'meta_overlay_images_per_s': round(len(rows) / dt_ov, 2)}))
     if not a.keep:
         shutil.rmtree(work, ignore_errors=True)
 

@@ -74,6 +74,18 @@ def run(inpath, model, image_paths, rank=0, world=1, batch_images=8, io_threads=
     io_threads = io_threads or max(2, min(32, (os.cpu_count() or 4) // max(world, 1)))
     window = max(2 * batch_images, io_threads)                             # images decoded ahead of the GPU
     pending_writes = threading.BoundedSemaphore(4 * batch_images + io_threads)   # bounds the outputs held in memory
+    # dozens of decoder / encoder threads hold the GIL in 5 ms slices by default; the device thread needs it only for
+    # microseconds between calls, so a short switch interval keeps the GPU fed
+    old_switch = sys.getswitchinterval()
+    sys.setswitchinterval(0.0005)
+    try:
+        return _run_threads(model, mine, start, per, rank, world, batch_images, io_threads, window, pending_writes, n_ec,
+                            status, log, stats)
+    finally:
+        sys.setswitchinterval(old_switch)
+
+
+def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads, window, pending_writes, n_ec, status, log, stats):
     t_gpu = 0.0
     with cf.ThreadPoolExecutor(io_threads) as readers, cf.ThreadPoolExecutor(io_threads) as writers:
         reads = {}
@@ -88,21 +100,21 @@ def run(inpath, model, image_paths, rank=0, world=1, batch_images=8, io_threads=
 
         write_futs = []
 
-        def flush(group):
+        def flush(batch):
             nonlocal t_gpu
+            group, imgs = batch
             if not group:
                 return
-            imgs = np.stack([g[1] for g in group])
             try:
                 t0 = time.perf_counter()
                 gray, post, nec = _segment_with_retry(model, imgs, log)
                 t_gpu += time.perf_counter() - t0
             except Exception as e:                         # a failing batch must not take the shard down
                 log("Skipping %d image(s) of shape %s: %s" % (len(group), imgs.shape[1:], e))
-                for k, _ in group:
+                for k in group:
                     status[k] = 2
                 return
-            for j, (k, _) in enumerate(group):
+            for j, k in enumerate(group):
                 n_ec[k] = int(nec[j])
                 pending_writes.acquire()
                 f = writers.submit(_write_outputs, mine[k], ~gray[j], post[j], log)
@@ -121,9 +133,12 @@ def run(inpath, model, image_paths, rank=0, world=1, batch_images=8, io_threads=
                 try:
                     flush(g)
                 except BaseException as e:                 # never leave the feeding loop blocked on a dead consumer
-                    log("Skipping %d image(s): %r" % (len(g), e))
-                    for k, _ in g:
+                    log("Skipping %d image(s): %r" % (len(g[0]), e))
+                    for k in g[0]:
                         status[k] = 2
+
+        def pack(group):                                   # the batch array is assembled by the feeder, not by the device thread
+            return [k for k, _ in group], np.stack([im for _, im in group])
 
         gpu_thread = threading.Thread(target=gpu_loop, name='ecseg-gpu')
         gpu_thread.start()
@@ -139,12 +154,12 @@ def run(inpath, model, image_paths, rank=0, world=1, batch_images=8, io_threads=
                     continue
                 kk = (img.shape, img.dtype.str)
                 if group and (kk != key or len(group) >= batch_images):
-                    batches.put(group)
+                    batches.put(pack(group))
                     group = []
                 group.append((k, img))
                 key = kk
             if group:
-                batches.put(group)
+                batches.put(pack(group))
         finally:
             batches.put(None)
             gpu_thread.join()

@@ -450,7 +450,6 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
         plan.ops.append(d)
 
     released = set()
-    plan_input_node = [in_nodes[0]]
 
     def release_after(step):
         for i in list(node_buf.keys()):
@@ -477,8 +476,6 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
             plan.tensors.append(dict(buffer=ti_['buffer'], h=h_, w=w_, c=c_, c_stride=c_, c_offset=0))
             tensor_of[j] = len(plan.tensors) - 1
             plan.layer_tensor[n['name']] = tensor_of[j]
-            if i == plan_input_node[0]:
-                pass
         elif k == 'concat':
             t = new_tensor(j)
             off = 0

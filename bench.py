@@ -247,7 +247,7 @@ def main():
     if args.gpus > 1 and not under_launcher:
         self_launch(args)
 
-    want_cpu = args.gpus <= 1 and not under_launcher and not args.no_cpu_baseline
+    want_cpu = args.gpus <= 1 and int(os.environ.get('WORLD_SIZE', '1')) == 1 and not args.no_cpu_baseline
     cpu_par = cpu_single = refs = None
     pools = cpu_pools_start() if want_cpu else None              # worker processes exist before this process initialises HIP
 

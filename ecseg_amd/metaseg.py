@@ -9,7 +9,8 @@ batches with a bounded number of images in flight (the reference's loop at src/m
 node, every rank writes the outputs of its own images and rank 0 writes ``ec_quantification.csv`` after one all-gather
 of the per-image records (the reference's analogue is the implicit all-device MirroredStrategy, src/metaseg.py:33-36).
 
-Optional config keys (defaults keep the reference's behaviour): ``batch_images`` (8), ``io_threads``, ``device_ids``.
+Optional config keys (defaults keep the reference's behaviour): ``batch_images`` (8), ``io_threads``, ``device_ids``,
+``resume`` (false; true: images whose ``labels/<stem>.npy``, ``.png`` and ``dapi/<name>`` exist are not segmented again).
 """
 import concurrent.futures as cf
 import os
@@ -30,7 +31,21 @@ from .utils import get_imgs, load_model, save_img
 MODEL_NAME = 'metaseg.h5'
 
 
-def _read(p):
+def _outputs_of(p):
+    path_split = os.path.split(p)
+    stem = os.path.join(path_split[0], 'labels', path_split[1][:-4])
+    return stem + '.npy', stem + '.png', os.path.join(path_split[0], 'dapi', path_split[1])
+
+
+def _read(p, resume=False):
+    if resume:
+        # optional resume ("checkpoint / resume"): an image whose three outputs already exist is not segmented
+        # again; its count is taken from the stored labels (count_cc(I == 3) on the device, as src/metaseg.py:46 does)
+        outs = _outputs_of(p)
+        if all(os.path.exists(o) and os.path.getsize(o) > 0 for o in outs):
+            lab = np.load(outs[0])
+            if lab.ndim == 2 and lab.dtype == np.int64:
+                return ('done', np.ascontiguousarray(lab == 3))
     img = image_io.imread(p)
     if img.dtype not in (np.uint8, np.uint16) or img.ndim not in (2, 3):
         raise ValueError('unsupported image array %s %s' % (img.dtype, img.shape))
@@ -65,7 +80,7 @@ def _segment_with_retry(model, imgs, log):
             h.set_images_per_group(group)
 
 
-def run(inpath, model, image_paths, rank=0, world=1, batch_images=8, io_threads=None, log=print, stats=None):
+def run(inpath, model, image_paths, rank=0, world=1, batch_images=8, io_threads=None, log=print, stats=None, resume=False):
     """Segment this rank's shard; returns records (one row per image of the WHOLE job after the all-gather)."""
     start, stop, per = dist.shard_bounds(len(image_paths), rank, world)
     mine = image_paths[start:stop]
@@ -80,12 +95,13 @@ def run(inpath, model, image_paths, rank=0, world=1, batch_images=8, io_threads=
     sys.setswitchinterval(0.0005)
     try:
         return _run_threads(model, mine, start, per, rank, world, batch_images, io_threads, window, pending_writes, n_ec,
-                            status, log, stats)
+                            status, log, stats, resume)
     finally:
         sys.setswitchinterval(old_switch)
 
 
-def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads, window, pending_writes, n_ec, status, log, stats):
+def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads, window, pending_writes, n_ec, status, log, stats,
+                 resume=False):
     t_gpu = 0.0
     with cf.ThreadPoolExecutor(io_threads) as readers, cf.ThreadPoolExecutor(io_threads) as writers:
         reads = {}
@@ -95,7 +111,7 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
             nonlocal next_submit
             while next_submit < min(len(mine), upto):
                 log("Processing image: ", mine[next_submit])
-                reads[next_submit] = readers.submit(_read, mine[next_submit])
+                reads[next_submit] = readers.submit(_read, mine[next_submit], resume)
                 next_submit += 1
 
         write_futs = []
@@ -104,6 +120,11 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
             nonlocal t_gpu
             group, imgs = batch
             if not group:
+                return
+            if imgs.dtype == np.bool_:                     # resumed images: only the count is needed
+                cnt, _ = model.handle.count_cc(imgs)
+                for j, k in enumerate(group):
+                    n_ec[k] = int(cnt[j])
                 return
             try:
                 t0 = time.perf_counter()
@@ -152,6 +173,9 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
                     log("Skipping %s: %s" % (mine[k], e))
                     status[k] = 1
                     continue
+                if isinstance(img, tuple):                 # ('done', ecDNA mask of the stored labels)
+                    img = img[1]
+                    log("Keeping existing outputs of ", mine[k])
                 kk = (img.shape, img.dtype.str)
                 if group and (kk != key or len(group) >= batch_images):
                     batches.put(pack(group))
@@ -223,7 +247,7 @@ def main(argv=None):
     t0 = time.perf_counter()
     stats = {}
     rec = run(inpath, model, image_paths, rank, world, batch_images=int(var.get('batch_images', 8)),
-              io_threads=var.get('io_threads'), stats=stats)
+              io_threads=var.get('io_threads'), stats=stats, resume=bool(var.get('resume', False)))
     failed = [r for r in rec if r[dist.F_STATUS] != 0]
     if rank == 0:
         rows = [[os.path.split(image_paths[int(r[dist.F_INDEX])])[1], int(r[dist.F_NEC])]

@@ -91,6 +91,30 @@ def test_corrupt_image_is_reported_and_exit_code_is_nonzero(workdir):
     assert os.path.exists(str(inp / 'labels' / 'img2.npy')) and not os.path.exists(str(inp / 'labels' / 'broken.npy'))
 
 
+def test_resume_keeps_existing_outputs_and_reproduces_the_csv(workdir):
+    """Optional `resume: true` (SURVEY 5 checkpoint / resume): a second run re-uses the stored labels - files untouched, the
+    CSV identical; a removed output is re-created."""
+    import time
+    from ecseg_amd import metaseg
+    tmp, inp = workdir
+    cfg = yaml.safe_load(open(tmp / 'config.yaml'))
+    cfg['metaseg']['resume'] = True
+    yaml.safe_dump(cfg, open(tmp / 'config.yaml', 'w'))
+    metaseg.main([])
+    first = open(str(inp / 'ec_quantification.csv')).read()
+    stamp = {n: os.stat(str(inp / 'labels' / n)).st_mtime_ns for n in os.listdir(str(inp / 'labels'))}
+    os.remove(str(inp / 'labels' / 'img1.png'))
+    time.sleep(0.05)
+    metaseg.main([])
+    assert open(str(inp / 'ec_quantification.csv')).read() == first
+    for n, t in stamp.items():
+        if n.startswith('img1'):
+            continue
+        assert os.stat(str(inp / 'labels' / n)).st_mtime_ns == t, n        # kept, not rewritten
+    assert os.path.exists(str(inp / 'labels' / 'img1.png'))                # the incomplete image was redone
+    assert os.stat(str(inp / 'labels' / 'img1.npy')).st_mtime_ns > stamp['img1.npy']
+
+
 def test_metaseg_cli_exit_codes(tmp_path, monkeypatch):
     from ecseg_amd import meta_overlay, metaseg
     with open(tmp_path / 'config.yaml', 'w') as f:

@@ -126,7 +126,9 @@ int ecseg_set_images_per_group(ecseg_ctx* h, int n);
  * is the only reader of a 64-channel F(4x4) convolution is computed by that convolution's output stage and the
  * 64-channel tensor is never written; 0: separate head kernel), "crop" (1 (default): in ecseg_segment_images the last
  * full-resolution F(4x4) convolutions compute only the 16x16 regions of every window that the stitch (or the halo of the
- * convolutions behind them) reads - 72 % of them at 1040x1392; results are unchanged; 0: whole windows). */
+ * convolutions behind them) reads - 72 % of them at 1040x1392; results are unchanged; 0: whole windows), "post_graph" (1: the
+ * ~60 short kernels of meta_inference + count are captured once per (buffers, geometry) into a HIP graph and replayed;
+ * 0 (default): plain launches - measured equal, the asynchronous launch queue already hides the launch gaps). */
 int ecseg_set_option(ecseg_ctx* h, const char* key, int value);
 
 /* ---- meta_preprocess (src/image_tools.py:86-101) ---------------------------------------------------------- */

@@ -171,3 +171,24 @@ def test_preprocess_vs_oracle(gpu):
     gray, inv = gpu.preprocess(g16)
     for i in range(2):
         assert np.array_equal(gray[i], preprocess.meta_preprocess(g16[i])), i
+
+
+def test_meta_inference_through_hip_graph_replay(gpu):
+    """Option post_graph=1: the kernels of meta_inference captured into a HIP graph and replayed must give the same labels
+    and counts as plain launches, also when the same buffers are used again with new contents."""
+    labs = np.stack([synth.label_map(400 + i, 300, 420) for i in range(3)])
+    plain, nec_plain = gpu.meta_inference(labs)
+    try:
+        gpu.set_option('post_graph', 1)
+        for rep in range(3):
+            x = np.roll(labs, rep * 7, axis=2)
+            got, nec = gpu.meta_inference(x)
+            want, wnec = (plain, nec_plain) if rep == 0 else (None, None)
+            for k in range(3):
+                w = postproc.meta_inference(x[k])
+                assert np.array_equal(got[k], w)
+                assert int(nec[k]) == postproc.count_cc(w == 3)[0]
+            if want is not None:
+                assert np.array_equal(got, want) and np.array_equal(nec, wnec)
+    finally:
+        gpu.set_option('post_graph', 0)

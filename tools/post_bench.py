@@ -23,6 +23,7 @@ def main():
     ap.add_argument('--images', type=int, default=64)
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--base', type=int, default=16)
+    ap.add_argument('--opt', action='append', default=[], help='library option key=value')
     a = ap.parse_args()
     import torch
     from ecseg_amd import synth
@@ -48,6 +49,8 @@ def main():
         d_out = torch.empty_like(d_in)
         nec = torch.zeros(n, dtype=torch.int32, device='cuda')
         hnd.set_option('post_chunk', n)
+        for kv in a.opt:
+            hnd.set_option(kv.split('=')[0], int(kv.split('=')[1]))
         hnd.meta_inference_dev(d_in.data_ptr(), n, H, W, d_out.data_ptr(), nec.data_ptr())
         ms = []
         for _ in range(a.reps):

@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(TView in, TView out, co
                 f32x4 o;
                 o[0] = acc[i][0]; o[1] = acc[i][1]; o[2] = acc[i][2]; o[3] = acc[i][3];
                 o = apply_act4(o, act, alpha);
-                *reinterpret_cast<f32x4*>(out.p + ((img * out.h + oy) * out.w + x0 + i) * out.cs + q * 4) = o;
+                __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(out.p + ((img * out.h + oy) * out.w + x0 + i) * out.cs + q * 4));
             }
         }
     }

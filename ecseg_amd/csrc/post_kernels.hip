@@ -203,8 +203,12 @@ __global__ __launch_bounds__(256) void ccl_local_kernel(CclGeom g, const uint8_t
 }
 
 // ---- phase 2: unions across tile borders (global atomicMin union-find) ----------------------------------------------
+// Workgroup = one tile, two waves: wave 0 takes the 64 pixels of the tile's first row (contacts with the tile above and,
+// for its first pixel, with the tile to the left), wave 1 the 32 + 32 pixels of the first and last column of the other
+// rows (lane = row | side << 5).  Every border pixel is one lane of ONE pass, so the dependent global loads of the
+// union-find walks of a tile overlap instead of queueing row after row.
 template <int CONN>
-__global__ __launch_bounds__(256) void ccl_border_kernel(CclGeom g, const uint8_t* __restrict__ img_all, uint32_t lut,
+__global__ __launch_bounds__(128) void ccl_border_kernel(CclGeom g, const uint8_t* __restrict__ img_all, uint32_t lut,
                                                          int32_t* __restrict__ L_all) {
     int img, y0, cx;
     if (!decode_block(g, img, y0, cx)) return;
@@ -212,35 +216,42 @@ __global__ __launch_bounds__(256) void ccl_border_kernel(CclGeom g, const uint8_
     const uint8_t* im = img_all + base;
     int32_t* L = L_all + base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = cx * 64 + lane;
+    const int ytile = y0 - wave * CCL_ROWS;                        // first row of the tile
     const int W = g.W;
-    for (int r = 0; r < CCL_ROWS; ++r) {
-        const int y = y0 + r;
-        if (y >= g.H) break;
-        const bool top = (wave == 0 && r == 0 && y > 0);          // first row of a tile
-        if (!(top || lane == 0 || lane == 63) || x >= W) continue;
+    if (wave == 0) {
+        // first row of a tile that has a tile above it
+        const int y = ytile, x = cx * 64 + lane;
+        if (y == 0 || x >= W) return;
         const int p = y * W + x;
         const int key = key_of(im[p], lut);
-        if (!key) continue;
+        if (!key) return;
         const bool left = x > 0 && key_of(im[p - 1], lut) == key;
         if (lane == 0 && left) uf_unite(L, p, p - 1);
-        if (y == 0) continue;
         const bool u0 = key_of(im[p - W], lut) == key;
         const bool ul = x > 0 && key_of(im[p - W - 1], lut) == key;
         const bool ur = x + 1 < W && key_of(im[p - W + 1], lut) == key;
-        if (top) {
-            if (CONN == 8) {
-                if (ur && !u0) uf_unite(L, p, p - W + 1);
-                if (!left) {
-                    if (u0) uf_unite(L, p, p - W);
-                    else if (ul) uf_unite(L, p, p - W - 1);
-                }
-            } else {
-                if (u0 && !(left && ul)) uf_unite(L, p, p - W);
+        if (CONN == 8) {
+            if (ur && !u0) uf_unite(L, p, p - W + 1);
+            if (!left) {
+                if (u0) uf_unite(L, p, p - W);
+                else if (ul) uf_unite(L, p, p - W - 1);
             }
-        } else if (CONN == 8) {                                    // diagonal contacts across a vertical tile border
-            if (lane == 0 && ul) uf_unite(L, p, p - W - 1);
-            if (lane == 63 && ur) uf_unite(L, p, p - W + 1);
+        } else {
+            if (u0 && !(left && ul)) uf_unite(L, p, p - W);
+        }
+    } else {
+        // first / last column of the rows that wave 0 does not cover (all rows of the image's first tile row)
+        const int r = lane & 31, side = lane >> 5;
+        const int y = ytile + r, x = cx * 64 + (side ? 63 : 0);
+        if ((r == 0 && ytile > 0) || y >= g.H || x >= W) return;
+        const int p = y * W + x;
+        const int key = key_of(im[p], lut);
+        if (!key) return;
+        if (side == 0) {
+            if (x > 0 && key_of(im[p - 1], lut) == key) uf_unite(L, p, p - 1);
+            if (CONN == 8 && y > 0 && x > 0 && key_of(im[p - W - 1], lut) == key) uf_unite(L, p, p - W - 1);
+        } else if (CONN == 8) {                                    // diagonal contact across the vertical tile border
+            if (y > 0 && x + 1 < W && key_of(im[p - W + 1], lut) == key) uf_unite(L, p, p - W + 1);
         }
     }
 }
@@ -262,11 +273,13 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8
                                                           const uint8_t* __restrict__ aux_img, int need,
                                                           int32_t* __restrict__ list1, int32_t* __restrict__ list2, size_t list_cap) {
     constexpr int TP = CCL_BLOCK_ROWS * 64;                    // pixels per tile
-    __shared__ int red[16];                                    // ncomp[1..3], npx[1..3], -, -, last root, list counts [9..10], list bases [11..12] (64 B keeps the dynamic LDS base 16-B aligned)
+    __shared__ int red[16];                                    // ncomp[1..3], npx[1..3], -, -, last root, list counts [9..10], list bases [11..12], owners [13] (64 B keeps the dynamic LDS base 16-B aligned)
     __shared__ int groot_s[TP];                                // tile root -> global root
     __shared__ uint32_t area_s[TP];
     __shared__ uint32_t flag_s[TP];
     __shared__ uint32_t used_s[TP / 32];                       // bit per slot: some run accumulated into it
+    __shared__ uint16_t own_s[TP];                             // compacted list of the slots in use
+    __shared__ int16_t lsl_s[TP];                              // NEED_LISTS: list position of owner k
     extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
     u64* sumy_s = reinterpret_cast<u64*>(dyn_smem);            // [TP] only when STAT_SUMS
     u64* sumx_s = sumy_s + TP;
@@ -288,6 +301,8 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8
     const int x = cx * 64 + lane;
     const int W = g.W, H = g.H;
     const int yblk = y0 - wave * CCL_ROWS;
+    const int tile_org = yblk * W + cx * 64;
+    const float inv_w = 1.0f / (float)W;
     int npx[4] = {0, 0, 0, 0};
     int troot[CCL_ROWS];                                       // tile-local index of this pixel's tile root, -1 = background
     // ---- A: per-run accumulation into the tile root's LDS slot ----
@@ -298,20 +313,30 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8
         const int p = y * W + x;
         uint8_t v = 0;
         int key = 0, lab = -1;
-        if (valid) {
+        if (valid) {                                           // two independent loads (ccl_local wrote -1 for background)
             v = im[p];
+            lab = L[p];
             key = key_of(v, lut);
-            if (key) lab = L[p];
         }
         // Slot of this pixel's tile component: the tile root it points at.  A tile root that ccl_border has meanwhile
         // linked to a pixel of another tile no longer points into the tile: it keeps its own slot (the other pixels
         // of its tile component still point at it).
         int tr = -1;
         if (key) {
-            const int ry = lab / W, rx = lab - ry * W;
-            const int dy = ry - yblk, dx = rx - cx * 64;
-            tr = ((unsigned)dy < (unsigned)CCL_BLOCK_ROWS && (unsigned)dx < 64u) ? dy * 64 + dx
-                                                                                    : (wave * CCL_ROWS + r) * 64 + lane;
+            // (dy, dx) of the root relative to the tile origin; an in-tile d < 32 W < 2^24 is exact in float, so the
+            // quotient by the reciprocal is off by at most one (no integer division per pixel)
+            const int d = lab - tile_org;
+            int dy, dx;
+            if (W < (1 << 19)) {
+                dy = (int)((float)d * inv_w);
+                dx = d - dy * W;
+                if (dx < 0) { dy -= 1; dx += W; } else if (dx >= W) { dy += 1; dx -= W; }
+            } else {                                           // 32 W >= 2^24: not exact in float
+                dy = d / W;
+                dx = d - dy * W;
+            }
+            tr = ((unsigned)d < (unsigned)(CCL_BLOCK_ROWS * W) && (unsigned)dy < (unsigned)CCL_BLOCK_ROWS && (unsigned)dx < 64u)
+                     ? dy * 64 + dx : (wave * CCL_ROWS + r) * 64 + lane;
         }
         troot[r] = tr;
         if (need & NEED_NPX) {
@@ -349,43 +374,55 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8
         }
     }
     __syncthreads();
-    // ---- B: slot owners (tile roots) resolve their global root and forward the slot's sums ----
+    // ---- B: slot owners (tile roots) resolve their global root and forward the slot's sums.  The owners are first
+    //      compacted into a list, then thread k takes owner k: the chain walks and global atomics of all owners of a tile
+    //      are in flight together (a loop over each thread's own eight rows queued up to eight walks behind each other) ----
     int ncomp[4] = {0, 0, 0, 0};
     int last_root = 0;
-    int16_t lslot[CCL_ROWS];                                   // (class << 12 | index inside the block's range), -1 = none
-#pragma unroll
-    for (int r = 0; r < CCL_ROWS; ++r) lslot[r] = -1;
 #pragma unroll
     for (int r = 0; r < CCL_ROWS; ++r) {
         const int li = (wave * CCL_ROWS + r) * 64 + lane;
-        if (!((used_s[li >> 5] >> (li & 31)) & 1u)) continue;  // nothing accumulated here: not a slot owner
-        const int p = (y0 + r) * W + x;
+        const bool own = (used_s[li >> 5] >> (li & 31)) & 1u;
+        const u64 m = __ballot(own);
+        if (!m) continue;                                      // wave-uniform
+        int at = 0;
+        const int first = __ffsll((long long)m) - 1;
+        if (lane == first) at = atomicAdd(&red[13], __popcll(m));
+        at = __shfl(at, first, 64);
+        if (own) own_s[at + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)li;
+    }
+    __syncthreads();
+    const int n_own = red[13];
+    for (int k = tid; k < n_own; k += 256) {
+        const int li = own_s[k];
+        const int p = (yblk + (li >> 6)) * W + cx * 64 + (li & 63);
         const int gr = uf_find(L, p);
         groot_s[li] = gr;
         if (stat & STAT_AREA) atomicAdd(area_all + base + gr, area_s[li]);
         if (stat & STAT_SUMS) { atomicAdd(sumy_all + base + gr, sumy_s[li]); atomicAdd(sumx_all + base + gr, sumx_s[li]); }
         if (flag_s[li]) atomicOr(flag_all + base + gr, flag_s[li]);
+        int16_t ls = -1;                                       // (class << 12 | index inside the block's range), -1 = none
         if (gr == p) {                                         // a global root lives in this tile
-            if (need & NEED_NCOMP) ncomp[key_of(im[p], lut) & 3] += 1;
+            const uint8_t v = im[p];
+            if (need & NEED_NCOMP) ncomp[key_of(v, lut) & 3] += 1;
             last_root = max(last_root, p + 1);
-            if (need & NEED_LISTS) {                           // roots of class 1 / 2 go to the per-image lists (nucleus test)
-                const uint8_t v = im[p];
-                if (v == 1 || v == 2) lslot[r] = (int16_t)((v << 12) | atomicAdd(&red[8 + v], 1));
-            }
+            // roots of class 1 / 2 go to the per-image lists (nucleus test)
+            if ((need & NEED_LISTS) && (v == 1 || v == 2)) ls = (int16_t)((v << 12) | atomicAdd(&red[8 + v], 1));
         }
+        if (need & NEED_LISTS) lsl_s[k] = ls;
     }
     __syncthreads();
     if (need & NEED_LISTS) {
         // one global atomic per workgroup and class reserves the block's range in the image's list
         if (tid < 2 && red[9 + tid]) red[11 + tid] = atomicAdd(G_all + (size_t)img * G_IMG + (tid == 0 ? G_NLIST1 : G_NLIST2), red[9 + tid]);
         __syncthreads();
-#pragma unroll
-        for (int r = 0; r < CCL_ROWS; ++r) {
-            if (lslot[r] < 0) continue;
-            const int v = lslot[r] >> 12, k = lslot[r] & 0xfff;
-            const int p = (y0 + r) * W + x;
-            if (v == 1) list1[(size_t)img * list_cap + red[11] + k] = p;
-            else list2[((size_t)img * list_cap + red[12] + k) * 4] = p;      // first word of the chromosome's centroid slot
+        for (int k = tid; k < n_own; k += 256) {
+            const int ls = lsl_s[k];
+            if (ls < 0) continue;
+            const int v = ls >> 12, idx = ls & 0xfff, li = own_s[k];
+            const int p = (yblk + (li >> 6)) * W + cx * 64 + (li & 63);
+            if (v == 1) list1[(size_t)img * list_cap + red[11] + idx] = p;
+            else list2[((size_t)img * list_cap + red[12] + idx) * 4] = p;      // first word of the chromosome's centroid slot
         }
     }
     // ---- C: every pixel takes its component's global root ----
@@ -488,11 +525,11 @@ static hipError_t run_ccl_pass(PostWorkspace& ws, const CclGeom& g, const CclPas
     if (c.conn == 8) {
         hipLaunchKernelGGL(ccl_local_kernel<8>, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy,
                            ws.sumx, ws.flag, c.stat);
-        hipLaunchKernelGGL(ccl_border_kernel<8>, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L);
+        hipLaunchKernelGGL(ccl_border_kernel<8>, dim3(grid), dim3(128), 0, s, g, c.key_img, c.lut, ws.L);
     } else {
         hipLaunchKernelGGL(ccl_local_kernel<4>, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy,
                            ws.sumx, ws.flag, c.stat);
-        hipLaunchKernelGGL(ccl_border_kernel<4>, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L);
+        hipLaunchKernelGGL(ccl_border_kernel<4>, dim3(grid), dim3(128), 0, s, g, c.key_img, c.lut, ws.L);
     }
     if (c.count_only) {        // counts per key only: no per-pixel roots, no statistics
         hipLaunchKernelGGL(count_roots_kernel, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L, ws.g);

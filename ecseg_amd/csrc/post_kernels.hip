@@ -275,21 +275,20 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8
     constexpr int TP = CCL_BLOCK_ROWS * 64;                    // pixels per tile
     __shared__ int red[16];                                    // ncomp[1..3], npx[1..3], -, -, last root, list counts [9..10], list bases [11..12], owners [13] (64 B keeps the dynamic LDS base 16-B aligned)
     __shared__ int groot_s[TP];                                // tile root -> global root
-    __shared__ uint32_t area_s[TP];
-    __shared__ uint32_t flag_s[TP];
+    __shared__ uint32_t af_s[TP];                              // bits 0-15: pixels of the slot (<= 2048), bits 16-20: flag bits
     __shared__ uint32_t used_s[TP / 32];                       // bit per slot: some run accumulated into it
     __shared__ uint16_t own_s[TP];                             // compacted list of the slots in use
-    __shared__ int16_t lsl_s[TP];                              // NEED_LISTS: list position of owner k
     extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
     u64* sumy_s = reinterpret_cast<u64*>(dyn_smem);            // [TP] only when STAT_SUMS
     u64* sumx_s = sumy_s + TP;
+    int16_t* lsl_s = reinterpret_cast<int16_t*>(dyn_smem + ((stat & STAT_SUMS) ? (size_t)TP * 16 : 0));   // [TP] only when NEED_LISTS: list position of owner k
     int img, y0, cx;
     if (!decode_block(g, img, y0, cx)) return;                 // block-uniform
     const int tid = threadIdx.x;
     if (tid < 16) red[tid] = 0;
     if (tid < TP / 32) used_s[tid] = 0u;
     for (int i = tid; i < TP; i += 256) {
-        area_s[i] = 0u; flag_s[i] = 0u;
+        af_s[i] = 0u;
         if (stat & STAT_SUMS) { sumy_s[i] = 0ull; sumx_s[i] = 0ull; }
     }
     __syncthreads();
@@ -362,7 +361,6 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8
             const int len = stop ? (__ffsll((long long)stop) - 1 - lane) : (64 - lane);
             const u64 run = (len == 64) ? ~0ull : (((1ull << len) - 1ull) << lane);
             atomicOr(&used_s[tr >> 5], 1u << (tr & 31));
-            if (stat & STAT_AREA) atomicAdd(&area_s[tr], (uint32_t)len);
             if (stat & STAT_SUMS) {
                 atomicAdd(&sumy_s[tr], (u64)y * (u64)len);
                 atomicAdd(&sumx_s[tr], (u64)x * (u64)len + (u64)len * (u64)(len - 1) / 2ull);
@@ -370,7 +368,9 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8
             uint32_t fb = 0;
 #pragma unroll
             for (int b = 0; b < 5; ++b) if (B[b] & run) fb |= 1u << b;
-            if (fb) atomicOr(&flag_s[tr], fb);
+            // pixel count and flag bits share a word (the count never carries into bit 16)
+            if (stat & STAT_AREA) atomicAdd(&af_s[tr], (uint32_t)len);
+            if (fb) atomicOr(&af_s[tr], fb << 16);
         }
     }
     __syncthreads();
@@ -398,9 +398,10 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8
         const int p = (yblk + (li >> 6)) * W + cx * 64 + (li & 63);
         const int gr = uf_find(L, p);
         groot_s[li] = gr;
-        if (stat & STAT_AREA) atomicAdd(area_all + base + gr, area_s[li]);
+        const uint32_t af = af_s[li];
+        if (stat & STAT_AREA) atomicAdd(area_all + base + gr, af & 0xffffu);
         if (stat & STAT_SUMS) { atomicAdd(sumy_all + base + gr, sumy_s[li]); atomicAdd(sumx_all + base + gr, sumx_s[li]); }
-        if (flag_s[li]) atomicOr(flag_all + base + gr, flag_s[li]);
+        if (af >> 16) atomicOr(flag_all + base + gr, af >> 16);
         int16_t ls = -1;                                       // (class << 12 | index inside the block's range), -1 = none
         if (gr == p) {                                         // a global root lives in this tile
             const uint8_t v = im[p];
@@ -536,7 +537,7 @@ static hipError_t run_ccl_pass(PostWorkspace& ws, const CclGeom& g, const CclPas
         hipLaunchKernelGGL(reduce_g_kernel, dim3(g.n_img), dim3(G_STRIDE), 0, s, ws.g, g.n_img);
         return hipGetLastError();
     }
-    const size_t dyn = (c.stat & STAT_SUMS) ? (size_t)CCL_BLOCK_ROWS * 64 * 16 : 0;
+    const size_t dyn = ((c.stat & STAT_SUMS) ? (size_t)CCL_BLOCK_ROWS * 64 * 16 : 0) + ((c.need & NEED_LISTS) ? (size_t)CCL_BLOCK_ROWS * 64 * 2 : 0);
     hipLaunchKernelGGL(ccl_flatten_kernel, dim3(grid), dim3(256), dyn, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy,
                        ws.sumx, ws.flag, ws.g, c.stat, c.aux_mode, c.aux_c, c.aux_img, c.need, c.list1, c.list2, c.list_cap);
     if (c.need) hipLaunchKernelGGL(reduce_g_kernel, dim3(g.n_img), dim3(G_STRIDE), 0, s, ws.g, g.n_img);

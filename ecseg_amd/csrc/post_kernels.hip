@@ -128,43 +128,50 @@ __device__ __forceinline__ void lds_unite(int* Ls, int a, int b) {
     }
 }
 
+// lane - 1 / lane + 1 of the whole wavefront in one VALU instruction (DPP wave shift; the end lane gets 0)
+__device__ __forceinline__ int wave_from_left(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }   // wave_shr:1
+__device__ __forceinline__ int wave_from_right(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }  // wave_shl:1
+
 template <int CONN>
 __global__ __launch_bounds__(256) void ccl_local_kernel(CclGeom g, const uint8_t* __restrict__ img_all, uint32_t lut,
                                                         int32_t* __restrict__ L_all, uint32_t* __restrict__ area_all,
                                                         u64* __restrict__ sumy_all, u64* __restrict__ sumx_all,
                                                         uint32_t* __restrict__ flag_all, int stat) {
     __shared__ int Ls[CCL_BLOCK_ROWS * 64];
-    __shared__ uint8_t Ks[CCL_BLOCK_ROWS * 64];
+    __shared__ uint8_t Kl[4][64];                          // keys of every wave's last row (the next wave's "row above")
     int img, y0, cx;
     if (!decode_block(g, img, y0, cx)) return;            // block-uniform
     const size_t base = (size_t)img * g.H * g.W;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = cx * 64 + lane;
     const int yblk = y0 - wave * CCL_ROWS;                 // first row of the tile
-    int keys[CCL_ROWS];
+    const u64 upto = (2ull << lane) - 1ull;                // lanes <= this one
+    // The keys of the wave's 8 rows stay in registers: the neighbours above come from the previous row's register through
+    // DPP wave shifts (one VALU instruction each) instead of byte reads from an LDS copy of the tile.
+    int keys[CCL_ROWS], hpos[CCL_ROWS];                    // key, lane of the pixel's run head
 #pragma unroll
     for (int r = 0; r < CCL_ROWS; ++r) {
         const int y = y0 + r, li = (wave * CCL_ROWS + r) * 64 + lane;
         const bool valid = y < g.H && x < g.W;
         const int key = valid ? key_of(img_all[base + (size_t)y * g.W + x], lut) : 0;
         keys[r] = key;
-        const int kprev = __shfl_up(key, 1, 64);
-        const bool start = key != 0 && (lane == 0 || kprev != key);
+        const int kprev = wave_from_left(key);
+        const bool start = key != 0 && kprev != key;       // (lane 0: kprev = 0)
         const u64 S = __ballot(start);
-        const u64 below = S & ((2ull << lane) - 1ull);
-        Ks[li] = (uint8_t)key;
-        Ls[li] = key ? (li - lane) + (63 - __clzll(below)) : -1;
+        const int hp = 63 - __clzll(S & upto);             // (meaningless where key == 0)
+        hpos[r] = hp;
+        Ls[li] = key ? (li - lane) + hp : -1;
     }
+    Kl[wave][lane] = (uint8_t)keys[CCL_ROWS - 1];
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < CCL_ROWS; ++r) {
         const int ly = wave * CCL_ROWS + r, li = ly * 64 + lane;
         const int key = keys[r];
+        const int above = r ? keys[r > 0 ? r - 1 : 0] : (wave ? (int)Kl[wave > 0 ? wave - 1 : 0][lane] : 0);
+        const int al = wave_from_left(above), ar = wave_from_right(above), kl = wave_from_left(key);   // all lanes active here
         if (!key || ly == 0) continue;
-        const bool left = lane > 0 && Ks[li - 1] == key;
-        const bool u0 = Ks[li - 64] == key;
-        const bool ul = lane > 0 && Ks[li - 65] == key;
-        const bool ur = lane < 63 && Ks[li - 63] == key;
+        const bool left = kl == key, u0 = above == key, ul = al == key, ur = ar == key;
         if (CONN == 8) {
             if (ur && !u0) lds_unite(Ls, li, li - 63);
             if (!left) {
@@ -180,14 +187,15 @@ __global__ __launch_bounds__(256) void ccl_local_kernel(CclGeom g, const uint8_t
     for (int r = 0; r < CCL_ROWS; ++r) {
         const int y = y0 + r, li = (wave * CCL_ROWS + r) * 64 + lane;
         const int key = keys[r];
-        // run heads look the tile root up, the rest of the run takes it by shuffle
-        const int kprev = __shfl_up(key, 1, 64);
-        const bool head = key != 0 && (lane == 0 || kprev != key);
-        const u64 Sh = __ballot(head);
-        int head_root = -1;
-        if (head) head_root = lds_find(Ls, li);
-        const u64 below = Sh & ((2ull << lane) - 1ull);
-        const int rl = __shfl(head_root, below ? 63 - __clzll(below) : 0, 64);
+        // run heads look the tile root up and leave it in their own slot (only finds run in this phase: a reader sees the
+        // old parent or the root, both are on the chain); the rest of the run reads the head's slot - LDS operations of one
+        // wave complete in order
+        const bool head = key != 0 && hpos[r] == lane;
+        if (head) {
+            const int root = lds_find(Ls, li);
+            Ls[li] = root;
+        }
+        const int rl = key ? Ls[(li - lane) + hpos[r]] : -1;
         if (y < g.H && x < g.W) {
             const size_t p = base + (size_t)y * g.W + x;
             int lab = -1;

@@ -561,16 +561,24 @@ static unsigned px_grid(size_t total) {
     return (unsigned)(b ? b : 1);
 }
 #define PX_LOOP(total) for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < (total); t += (size_t)gridDim.x * blockDim.x)
+// The same over a batch with the image index in blockIdx.y (grid from img_grid): no 64-bit division per pixel to find the
+// image a flat index belongs to.  Defines im (image), ib (its first flat index) and t (flat index) for the body.
+#define IMG_PX_LOOP(n_img, px)                                                      \
+    for (int im = blockIdx.y; im < (n_img); im += gridDim.y)                        \
+        for (size_t ib = (size_t)im * (px), q_ = (size_t)blockIdx.x * blockDim.x + threadIdx.x, t = ib + q_; q_ < (px); \
+             q_ += (size_t)gridDim.x * blockDim.x, t = ib + q_)
+static dim3 img_grid(size_t px, int n_img) {
+    size_t bx = (px + 255) / 256;
+    if (bx > 2048) bx = 2048;
+    return dim3((unsigned)(bx ? bx : 1), (unsigned)(n_img < 65535 ? (n_img > 0 ? n_img : 1) : 65535));
+}
 
 // fill_holes (src/image_tools.py:36-39): pixels != c whose 4-connected background component does not reach the border
 __global__ __launch_bounds__(256) void apply_fill_kernel(uint8_t* __restrict__ img, const int32_t* __restrict__ L,
-                                                         const uint32_t* __restrict__ flag, size_t total, size_t px, int c) {
-    PX_LOOP(total) {
+                                                         const uint32_t* __restrict__ flag, int n_img, size_t px, int c) {
+    IMG_PX_LOOP(n_img, px) {
         const int r = L[t];
-        if (r >= 0) {
-            const size_t base = (t / px) * px;
-            if (!(flag[base + r] & 1u)) img[t] = (uint8_t)c;
-        }
+        if (r >= 0 && !(flag[ib + r] & 1u)) img[t] = (uint8_t)c;
     }
 }
 
@@ -579,17 +587,16 @@ __global__ __launch_bounds__(256) void apply_fill_kernel(uint8_t* __restrict__ i
 // reassignment) smaller than 15 px -> 0.  Means are exact integer sums divided in float64; NaN compares false.
 __global__ __launch_bounds__(256) void apply_size_thresh_kernel(uint8_t* __restrict__ img, const int32_t* __restrict__ L,
                                                                 const uint32_t* __restrict__ area,
-                                                                const int32_t* __restrict__ G_all, size_t total, size_t px,
+                                                                const int32_t* __restrict__ G_all, int n_img, size_t px,
                                                                 int ec_thresh) {
-    PX_LOOP(total) {
+    IMG_PX_LOOP(n_img, px) {
         const int r = L[t];
         if (r < 0) continue;
-        const size_t im = t / px;
-        const int32_t* G = G_all + im * G_IMG;
+        const int32_t* G = G_all + (size_t)im * G_IMG;
         // area < mean(areas) = S / n, evaluated exactly in integers: area * n < S.  (The reference compares in float64;
         // S / n is either an integer or at least 1 / n away from one, far more than a rounding error, so both orders
         // agree.  n == 0: the reference's mean is NaN and every comparison false; here S == 0 gives the same.)
-        const long long a = (long long)area[im * px + r];
+        const long long a = (long long)area[ib + r];
         const uint8_t v = img[t];
         if (v == 1) { if (a * (long long)G[G_NCOMP + 2] < (long long)G[G_NPX + 2]) img[t] = 0; }
         else if (v == 2) { if (a * (long long)G[G_NCOMP + 3] < (long long)G[G_NPX + 3]) img[t] = 3; }
@@ -636,13 +643,16 @@ __global__ __launch_bounds__(256) void ec_dilate_kernel(const uint8_t* __restric
 // 3 opening + combine (A = eroded image; B = label image, updated in place; C = merge_comp's working image).
 template <int OP>
 __global__ __launch_bounds__(256) void stencil4_kernel(const uint8_t* __restrict__ A, const uint8_t* B,
-                                                       const uint8_t* __restrict__ C, uint8_t* out, size_t total4,
-                                                       int H, int W, int c, int m) {
+                                                       const uint8_t* __restrict__ C, uint8_t* out, int n_img,
+                                                       int H, int W, int c, int m, uint32_t w4_magic) {
     const int W4 = W >> 2;
-    const size_t px4 = (size_t)H * W4;
-    PX_LOOP(total4) {
-        const size_t q = t % px4;
-        const int y = (int)(q / W4), x4 = (int)(q % W4);
+    const size_t px4 = (size_t)H * W4;                         // (< 2^30: H * W < 2^31 everywhere in this file)
+    IMG_PX_LOOP(n_img, px4) {
+        // row / column of the 4-pixel group inside its image: quotient by the host's floor(2^32 / W4), short by at most 2
+        const uint32_t q = (uint32_t)(t - ib);
+        uint32_t yq = __umulhi(q, w4_magic), xq = q - yq * (uint32_t)W4;
+        while (xq >= (uint32_t)W4) { xq -= (uint32_t)W4; ++yq; }
+        const int y = (int)yq, x4 = (int)xq;
         const size_t p = t * 4;
         const uint32_t cw = *reinterpret_cast<const uint32_t*>(A + p);
         const bool hn = y > 0, hs = y < H - 1, hw = x4 > 0, he = x4 < W4 - 1;
@@ -742,11 +752,11 @@ __global__ __launch_bounds__(256) void nucleus_test_kernel(const uint32_t* __res
 }
 
 __global__ __launch_bounds__(256) void apply_nucleus_kill_kernel(uint8_t* __restrict__ img, const int32_t* __restrict__ L,
-                                                                 const uint32_t* __restrict__ flag, size_t total, size_t px) {
-    PX_LOOP(total) {
+                                                                 const uint32_t* __restrict__ flag, int n_img, size_t px) {
+    IMG_PX_LOOP(n_img, px) {
         if (img[t] != 1) continue;
         const int r = L[t];
-        if (r >= 0 && (flag[(t / px) * px + r] & 2u)) img[t] = 0;
+        if (r >= 0 && (flag[ib + r] & 2u)) img[t] = 0;
     }
 }
 
@@ -755,16 +765,15 @@ __global__ __launch_bounds__(256) void apply_nucleus_kill_kernel(uint8_t* __rest
 // whose first pixel comes last in raster order).  Output: the working image `t`.
 __global__ __launch_bounds__(256) void apply_merge_kernel(const uint8_t* __restrict__ img, uint8_t* __restrict__ tmp,
                                                           const int32_t* __restrict__ L, const uint32_t* __restrict__ flag,
-                                                          const int32_t* __restrict__ G_all, size_t total, size_t px,
+                                                          const int32_t* __restrict__ G_all, int n_img, size_t px,
                                                           int c, int m) {
-    PX_LOOP(total) {
+    IMG_PX_LOOP(n_img, px) {
         uint8_t v = img[t];
         if (v == m) v = 0;
         const int r = L[t];
         if (r >= 0) {
-            const size_t im = t / px;
-            const int last = G_all[im * G_IMG + G_LAST_ROOT] - 1;
-            if ((flag[im * px + r] & 1u) && r != last) v = (uint8_t)c;
+            const int last = G_all[(size_t)im * G_IMG + G_LAST_ROOT] - 1;
+            if ((flag[ib + r] & 1u) && r != last) v = (uint8_t)c;
         }
         tmp[t] = v;
     }
@@ -822,30 +831,31 @@ hipError_t run_meta_inference(PostWorkspace& ws, uint8_t* img, int n_img, int H,
     const CclGeom g = make_geom(n_img, H, W);
     const size_t px = (size_t)H * W, total = px * n_img;
     const unsigned pg = px_grid(total);
+    const dim3 ig = img_grid(px, n_img);
     hipError_t e;
     // 1. fill_holes(1), fill_holes(2)
     for (int c = 1; c <= 2; ++c) {
         CclPass p{img, lut_ne(c), 4, 0, AUX_BORDER, 0, nullptr, 0};
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
-        hipLaunchKernelGGL(apply_fill_kernel, dim3(pg), dim3(256), 0, s, img, ws.L, ws.flag, total, px, c);
+        hipLaunchKernelGGL(apply_fill_kernel, ig, dim3(256), 0, s, img, ws.L, ws.flag, n_img, px, c);
     }
     // 2-4. size_thresh
     {
         CclPass p{img, LUT_MULTI, 8, STAT_AREA, AUX_NONE, 0, nullptr, NEED_NCOMP | NEED_NPX};
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
-        hipLaunchKernelGGL(apply_size_thresh_kernel, dim3(pg), dim3(256), 0, s, img, ws.L, ws.area, ws.g, total, px, 15);
+        hipLaunchKernelGGL(apply_size_thresh_kernel, ig, dim3(256), 0, s, img, ws.L, ws.area, ws.g, n_img, px, 15);
     }
     // From here on the working image is ws.tmpA and the caller's buffer is a scratch image (no copies back and forth);
     // the last stencil writes the result into the caller's buffer.  W % 4 == 0: four pixels per thread.
     const bool v4 = (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(img) | reinterpret_cast<uintptr_t>(ws.tmpA) |
                                       reinterpret_cast<uintptr_t>(ws.tmpB)) & 3) == 0;
-    const size_t total4 = total / 4;
-    const unsigned pg4 = px_grid(total4);
+    const dim3 ig4 = img_grid(px / 4, n_img);
+    const uint32_t w4_magic = W >= 8 ? (uint32_t)((1ull << 32) / (uint64_t)(W >> 2)) : 0xffffffffu / (uint32_t)(W >= 4 ? (W >> 2) : 1);
     uint8_t* cur = ws.tmpA;
     uint8_t* t1 = img;
     uint8_t* t2 = ws.tmpB;
     // 5. ecDNA band removal
-    if (v4) hipLaunchKernelGGL(stencil4_kernel<0>, dim3(pg4), dim3(256), 0, s, img, nullptr, nullptr, cur, total4, H, W, 0, 0);
+    if (v4) hipLaunchKernelGGL(stencil4_kernel<0>, ig4, dim3(256), 0, s, img, nullptr, nullptr, cur, n_img, H, W, 0, 0, w4_magic);
     else hipLaunchKernelGGL(band_removal_kernel, dim3(pg), dim3(256), 0, s, img, cur, total, H, W);
     // 6. nucleus-in-metaphase test
     {
@@ -859,24 +869,24 @@ hipError_t run_meta_inference(PostWorkspace& ws, uint8_t* img, int n_img, int H,
         const int bpi = 32;
         hipLaunchKernelGGL(nucleus_test_kernel, dim3(n_img * bpi), dim3(256), 0, s, ws.area, ws.sumy, ws.sumx, ws.g, list1,
                            list2, ws.flag, px, cap, bpi, 70.0, 5);
-        hipLaunchKernelGGL(apply_nucleus_kill_kernel, dim3(pg), dim3(256), 0, s, cur, ws.L, ws.flag, total, px);
+        hipLaunchKernelGGL(apply_nucleus_kill_kernel, ig, dim3(256), 0, s, cur, ws.L, ws.flag, n_img, px);
     }
     // 7-8. merge_comp(1), merge_comp(2)
     for (int c = 1; c <= 2; ++c) {
         const int m = (c == 1) ? 2 : 1;
         CclPass p{cur, lut_nonzero_except(m), 8, 0, AUX_VALUE_EQ, c, nullptr, NEED_LAST};
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
-        hipLaunchKernelGGL(apply_merge_kernel, dim3(pg), dim3(256), 0, s, cur, t1, ws.L, ws.flag, ws.g, total, px, c, m);
+        hipLaunchKernelGGL(apply_merge_kernel, ig, dim3(256), 0, s, cur, t1, ws.L, ws.flag, ws.g, n_img, px, c, m);
         if (v4) {
-            hipLaunchKernelGGL(stencil4_kernel<2>, dim3(pg4), dim3(256), 0, s, t1, nullptr, nullptr, t2, total4, H, W, 0, 0);
-            hipLaunchKernelGGL(stencil4_kernel<3>, dim3(pg4), dim3(256), 0, s, t2, cur, t1, cur, total4, H, W, c, m);
+            hipLaunchKernelGGL(stencil4_kernel<2>, ig4, dim3(256), 0, s, t1, nullptr, nullptr, t2, n_img, H, W, 0, 0, w4_magic);
+            hipLaunchKernelGGL(stencil4_kernel<3>, ig4, dim3(256), 0, s, t2, cur, t1, cur, n_img, H, W, c, m, w4_magic);
         } else {
             hipLaunchKernelGGL(grey_erode_kernel, dim3(pg), dim3(256), 0, s, t1, t2, total, H, W);
             hipLaunchKernelGGL(open_combine_kernel, dim3(pg), dim3(256), 0, s, cur, t1, t2, total, H, W, c, m);
         }
     }
     // 9. final ecDNA dilation, back into the caller's buffer
-    if (v4) hipLaunchKernelGGL(stencil4_kernel<1>, dim3(pg4), dim3(256), 0, s, cur, nullptr, nullptr, img, total4, H, W, 0, 0);
+    if (v4) hipLaunchKernelGGL(stencil4_kernel<1>, ig4, dim3(256), 0, s, cur, nullptr, nullptr, img, n_img, H, W, 0, 0, w4_magic);
     else hipLaunchKernelGGL(ec_dilate_kernel, dim3(pg), dim3(256), 0, s, cur, img, total, H, W);
     // 10. count_cc(img == 3)[0]
     if (n_ec_dev) {

@@ -569,7 +569,8 @@ static unsigned px_grid(size_t total) {
              q_ += (size_t)gridDim.x * blockDim.x, t = ib + q_)
 static dim3 img_grid(size_t px, int n_img) {
     size_t bx = (px + 255) / 256;
-    if (bx > 2048) bx = 2048;
+    const size_t cap = (size_t)(256 * 64) / (size_t)(n_img > 0 ? (n_img < 16384 ? n_img : 16384) : 1);   // ~16 k blocks in all, several pixels per thread
+    if (bx > cap) bx = cap;
     return dim3((unsigned)(bx ? bx : 1), (unsigned)(n_img < 65535 ? (n_img > 0 ? n_img : 1) : 65535));
 }
 

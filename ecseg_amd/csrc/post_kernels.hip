@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8
     const int x = cx * 64 + lane;
     const int W = g.W, H = g.H;
     const int yblk = y0 - wave * CCL_ROWS;
-    const int tile_org = yblk * W + cx * 64;
+    const int strip_org = yblk * W;                           // first pixel of the tile's first image row
     const float inv_w = 1.0f / (float)W;
     int npx[4] = {0, 0, 0, 0};
     int troot[CCL_ROWS];                                       // tile-local index of this pixel's tile root, -1 = background
@@ -330,18 +330,20 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8
         // of its tile component still point at it).
         int tr = -1;
         if (key) {
-            // (dy, dx) of the root relative to the tile origin; an in-tile d < 32 W < 2^24 is exact in float, so the
-            // quotient by the reciprocal is off by at most one (no integer division per pixel)
-            const int d = lab - tile_org;
-            int dy, dx;
+            // (row, column) of the root relative to the tile's first image row: an in-strip d < 32 W < 2^24 is exact in
+            // float, so the quotient by the reciprocal is off by at most one (no integer division per pixel).  The COLUMN
+            // must be the root's true image column: a root left of the tile in a later row is not in the tile.
+            const int d = lab - strip_org;
+            int dy, rx;
             if (W < (1 << 19)) {
                 dy = (int)((float)d * inv_w);
-                dx = d - dy * W;
-                if (dx < 0) { dy -= 1; dx += W; } else if (dx >= W) { dy += 1; dx -= W; }
+                rx = d - dy * W;
+                if (rx < 0) { dy -= 1; rx += W; } else if (rx >= W) { dy += 1; rx -= W; }
             } else {                                           // 32 W >= 2^24: not exact in float
                 dy = d / W;
-                dx = d - dy * W;
+                rx = d - dy * W;
             }
+            const int dx = rx - cx * 64;
             tr = ((unsigned)d < (unsigned)(CCL_BLOCK_ROWS * W) && (unsigned)dy < (unsigned)CCL_BLOCK_ROWS && (unsigned)dx < 64u)
                      ? dy * 64 + dx : (wave * CCL_ROWS + r) * 64 + lane;
         }

@@ -73,7 +73,7 @@ __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {   
 
 // ABL: timing-only ablations for tools/w4_ablate.py (ECSEG_W4_ABL): 1 no halo LDS reads, 2 no filter DMA, 4 no halo DMA,
 // 8 no MFMA, 32 instruction mix of a (row, column-half) wave split, 64 instruction mix of a transform shared between
-// the two channel-half waves of a row through LDS; STAMP (ECSEG_W4_ABL=100): s_memtime stamps
+// the two channel-half waves of a row through LDS, 128 halo pieces from consecutive addresses; STAMP (ECSEG_W4_ABL=100): s_memtime stamps
 template <int ABL, bool STAMP = false, bool HEAD = false>
 __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_x, int regs_y, int npairs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -146,6 +146,13 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             if (img >= 0 && iy >= 0 && iy < H && ix >= 0 && ix < W)
                 d = (unsigned long long)(size_t)(p.in.p + (((size_t)img * H + iy) * W + ix) * p.in.cs + 4 * h) | 1ull | (h ? 2ull : 0ull);
         }
+        if (ABL & 128) {
+            // timing model of a channel-blocked activation layout: the 64 lanes of a piece read 1 KB of consecutive
+            // addresses (distinct per workgroup and group, wrong data)
+            const size_t tensor = (size_t)p.n * H * W * p.in.cs;
+            const size_t off = (((size_t)pair * 4099u) % (tensor / 8192 > 201 ? tensor / 8192 - 200 : 1)) * 8192 + (size_t)a * 4;
+            d = (unsigned long long)(size_t)(p.in.p + off) | 1ull;
+        }
         Hd[i * 768] = d;
     }
     auto dma_halo_piece = [&](int grp, auto ii) {            // piece ii (0 | 1) of halo group grp (< ngroups)
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         unsigned long long d = Hd[i * 768];
         // Cin % 8 == 4: the upper channel half of the last group does not exist - its lanes (bit 1) read the zero page
         if (tail4 && grp == ngroups - 1 && (d & 2ull)) d = (unsigned long long)(size_t)p.zero;
-        const float* src = reinterpret_cast<const float*>((size_t)(d & ~3ull)) + (d & 1ull ? grp * 8 : 0);
+        const float* src = reinterpret_cast<const float*>((size_t)(d & ~3ull)) + (d & 1ull ? ((ABL & 128) ? grp * 6144 : grp * 8) : 0);
         glds16<0>(src, lds_base + (unsigned)((grp % 3) * W4_HS + 64 * (wave + 12 * i)) * 16u);
     };
     // ---- filter DMA: wt4[nb][stage][wave][point nu][h][cout 32][k 2], 768 floats per wave and stage ----
@@ -595,6 +602,7 @@ hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s) {
         case 8: kern = conv_wino4_kernel<8>; break;
         case 32: kern = conv_wino4_kernel<32>; break;
         case 64: kern = conv_wino4_kernel<64>; break;
+        case 128: kern = conv_wino4_kernel<128>; break;
         case 100: kern = conv_wino4_kernel<0, true>; break;        // in-kernel cycle stamps (tools/w4_stamp_probe.py)
         default: break;
     }

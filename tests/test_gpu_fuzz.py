@@ -124,3 +124,34 @@ def test_fuzz_stitch_quantised_argmax(gpu, seed):
         p[m, 1] = ((q[m, 1] // 2) + 0.5) / 255.0
         got = gpu.stitch_argmax(p, 1, H, W)[0]
         assert np.array_equal(got, quant.quantised_argmax(tiling.stitch(p, pos))), (seed, H, W)
+
+
+# Seeds of tools/fuzz_campaign.py that once failed: a tile root in the image's last 64-column chunk pointed at a root LEFT of
+# the tile in a later row, and ccl_flatten's division-free in-tile test took the row-wrapped offset for an in-tile column.
+CAMPAIGN_REGRESSIONS = (1405, 2096, 2602, 2765, 2776, 3812, 4193, 4826, 4948, 6014, 6136)
+
+
+def _campaign_case(seed):
+    """The case tools/fuzz_campaign.py builds for `seed` (same generator calls in the same order)."""
+    rng = np.random.default_rng(10 ** 6 + seed)
+    big = seed % 3 == 0
+    H = int(rng.integers(200, 1100)) if big else int(rng.integers(1, 260))
+    W = int(rng.integers(300, 1500)) if big else int(rng.integers(1, 400))
+    n = int(rng.integers(1, 4))
+    masks = np.stack([_random_mask(rng, H, W) for _ in range(n)])
+    labs = np.stack([_random_labels(rng, H, W) for _ in range(n)]) if H >= 3 and W >= 3 else None
+    return masks, labs
+
+
+@pytest.mark.parametrize('seed', CAMPAIGN_REGRESSIONS)
+def test_fuzz_campaign_regressions(gpu, seed):
+    masks, labs = _campaign_case(seed)
+    for conn, lab_fn in ((8, postproc.label8), (4, postproc.label4)):
+        got = gpu.ccl_labels(masks, conn)
+        for k in range(len(masks)):
+            assert np.array_equal(got[k], _canon(lab_fn(masks[k])[0])), (seed, conn, k)
+    out, nec = gpu.meta_inference(labs)
+    for k in range(len(labs)):
+        want = postproc.meta_inference(labs[k])
+        assert np.array_equal(out[k], want), (seed, k, labs.shape)
+        assert int(nec[k]) == postproc.count_cc(want == 3)[0]

@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Randomised layer-graph parity: small random Keras graphs (convolutions of several kernel sizes / strides / paddings,
+pooling, transposed convolutions, up-sampling, concatenation, BatchNormalization, 1x1 heads; channel counts and extents
+chosen so that every convolution kernel - Winograd F(4x4), F(2x2), direct MFMA, small-Cin, generic - and every fusion gets
+hit) through the device under all three `winograd` modes, against the CPU oracle (oracle/unet.py), tolerance 1e-3 relative to
+the output range.  Runs for --seconds; exit code 1 on any mismatch.
+
+    python tools/fuzz_layers.py --seconds 300 [--seed0 0]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CH = (4, 8, 12, 16, 24, 32, 40, 64, 96, 128)
+HW = (16, 32, 48, 64, 20, 36, 80)
+
+
+def _L(cls, name, inb, **c):
+    return {'class_name': cls, 'name': name, 'config': dict(c, name=name),
+            'inbound_nodes': [[[i, 0, 0, {}] for i in inb]] if inb else []}
+
+
+def random_graph(rng):
+    """-> (model_config, weights dict).  A small encoder / decoder with one skip; every choice is random."""
+    h = int(rng.choice(HW)); w = int(rng.choice(HW))
+    cin = int(rng.choice((1, 3, 4, 8, 16, 32)))
+    layers = [_L('InputLayer', 'in', [], batch_input_shape=[None, h, w, cin])]
+    weights = {}
+    shape = {'in': (h, w, cin)}
+
+    def conv(name, src, cout, k, stride=1, padding='same', act='relu', bias=True):
+        hh, ww, cc = shape[src]
+        layers.append(_L('Conv2D', name, [src], filters=cout, kernel_size=[k, k], strides=[stride, stride], padding=padding,
+                         activation=act, use_bias=bias))
+        ws = [(rng.normal(size=(k, k, cc, cout)) / np.sqrt(k * k * cc)).astype(np.float32)]
+        if bias:
+            ws.append((rng.normal(size=cout) * 0.1).astype(np.float32))
+        weights[name] = ws
+        if padding == 'same':
+            shape[name] = (-(-hh // stride), -(-ww // stride), cout)
+        else:
+            shape[name] = ((hh - k) // stride + 1, (ww - k) // stride + 1, cout)
+        return name
+
+    # first layer scales the uint8 input down
+    c0 = int(rng.choice(CH))
+    prev = conv('c0', 'in', c0, int(rng.choice((1, 3, 3, 5))), act=str(rng.choice(('relu', 'linear', 'tanh'))))
+    weights['c0'][0] = weights['c0'][0] / 128.0
+    if rng.random() < 0.3:
+        cc = shape[prev][2]
+        layers.append(_L('BatchNormalization', 'bn0', [prev], axis=[3], epsilon=1e-3, center=True, scale=True))
+        weights['bn0'] = [rng.uniform(0.5, 1.5, cc).astype(np.float32), (rng.normal(size=cc) * 0.1).astype(np.float32),
+                          (rng.normal(size=cc) * 0.1).astype(np.float32), rng.uniform(0.5, 1.5, cc).astype(np.float32)]
+        shape['bn0'] = shape[prev]
+        prev = 'bn0'
+    prev = conv('c1', prev, int(rng.choice(CH)), 3, act=str(rng.choice(('relu', 'relu', 'sigmoid', 'linear'))))
+    skip = prev
+    hh, ww, cc = shape[prev]
+    if hh % 2 == 0 and ww % 2 == 0 and rng.random() < 0.8:
+        pool = str(rng.choice(('MaxPooling2D', 'MaxPooling2D', 'AveragePooling2D')))
+        layers.append(_L(pool, 'p', [prev], pool_size=[2, 2], strides=[2, 2], padding='valid'))
+        shape['p'] = (hh // 2, ww // 2, cc)
+        prev = conv('c2', 'p', int(rng.choice(CH)), int(rng.choice((3, 3, 3, 1, 2))), act='relu')
+        prev = conv('c3', prev, int(rng.choice(CH)), 3, act=str(rng.choice(('relu', 'elu'))), bias=bool(rng.random() < 0.8))
+        h2, w2, c2 = shape[prev]
+        if rng.random() < 0.6:
+            cu = int(rng.choice(CH))
+            layers.append(_L('Conv2DTranspose', 'up', [prev], filters=cu, kernel_size=[2, 2], strides=[2, 2], padding='same',
+                             activation=str(rng.choice(('linear', 'relu'))), use_bias=True))
+            weights['up'] = [(rng.normal(size=(2, 2, cu, c2)) / np.sqrt(c2)).astype(np.float32),
+                             (rng.normal(size=cu) * 0.1).astype(np.float32)]
+            shape['up'] = (h2 * 2, w2 * 2, cu)
+        else:
+            layers.append(_L('UpSampling2D', 'up', [prev], size=[2, 2], interpolation=str(rng.choice(('nearest', 'bilinear')))))
+            shape['up'] = (h2 * 2, w2 * 2, c2)
+        if shape['up'][:2] == shape[skip][:2]:
+            order = [skip, 'up'] if rng.random() < 0.5 else ['up', skip]
+            layers.append(_L('Concatenate', 'cat', order, axis=-1))
+            shape['cat'] = (hh, ww, shape['up'][2] + shape[skip][2])
+            prev = 'cat'
+        else:
+            prev = 'up'
+        prev = conv('c4', prev, int(rng.choice(CH)), 3, act='relu')
+    last = conv('c5', prev, int(rng.choice((32, 64, 64, 16, 24))), 3, act='relu')
+    ncls = int(rng.choice((2, 3, 4, 4, 5)))
+    head = conv('head', last, ncls, 1, act=str(rng.choice(('softmax', 'softmax', 'sigmoid'))))
+    cfg = {'class_name': 'Functional', 'config': {'name': 'fuzz', 'layers': layers, 'input_layers': [['in', 0, 0]],
+                                                 'output_layers': [[head, 0, 0]]}}
+    return cfg, weights, shape['in']
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--seconds', type=float, default=300)
+    ap.add_argument('--seed0', type=int, default=0)
+    ap.add_argument('--seeds', default=None)
+    a = ap.parse_args()
+    import torch  # noqa: F401
+    from ecseg_amd.model import MetasegModel
+    from oracle import unet as oracle_unet
+    t0 = time.time()
+    seed = a.seed0
+    todo = [int(x) for x in a.seeds.split(',')] if a.seeds else None
+    n_graphs = fails = 0
+    worst = 0.0
+    while time.time() - t0 < a.seconds:
+        if todo is not None:
+            if not todo:
+                break
+            seed = todo.pop(0)
+        rng = np.random.default_rng(5 * 10 ** 6 + seed)
+        cfg, weights, (h, w, cin) = random_graph(rng)
+        n = int(rng.integers(1, 5))
+        x = rng.integers(0, 256, size=(n, h, w, cin), dtype=np.uint8)
+        want = oracle_unet.forward(cfg, weights, x.astype(np.float32))
+        scale = max(1.0, float(np.abs(want).max()))
+        try:
+            m = MetasegModel(cfg, weights, device=0)
+            for mode in (2, 1, 0):
+                m.handle.set_option('winograd', mode)
+                for fuse in (1, 0):
+                    m.handle.set_option('fuse_pool', fuse)
+                    m.handle.set_option('fuse_head', fuse)
+                    got = m.handle.forward_patches(x)
+                    err = float(np.abs(got - want).max()) / scale
+                    worst = max(worst, err)
+                    if not np.isfinite(got).all() or err > 1e-3:
+                        desc = ' '.join('%s:%s' % (L['class_name'][:6], L['config'].get('filters', '')) for L in cfg['config']['layers'])
+                        print('FAIL seed %d mode %d fuse %d err %.3e  in %s x%d  %s' % (seed, mode, fuse, err, (h, w, cin), n, desc), flush=True)
+                        fails += 1
+            del m
+        except Exception as e:  # a graph the plan rejects is a finding too
+            print('ERROR seed %d: %s: %s' % (seed, type(e).__name__, e), flush=True)
+            fails += 1
+        n_graphs += 1
+        seed += 1
+    print('layer fuzz: %d random graphs x 3 kernel modes x 2 fusion settings, worst relative error %.2e, %d failure(s), %.0f s'
+          % (n_graphs, worst, fails, time.time() - t0), flush=True)
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == '__main__':
+    main()

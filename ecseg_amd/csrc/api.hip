@@ -368,7 +368,7 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                         if (oi + 1 < h->ops.size()) {
                             const ecseg_op_desc& nx = h->ops[oi + 1].d;
                             const TView po = nx.op == ECSEG_OP_MAXPOOL ? view_of(h, nx.out) : TView{};
-                            if (nx.op == ECSEG_OP_MAXPOOL && nx.in0 == d.out && nx.kh == 2 && nx.kw == 2 && nx.stride == 2 &&
+                            if (nx.op == ECSEG_OP_MAXPOOL && nx.mode == 0 /* max, not average */ && nx.in0 == d.out && nx.kh == 2 && nx.kw == 2 && nx.stride == 2 &&
                                 h->fuse_pool && !softmax && po.h * 2 == out.h && po.w * 2 == out.w && po.c == out.c && po.cs % 4 == 0 &&
                                 reinterpret_cast<uintptr_t>(po.p) % 16 == 0 &&
                                 h->tensors[nx.out].buffer != h->tensors[d.in0].buffer && h->tensors[nx.out].buffer != h->tensors[d.out].buffer) {

@@ -155,3 +155,28 @@ def test_fuzz_campaign_regressions(gpu, seed):
         want = postproc.meta_inference(labs[k])
         assert np.array_equal(out[k], want), (seed, k, labs.shape)
         assert int(nec[k]) == postproc.count_cc(want == 3)[0]
+
+
+# Random layer graphs (tools/fuzz_layers.py) under every kernel mode and fusion setting.  The second seed block once failed:
+# an AveragePooling2D behind a Winograd F(4x4) convolution was taken for the max-pool the output stage can write itself.
+@pytest.mark.parametrize('seed0', (0, 8, 16, 4090, 4117, 4121, 4227))
+def test_fuzz_layer_graphs(seed0):
+    from ecseg_amd.model import MetasegModel
+    from oracle import unet as oracle_unet
+    from tools.fuzz_layers import random_graph
+    for seed in range(seed0, seed0 + (8 if seed0 < 100 else 1)):
+        rng = np.random.default_rng(5 * 10 ** 6 + seed)
+        cfg, weights, (h, w, cin) = random_graph(rng)
+        n = int(rng.integers(1, 5))
+        x = rng.integers(0, 256, size=(n, h, w, cin), dtype=np.uint8)
+        want = oracle_unet.forward(cfg, weights, x.astype(np.float32))
+        scale = max(1.0, float(np.abs(want).max()))
+        m = MetasegModel(cfg, weights, device=0)
+        for mode in (2, 1, 0):
+            m.handle.set_option('winograd', mode)
+            for fuse in (1, 0):
+                m.handle.set_option('fuse_pool', fuse)
+                m.handle.set_option('fuse_head', fuse)
+                got = m.handle.forward_patches(x)
+                assert np.isfinite(got).all() and float(np.abs(got - want).max()) / scale <= 1e-3, (seed, mode, fuse)   # tolerance: BASELINE.json north_star
+        del m

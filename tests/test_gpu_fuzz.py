@@ -180,3 +180,14 @@ def test_fuzz_layer_graphs(seed0):
                 got = m.handle.forward_patches(x)
                 assert np.isfinite(got).all() and float(np.abs(got - want).max()) / scale <= 1e-3, (seed, mode, fuse)   # tolerance: BASELINE.json north_star
         del m
+
+
+def test_fuzz_pipeline_cases(monkeypatch):
+    """Six cases of tools/fuzz_pipeline.py (random small U-Nets x random image sizes: crop on == off, probabilities vs the
+    oracle, clean-up / counts on the device raw labels, meta_preprocess, overlay rows)."""
+    import runpy
+    import sys
+    monkeypatch.setattr(sys, 'argv', ['fuzz_pipeline.py', '--seeds', '0,1,2,3,4,5'])
+    with pytest.raises(SystemExit) as e:
+        runpy.run_path('tools/fuzz_pipeline.py', run_name='__main__')
+    assert e.value.code == 0

@@ -185,9 +185,11 @@ def test_fuzz_layer_graphs(seed0):
 def test_fuzz_pipeline_cases(monkeypatch):
     """Six cases of tools/fuzz_pipeline.py (random small U-Nets x random image sizes: crop on == off, probabilities vs the
     oracle, clean-up / counts on the device raw labels, meta_preprocess, overlay rows)."""
+    import os
     import runpy
     import sys
     monkeypatch.setattr(sys, 'argv', ['fuzz_pipeline.py', '--seeds', '0,1,2,3,4,5'])
     with pytest.raises(SystemExit) as e:
-        runpy.run_path('tools/fuzz_pipeline.py', run_name='__main__')
+        runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'fuzz_pipeline.py'),
+                       run_name='__main__')
     assert e.value.code == 0

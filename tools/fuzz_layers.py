@@ -26,7 +26,7 @@ def _L(cls, name, inb, **c):
             'inbound_nodes': [[[i, 0, 0, {}] for i in inb]] if inb else []}
 
 
-def random_graph(rng):
+def random_graph(rng, seed_kind=0):
     """-> (model_config, weights dict).  A small encoder / decoder with one skip; every choice is random."""
     h = int(rng.choice(HW)); w = int(rng.choice(HW))
     cin = int(rng.choice((1, 3, 4, 8, 16, 32)))
@@ -50,7 +50,11 @@ def random_graph(rng):
 
     # first layer scales the uint8 input down
     c0 = int(rng.choice(CH))
-    prev = conv('c0', 'in', c0, int(rng.choice((1, 3, 3, 5))), act=str(rng.choice(('relu', 'linear', 'tanh'))))
+    if seed_kind == 1 and h >= 32 and w >= 32:                 # classifier-style stem: strided and / or 'valid' convolution
+        prev = conv('c0', 'in', c0, int(rng.choice((3, 5, 2))), stride=int(rng.choice((1, 2, 2))),
+                    padding=str(rng.choice(('same', 'valid'))), act='relu')
+    else:
+        prev = conv('c0', 'in', c0, int(rng.choice((1, 3, 3, 5))), act=str(rng.choice(('relu', 'linear', 'tanh'))))
     weights['c0'][0] = weights['c0'][0] / 128.0
     if rng.random() < 0.3:
         cc = shape[prev][2]
@@ -89,7 +93,23 @@ def random_graph(rng):
         prev = conv('c4', prev, int(rng.choice(CH)), 3, act='relu')
     last = conv('c5', prev, int(rng.choice((32, 64, 64, 16, 24))), 3, act='relu')
     ncls = int(rng.choice((2, 3, 4, 4, 5)))
-    head = conv('head', last, ncls, 1, act=str(rng.choice(('softmax', 'softmax', 'sigmoid'))))
+    if seed_kind == 1 and rng.random() < 0.7:                  # classifier tail: pooling / flatten -> Dense -> Dense
+        hh, ww, cc = shape[last]
+        if rng.random() < 0.5 or hh * ww * cc > 40000:
+            pool = str(rng.choice(('GlobalAveragePooling2D', 'GlobalMaxPooling2D')))
+            layers.append(_L(pool, 'gp', [last]))
+            feat = cc
+        else:
+            layers.append(_L('Flatten', 'gp', [last]))
+            feat = hh * ww * cc
+        nh = int(rng.choice((8, 16, 33, 64)))
+        layers.append(_L('Dense', 'd0', ['gp'], units=nh, activation='relu', use_bias=True))
+        weights['d0'] = [(rng.normal(size=(feat, nh)) / np.sqrt(feat)).astype(np.float32), (rng.normal(size=nh) * 0.1).astype(np.float32)]
+        layers.append(_L('Dense', 'head', ['d0'], units=ncls, activation=str(rng.choice(('softmax', 'sigmoid'))), use_bias=True))
+        weights['head'] = [(rng.normal(size=(nh, ncls)) / np.sqrt(nh)).astype(np.float32), (rng.normal(size=ncls) * 0.1).astype(np.float32)]
+        head = 'head'
+    else:
+        head = conv('head', last, ncls, 1, act=str(rng.choice(('softmax', 'softmax', 'sigmoid'))))
     cfg = {'class_name': 'Functional', 'config': {'name': 'fuzz', 'layers': layers, 'input_layers': [['in', 0, 0]],
                                                  'output_layers': [[head, 0, 0]]}}
     return cfg, weights, shape['in']
@@ -115,7 +135,7 @@ def main():
                 break
             seed = todo.pop(0)
         rng = np.random.default_rng(5 * 10 ** 6 + seed)
-        cfg, weights, (h, w, cin) = random_graph(rng)
+        cfg, weights, (h, w, cin) = random_graph(rng, seed_kind=1 if seed >= 10 ** 5 else 0)
         n = int(rng.integers(1, 5))
         x = rng.integers(0, 256, size=(n, h, w, cin), dtype=np.uint8)
         want = oracle_unet.forward(cfg, weights, x.astype(np.float32))

@@ -61,6 +61,14 @@ def main():
         try:
             m = MetasegModel(cfg, w, device=0)
             h = m.handle
+            # random execution options: none of them may change a single label
+            opts = {'images_per_group': int(rng.integers(1, 4)), 'overlap_post': int(rng.integers(0, 2)),
+                    'post_graph': int(rng.integers(0, 2)), 'winograd': int(rng.choice((2, 2, 1, 0)))}
+            if rng.random() < 0.5:
+                opts['post_chunk'] = int(rng.integers(1, 4))
+            for kk, vv in opts.items():
+                h.set_option(kk, vv)
+            tag += ' ' + ','.join('%s=%d' % kv for kv in sorted(opts.items()))
             h.set_option('crop', 1)
             raw1, post1, nec1 = h.segment_images(imgs, want_raw=True)
             h.set_option('crop', 0)

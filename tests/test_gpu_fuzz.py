@@ -193,3 +193,16 @@ def test_fuzz_pipeline_cases(monkeypatch):
         runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'fuzz_pipeline.py'),
                        run_name='__main__')
     assert e.value.code == 0
+
+
+def test_fuzz_cli_folders(monkeypatch):
+    """Eight folders of tools/fuzz_cli.py: mixed image sizes / sample types / TIFF flavours / .npy inputs through the
+    `make metaseg` and `make meta_overlay` loops with random batch sizes and I/O thread counts."""
+    import os
+    import runpy
+    import sys
+    monkeypatch.setattr(sys, 'argv', ['fuzz_cli.py', '--seeds', '0,1,2,3,4,5,6,7'])
+    with pytest.raises(SystemExit) as e:
+        runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'fuzz_cli.py'),
+                       run_name='__main__')
+    assert e.value.code == 0

@@ -19,6 +19,8 @@ sys.path.insert(0, ROOT)
 
 CH = (4, 8, 12, 16, 24, 32, 40, 64, 96, 128)
 HW = (16, 32, 48, 64, 20, 36, 80)
+CH_WIDE = (12, 36, 44, 64, 100, 160, 192, 224, 288, 320)       # --wide: Cin % 8 == 4 tails, Cout % 64 == 32, several channel blocks
+HW_WIDE = (16, 32, 48, 96, 112, 128, 24, 40)
 
 
 def _L(cls, name, inb, **c):
@@ -26,7 +28,8 @@ def _L(cls, name, inb, **c):
             'inbound_nodes': [[[i, 0, 0, {}] for i in inb]] if inb else []}
 
 
-def random_graph(rng, seed_kind=0):
+def random_graph(rng, seed_kind=0, wide=False):
+    CH, HW = (CH_WIDE, HW_WIDE) if wide else (globals()['CH'], globals()['HW'])
     """-> (model_config, weights dict).  A small encoder / decoder with one skip; every choice is random."""
     h = int(rng.choice(HW)); w = int(rng.choice(HW))
     cin = int(rng.choice((1, 3, 4, 8, 16, 32)))
@@ -120,6 +123,7 @@ def main():
     ap.add_argument('--seconds', type=float, default=300)
     ap.add_argument('--seed0', type=int, default=0)
     ap.add_argument('--seeds', default=None)
+    ap.add_argument('--wide', action='store_true', help='wider layers / larger extents')
     a = ap.parse_args()
     import torch  # noqa: F401
     from ecseg_amd.model import MetasegModel
@@ -135,7 +139,7 @@ def main():
                 break
             seed = todo.pop(0)
         rng = np.random.default_rng(5 * 10 ** 6 + seed)
-        cfg, weights, (h, w, cin) = random_graph(rng, seed_kind=1 if seed >= 10 ** 5 else 0)
+        cfg, weights, (h, w, cin) = random_graph(rng, seed_kind=1 if seed >= 10 ** 5 else 0, wide=a.wide)
         n = int(rng.integers(1, 5))
         x = rng.integers(0, 256, size=(n, h, w, cin), dtype=np.uint8)
         want = oracle_unet.forward(cfg, weights, x.astype(np.float32))

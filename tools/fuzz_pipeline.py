@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--seconds', type=float, default=300)
     ap.add_argument('--seed0', type=int, default=0)
     ap.add_argument('--seeds', default=None)
+    ap.add_argument('--deep', action='store_true', help='depth up to 4, images up to 1100 x 1500')
     a = ap.parse_args()
     import torch  # noqa: F401
     from ecseg_amd import synth
@@ -49,13 +50,15 @@ def main():
             seed = todo.pop(0)
         rng = np.random.default_rng(9 * 10 ** 6 + seed)
         base = int(rng.choice((8, 8, 16, 16, 24, 32)))
-        depth = int(rng.choice((1, 2, 2, 3)))
+        depth = int(rng.choice((3, 4, 4))) if a.deep else int(rng.choice((1, 2, 2, 3)))
+        if a.deep:
+            base = 8
         up = str(rng.choice(('transpose', 'transpose', 'upsample')))
         bn = bool(rng.random() < 0.25)
         cfg = synth.unet_config(base=base, depth=depth, up=up, batchnorm=bn)
         w = synth.unet_weights(cfg, seed=int(rng.integers(0, 1000)))
-        H = int(rng.integers(256, 620)); W = int(rng.integers(256, 700))
-        n = int(rng.integers(1, 4))
+        H = int(rng.integers(256, 1100 if a.deep else 620)); W = int(rng.integers(256, 1500 if a.deep else 700))
+        n = int(rng.integers(1, 3 if a.deep else 4))
         imgs = np.stack([synth.dapi_image(int(rng.integers(0, 10 ** 6)), H, W) for _ in range(n)])
         tag = 'base %d depth %d %s%s, %d x %dx%d' % (base, depth, up, ' +bn' if bn else '', n, H, W)
         try:

@@ -99,6 +99,7 @@ struct PostWorkspace {
     uint8_t* tmpB;
     int32_t* list;       // per image: compacted root lists for the nucleus-in-metaphase test
     int32_t* g;          // per image: small block of global counters (G_STRIDE ints)
+    uint8_t* tile_any;   // per image and 64 x 32 labelling tile: the tile holds a keyed pixel (written by ccl_local)
     int cap_img;
     size_t cap_px;
 };

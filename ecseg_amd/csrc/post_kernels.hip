@@ -83,6 +83,11 @@ __device__ __forceinline__ bool decode_block(const CclGeom& g, int& img, int& y0
     return true;
 }
 
+// index of this block's tile in PostWorkspace::tile_any (valid after decode_block returned true)
+__device__ __forceinline__ size_t tile_index(const CclGeom& g, int img) {
+    return (size_t)img * g.blocks_per_img + (blockIdx.x >> 3) % (unsigned)g.blocks_per_img;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // union-find
 // ---------------------------------------------------------------------------------------------------------------
@@ -136,7 +141,8 @@ template <int CONN>
 __global__ __launch_bounds__(256) void ccl_local_kernel(CclGeom g, const uint8_t* __restrict__ img_all, uint32_t lut,
                                                         int32_t* __restrict__ L_all, uint32_t* __restrict__ area_all,
                                                         u64* __restrict__ sumy_all, u64* __restrict__ sumx_all,
-                                                        uint32_t* __restrict__ flag_all, int stat) {
+                                                        uint32_t* __restrict__ flag_all, int stat, int sparse,
+                                                        uint8_t* __restrict__ tile_any) {
     __shared__ int Ls[CCL_BLOCK_ROWS * 64];
     __shared__ uint8_t Kl[4][64];                          // keys of every wave's last row (the next wave's "row above")
     int img, y0, cx;
@@ -163,7 +169,16 @@ __global__ __launch_bounds__(256) void ccl_local_kernel(CclGeom g, const uint8_t
         Ls[li] = key ? (li - lane) + hp : -1;
     }
     Kl[wave][lane] = (uint8_t)keys[CCL_ROWS - 1];
-    __syncthreads();
+    int mine = 0;
+#pragma unroll
+    for (int r = 0; r < CCL_ROWS; ++r) mine |= keys[r];
+    // sparse mode (every consumer of this labelling looks at the key before it reads a parent): a tile without a keyed
+    // pixel writes nothing, the others write only their keyed pixels - the parents of background pixels stay stale
+    // The vote is also left in tile_any for the later kernels of this labelling: ccl_border, ccl_flatten and count_roots
+    // skip a tile without a keyed pixel before they load anything of it.
+    const int any = __syncthreads_or(mine);
+    if (threadIdx.x == 0) tile_any[tile_index(g, img)] = (uint8_t)(any != 0);
+    if (!any && sparse) return;
 #pragma unroll
     for (int r = 0; r < CCL_ROWS; ++r) {
         const int ly = wave * CCL_ROWS + r, li = ly * 64 + lane;
@@ -200,7 +215,7 @@ __global__ __launch_bounds__(256) void ccl_local_kernel(CclGeom g, const uint8_t
             const size_t p = base + (size_t)y * g.W + x;
             int lab = -1;
             if (key) lab = (yblk + (rl >> 6)) * g.W + cx * 64 + (rl & 63);
-            L_all[p] = lab;
+            if (key || !sparse) L_all[p] = lab;
             if (key && rl == li) {                                 // only tile roots can become global roots
                 flag_all[p] = 0u;
                 if (stat & STAT_AREA) area_all[p] = 0u;
@@ -217,9 +232,10 @@ __global__ __launch_bounds__(256) void ccl_local_kernel(CclGeom g, const uint8_t
 // union-find walks of a tile overlap instead of queueing row after row.
 template <int CONN>
 __global__ __launch_bounds__(128) void ccl_border_kernel(CclGeom g, const uint8_t* __restrict__ img_all, uint32_t lut,
-                                                         int32_t* __restrict__ L_all) {
+                                                         int32_t* __restrict__ L_all, const uint8_t* __restrict__ tile_any) {
     int img, y0, cx;
     if (!decode_block(g, img, y0, cx)) return;
+    if (!tile_any[tile_index(g, img)]) return;                    // no keyed pixel in this tile: nothing to unite from here
     const size_t base = (size_t)img * g.H * g.W;
     const uint8_t* im = img_all + base;
     int32_t* L = L_all + base;
@@ -279,7 +295,8 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8
                                                           uint32_t* __restrict__ flag_all, int32_t* __restrict__ G_all,
                                                           int stat, int aux_mode, int aux_c,
                                                           const uint8_t* __restrict__ aux_img, int need,
-                                                          int32_t* __restrict__ list1, int32_t* __restrict__ list2, size_t list_cap) {
+                                                          int32_t* __restrict__ list1, int32_t* __restrict__ list2, size_t list_cap,
+                                                          const uint8_t* __restrict__ tile_any) {
     constexpr int TP = CCL_BLOCK_ROWS * 64;                    // pixels per tile
     __shared__ int red[16];                                    // ncomp[1..3], npx[1..3], -, -, last root, list counts [9..10], list bases [11..12], owners [13] (64 B keeps the dynamic LDS base 16-B aligned)
     __shared__ int groot_s[TP];                                // tile root -> global root
@@ -293,6 +310,23 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8
     int img, y0, cx;
     if (!decode_block(g, img, y0, cx)) return;                 // block-uniform
     const int tid = threadIdx.x;
+    if (!tile_any[tile_index(g, img)]) return;                 // ccl_local's vote: no keyed pixel, nothing to accumulate or rewrite
+    // all sixteen loads of the thread (pixel values and parents of its eight rows) go out together, before the LDS set-up;
+    // stale parents of unkeyed pixels are read and ignored
+    uint8_t vals[CCL_ROWS];
+    int labs[CCL_ROWS];
+    {
+        const uint8_t* im0 = img_all + (size_t)img * g.H * g.W;
+        const int32_t* L0 = L_all + (size_t)img * g.H * g.W;
+        const int x0 = cx * 64 + (tid & 63);
+#pragma unroll
+        for (int r = 0; r < CCL_ROWS; ++r) {
+            const int y = y0 + r;
+            const bool ok = y < g.H && x0 < g.W;
+            vals[r] = ok ? im0[y * g.W + x0] : (uint8_t)0;
+            labs[r] = ok ? L0[y * g.W + x0] : -1;
+        }
+    }
     if (tid < 16) red[tid] = 0;
     if (tid < TP / 32) used_s[tid] = 0u;
     for (int i = tid; i < TP; i += 256) {
@@ -318,13 +352,9 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8
         const int y = y0 + r;
         const bool valid = y < H && x < W;
         const int p = y * W + x;
-        uint8_t v = 0;
-        int key = 0, lab = -1;
-        if (valid) {                                           // two independent loads (ccl_local wrote -1 for background)
-            v = im[p];
-            lab = L[p];
-            key = key_of(v, lut);
-        }
+        const uint8_t v = vals[r];
+        const int key = valid ? key_of(v, lut) : 0;
+        const int lab = labs[r];
         // Slot of this pixel's tile component: the tile root it points at.  A tile root that ccl_border has meanwhile
         // linked to a pixel of another tile no longer points into the tile: it keeps its own slot (the other pixels
         // of its tile component still point at it).
@@ -461,10 +491,12 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8
 // count_cc needs no flatten: after ccl_local + ccl_border a component's root is the one pixel that still points at itself,
 // so components and pixels per key are counted straight from (image, parents).
 __global__ __launch_bounds__(256) void count_roots_kernel(CclGeom g, const uint8_t* __restrict__ img_all, uint32_t lut,
-                                                          const int32_t* __restrict__ L_all, int32_t* __restrict__ G_all) {
+                                                          const int32_t* __restrict__ L_all, int32_t* __restrict__ G_all,
+                                                          const uint8_t* __restrict__ tile_any) {
     __shared__ int red[8];
     int img, y0, cx;
     if (!decode_block(g, img, y0, cx)) return;
+    if (!tile_any[tile_index(g, img)]) return;
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid < 8) red[tid] = 0;
     __syncthreads();
@@ -524,6 +556,7 @@ struct CclPass {
     const uint8_t* aux_img;
     int need;      // NEED_* counters this pass has to produce
     bool count_only = false;   // only NEED_NCOMP | NEED_NPX are wanted: count roots instead of flattening
+    bool sparse = false;       // every consumer checks the key before it reads a parent: background parents are not written
     int32_t* list1 = nullptr;  // NEED_LISTS: per-image lists of class-1 roots / class-2 roots (first word of 16-byte slots)
     int32_t* list2 = nullptr;
     size_t list_cap = 0;
@@ -535,21 +568,21 @@ static hipError_t run_ccl_pass(PostWorkspace& ws, const CclGeom& g, const CclPas
     const unsigned grid = geom_grid(g);
     if (c.conn == 8) {
         hipLaunchKernelGGL(ccl_local_kernel<8>, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy,
-                           ws.sumx, ws.flag, c.stat);
-        hipLaunchKernelGGL(ccl_border_kernel<8>, dim3(grid), dim3(128), 0, s, g, c.key_img, c.lut, ws.L);
+                           ws.sumx, ws.flag, c.stat, c.sparse ? 1 : 0, ws.tile_any);
+        hipLaunchKernelGGL(ccl_border_kernel<8>, dim3(grid), dim3(128), 0, s, g, c.key_img, c.lut, ws.L, ws.tile_any);
     } else {
         hipLaunchKernelGGL(ccl_local_kernel<4>, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy,
-                           ws.sumx, ws.flag, c.stat);
-        hipLaunchKernelGGL(ccl_border_kernel<4>, dim3(grid), dim3(128), 0, s, g, c.key_img, c.lut, ws.L);
+                           ws.sumx, ws.flag, c.stat, c.sparse ? 1 : 0, ws.tile_any);
+        hipLaunchKernelGGL(ccl_border_kernel<4>, dim3(grid), dim3(128), 0, s, g, c.key_img, c.lut, ws.L, ws.tile_any);
     }
     if (c.count_only) {        // counts per key only: no per-pixel roots, no statistics
-        hipLaunchKernelGGL(count_roots_kernel, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L, ws.g);
+        hipLaunchKernelGGL(count_roots_kernel, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L, ws.g, ws.tile_any);
         hipLaunchKernelGGL(reduce_g_kernel, dim3(g.n_img), dim3(G_STRIDE), 0, s, ws.g, g.n_img);
         return hipGetLastError();
     }
     const size_t dyn = ((c.stat & STAT_SUMS) ? (size_t)CCL_BLOCK_ROWS * 64 * 16 : 0) + ((c.need & NEED_LISTS) ? (size_t)CCL_BLOCK_ROWS * 64 * 2 : 0);
     hipLaunchKernelGGL(ccl_flatten_kernel, dim3(grid), dim3(256), dyn, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy,
-                       ws.sumx, ws.flag, ws.g, c.stat, c.aux_mode, c.aux_c, c.aux_img, c.need, c.list1, c.list2, c.list_cap);
+                       ws.sumx, ws.flag, ws.g, c.stat, c.aux_mode, c.aux_c, c.aux_img, c.need, c.list1, c.list2, c.list_cap, ws.tile_any);
     if (c.need) hipLaunchKernelGGL(reduce_g_kernel, dim3(g.n_img), dim3(G_STRIDE), 0, s, ws.g, g.n_img);
     return hipGetLastError();
 }
@@ -578,10 +611,11 @@ static dim3 img_grid(size_t px, int n_img) {
 
 // fill_holes (src/image_tools.py:36-39): pixels != c whose 4-connected background component does not reach the border
 __global__ __launch_bounds__(256) void apply_fill_kernel(uint8_t* __restrict__ img, const int32_t* __restrict__ L,
-                                                         const uint32_t* __restrict__ flag, int n_img, size_t px, int c) {
+                                                         const uint32_t* __restrict__ flag, int n_img, size_t px, int c, uint32_t lut) {
     IMG_PX_LOOP(n_img, px) {
+        if (!key_of(img[t], lut)) continue;                    // not part of the labelled background: its parent is stale
         const int r = L[t];
-        if (r >= 0 && !(flag[ib + r] & 1u)) img[t] = (uint8_t)c;
+        if (!(flag[ib + r] & 1u)) img[t] = (uint8_t)c;
     }
 }
 
@@ -593,14 +627,14 @@ __global__ __launch_bounds__(256) void apply_size_thresh_kernel(uint8_t* __restr
                                                                 const int32_t* __restrict__ G_all, int n_img, size_t px,
                                                                 int ec_thresh) {
     IMG_PX_LOOP(n_img, px) {
+        const uint8_t v = img[t];
+        if (!key_of(v, LUT_MULTI)) continue;                   // background: not labelled, its parent is stale
         const int r = L[t];
-        if (r < 0) continue;
         const int32_t* G = G_all + (size_t)im * G_IMG;
         // area < mean(areas) = S / n, evaluated exactly in integers: area * n < S.  (The reference compares in float64;
         // S / n is either an integer or at least 1 / n away from one, far more than a rounding error, so both orders
         // agree.  n == 0: the reference's mean is NaN and every comparison false; here S == 0 gives the same.)
         const long long a = (long long)area[ib + r];
-        const uint8_t v = img[t];
         if (v == 1) { if (a * (long long)G[G_NCOMP + 2] < (long long)G[G_NPX + 2]) img[t] = 0; }
         else if (v == 2) { if (a * (long long)G[G_NCOMP + 3] < (long long)G[G_NPX + 3]) img[t] = 3; }
         else if (v == 3) { if (a < (long long)ec_thresh) img[t] = 0; }
@@ -759,7 +793,7 @@ __global__ __launch_bounds__(256) void apply_nucleus_kill_kernel(uint8_t* __rest
     IMG_PX_LOOP(n_img, px) {
         if (img[t] != 1) continue;
         const int r = L[t];
-        if (r >= 0 && (flag[ib + r] & 2u)) img[t] = 0;
+        if (flag[ib + r] & 2u) img[t] = 0;
     }
 }
 
@@ -769,12 +803,12 @@ __global__ __launch_bounds__(256) void apply_nucleus_kill_kernel(uint8_t* __rest
 __global__ __launch_bounds__(256) void apply_merge_kernel(const uint8_t* __restrict__ img, uint8_t* __restrict__ tmp,
                                                           const int32_t* __restrict__ L, const uint32_t* __restrict__ flag,
                                                           const int32_t* __restrict__ G_all, int n_img, size_t px,
-                                                          int c, int m) {
+                                                          int c, int m, uint32_t lut) {
     IMG_PX_LOOP(n_img, px) {
         uint8_t v = img[t];
         if (v == m) v = 0;
-        const int r = L[t];
-        if (r >= 0) {
+        if (key_of(img[t], lut)) {                             // a labelled pixel (key = value not in {0, m})
+            const int r = L[t];
             const int last = G_all[(size_t)im * G_IMG + G_LAST_ROOT] - 1;
             if ((flag[ib + r] & 1u) && r != last) v = (uint8_t)c;
         }
@@ -839,12 +873,14 @@ hipError_t run_meta_inference(PostWorkspace& ws, uint8_t* img, int n_img, int H,
     // 1. fill_holes(1), fill_holes(2)
     for (int c = 1; c <= 2; ++c) {
         CclPass p{img, lut_ne(c), 4, 0, AUX_BORDER, 0, nullptr, 0};
+        p.sparse = true;
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
-        hipLaunchKernelGGL(apply_fill_kernel, ig, dim3(256), 0, s, img, ws.L, ws.flag, n_img, px, c);
+        hipLaunchKernelGGL(apply_fill_kernel, ig, dim3(256), 0, s, img, ws.L, ws.flag, n_img, px, c, lut_ne(c));
     }
     // 2-4. size_thresh
     {
         CclPass p{img, LUT_MULTI, 8, STAT_AREA, AUX_NONE, 0, nullptr, NEED_NCOMP | NEED_NPX};
+        p.sparse = true;
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
         hipLaunchKernelGGL(apply_size_thresh_kernel, ig, dim3(256), 0, s, img, ws.L, ws.area, ws.g, n_img, px, 15);
     }
@@ -866,6 +902,7 @@ hipError_t run_meta_inference(PostWorkspace& ws, uint8_t* img, int n_img, int H,
         int32_t* list1 = ws.list;
         double2* list2 = reinterpret_cast<double2*>(ws.list + (((size_t)n_img * cap + 3) & ~(size_t)3));
         CclPass p{cur, LUT_MULTI, 8, STAT_AREA | STAT_SUMS, AUX_NONE, 0, nullptr, NEED_LISTS};
+        p.sparse = true;
         p.list1 = list1; p.list2 = reinterpret_cast<int32_t*>(list2); p.list_cap = cap;
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
         hipLaunchKernelGGL(centroids_kernel, dim3(8, n_img), dim3(256), 0, s, ws.area, ws.sumy, ws.sumx, ws.g, list2, px, cap);
@@ -878,8 +915,9 @@ hipError_t run_meta_inference(PostWorkspace& ws, uint8_t* img, int n_img, int H,
     for (int c = 1; c <= 2; ++c) {
         const int m = (c == 1) ? 2 : 1;
         CclPass p{cur, lut_nonzero_except(m), 8, 0, AUX_VALUE_EQ, c, nullptr, NEED_LAST};
+        p.sparse = true;
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
-        hipLaunchKernelGGL(apply_merge_kernel, ig, dim3(256), 0, s, cur, t1, ws.L, ws.flag, ws.g, n_img, px, c, m);
+        hipLaunchKernelGGL(apply_merge_kernel, ig, dim3(256), 0, s, cur, t1, ws.L, ws.flag, ws.g, n_img, px, c, m, lut_nonzero_except(m));
         if (v4) {
             hipLaunchKernelGGL(stencil4_kernel<2>, ig4, dim3(256), 0, s, t1, nullptr, nullptr, t2, n_img, H, W, 0, 0, w4_magic);
             hipLaunchKernelGGL(stencil4_kernel<3>, ig4, dim3(256), 0, s, t2, cur, t1, cur, n_img, H, W, c, m, w4_magic);
@@ -894,6 +932,7 @@ hipError_t run_meta_inference(PostWorkspace& ws, uint8_t* img, int n_img, int H,
     // 10. count_cc(img == 3)[0]
     if (n_ec_dev) {
         CclPass p{img, lut_eq(3), 8, 0, AUX_NONE, 0, nullptr, NEED_NCOMP | NEED_NPX, true};
+        p.sparse = true;
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
         hipLaunchKernelGGL(gather_counts_kernel, dim3((n_img + 63) / 64), dim3(64), 0, s, ws.g, n_img, 1, n_ec_dev,
                            (long long*)nullptr, (long long)px);
@@ -909,6 +948,7 @@ hipError_t run_count_cc(PostWorkspace& ws, const uint8_t* mask, int n_img, int H
     if (n_img <= 0) return hipSuccess;
     const CclGeom g = make_geom(n_img, H, W);
     CclPass p{mask, LUT_NONZERO, 8, 0, AUX_NONE, 0, nullptr, NEED_NCOMP | NEED_NPX, true};
+    p.sparse = true;                                           // count_roots looks at the key first
     hipError_t e = run_ccl_pass(ws, g, p, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(gather_counts_kernel, dim3((n_img + 63) / 64), dim3(64), 0, s, ws.g, n_img, 1, n_dev, px_dev,

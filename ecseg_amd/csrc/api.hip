@@ -581,7 +581,7 @@ int ensure_post(ecseg_ctx* h, int n_img, size_t px) {
     drop_post_graphs(h);                                     // the captured launches hold the old workspace pointers
     const int ni = std::max(n_img, w.cap_img);
     const size_t np = std::max(px, w.cap_px);
-    void* ptrs[] = {w.L, w.area, w.sumy, w.sumx, w.flag, w.tmpA, w.tmpB, w.list, w.g, w.tile_any};
+    void* ptrs[] = {w.L, w.area, w.sumy, w.sumx, w.flag, w.tmpA, w.tmpB, w.list, w.g, w.tile_any, w.binned, w.binstart};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     w = PostWorkspace{};
     const size_t tot = (size_t)ni * np;
@@ -601,9 +601,12 @@ int ensure_post(ecseg_ctx* h, int n_img, size_t px) {
     A(reinterpret_cast<void**>(&w.tmpB), tot);
     A(reinterpret_cast<void**>(&w.list), list_bytes);
     A(reinterpret_cast<void**>(&w.g), (size_t)ni * G_STRIDE * G_SHARDS * 4);
-    A(reinterpret_cast<void**>(&w.tile_any), (size_t)ni * (np / 16 + 2));   // (W/64 + 1)(H/32 + 1) <= px/16 + 1 tiles per image
+    A(reinterpret_cast<void**>(&w.tile_any), (size_t)ni * (np / 16 + 2));
+    const size_t binned_cap = std::min(list_cap, (size_t)1 << 20);
+    A(reinterpret_cast<void**>(&w.binned), (size_t)ni * 2 * binned_cap * sizeof(double));
+    A(reinterpret_cast<void**>(&w.binstart), (size_t)ni * 2 * (NUCLEUS_BIN_EXTENT + 2) * sizeof(int32_t));   // (W/64 + 1)(H/32 + 1) <= px/16 + 1 tiles per image
     if (e != hipSuccess) return fail(h, ECSEG_E_NOMEM, std::string("hipMalloc(post workspace): ") + hipGetErrorString(e));
-    w.cap_img = ni; w.cap_px = np;
+    w.cap_img = ni; w.cap_px = np; w.binned_cap = binned_cap;
     h->ws_list_bytes = list_bytes;
     return ECSEG_OK;
 }
@@ -735,7 +738,7 @@ void ecseg_destroy(ecseg_ctx* h) {
     }
     if (h->zero_page) (void)hipFree(h->zero_page);
     void* ptrs[] = {h->d_gray, h->d_raw, h->d_post, h->d_aux8, h->d_u8in, h->d_i32, h->d_i64, h->d_probs_in, h->d_hist,
-                    h->ws.L, h->ws.area, h->ws.sumy, h->ws.sumx, h->ws.flag, h->ws.tmpA, h->ws.tmpB, h->ws.list, h->ws.g, h->ws.tile_any};
+                    h->ws.L, h->ws.area, h->ws.sumy, h->ws.sumx, h->ws.flag, h->ws.tmpA, h->ws.tmpB, h->ws.list, h->ws.g, h->ws.tile_any, h->ws.binned, h->ws.binstart};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);

@@ -100,10 +100,14 @@ struct PostWorkspace {
     int32_t* list;       // per image: compacted root lists for the nucleus-in-metaphase test
     int32_t* g;          // per image: small block of global counters (G_STRIDE ints)
     uint8_t* tile_any;   // per image and 64 x 32 labelling tile: the tile holds a keyed pixel (written by ccl_local)
+    double* binned;      // per image and axis: the chromosome centroids' coordinates grouped by integer bin (nucleus test)
+    int32_t* binstart;   // per image and axis: first entry of every bin in `binned` (NUCLEUS_BIN_EXTENT + 2 ints)
+    size_t binned_cap;   // entries per image and axis in `binned`
     int cap_img;
     size_t cap_px;
 };
 enum { G_STRIDE = 32, G_SHARDS = 16 };
+enum { NUCLEUS_BIN_EXTENT = 32768 };   // largest image extent for which the nucleus test runs on binned coordinates (LDS histogram)
 
 // meta_inference on n_img uint8 label images, in place; n_ec receives count_cc(img==3)[0] per image
 hipError_t run_meta_inference(PostWorkspace& ws, uint8_t* img, int n_img, int H, int W, int32_t* n_ec_dev,

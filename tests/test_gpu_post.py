@@ -192,3 +192,38 @@ def test_meta_inference_through_hip_graph_replay(gpu):
                 assert np.array_equal(got, want) and np.array_equal(nec, wnec)
     finally:
         gpu.set_option('post_graph', 0)
+
+
+def test_nucleus_test_binned_and_pair_paths(gpu):
+    """The nucleus-in-metaphase test runs on binned centroid coordinates (counting sort) and falls back to pair tests for images
+    wider / taller than 32768: dense grids of chromosomes (5.7 k and 35 k per image) with nuclei that are erased and nuclei that
+    keep an empty band, and a 3 x 33000 strip for the fall-back."""
+    import numpy as np
+    from oracle import postproc
+    rng = np.random.default_rng(77)
+    labs = []
+    for step in (5, 2):
+        H, W = 480, 480
+        lab = np.zeros((H, W), np.uint8)
+        lab[4::step, 4:300:step] = 2                        # chromosomes only left of x = 300: nuclei right of it keep an empty band
+        yy, xx = np.ogrid[:H, :W]
+        for cy, cx, r in ((120, 130, 14), (300, 340, 9), (20, 460, 6), (440, 40, 11), (240, 296, 3)):
+            lab[(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = 1
+        lab[rng.random((H, W)) < 0.001] = 3
+        labs.append(lab)
+    labs = np.stack(labs)
+    kept = [int((postproc.meta_inference(l) == 1).sum()) for l in labs]
+    assert all(0 < k < int((l == 1).sum()) for k, l in zip(kept, labs)), kept      # some nuclei erased, some kept
+    out, nec = gpu.meta_inference(labs)
+    for k in range(2):
+        want = postproc.meta_inference(labs[k])
+        assert np.array_equal(out[k], want), (k, int((out[k] != want).sum()))
+        assert int(nec[k]) == postproc.count_cc(want == 3)[0]
+    strip = np.zeros((40, 33000), np.uint8)                 # wider than the binned path takes
+    strip[2:38:2, 10:2000:2] = 2
+    for x0 in (1000, 1990, 30000):
+        strip[18:23, x0:x0 + 5] = 1
+    want = postproc.meta_inference(strip)
+    assert 0 < int((want == 1).sum()) < int((strip == 1).sum())
+    out, nec = gpu.meta_inference(strip[None])
+    assert np.array_equal(out[0], want) and int(nec[0]) == postproc.count_cc(want == 3)[0]

@@ -618,26 +618,29 @@ hipError_t launch_conv_small_cin(const TView& in, const TView& out, const float*
     return hipGetLastError();
 }
 
-// 1x1 conv with few outputs (the 4-class head) + optional channel softmax.  16 lanes share one pixel: each lane
-// reads float4 slices of the pixel's channel vector (256 B contiguous per pixel at Cin = 64), partial sums are
+// 1x1 conv with few outputs (the 4-class head) + optional channel softmax.  LPP lanes share one pixel (16 at Cin >= 64,
+// 8 / 4 for narrower inputs - with 16 lanes on a 16-channel pixel twelve of them idled and the layer ran at 1 TB/s): each
+// lane reads float4 slices of the pixel's channel vector (256 B contiguous per pixel at Cin = 64), partial sums are
 // reduced with wave shuffles, lane 0 of the group finishes bias / softmax and writes the pixel.
-template <int COUT>
+template <int COUT, int LPP>
 __global__ __launch_bounds__(256) void conv_head_kernel(TView in, TView out, const float* __restrict__ w,
                                                         const float* __restrict__ bias, size_t npix, int act, float alpha) {
-    const int sub = threadIdx.x & 15;
+    constexpr int PPW = 64 / LPP;                              // pixels per wave
+    const int sub = threadIdx.x & (LPP - 1);
     const int c4n = in.c >> 2;
-    for (size_t pix = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; ; pix += ((size_t)gridDim.x * blockDim.x) >> 4) {
-        // all 16 lanes of a group share `pix`; groups of one wave may run out at different times, so keep the whole
+    for (size_t pix = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LPP; ; pix += ((size_t)gridDim.x * blockDim.x) / LPP) {
+        // all LPP lanes of a group share `pix`; groups of one wave may run out at different times, so keep the whole
         // wave in the loop and mask the work instead of breaking (shuffles need every lane present)
-        const size_t wave_first = pix - (((size_t)threadIdx.x & 63) >> 4);
+        const size_t wave_first = pix - (((size_t)threadIdx.x & 63) / LPP);
         if (wave_first >= npix) break;
+        (void)PPW;
         const bool live = pix < npix;
         float acc[COUT];
 #pragma unroll
         for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
         if (live) {
             const float* ip = in.p + pix * in.cs;
-            for (int c4 = sub; c4 < c4n; c4 += 16) {
+            for (int c4 = sub; c4 < c4n; c4 += LPP) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(ip + c4 * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -650,8 +653,8 @@ __global__ __launch_bounds__(256) void conv_head_kernel(TView in, TView out, con
 #pragma unroll
         for (int o = 0; o < COUT; ++o) {
             float v = acc[o];
-            v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64);
-            v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+#pragma unroll
+            for (int d = LPP / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
             acc[o] = v;
         }
         if (live && sub == 0) {
@@ -677,19 +680,28 @@ __global__ __launch_bounds__(256) void conv_head_kernel(TView in, TView out, con
     }
 }
 
-hipError_t launch_conv_head(const TView& in, const TView& out, const float* w, const float* bias, int n, int act,
-                            float alpha, hipStream_t s) {
-    const size_t npix = (size_t)n * out.h * out.w;
-    if (!npix) return hipSuccess;
-    size_t blocks = (npix * 16 + 255) / 256;
+template <int LPP>
+static hipError_t launch_conv_head_l(const TView& in, const TView& out, const float* w, const float* bias, size_t npix, int act,
+                                     float alpha, hipStream_t s) {
+    size_t blocks = (npix * LPP + 255) / 256;
     if (blocks > 65536 * 8) blocks = 65536 * 8;
-#define HEAD_CASE(C) case C: hipLaunchKernelGGL(conv_head_kernel<C>, dim3((unsigned)blocks), dim3(256), 0, s, in, out, w, bias, npix, act, alpha); break;
+#define HEAD_CASE(C) case C: hipLaunchKernelGGL((conv_head_kernel<C, LPP>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, w, bias, npix, act, alpha); break;
     switch (out.c) {
         HEAD_CASE(1) HEAD_CASE(2) HEAD_CASE(3) HEAD_CASE(4) HEAD_CASE(5) HEAD_CASE(6) HEAD_CASE(7) HEAD_CASE(8)
         default: return hipErrorInvalidValue;
     }
 #undef HEAD_CASE
     return hipGetLastError();
+}
+
+hipError_t launch_conv_head(const TView& in, const TView& out, const float* w, const float* bias, int n, int act,
+                            float alpha, hipStream_t s) {
+    const size_t npix = (size_t)n * out.h * out.w;
+    if (!npix) return hipSuccess;
+    const int c4n = in.c >> 2;                               // lanes per pixel: as many as there are 4-channel slices, up to 16
+    if (c4n >= 16) return launch_conv_head_l<16>(in, out, w, bias, npix, act, alpha, s);
+    if (c4n >= 8) return launch_conv_head_l<8>(in, out, w, bias, npix, act, alpha, s);
+    return launch_conv_head_l<4>(in, out, w, bias, npix, act, alpha, s);
 }
 
 // Generic direct convolution: thread = (pixel, output channel).  Correctness fall-back for shapes the MFMA kernel

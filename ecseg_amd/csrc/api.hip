@@ -355,6 +355,20 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                         const int npt = p.convt ? p.kT * p.kT * o.coutp : o.coutp;
                         p.wt_chunk_stride = wt_chunk_pitch(npt); p.wt_tap_stride = wt_tap_pitch(npt, o.cin_chunks);
                     }
+                    // Winograd output stages can write the 2x2 max-pool of their result themselves: a MaxPooling2D(2x2, stride
+                    // 2) that follows directly (even extents, its own buffer) is then done with the convolution
+                    auto fuse_following_pool = [&]() {
+                        if (oi + 1 >= h->ops.size()) return;
+                        const ecseg_op_desc& nx = h->ops[oi + 1].d;
+                        const TView po = nx.op == ECSEG_OP_MAXPOOL ? view_of(h, nx.out) : TView{};
+                        if (nx.op == ECSEG_OP_MAXPOOL && nx.mode == 0 /* max, not average */ && nx.in0 == d.out && nx.kh == 2 && nx.kw == 2 && nx.stride == 2 &&
+                            h->fuse_pool && !softmax && po.h * 2 == out.h && po.w * 2 == out.w && po.c == out.c && po.cs % 4 == 0 &&
+                            reinterpret_cast<uintptr_t>(po.p) % 16 == 0 &&
+                            h->tensors[nx.out].buffer != h->tensors[d.in0].buffer && h->tensors[nx.out].buffer != h->tensors[d.out].buffer) {
+                            p.pool = po;
+                            ++oi;                              // the pooling op is done
+                        }
+                    };
                     if (wino4) {
                         p.wt = o.wt_wino4; p.coutp = out.c;
                         if (crop && h->crop && o.crop_ok && n % crop->n_pos == 0) {
@@ -365,17 +379,7 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                             }
                         }
                         // a MaxPooling2D(2x2, stride 2) that follows directly is written by the same output stage
-                        if (oi + 1 < h->ops.size()) {
-                            const ecseg_op_desc& nx = h->ops[oi + 1].d;
-                            const TView po = nx.op == ECSEG_OP_MAXPOOL ? view_of(h, nx.out) : TView{};
-                            if (nx.op == ECSEG_OP_MAXPOOL && nx.mode == 0 /* max, not average */ && nx.in0 == d.out && nx.kh == 2 && nx.kw == 2 && nx.stride == 2 &&
-                                h->fuse_pool && !softmax && po.h * 2 == out.h && po.w * 2 == out.w && po.c == out.c && po.cs % 4 == 0 &&
-                                reinterpret_cast<uintptr_t>(po.p) % 16 == 0 &&
-                                h->tensors[nx.out].buffer != h->tensors[d.in0].buffer && h->tensors[nx.out].buffer != h->tensors[d.out].buffer) {
-                                p.pool = po;
-                                ++oi;                          // the pooling op is done
-                            }
-                        }
+                        fuse_following_pool();
                         // a 1x1 head (<= 4 classes) that is the only reader of this 64-channel output is computed by the
                         // same output stage; the 64-channel tensor is then never written
                         if (p.pool.p == nullptr && oi + 1 < h->ops.size() && h->fuse_head && out.c == 64 && !softmax) {
@@ -395,6 +399,7 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                     } else if (wino) {
                         p.wt = o.wt_wino; p.coutp = o.coutp_wino;
                         p.wt_chunk_stride = wt_chunk_pitch(o.coutp_wino); p.wt_tap_stride = wt_tap_pitch(o.coutp_wino, o.cin_chunks);
+                        if (out.c % 4 == 0) fuse_following_pool();
                         e = launch_conv_wino(p, s);
                     } else {
                         if (crop && h->crop && o.crop_ok && p.convt && n % crop->n_pos == 0 && in.h == in.w) {

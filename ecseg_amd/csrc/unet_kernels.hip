@@ -257,8 +257,10 @@ __device__ __forceinline__ void wino_store_Y(const float* Rs, const ConvParams& 
     const int co = n0 + 4 * q;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (p.bias != nullptr && co + 3 < Cout) bv = *reinterpret_cast<const f32x4*>(p.bias + co);
-    // 32 tiles x 2 column parities, 4 waves x TPI tiles per step
-    for (int it = wa; it < (32 / TPI) * 2; it += 4) {
+    f32x4 pm = {0.f, 0.f, 0.f, 0.f};
+    // 32 tiles x 2 column parities, 4 waves x TPI tiles per step; a wave does both column parities of its tiles (the
+    // fused 2x2 max-pool below needs the 2 x 2 outputs of a tile in one thread)
+    for (int it = 2 * wa; it < (32 / TPI) * 2; it += (it & 1) ? 7 : 1) {
         const int jp = it & 1, t = (it >> 1) * TPI + tsub;
         const f32x4 q0 = *reinterpret_cast<const f32x4*>(Rs + ((0 * 2 + jp) * 32 + t) * BN + 4 * q);
         const f32x4 q1 = *reinterpret_cast<const f32x4*>(Rs + ((1 * 2 + jp) * 32 + t) * BN + 4 * q);
@@ -271,6 +273,13 @@ __device__ __forceinline__ void wino_store_Y(const float* Rs, const ConvParams& 
             float* o = p.out.p + (((size_t)img * Hout + oy) * Wout + ox) * p.out.cs + co;
             if (oy < Hout) *reinterpret_cast<f32x4*>(o) = y0;
             if (oy + 1 < Hout) *reinterpret_cast<f32x4*>(o + (size_t)Wout * p.out.cs) = y1;
+        }
+        if (p.pool.p != nullptr) {
+            // fused MaxPooling2D(2x2, stride 2): even extents (checked by the caller), so a tile is inside or outside as a whole
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pm[c] = jp ? fmaxf(pm[c], fmaxf(y0[c], y1[c])) : fmaxf(y0[c], y1[c]);
+            if (jp && co + 3 < Cout && ox < Wout && oy + 1 < Hout)
+                *reinterpret_cast<f32x4*>(p.pool.p + (((size_t)img * p.pool.h + (oy >> 1)) * p.pool.w + (ox >> 1)) * p.pool.cs + co) = pm;
         }
     }
 }

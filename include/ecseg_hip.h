@@ -119,10 +119,10 @@ int ecseg_set_images_per_group(ecseg_ctx* h, int n);
 /* Tuning knobs: "overlap_post" (1: clean-up + count of group g run on a second stream beside the U-Net of group g+1;
  * 0 (default): everything on one stream - measured equal, the MFMA convs already fill the chip), "post_chunk"
  * (images per post-processing launch set), "images_per_group", "winograd" (3x3 / stride-1 / 'same'
- * convolutions: 2 (default) Winograd F(4x4,3x3) where the layer allows it (extents % 16, Cin % 8, Cout % 64), else
+ * convolutions: 2 (default) Winograd F(4x4,3x3) where the layer allows it (extents % 16, Cin % 4 and >= 8, Cout % 32), else
  * F(2x2,3x3); 1: F(2x2,3x3); 0: the direct implicit-GEMM kernel; all three are fp32 MFMA kernels), "fuse_pool" (1
- * (default): a MaxPooling2D(2x2, stride 2) that directly follows an F(4x4) convolution is written by that convolution's
- * output stage; 0: separate max-pool kernel), "fuse_head" (1 (default): a 1x1 convolution with <= 4 output channels that
+ * (default): a MaxPooling2D(2x2, stride 2) that directly follows a Winograd (F(4x4) or F(2x2)) convolution is written by that
+ * convolution's output stage; 0: separate max-pool kernel), "fuse_head" (1 (default): a 1x1 convolution with <= 4 output channels that
  * is the only reader of a 64-channel F(4x4) convolution is computed by that convolution's output stage and the
  * 64-channel tensor is never written; 0: separate head kernel), "crop" (1 (default): in ecseg_segment_images the last
  * full-resolution F(4x4) convolutions compute only the 16x16 regions of every window that the stitch (or the halo of the

@@ -98,6 +98,7 @@ struct ecseg_ctx {
     int crop = 1;             // segment path: skip output regions of the last full-resolution convolutions that the stitch never reads
     int fuse_head = 1;        // 1x1 head (<= 4 classes) computed by the output stage of the last F(4x4) convolution
     int use_winograd = 2;     // 0 direct, 1 Winograd F(2x2,3x3), 2 F(4x4,3x3) where eligible (else F(2x2))
+    int wino_resident = 1;    // F(2x2) layers with <= 32 input and output channels: filter-resident kernel (conv_wino_res_kernel)
 
     // timing
     hipEvent_t ev[ECSEG_T_N + 1] = {};
@@ -107,7 +108,7 @@ struct ecseg_ctx {
     std::vector<hipEvent_t> grp_events;    // 6 per image group of segment_dev
     size_t prof_used = 0;
     double prof_flops = 0.0, prof_exec_flops = 0.0;
-    struct ProfRec { int op; int kind; double flops, exec_flops; float ms; };   // kind: 0 direct, 1 F(2x2), 2 F(4x4)
+    struct ProfRec { int op; int kind; double flops, exec_flops; float ms; };   // kind: 0 direct, 1 F(2x2), 2 F(4x4), 3 filter-resident F(2x2)
     std::vector<ProfRec> prof_recs;        // one per profiled launch of the last segment / forward call
     double last_conv_ms = 0.0; long long last_conv_launches = 0; double last_conv_flops = 0.0, last_conv_exec_flops = 0.0;
 };
@@ -399,6 +400,7 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                     } else if (wino) {
                         p.wt = o.wt_wino; p.coutp = o.coutp_wino;
                         p.wt_chunk_stride = wt_chunk_pitch(o.coutp_wino); p.wt_tap_stride = wt_tap_pitch(o.coutp_wino, o.cin_chunks);
+                        p.resident = h->wino_resident;
                         if (out.c % 4 == 0) fuse_following_pool();
                         e = launch_conv_wino(p, s);
                     } else {
@@ -423,7 +425,8 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                         h->prof_flops += o.flops * n;
                         const double ex = o.flops * n * computed * (wino4 ? 0.25 : wino ? 16.0 / 36.0 : 1.0);   // multiplies actually issued
                         h->prof_exec_flops += ex;
-                        h->prof_recs.push_back({(int)oi_first, wino4 ? 2 : wino ? 1 : 0, o.flops * n, ex, 0.f});
+                        const bool res = wino && p.resident && p.coutp == 32 && p.cin_chunks <= 4;
+                        h->prof_recs.push_back({(int)oi_first, wino4 ? 2 : res ? 3 : wino ? 1 : 0, o.flops * n, ex, 0.f});
                     }
                 } else if (o.path == PATH_SMALL_CIN) {
                     e = launch_conv_small_cin(in, out, o.wt, o.bias, n, d.kh, d.kw, d.pad_top, d.pad_left, act, d.alpha, s);
@@ -775,6 +778,7 @@ int ecseg_set_option(ecseg_ctx* h, const char* key, int value) {
     if (k == "overlap_post") h->overlap_post = value != 0;
     else if (k == "fuse_pool") h->fuse_pool = value != 0;
     else if (k == "fuse_head") h->fuse_head = value != 0;
+    else if (k == "wino_resident") h->wino_resident = value != 0;
     else if (k == "crop") h->crop = value != 0;
     else if (k == "winograd") h->use_winograd = value < 0 ? 0 : value > 2 ? 2 : (int)value;   // 0 direct, 1 F(2x2), 2 F(4x4)
     else if (k == "post_chunk" && value >= 1) h->post_chunk = value;

@@ -40,6 +40,8 @@ struct ConvParams {
     // conv_mfma (transposed convolutions): the same list idea over its TH x TW tiles of the INPUT extent; force_tw = 16 | 32
     // selects the tile shape the list was built for (0: the launcher's own choice)
     int force_tw;
+    // conv_wino (F(2x2)): 1: layers with <= 32 input and <= 32 output channels take the filter-resident kernel
+    int resident;
     // filter image strides in floats: [tap][chunk][half][N padded][4] with padded chunk / tap pitches (power-of-two
     // pitches put the 16 transform points of a K-chunk on the same L2 channel and set)
     long wt_chunk_stride, wt_tap_stride;

@@ -467,9 +467,157 @@ static hipError_t launch_conv_wino_t(const ConvParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Filter-resident F(2x2, 3x3) for NARROW layers (Cin <= 32, Cout <= 32: the full-resolution levels of base-16 / base-32
+// U-Nets).  conv_wino_kernel streams a 16-point filter slab per 8 input channels for every 8 x 16 output pixels; with
+// <= 32 channels that slab (16 KB) is larger than the input tile it is multiplied with, and the layer runs at the
+// filter stream's L2 rate (1.6 TB/s of HBM-side traffic, 0.16-0.23 of the MFMA peak).  Here the whole transformed
+// filter of a wave's transform row (4 points x Cin x 32 output channels = 16 * CH registers) is loaded ONCE into
+// registers and the workgroup walks `tpw` tiles of a tile row: per tile only the input halo (all channels, one LDS
+// image) and the outputs move.  Same arithmetic, lane maps and output stage as conv_wino_kernel<1, 1> (bit-identical
+// results): wave a = transform row a, 32 MFMAs per 8 input channels and tile.
+// Pipeline per tile (two barriers): the next tile's halo is fetched into registers before the MFMAs of the current one,
+// stored to LDS after the exchange barrier (the halo image is dead by then) and before the output stores are issued.
+// ------------------------------------------------------------------------------------------------------------
+template <int CH>
+__global__ __launch_bounds__(256, 2) void conv_wino_res_kernel(ConvParams p, int tiles_x, int tiles_y, int segs_x, int tpw) {
+    constexpr int HR = 10, HC = 18;                          // halo of 4 x 8 Winograd tiles: 10 x 18 pixels
+    constexpr int CS = 12;                                   // slots per (plane, row): 9 used
+    constexpr int PLANE = HR * CS;
+    constexpr int A_SLOTS = 4 * PLANE;                       // per 8-channel chunk: [h][column parity]
+    constexpr int PIECES = HR * HC * 2 * CH;                 // 16-byte pieces of one halo (all channels)
+    constexpr int A_PER_T = (PIECES + 255) / 256;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* As = reinterpret_cast<f32x4*>(smem);              // [CH][A_SLOTS]
+    float* Rs = reinterpret_cast<float*>(As + CH * A_SLOTS); // [4][2][32][32] output exchange image
+
+    const int tid = threadIdx.x;
+    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int seg = bid % segs_x; bid /= segs_x;
+    const int by = bid % tiles_y; bid /= tiles_y;
+    const int img = bid;
+    const int bx0 = seg * tpw;
+    const int ntile = min(tpw, tiles_x - bx0);
+    const int oy0 = by * 8;
+    const int Hin = p.in.h, Win = p.in.w, Cin = p.in.c;
+    const size_t in_img = (size_t)img * Hin * Win * p.in.cs;
+
+    // halo pieces of this thread: consecutive threads take the 2 * CH channel quads of one pixel (Cin * 4 contiguous bytes)
+    long a_off[A_PER_T];                                     // offset of the piece for tile column 0 (may be "negative" at x = -1)
+    int a_lds[A_PER_T], a_hx[A_PER_T];                       // LDS slot (-1: no piece), halo column | 0x100 when the row / channels are outside
+#pragma unroll
+    for (int k = 0; k < A_PER_T; ++k) {
+        const int q = tid + k * 256;
+        a_off[k] = 0; a_lds[k] = -1; a_hx[k] = 0x100;
+        if (q < PIECES) {
+            const int pix = q / (2 * CH), sub = q - pix * (2 * CH);
+            const int c = sub >> 1, h = sub & 1;
+            const int hy = pix / HC, hx = pix - hy * HC;
+            const int iy = oy0 - 1 + hy;
+            a_lds[k] = c * A_SLOTS + (h * 2 + (hx & 1)) * PLANE + hy * CS + (hx >> 1);
+            const bool ok = iy >= 0 && iy < Hin && c * 8 + h * 4 < Cin;
+            a_hx[k] = hx | (ok ? 0 : 0x100);
+            a_off[k] = (long)in_img + ((long)iy * Win + (long)(bx0 * 16 - 1 + hx)) * p.in.cs + c * 8 + h * 4;
+        }
+    }
+    f32x4 a_reg[A_PER_T];
+    auto load_a = [&](int t) {                               // tile t of this workgroup's walk
+#pragma unroll
+        for (int k = 0; k < A_PER_T; ++k) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            const int ix = (bx0 + t) * 16 - 1 + (a_hx[k] & 0xff);
+            if (!(a_hx[k] & 0x100) && ix >= 0 && ix < Win)
+                v = *reinterpret_cast<const f32x4*>(p.in.p + a_off[k] + (long)t * 16 * p.in.cs);
+            a_reg[k] = v;
+        }
+    };
+    auto store_a = [&]() {
+#pragma unroll
+        for (int k = 0; k < A_PER_T; ++k)
+            if (a_lds[k] >= 0) As[a_lds[k]] = a_reg[k];
+    };
+
+    const int lane = tid & 63, wa = tid >> 6;                // wave = transform row a
+    const int li = lane & 31, lh = lane >> 5;
+    const int ti = li >> 3, tj = li & 7;
+    const int r0 = (wa == 0) ? 0 : 1, r1 = (wa == 3) ? 3 : 2;
+    const float s0 = (wa == 2) ? -1.f : 1.f, s1 = (wa == 0 || wa == 3) ? -1.f : 1.f;
+    const int a0_off = (lh * 2) * PLANE + (2 * ti + r0) * CS + tj;
+    const int a1_off = (lh * 2) * PLANE + (2 * ti + r1) * CS + tj;
+
+    load_a(0);
+    // the wave's filter fragments: [chunk][column point b]: 4 k-steps of the MFMA B operand (lane = (channel half lh, cout li))
+    f32x4 w[CH][4];
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            w[c][b] = *reinterpret_cast<const f32x4*>(p.wt + (size_t)(wa * 4 + b) * (size_t)p.wt_tap_stride +
+                                                      (size_t)c * (size_t)p.wt_chunk_stride + ((size_t)lh * p.coutp + li) * 4);
+    store_a();
+    __syncthreads();
+
+    for (int t = 0; t < ntile; ++t) {
+        const bool more = t + 1 < ntile;
+        if (more) load_a(t + 1);                             // lands under this tile's MFMAs
+        f32x16 acc[4][1];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[b][0][e] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const f32x4* A0 = As + c * A_SLOTS + a0_off;
+            const f32x4* A1 = As + c * A_SLOTS + a1_off;
+            const f32x4 d0 = A0[0], d1 = A1[0], d2 = A0[PLANE], d3 = A1[PLANE];
+            const f32x4 d4 = A0[1], d5 = A1[1], d6 = A0[PLANE + 1], d7 = A1[PLANE + 1];
+            const f32x4 t0 = s0 * d0 + s1 * d1;
+            const f32x4 t1 = s0 * d2 + s1 * d3;
+            const f32x4 t2 = s0 * d4 + s1 * d5;
+            const f32x4 t3 = s0 * d6 + s1 * d7;
+            f32x4 V[4];
+            V[0] = t0 - t2; V[1] = t1 + t2; V[2] = t2 - t1; V[3] = t1 - t3;
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[b][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b][e], w[c][b][e], acc[b][0], 0, 0, 0);
+        }
+        wino_write_R<1>(Rs, acc, wa, lane);
+        __syncthreads();                                     // R complete; every wave is done with this tile's halo image
+        if (more) store_a();
+        wino_store_Y<1>(Rs, p, img, oy0, (bx0 + t) * 16, 0, wa, lane);
+        __syncthreads();                                     // next halo visible; Rs free again
+    }
+}
+
+template <int CH>
+static hipError_t launch_conv_wino_res_t(const ConvParams& p, hipStream_t s) {
+    const int tiles_x = (p.out.w + 15) / 16, tiles_y = (p.out.h + 7) / 8;
+    // tiles per workgroup: as many as keep >= ~2 workgroups per CU-slot in the launch
+    int tpw = 16;
+    while (tpw > 1 && (size_t)p.n * tiles_y * ((tiles_x + tpw - 1) / tpw) < 2048) tpw >>= 1;
+    const int segs_x = (tiles_x + tpw - 1) / tpw;
+    const size_t grid = (size_t)p.n * tiles_y * segs_x;
+    if (grid == 0) return hipSuccess;
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    const size_t lds = (size_t)CH * 4 * 10 * 12 * 16 + (size_t)4 * 2 * 32 * 32 * 4;
+    hipLaunchKernelGGL((conv_wino_res_kernel<CH>), dim3((unsigned)grid), dim3(256), lds, s, p, tiles_x, tiles_y, segs_x, tpw);
+    return hipGetLastError();
+}
+
 int conv_wino_ntile(int cout) { return (cout % 64 == 0 || cout > 64) ? 64 : 32; }
 
 hipError_t launch_conv_wino(const ConvParams& p, hipStream_t s) {
+    if (p.resident && p.coutp == 32 && p.cin_chunks >= 1 && p.cin_chunks <= 4) {
+        switch (p.cin_chunks) {
+            case 1: return launch_conv_wino_res_t<1>(p, s);
+            case 2: return launch_conv_wino_res_t<2>(p, s);
+            case 3: return launch_conv_wino_res_t<3>(p, s);
+            default: return launch_conv_wino_res_t<4>(p, s);
+        }
+    }
     return conv_wino_ntile(p.out.c) == 64 ? launch_conv_wino_t<2, 1>(p, s) : launch_conv_wino_t<1, 1>(p, s);
 }
 

@@ -238,3 +238,41 @@ def test_fused_head_on_plain_conv_stack(gpu, n_convs):
         gpu.set_option('fuse_head', 1)
     assert np.abs(fused - want).max() < TOL
     assert np.abs(fused - unfused).max() < 1e-5
+
+
+@pytest.mark.parametrize('cin,cout,hw,n', [(16, 16, (256, 256), 40),      # 16 tiles per workgroup walk (one segment per tile row)
+                                           (32, 32, (64, 208), 80),       # 13 tiles per row: segments of 8 + 5
+                                           (24, 16, (72, 208), 114),      # one 13-tile segment, Cin = 3 chunks
+                                           (8, 32, (40, 56), 3),          # small launch: one tile per workgroup, overhanging tiles
+                                           (12, 20, (37, 53), 2)])        # Cin % 8 == 4, Cout % 4 == 0 only, odd extents
+def test_winograd_resident_filter_kernel(gpu, cin, cout, hw, n):
+    """Narrow layers (Cin <= 32, Cout <= 32) under F(2x2): the filter-resident kernel (filters in registers, a workgroup walks
+    several tiles of a tile row) does the arithmetic of the streaming kernel in the same order - identical results - and
+    agrees with the oracle."""
+    rng = np.random.default_rng(cin * 11 + cout)
+    H, W = hw
+    cfg = {'class_name': 'Functional', 'config': {'name': 'm', 'layers': [
+        {'class_name': 'InputLayer', 'name': 'in', 'config': {'name': 'in', 'batch_input_shape': [None, H, W, cin]},
+         'inbound_nodes': []},
+        {'class_name': 'Conv2D', 'name': 'c', 'config': {'name': 'c', 'filters': cout, 'kernel_size': [3, 3],
+                                                         'strides': [1, 1], 'padding': 'same', 'activation': 'relu',
+                                                         'use_bias': True}, 'inbound_nodes': [[['in', 0, 0, {}]]]}],
+        'input_layers': [['in', 0, 0]], 'output_layers': [['c', 0, 0]]}}
+    weights = {'c': [(rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin) / 64).astype(np.float32),
+                     rng.normal(size=cout).astype(np.float32)]}
+    x = rng.integers(0, 256, size=(n, H, W, cin), dtype=np.uint8)
+    try:
+        gpu.set_option('winograd', 1)
+        gpu.set_option('wino_resident', 1)
+        res, _ = _run(gpu, cfg, weights, x, fuse=True)
+        gpu.set_option('wino_resident', 0)
+        stream = gpu.forward_patches(x)
+    finally:
+        gpu.set_option('winograd', 2)
+        gpu.set_option('wino_resident', 1)
+    assert np.array_equal(res, stream), float(np.abs(res - stream).max())
+    k = min(n, 4)                                              # the oracle on a few patches from both ends of the batch
+    sel = np.r_[0:k // 2, n - (k - k // 2):n]
+    want = oracle_unet.forward(cfg, weights, x[sel])
+    scale = max(1.0, float(np.abs(want).max()))
+    assert np.abs(res[sel] - want).max() < 2e-4 * scale, np.abs(res[sel] - want).max()

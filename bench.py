@@ -216,7 +216,7 @@ def layer_table(model, recs, steps):
         rows.append({'op': op, 'layer': names.get(o['out'], '?'), 'type': 'conv%dx%d' % (o['kh'], o['kw']) if o['op'] == 1 else 'convT%dx%d' % (o['kh'], o['kw']),
                      'in': [ti['h'], ti['w'], ti['c']], 'out': [to['h'], to['w'], to['c']],
                      'kernel': ('conv_mfma_kernel', 'conv_wino_kernel F(2x2)', 'conv_wino4_kernel F(4x4)',
-                                'conv_wino_res_kernel F(2x2), filter-resident')[a['kind']],
+                                'conv_wino_res_kernel F(2x2), filter-resident', 'conv_wino16_kernel F(2x2), 16x16x4 MFMA')[a['kind']],
                      'launches': a['launches'], 'avg_ms': round(ms, 4),
                      'algorithmic_gflop_per_launch': round(a['flops'] / a['launches'] / 1e9, 2),
                      'executed_gflop_per_launch': round(a['executed'] / a['launches'] / 1e9, 2),

@@ -24,6 +24,7 @@ struct OpRt {                 // run-time form of one plan operator
     float* wt = nullptr;      // device weights in the layout the chosen kernel wants
     float* wt_wino = nullptr; // Winograd-transformed filter (16 points) when the op is eligible
     float* wt_wino4 = nullptr; // F(4x4,3x3) filter image (36 points, per-wave stage layout of wino4_kernel.hip)
+    float* wt_wino16 = nullptr; // F(2x2,3x3) filter image of wino16_kernel.hip (Cin, Cout in {16, 32})
     int coutp_wino = 0;
     float* bias = nullptr;
     float* head_w4 = nullptr; // PATH_HEAD with <= 4 classes: [cin][4] / [4] zero-padded copies for the fused output stage
@@ -98,6 +99,7 @@ struct ecseg_ctx {
     int crop = 1;             // segment path: skip output regions of the last full-resolution convolutions that the stitch never reads
     int fuse_head = 1;        // 1x1 head (<= 4 classes) computed by the output stage of the last F(4x4) convolution
     int use_winograd = 2;     // 0 direct, 1 Winograd F(2x2,3x3), 2 F(4x4,3x3) where eligible (else F(2x2))
+    int wino16 = 1;           // F(2x2) layers with 16 / 32 input and output channels: conv_wino16_kernel (16x16x4 MFMA, register output stage)
     int wino_resident = 1;    // F(2x2) layers with <= 32 input and output channels: filter-resident kernel (conv_wino_res_kernel)
 
     // timing
@@ -108,7 +110,7 @@ struct ecseg_ctx {
     std::vector<hipEvent_t> grp_events;    // 6 per image group of segment_dev
     size_t prof_used = 0;
     double prof_flops = 0.0, prof_exec_flops = 0.0;
-    struct ProfRec { int op; int kind; double flops, exec_flops; float ms; };   // kind: 0 direct, 1 F(2x2), 2 F(4x4), 3 filter-resident F(2x2)
+    struct ProfRec { int op; int kind; double flops, exec_flops; float ms; };   // kind: 0 direct, 1 F(2x2), 2 F(4x4), 3 filter-resident F(2x2), 4 F(2x2) on 16x16x4 MFMAs (wino16)
     std::vector<ProfRec> prof_recs;        // one per profiled launch of the last segment / forward call
     double last_conv_ms = 0.0; long long last_conv_launches = 0; double last_conv_flops = 0.0, last_conv_exec_flops = 0.0;
 };
@@ -178,6 +180,22 @@ std::vector<float> relayout_conv(const float* w, int R, int S, int cin, int cout
             float* dst = o.data() + (size_t)t * tp + (size_t)chunk * cp + ((size_t)hh * np) * 4 + e;
             for (int co = 0; co < cout; ++co) dst[(size_t)co * 4] = src[co];
         }
+    return o;
+}
+// Filter image of conv_wino16_kernel: MFMA A fragments [point 16][Cin / 16][Cout / 16][lane 64][k-step 4]; lane =
+// (channel quad kq = lane / 16, output channel m = lane % 16) holds U[point][16 kc + 4 kq + s][16 nb + m] for s = 0..3
+std::vector<float> relayout_wino16(const std::vector<float>& u, int cin, int cout) {
+    const int KC = cin / 16, NB = cout / 16;
+    std::vector<float> o((size_t)16 * KC * NB * 64 * 4);
+    for (int pt = 0; pt < 16; ++pt)
+        for (int kc = 0; kc < KC; ++kc)
+            for (int nb = 0; nb < NB; ++nb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int s = 0; s < 4; ++s) {
+                        const int kq = lane >> 4, m = lane & 15;
+                        o[((((size_t)pt * KC + kc) * NB + nb) * 64 + lane) * 4 + s] =
+                            u[((size_t)pt * cin + 16 * kc + 4 * kq + s) * cout + 16 * nb + m];
+                    }
     return o;
 }
 // Winograd F(2x2,3x3) filter transform U = G g G^T (float64), as 16 "taps" in HWIO order [a*4+b][cin][cout]
@@ -352,6 +370,7 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                     double computed = 1.0;                     // fraction of the layer a cropped launch really computes
                     const bool wino4 = h->use_winograd >= 2 && o.wt_wino4 && conv_wino4_supported(p);
                     const bool wino = !wino4 && h->use_winograd && o.wt_wino && out.h >= 4 && out.w >= 8;
+                    bool w16 = false;
                     {
                         const int npt = p.convt ? p.kT * p.kT * o.coutp : o.coutp;
                         p.wt_chunk_stride = wt_chunk_pitch(npt); p.wt_tap_stride = wt_tap_pitch(npt, o.cin_chunks);
@@ -397,6 +416,11 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                             }
                         }
                         e = launch_conv_wino4(p, s);
+                    } else if (wino && h->wino16 && o.wt_wino16 && conv_wino16_supported(p)) {
+                        w16 = true;
+                        p.wt = o.wt_wino16;
+                        fuse_following_pool();
+                        e = launch_conv_wino16(p, s);
                     } else if (wino) {
                         p.wt = o.wt_wino; p.coutp = o.coutp_wino;
                         p.wt_chunk_stride = wt_chunk_pitch(o.coutp_wino); p.wt_tap_stride = wt_tap_pitch(o.coutp_wino, o.cin_chunks);
@@ -426,7 +450,7 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                         const double ex = o.flops * n * computed * (wino4 ? 0.25 : wino ? 16.0 / 36.0 : 1.0);   // multiplies actually issued
                         h->prof_exec_flops += ex;
                         const bool res = wino && p.resident && p.coutp == 32 && p.cin_chunks <= 4;
-                        h->prof_recs.push_back({(int)oi_first, wino4 ? 2 : res ? 3 : wino ? 1 : 0, o.flops * n, ex, 0.f});
+                        h->prof_recs.push_back({(int)oi_first, wino4 ? 2 : w16 ? 4 : res ? 3 : wino ? 1 : 0, o.flops * n, ex, 0.f});
                     }
                 } else if (o.path == PATH_SMALL_CIN) {
                     e = launch_conv_small_cin(in, out, o.wt, o.bias, n, d.kh, d.kw, d.pad_top, d.pad_left, act, d.alpha, s);
@@ -779,6 +803,7 @@ int ecseg_set_option(ecseg_ctx* h, const char* key, int value) {
     else if (k == "fuse_pool") h->fuse_pool = value != 0;
     else if (k == "fuse_head") h->fuse_head = value != 0;
     else if (k == "wino_resident") h->wino_resident = value != 0;
+    else if (k == "wino16") h->wino16 = value != 0;
     else if (k == "crop") h->crop = value != 0;
     else if (k == "winograd") h->use_winograd = value < 0 ? 0 : value > 2 ? 2 : (int)value;   // 0 direct, 1 F(2x2), 2 F(4x4)
     else if (k == "post_chunk" && value >= 1) h->post_chunk = value;
@@ -877,6 +902,8 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
                         o.coutp_wino = (cout + bnw - 1) / bnw * bnw;
                         const std::vector<float> u = winograd_filter(kw, cin, cout);
                         if ((rc = upload(h, relayout_conv(u.data(), 4, 4, cin, cout, o.cin_chunks, o.coutp_wino), &o.wt_wino))) return rc;
+                        if ((cin == 16 || cin == 32) && (cout == 16 || cout == 32) && to.h >= 16 && to.w >= 32)
+                            if ((rc = upload(h, relayout_wino16(u, cin, cout), &o.wt_wino16))) return rc;
                         // F(4x4): a lone 32-channel block wastes its second channel-half waves on zeros; measured on
                         // MI355X (profiles/r02_kernel_map.json) that still beats F(2x2) once the K loop is long enough
                         if (cin % 4 == 0 && cin >= 8 && cout % 32 == 0 && (cout != 32 || cin >= 64) && to.h % 16 == 0 && to.w % 16 == 0)

@@ -59,6 +59,10 @@ int        conv_mfma_ntile(int cout);   // N tile (32 | 64 | 128) used for a giv
 // conv_wino_ntile()
 hipError_t launch_conv_wino(const ConvParams& p, hipStream_t s);
 int        conv_wino_ntile(int cout);
+// Winograd F(2x2,3x3) for 16 / 32 input and output channels on 16x16x4 MFMAs (wino16_kernel.hip); p.wt = image written by
+// relayout_wino16 (api.hip)
+hipError_t launch_conv_wino16(const ConvParams& p, hipStream_t s);
+bool       conv_wino16_supported(const ConvParams& p);
 // Winograd F(4x4,3x3) (wino4_kernel.hip); p.wt = image written by winograd4_filter (api.hip)
 hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s);
 bool       conv_wino4_supported(const ConvParams& p);

@@ -1,0 +1,256 @@
+// Winograd F(2x2, 3x3) for NARROW layers (Cin, Cout in {16, 32}: the full-resolution levels of base-16 / base-32 U-Nets)
+// on v_mfma_f32_16x16x4_f32 (gfx950).
+//
+// These layers are within 1.5x of their HBM bound (36-72 flop/B); the 32-wide kernels (conv_wino_kernel,
+// conv_wino_res_kernel) run them at 0.16-0.45 of the MFMA peak because (a) a 32-column MFMA tile is half empty at 16
+// output channels, (b) their four waves split the transform ROWS and have to meet through LDS after every tile
+// (64 KB of LDS traffic and two barriers per 128 output pixels), (c) the streaming kernel re-reads a filter slab that is
+// larger than its input tile.  This kernel is built the other way round:
+//   * MFMA roles swapped: A = transformed filter (M = 16 output channels), B = transformed input (N = 16 Winograd tiles),
+//     K = 4 channels.  The accumulator of a lane is then 4 CONSECUTIVE OUTPUT CHANNELS of ONE tile for each of the 16
+//     transform points: the output transform Y = A^T M A, bias, activation, a fused 2x2 max-pool and the 16-byte stores
+//     all happen in registers - no exchange through LDS, no barrier on the output path;
+//   * a wave owns 16 tiles (2 x 8) and ALL 16 points; lane = (tile, channel quad kq): it reads its tile's 4 x 4 input
+//     pixels x 4 channels with 16 conflict-free ds_read_b128, transforms them (32 adds per channel) and feeds 64 * NB
+//     MFMAs per 16 input channels;
+//   * workgroup = 8 waves = 16 x 32 output pixels; it walks `bpw` such blocks of a 16-row strip.  The whole transformed
+//     filter (16 KB per 16 x 16 channels) is loaded into LDS once per workgroup; the input halo (18 x 34 pixels x 16
+//     channels) arrives by LDS-DMA into a double buffer, one stage (block, 16-channel chunk) ahead; one s_barrier per stage.
+//
+// LDS halo image (16-byte slots = 4 channels of a pixel): slot(y, x, cq) = y * 152 + OFF[cq][x & 1] + (x >> 1) with
+// OFF = {0, 17 | 40, 57 | 74, 91 | 114, 131}: the four 16-lane groups of a ds_read_b128 hold 8 tiles of channel quad kq
+// and the other 8 tiles of quad kq ^ 1; OFF[kq ^ 1] - OFF[kq] = 40 = 8 (mod 16) and two tile rows are 304 = 0 (mod 16)
+// slots apart, so the 16 lanes of a group land on 16 different 16-byte bank columns: conflict-free.
+#include <type_traits>
+
+#include "common.h"
+#include "device_util.h"
+
+namespace ecseg {
+
+namespace {
+
+constexpr int W16_PITCH = 152;       // slots per halo row (136 used)
+constexpr int W16_ROWS = 18;
+constexpr int W16_PIECES = 43;       // 64-slot DMA pieces per halo buffer (18 * 152 = 2736 slots, padded to 2752)
+constexpr int W16_HS = W16_PIECES * 64;
+constexpr int W16_NP = 6;            // pieces per thread and stage: piece = wave + 8 k
+
+typedef __attribute__((address_space(3))) void* w16_lptr_t;
+
+// One LDS-DMA piece: 64 lanes x 16 bytes, global (per-lane address) -> LDS bytes [lds_dst + 16 * lane] (lds_dst is
+// wave-uniform).  Inline asm for the reason given in wino4_kernel.hip: behind the builtin the compiler drains vmcnt
+// before every later LDS read.  The waits in the kernel below are the only ordering; M0 is restored.
+__device__ __forceinline__ void w16_dma16(const float* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+}  // namespace
+
+template <int KC, int NB>
+__global__ __launch_bounds__(512) void conv_wino16_kernel(ConvParams p, int blocks_x, int strips_y, int segs_x, int bpw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* Hs = reinterpret_cast<f32x4*>(smem);              // [2][W16_HS] halo double buffer
+    f32x4* Fs = Hs + 2 * W16_HS;                             // [16 points][KC][NB][64 lanes]: MFMA A fragments, 4 k-steps each
+    const unsigned lds_base = (unsigned)(size_t)(w16_lptr_t)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int seg = bid % segs_x; bid /= segs_x;
+    const int by = bid % strips_y; bid /= strips_y;
+    const int img = bid;
+    const int bx0 = seg * bpw;
+    const int nblk = min(bpw, blocks_x - bx0);
+    const int oy0 = by * 16;
+    const int H = p.in.h, W = p.in.w;                        // output extent == input extent
+
+    // ---- DMA descriptors of this thread: slot q = (wave + 8 k) * 64 + lane of a halo buffer ----
+    long d_off[W16_NP];                                      // float offset of the piece for block 0, chunk 0 of the walk
+    int d_meta[W16_NP];                                      // halo column (0..33) | 0x100: padding slot / row outside the image
+#pragma unroll
+    for (int k = 0; k < W16_NP; ++k) {
+        const int q = (wave + 8 * k) * 64 + lane;
+        const int y = q / W16_PITCH, r = q - y * W16_PITCH;
+        int cq = -1, rr = 0;
+        if (r < 34) { cq = 0; rr = r; }
+        else if (r >= 40 && r < 74) { cq = 1; rr = r - 40; }
+        else if (r >= 74 && r < 108) { cq = 2; rr = r - 74; }
+        else if (r >= 114 && r < 148) { cq = 3; rr = r - 114; }
+        const int par = rr >= 17 ? 1 : 0, x = 2 * (rr - 17 * par) + par;
+        const int iy = oy0 - 1 + y;
+        const bool ok = cq >= 0 && y < W16_ROWS && iy >= 0 && iy < H;
+        d_meta[k] = x | (ok ? 0 : 0x100);
+        d_off[k] = (((long)img * H + iy) * W + (long)(bx0 * 32 - 1 + x)) * p.in.cs + (cq < 0 ? 0 : cq) * 4;
+    }
+    auto dma_halo = [&](int blk, int kc, int buf) {
+#pragma unroll
+        for (int k = 0; k < W16_NP; ++k) {
+            const int piece = wave + 8 * k;                  // wave-uniform
+            if (piece < W16_PIECES) {
+                const int ix = (bx0 + blk) * 32 - 1 + (d_meta[k] & 0xff);
+                const float* src = p.zero;
+                if (!(d_meta[k] & 0x100) && ix >= 0 && ix < W) src = p.in.p + d_off[k] + (long)blk * 32 * p.in.cs + kc * 16;
+                w16_dma16(src, lds_base + (unsigned)(buf * W16_HS + piece * 64) * 16u);
+            }
+        }
+    };
+
+    // ---- prologue: the filter image (linear copy) and the first halo ----
+#pragma unroll
+    for (int k = 0; k < 2 * KC * NB; ++k) {
+        const int piece = wave + 8 * k;                      // 16 * KC * NB pieces in all
+        w16_dma16(p.wt + ((size_t)piece * 64 + lane) * 4, lds_base + (unsigned)(2 * W16_HS + piece * 64) * 16u);
+    }
+    dma_halo(0, 0, 0);
+
+    // ---- lane geometry: tile (tr, tc) of the wave's 2 x 8 tiles, channel quad kq ----
+    const int m = lane & 15, kq = lane >> 4;
+    const int TR = 2 * (wave & 3) + (m >> 3), TC = 8 * (wave >> 2) + (m & 7);
+    const int off_a = (2 * TR) * W16_PITCH + TC + 40 * (kq & 1) + 74 * (kq >> 1);   // even halo columns of the tile
+    const int off_b = off_a + 17;                                                    // odd halo columns
+
+    f32x4 bv[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        bv[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr) bv[nb] = *reinterpret_cast<const f32x4*>(p.bias + 16 * nb + 4 * kq);
+    }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+
+    const int nstage = nblk * KC;
+    int st = 0;
+    for (int blk = 0; blk < nblk; ++blk) {
+        f32x4 acc[16][NB];
+#pragma unroll
+        for (int pt = 0; pt < 16; ++pt)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[pt][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc, ++st) {
+            // next stage's halo goes out first: it lands under this stage's MFMAs (its buffer was last read in stage st - 1)
+            if (st + 1 < nstage) {
+                if (kc + 1 < KC) dma_halo(blk, kc + 1, (st + 1) & 1);
+                else dma_halo(blk + 1, 0, (st + 1) & 1);
+            }
+            const f32x4* Hb = Hs + (st & 1) * W16_HS;
+            f32x4 d[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[i][j] = Hb[((j & 1) ? off_b : off_a) + i * W16_PITCH + (j >> 1)];
+            // V = B^T d B per channel (k-step) s: 32 adds
+            float V[4][16];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float t[4][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    t[0][j] = d[0][j][s] - d[2][j][s];
+                    t[1][j] = d[1][j][s] + d[2][j][s];
+                    t[2][j] = d[2][j][s] - d[1][j][s];
+                    t[3][j] = d[1][j][s] - d[3][j][s];
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    V[s][a * 4 + 0] = t[a][0] - t[a][2];
+                    V[s][a * 4 + 1] = t[a][1] + t[a][2];
+                    V[s][a * 4 + 2] = t[a][2] - t[a][1];
+                    V[s][a * 4 + 3] = t[a][1] - t[a][3];
+                }
+            }
+            // 64 * NB MFMAs; two points at a time so that consecutive MFMAs hit different accumulators
+            const f32x4* Fk = Fs + (kc * NB) * 64 + lane;
+#pragma unroll
+            for (int p2 = 0; p2 < 8; ++p2) {
+                f32x4 F[2][NB];
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) F[pp][nb] = Fk[((2 * p2 + pp) * KC * NB + nb) * 64];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[2 * p2 + pp][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(F[pp][nb][s], V[s][2 * p2 + pp],
+                                                                                        acc[2 * p2 + pp][nb], 0, 0, 0);
+            }
+            // own DMA pieces of the next stage have landed (and every LDS read of this stage has returned)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (kc == KC - 1) {
+                // ---- output: Y = A^T M A + bias, activation, 16-byte stores (lane = 4 output channels of one tile) ----
+                const int oy = oy0 + 2 * TR, ox = (bx0 + blk) * 32 + 2 * TC;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    f32x4 R[4][2];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        R[a][0] = acc[a * 4 + 0][nb] + acc[a * 4 + 1][nb] + acc[a * 4 + 2][nb];
+                        R[a][1] = acc[a * 4 + 1][nb] - acc[a * 4 + 2][nb] - acc[a * 4 + 3][nb];
+                    }
+                    f32x4 Y[2][2];
+#pragma unroll
+                    for (int x = 0; x < 2; ++x) {
+                        Y[0][x] = apply_act4(R[0][x] + R[1][x] + R[2][x] + bv[nb], p.act, p.alpha);
+                        Y[1][x] = apply_act4(R[1][x] - R[2][x] - R[3][x] + bv[nb], p.act, p.alpha);
+                    }
+                    const int co = 16 * nb + 4 * kq;
+#pragma unroll
+                    for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+                        for (int x = 0; x < 2; ++x)
+                            if (oy + yy < H && ox + x < W)
+                                *reinterpret_cast<f32x4*>(p.out.p + (((size_t)img * H + oy + yy) * W + ox + x) * p.out.cs + co) = Y[yy][x];
+                    if (p.pool.p != nullptr && (oy >> 1) < p.pool.h && (ox >> 1) < p.pool.w) {
+                        // fused MaxPooling2D(2x2, stride 2): a Winograd tile is one pooling window (even extents: checked by the caller)
+                        f32x4 mx;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) mx[c] = fmaxf(fmaxf(Y[0][0][c], Y[0][1][c]), fmaxf(Y[1][0][c], Y[1][1][c]));
+                        *reinterpret_cast<f32x4*>(p.pool.p + (((size_t)img * p.pool.h + (oy >> 1)) * p.pool.w + (ox >> 1)) * p.pool.cs + co) = mx;
+                    }
+                }
+            }
+            asm volatile("s_barrier" ::: "memory");
+        }
+    }
+}
+
+// Eligibility beyond "3x3, stride 1, pad 1, same size" (checked by the caller): 16 or 32 input and output channels, at
+// least one 16 x 32 block, 16-byte aligned views.
+bool conv_wino16_supported(const ConvParams& p) {
+    return p.in.h == p.out.h && p.in.w == p.out.w && (p.in.c == 16 || p.in.c == 32) && (p.out.c == 16 || p.out.c == 32) &&
+           p.out.h >= 16 && p.out.w >= 32 && p.in.cs % 4 == 0 && p.out.cs % 4 == 0 && p.zero != nullptr;
+}
+
+template <int KC, int NB>
+static hipError_t launch_conv_wino16_t(const ConvParams& p, hipStream_t s) {
+    const int blocks_x = (p.out.w + 31) / 32, strips_y = (p.out.h + 15) / 16;
+    int bpw = 8;                                             // blocks per workgroup walk: the filter load is amortised over them
+    while (bpw > 1 && (size_t)p.n * strips_y * ((blocks_x + bpw - 1) / bpw) < 1024) bpw >>= 1;
+    const int segs_x = (blocks_x + bpw - 1) / bpw;
+    const size_t grid = (size_t)p.n * strips_y * segs_x;
+    if (grid == 0) return hipSuccess;
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    const size_t lds = ((size_t)2 * W16_HS + (size_t)16 * KC * NB * 64) * 16;
+    static DeviceOnce attr_set;                              // the attribute is per device (and per template instance)
+    if (attr_set.first()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino16_kernel<KC, NB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { attr_set.reset(); return e; }
+    }
+    hipLaunchKernelGGL((conv_wino16_kernel<KC, NB>), dim3((unsigned)grid), dim3(512), lds, s, p, blocks_x, strips_y, segs_x, bpw);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_wino16(const ConvParams& p, hipStream_t s) {
+    if (p.in.c == 16) return p.out.c == 16 ? launch_conv_wino16_t<1, 1>(p, s) : launch_conv_wino16_t<1, 2>(p, s);
+    return p.out.c == 16 ? launch_conv_wino16_t<2, 1>(p, s) : launch_conv_wino16_t<2, 2>(p, s);
+}
+
+}  // namespace ecseg

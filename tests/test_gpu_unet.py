@@ -264,15 +264,54 @@ def test_winograd_resident_filter_kernel(gpu, cin, cout, hw, n):
     try:
         gpu.set_option('winograd', 1)
         gpu.set_option('wino_resident', 1)
+        gpu.set_option('wino16', 0)
         res, _ = _run(gpu, cfg, weights, x, fuse=True)
         gpu.set_option('wino_resident', 0)
         stream = gpu.forward_patches(x)
     finally:
         gpu.set_option('winograd', 2)
         gpu.set_option('wino_resident', 1)
+        gpu.set_option('wino16', 1)
     assert np.array_equal(res, stream), float(np.abs(res - stream).max())
     k = min(n, 4)                                              # the oracle on a few patches from both ends of the batch
     sel = np.r_[0:k // 2, n - (k - k // 2):n]
     want = oracle_unet.forward(cfg, weights, x[sel])
     scale = max(1.0, float(np.abs(want).max()))
     assert np.abs(res[sel] - want).max() < 2e-4 * scale, np.abs(res[sel] - want).max()
+
+
+@pytest.mark.parametrize('cin,cout,hw,n', [(16, 16, (256, 256), 64),      # walks of 8 blocks (16 x 32 pixels each)
+                                           (16, 32, (48, 304), 171),      # 10 blocks per strip: walks of 8 + 2, last block partial
+                                           (32, 16, (64, 208), 5),        # small launch: one block per workgroup, 6.5 blocks per strip
+                                           (32, 32, (16, 96), 512),       # walks of 2 + 1 blocks, two 16-channel stages per block
+                                           (32, 32, (40, 56), 3)])        # partial blocks in both directions
+def test_winograd_wino16_kernel(gpu, cin, cout, hw, n):
+    """Narrow layers (16 / 32 input and output channels) under F(2x2): conv_wino16_kernel (16x16x4 MFMAs with the filter as
+    the A operand, register output stage, LDS-DMA halo double buffer) against the 32-wide F(2x2) kernel and the oracle."""
+    rng = np.random.default_rng(cin * 13 + cout)
+    H, W = hw
+    cfg = {'class_name': 'Functional', 'config': {'name': 'm', 'layers': [
+        {'class_name': 'InputLayer', 'name': 'in', 'config': {'name': 'in', 'batch_input_shape': [None, H, W, cin]},
+         'inbound_nodes': []},
+        {'class_name': 'Conv2D', 'name': 'c', 'config': {'name': 'c', 'filters': cout, 'kernel_size': [3, 3],
+                                                         'strides': [1, 1], 'padding': 'same', 'activation': 'relu',
+                                                         'use_bias': True}, 'inbound_nodes': [[['in', 0, 0, {}]]]}],
+        'input_layers': [['in', 0, 0]], 'output_layers': [['c', 0, 0]]}}
+    weights = {'c': [(rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin) / 64).astype(np.float32),
+                     rng.normal(size=cout).astype(np.float32)]}
+    x = rng.integers(0, 256, size=(n, H, W, cin), dtype=np.uint8)
+    try:
+        gpu.set_option('winograd', 1)
+        gpu.set_option('wino16', 1)
+        w16, _ = _run(gpu, cfg, weights, x, fuse=True)
+        gpu.set_option('wino16', 0)
+        ref = gpu.forward_patches(x)
+    finally:
+        gpu.set_option('winograd', 2)
+        gpu.set_option('wino16', 1)
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.abs(w16 - ref).max() < 1e-4 * scale, float(np.abs(w16 - ref).max())
+    k = min(n, 4)                                              # the oracle on a few patches from both ends of the batch
+    sel = np.r_[0:k // 2, n - (k - k // 2):n]
+    want = oracle_unet.forward(cfg, weights, x[sel])
+    assert np.abs(w16[sel] - want).max() < 2e-4 * scale, np.abs(w16[sel] - want).max()

@@ -17,9 +17,9 @@ done
 wait
 for v in "$@"; do
   if [ "$v" = diag ]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libecseg_diag.so /tmp/w4/api_diag.o unet_kernels.o /tmp/w4/wino4_diag.o post_kernels.o host_codec.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libecseg_diag.so /tmp/w4/api_diag.o unet_kernels.o /tmp/w4/wino4_diag.o wino16_kernel.o post_kernels.o host_codec.o
   else
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libecseg_v$v.so api.o unet_kernels.o /tmp/w4/wino4_v$v.o post_kernels.o host_codec.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libecseg_v$v.so api.o unet_kernels.o /tmp/w4/wino4_v$v.o wino16_kernel.o post_kernels.o host_codec.o
   fi
 done
 ls -la ../libecseg_*.so

@@ -124,6 +124,14 @@ __global__ __launch_bounds__(512) void conv_wino16_kernel(ConvParams p, int bloc
 
     const int nstage = nblk * KC;
     int st = 0;
+    // in-kernel cycle stamps per phase (tools/w16_stamp_probe.py): diagnostic builds only (tools/build_variants.sh diag)
+#ifdef ECSEG_DIAG
+    unsigned long long stp[6] = {0, 0, 0, 0, 0, 0}, tk = __builtin_amdgcn_s_memtime();
+    const unsigned long long tk0 = tk;
+#define W16_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); stp[i] += now - tk; tk = now; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define W16_STAMP(i) do { } while (0)
+#endif
     for (int blk = 0; blk < nblk; ++blk) {
         f32x4 acc[16][NB];
 #pragma unroll
@@ -137,6 +145,7 @@ __global__ __launch_bounds__(512) void conv_wino16_kernel(ConvParams p, int bloc
                 if (kc + 1 < KC) dma_halo(blk, kc + 1, (st + 1) & 1);
                 else dma_halo(blk + 1, 0, (st + 1) & 1);
             }
+            W16_STAMP(0);                                    // [0] DMA issue
             const f32x4* Hb = Hs + (st & 1) * W16_HS;
             f32x4 d[4][4];
 #pragma unroll
@@ -163,6 +172,7 @@ __global__ __launch_bounds__(512) void conv_wino16_kernel(ConvParams p, int bloc
                     V[s][a * 4 + 3] = t[a][1] - t[a][3];
                 }
             }
+            W16_STAMP(1);                                    // [1] halo reads + transform
             // 64 * NB MFMAs; two points at a time so that consecutive MFMAs hit different accumulators
             const f32x4* Fk = Fs + (kc * NB) * 64 + lane;
 #pragma unroll
@@ -181,8 +191,10 @@ __global__ __launch_bounds__(512) void conv_wino16_kernel(ConvParams p, int bloc
                             acc[2 * p2 + pp][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(F[pp][nb][s], V[s][2 * p2 + pp],
                                                                                         acc[2 * p2 + pp][nb], 0, 0, 0);
             }
+            W16_STAMP(2);                                    // [2] filter reads + MFMA issue
             // own DMA pieces of the next stage have landed (and every LDS read of this stage has returned)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            W16_STAMP(3);                                    // [3] wait for the DMA
             if (kc == KC - 1) {
                 // ---- output: Y = A^T M A + bias, activation, 16-byte stores (lane = 4 output channels of one tile) ----
                 const int oy = oy0 + 2 * TR, ox = (bx0 + blk) * 32 + 2 * TC;
@@ -216,9 +228,20 @@ __global__ __launch_bounds__(512) void conv_wino16_kernel(ConvParams p, int bloc
                     }
                 }
             }
+            W16_STAMP(4);                                    // [4] output stage
             asm volatile("s_barrier" ::: "memory");
+            W16_STAMP(5);                                    // [5] barrier
         }
     }
+#ifdef ECSEG_DIAG
+    if (blockIdx.x == gridDim.x / 2 && lane == 0) {
+        float* dbg = const_cast<float*>(p.zero) + 16 + wave * 8;
+        for (int i = 0; i < 6; ++i) dbg[i] = (float)stp[i];
+        dbg[6] = (float)(__builtin_amdgcn_s_memtime() - tk0);
+        dbg[7] = (float)nstage;
+    }
+#endif
+#undef W16_STAMP
 }
 
 // Eligibility beyond "3x3, stride 1, pad 1, same size" (checked by the caller): 16 or 32 input and output channels, at

@@ -10,6 +10,7 @@ for v in "$@"; do
   if [ "$v" = diag ]; then
     $HC -fno-slp-vectorize -DECSEG_DIAG -c wino4_kernel.hip -o /tmp/w4/wino4_diag.o &
     $HC -DECSEG_DIAG -c api.hip -o /tmp/w4/api_diag.o &
+    $HC -DECSEG_DIAG -c wino16_kernel.hip -o /tmp/w4/wino16_diag.o &
   else
     $HC -fno-slp-vectorize -DW4_VARIANT=$v -c wino4_kernel.hip -o /tmp/w4/wino4_v$v.o &
   fi
@@ -17,7 +18,7 @@ done
 wait
 for v in "$@"; do
   if [ "$v" = diag ]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libecseg_diag.so /tmp/w4/api_diag.o unet_kernels.o /tmp/w4/wino4_diag.o wino16_kernel.o post_kernels.o host_codec.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libecseg_diag.so /tmp/w4/api_diag.o unet_kernels.o /tmp/w4/wino4_diag.o /tmp/w4/wino16_diag.o post_kernels.o host_codec.o
   else
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libecseg_v$v.so api.o unet_kernels.o /tmp/w4/wino4_v$v.o wino16_kernel.o post_kernels.o host_codec.o
   fi

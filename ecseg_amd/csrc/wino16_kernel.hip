@@ -49,11 +49,15 @@ __device__ __forceinline__ void w16_dma16(const float* gsrc, unsigned lds_dst) {
 
 }  // namespace
 
-template <int KC, int NB>
-__global__ __launch_bounds__(512) void conv_wino16_kernel(ConvParams p, int blocks_x, int strips_y, int segs_x, int bpw) {
+// NBUF = 2: halo double buffer, the next stage's DMA goes out at the stage start, one barrier per stage.  NBUF = 1 (16 -> 16
+// channels): one halo buffer - the transform is the only reader of the halo, so a barrier right behind it frees the buffer
+// and the next stage's DMA lands under the MFMAs and the output stage: two barriers per stage, but 60 instead of 104 KB of
+// LDS and <= 128 registers: two workgroups (four waves per SIMD) share a CU and fill each other's VALU / wait phases.
+template <int KC, int NB, int NBUF>
+__global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(ConvParams p, int blocks_x, int strips_y, int segs_x, int bpw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4* Hs = reinterpret_cast<f32x4*>(smem);              // [2][W16_HS] halo double buffer
-    f32x4* Fs = Hs + 2 * W16_HS;                             // [16 points][KC][NB][64 lanes]: MFMA A fragments, 4 k-steps each
+    f32x4* Hs = reinterpret_cast<f32x4*>(smem);              // [NBUF][W16_HS] halo buffer(s)
+    f32x4* Fs = Hs + NBUF * W16_HS;                             // [16 points][KC][NB][64 lanes]: MFMA A fragments, 4 k-steps each
     const unsigned lds_base = (unsigned)(size_t)(w16_lptr_t)smem;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(512) void conv_wino16_kernel(ConvParams p, int bloc
 #pragma unroll
     for (int k = 0; k < 2 * KC * NB; ++k) {
         const int piece = wave + 8 * k;                      // 16 * KC * NB pieces in all
-        w16_dma16(p.wt + ((size_t)piece * 64 + lane) * 4, lds_base + (unsigned)(2 * W16_HS + piece * 64) * 16u);
+        w16_dma16(p.wt + ((size_t)piece * 64 + lane) * 4, lds_base + (unsigned)(NBUF * W16_HS + piece * 64) * 16u);
     }
     dma_halo(0, 0, 0);
 
@@ -141,12 +145,12 @@ __global__ __launch_bounds__(512) void conv_wino16_kernel(ConvParams p, int bloc
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc, ++st) {
             // next stage's halo goes out first: it lands under this stage's MFMAs (its buffer was last read in stage st - 1)
-            if (st + 1 < nstage) {
+            if (NBUF == 2 && st + 1 < nstage) {
                 if (kc + 1 < KC) dma_halo(blk, kc + 1, (st + 1) & 1);
                 else dma_halo(blk + 1, 0, (st + 1) & 1);
             }
             W16_STAMP(0);                                    // [0] DMA issue
-            const f32x4* Hb = Hs + (st & 1) * W16_HS;
+            const f32x4* Hb = Hs + (NBUF == 2 ? (st & 1) : 0) * W16_HS;
             f32x4 d[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -170,6 +174,15 @@ __global__ __launch_bounds__(512) void conv_wino16_kernel(ConvParams p, int bloc
                     V[s][a * 4 + 1] = t[a][1] + t[a][2];
                     V[s][a * 4 + 2] = t[a][2] - t[a][1];
                     V[s][a * 4 + 3] = t[a][1] - t[a][3];
+                }
+            }
+            if (NBUF == 1) {
+                // every wave has its halo values in registers: the buffer is free for the next stage
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("s_barrier" ::: "memory");
+                if (st + 1 < nstage) {
+                    if (kc + 1 < KC) dma_halo(blk, kc + 1, 0);
+                    else dma_halo(blk + 1, 0, 0);
                 }
             }
             W16_STAMP(1);                                    // [1] halo reads + transform
@@ -251,7 +264,7 @@ bool conv_wino16_supported(const ConvParams& p) {
            p.out.h >= 16 && p.out.w >= 32 && p.in.cs % 4 == 0 && p.out.cs % 4 == 0 && p.zero != nullptr;
 }
 
-template <int KC, int NB>
+template <int KC, int NB, int NBUF>
 static hipError_t launch_conv_wino16_t(const ConvParams& p, hipStream_t s) {
     const int blocks_x = (p.out.w + 31) / 32, strips_y = (p.out.h + 15) / 16;
     int bpw = 8;                                             // blocks per workgroup walk: the filter load is amortised over them
@@ -260,20 +273,23 @@ static hipError_t launch_conv_wino16_t(const ConvParams& p, hipStream_t s) {
     const size_t grid = (size_t)p.n * strips_y * segs_x;
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    const size_t lds = ((size_t)2 * W16_HS + (size_t)16 * KC * NB * 64) * 16;
+    const size_t lds = ((size_t)NBUF * W16_HS + (size_t)16 * KC * NB * 64) * 16;
     static DeviceOnce attr_set;                              // the attribute is per device (and per template instance)
     if (attr_set.first()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino16_kernel<KC, NB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino16_kernel<KC, NB, NBUF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { attr_set.reset(); return e; }
     }
-    hipLaunchKernelGGL((conv_wino16_kernel<KC, NB>), dim3((unsigned)grid), dim3(512), lds, s, p, blocks_x, strips_y, segs_x, bpw);
+    hipLaunchKernelGGL((conv_wino16_kernel<KC, NB, NBUF>), dim3((unsigned)grid), dim3(512), lds, s, p, blocks_x, strips_y, segs_x, bpw);
     return hipGetLastError();
 }
 
 hipError_t launch_conv_wino16(const ConvParams& p, hipStream_t s) {
-    if (p.in.c == 16) return p.out.c == 16 ? launch_conv_wino16_t<1, 1>(p, s) : launch_conv_wino16_t<1, 2>(p, s);
-    return p.out.c == 16 ? launch_conv_wino16_t<2, 1>(p, s) : launch_conv_wino16_t<2, 2>(p, s);
+    // 16 -> 16: single halo buffer, two workgroups per CU (1.40 -> 1.27 / 1.27 -> 1.07 ms on the two such layers of the base-16
+    // U-Net at 256 x 256, 560 windows); the other shapes need > 128 registers (a second workgroup would spill: 32 -> 16
+    // measured 2.27 -> 3.71 ms) and keep the double buffer
+    if (p.in.c == 16) return p.out.c == 16 ? launch_conv_wino16_t<1, 1, 1>(p, s) : launch_conv_wino16_t<1, 2, 2>(p, s);
+    return p.out.c == 16 ? launch_conv_wino16_t<2, 1, 2>(p, s) : launch_conv_wino16_t<2, 2, 2>(p, s);
 }
 
 }  // namespace ecseg

@@ -24,6 +24,7 @@ def main():
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--base', type=int, default=16)
     ap.add_argument('--opt', action='append', default=[], help='library option key=value')
+    ap.add_argument('--only', default=None, help='time only the input kinds whose name contains this text (per-kind rocprofv3 runs)')
     a = ap.parse_args()
     import torch
     from ecseg_amd import synth
@@ -45,6 +46,8 @@ def main():
         hnd = m.handle
     out = {'images_per_call': n, 'image_size': [H, W], 'algorithmic_bytes_per_image': ALG_BYTES_PER_IMAGE, 'hbm_peak_GBs': 8000.0, 'inputs': {}}
     for tag, lab in kinds.items():
+        if a.only and a.only not in tag:
+            continue
         d_in = torch.from_numpy(np.ascontiguousarray(lab)).cuda()
         d_out = torch.empty_like(d_in)
         nec = torch.zeros(n, dtype=torch.int32, device='cuda')

@@ -1,18 +1,20 @@
 #!/bin/bash
 # Round profile set (run on the GPU box through gpurun): kernel trace + stats, then PMC passes in their own runs
 # (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass; --pmc never together with --sys-trace etc.).
-#   bash tools/profile_round.sh <tag>     -> gpurun_out/prof_<tag>/...
+#   bash tools/profile_round.sh <tag> [bench args, e.g. --base 16]     -> gpurun_out/prof_<tag>/...
 set -u
 TAG=${1:-r02}
+shift
+XARGS="$*"
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --no-cpu-baseline --no-host-inclusive --steps 4 --warmup 1"
+BENCH="python3 $R/bench.py $XARGS --no-cpu-baseline --no-host-inclusive --steps 4 --warmup 1"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $BENCH > $OUT/stats.log 2>&1
 echo "stats rc $?"
 rocprofv3 -L 2>/dev/null | grep -io "SQ_[A-Z_0-9]*MFMA[A-Z_0-9]*" | sort -u > $OUT/mfma_counters.txt
-PMC1="python3 $R/bench.py --no-cpu-baseline --no-host-inclusive --steps 1 --warmup 1"
+PMC1="python3 $R/bench.py $XARGS --no-cpu-baseline --no-host-inclusive --steps 1 --warmup 1"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o bench -- $PMC1 > $OUT/pmc_$c.log 2>&1
   echo "pmc $c rc $?"

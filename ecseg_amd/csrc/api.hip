@@ -389,6 +389,22 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                             ++oi;                              // the pooling op is done
                         }
                     };
+                    // a 1x1 head (<= 4 classes) that is the only reader of this convolution's output is computed by the same output
+                    // stage (conv_wino4: 64 channels, conv_wino16: 16 / 32); the feature tensor is then never written
+                    auto fuse_following_head = [&](int channels) {
+                        if (p.pool.p != nullptr || oi + 1 >= h->ops.size() || !h->fuse_head || out.c != channels || softmax) return;
+                        const OpRt& hx = h->ops[oi + 1];
+                        const ecseg_tensor_desc& td = h->tensors[d.out];
+                        if (hx.d.op == ECSEG_OP_CONV && hx.path == PATH_HEAD && hx.head_w4 && hx.d.in0 == d.out &&
+                            h->consumers[d.out] == 1 && d.out != h->output_tensor && td.c_stride == td.c && td.c_offset == 0 &&
+                            // workgroups write head pixels while others still read the convolution's input halo
+                            h->tensors[hx.d.out].buffer != h->tensors[d.in0].buffer &&
+                            h->tensors[hx.d.out].buffer != td.buffer) {
+                            p.head_w = hx.head_w4; p.head_b = hx.head_b4; p.head_out = view_of(h, hx.d.out);
+                            p.head_k = p.head_out.c; p.head_act = hx.d.act; p.head_only = 1;
+                            ++oi;                              // the head op is done
+                        }
+                    };
                     if (wino4) {
                         p.wt = o.wt_wino4; p.coutp = out.c;
                         if (crop && h->crop && o.crop_ok && n % crop->n_pos == 0) {
@@ -400,26 +416,13 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                         }
                         // a MaxPooling2D(2x2, stride 2) that follows directly is written by the same output stage
                         fuse_following_pool();
-                        // a 1x1 head (<= 4 classes) that is the only reader of this 64-channel output is computed by the
-                        // same output stage; the 64-channel tensor is then never written
-                        if (p.pool.p == nullptr && oi + 1 < h->ops.size() && h->fuse_head && out.c == 64 && !softmax) {
-                            const OpRt& hx = h->ops[oi + 1];
-                            const ecseg_tensor_desc& td = h->tensors[d.out];
-                            if (hx.d.op == ECSEG_OP_CONV && hx.path == PATH_HEAD && hx.head_w4 && hx.d.in0 == d.out &&
-                                h->consumers[d.out] == 1 && d.out != h->output_tensor && td.c_stride == td.c && td.c_offset == 0 &&
-                                // workgroups write head pixels while others still read the convolution's input halo
-                                h->tensors[hx.d.out].buffer != h->tensors[d.in0].buffer &&
-                                h->tensors[hx.d.out].buffer != td.buffer) {
-                                p.head_w = hx.head_w4; p.head_b = hx.head_b4; p.head_out = view_of(h, hx.d.out);
-                                p.head_k = p.head_out.c; p.head_act = hx.d.act; p.head_only = 1;
-                                ++oi;                          // the head op is done
-                            }
-                        }
+                        fuse_following_head(64);
                         e = launch_conv_wino4(p, s);
                     } else if (wino && h->wino16 && o.wt_wino16 && conv_wino16_supported(p)) {
                         w16 = true;
                         p.wt = o.wt_wino16;
                         fuse_following_pool();
+                        fuse_following_head(out.c);
                         e = launch_conv_wino16(p, s);
                     } else if (wino) {
                         p.wt = o.wt_wino; p.coutp = o.coutp_wino;

@@ -53,11 +53,15 @@ __device__ __forceinline__ void w16_dma16(const float* gsrc, unsigned lds_dst) {
 // channels): one halo buffer - the transform is the only reader of the halo, so a barrier right behind it frees the buffer
 // and the next stage's DMA lands under the MFMAs and the output stage: two barriers per stage, but 60 instead of 104 KB of
 // LDS and <= 128 registers: two workgroups (four waves per SIMD) share a CU and fill each other's VALU / wait phases.
-template <int KC, int NB, int NBUF>
+// HEAD: a following 1x1 convolution with <= 4 output channels (the U-Net's softmax head) is finished by the output stage:
+// a lane holds 4 of a pixel's channels, the four lanes kq = 0..3 of a tile hold them all - partial logits per lane, a
+// reduce-scatter over the two lane bits (12 cross-lane moves), lane kq finishes pixel kq of the tile's 2 x 2.
+template <int KC, int NB, int NBUF, bool HEAD>
 __global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(ConvParams p, int blocks_x, int strips_y, int segs_x, int bpw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* Hs = reinterpret_cast<f32x4*>(smem);              // [NBUF][W16_HS] halo buffer(s)
-    f32x4* Fs = Hs + NBUF * W16_HS;                             // [16 points][KC][NB][64 lanes]: MFMA A fragments, 4 k-steps each
+    f32x4* Fs = Hs + NBUF * W16_HS;                          // [16 points][KC][NB][64 lanes]: MFMA A fragments, 4 k-steps each
+    f32x4* Hw = Fs + 16 * KC * NB * 64;                      // HEAD: [16 NB channels] x 4 classes
     const unsigned lds_base = (unsigned)(size_t)(w16_lptr_t)smem;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -123,7 +127,8 @@ __global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(C
         if (p.bias != nullptr) bv[nb] = *reinterpret_cast<const f32x4*>(p.bias + 16 * nb + 4 * kq);
     }
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (HEAD && tid < 16 * NB) Hw[tid] = reinterpret_cast<const f32x4*>(p.head_w)[tid];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
 
     const int nstage = nblk * KC;
@@ -211,6 +216,11 @@ __global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(C
             if (kc == KC - 1) {
                 // ---- output: Y = A^T M A + bias, activation, 16-byte stores (lane = 4 output channels of one tile) ----
                 const int oy = oy0 + 2 * TR, ox = (bx0 + blk) * 32 + 2 * TC;
+                f32x4 hl[2][2];                                  // HEAD: partial logits [row][column] of the tile's pixels
+#pragma unroll
+                for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+                    for (int x = 0; x < 2; ++x) hl[yy][x] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     f32x4 R[4][2];
@@ -226,12 +236,26 @@ __global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(C
                         Y[1][x] = apply_act4(R[1][x] - R[2][x] - R[3][x] + bv[nb], p.act, p.alpha);
                     }
                     const int co = 16 * nb + 4 * kq;
+                    if (!(HEAD && p.head_only)) {
 #pragma unroll
-                    for (int yy = 0; yy < 2; ++yy)
+                        for (int yy = 0; yy < 2; ++yy)
 #pragma unroll
-                        for (int x = 0; x < 2; ++x)
-                            if (oy + yy < H && ox + x < W)
-                                *reinterpret_cast<f32x4*>(p.out.p + (((size_t)img * H + oy + yy) * W + ox + x) * p.out.cs + co) = Y[yy][x];
+                            for (int x = 0; x < 2; ++x)
+                                if (oy + yy < H && ox + x < W)
+                                    *reinterpret_cast<f32x4*>(p.out.p + (((size_t)img * H + oy + yy) * W + ox + x) * p.out.cs + co) = Y[yy][x];
+                    }
+                    if (HEAD) {                                  // this lane's 4 channels x 4 classes, for the tile's 2 x 2 pixels
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const f32x4 w = Hw[co + r];
+#pragma unroll
+                            for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+                                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                                    for (int c = 0; c < 4; ++c) hl[yy][x][c] = __builtin_fmaf(Y[yy][x][r], w[c], hl[yy][x][c]);
+                        }
+                    }
                     if (p.pool.p != nullptr && (oy >> 1) < p.pool.h && (ox >> 1) < p.pool.w) {
                         // fused MaxPooling2D(2x2, stride 2): a Winograd tile is one pooling window (even extents: checked by the caller)
                         f32x4 mx;
@@ -240,7 +264,51 @@ __global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(C
                         *reinterpret_cast<f32x4*>(p.pool.p + (((size_t)img * p.pool.h + (oy >> 1)) * p.pool.w + (ox >> 1)) * p.pool.cs + co) = mx;
                     }
                 }
-            }
+                            if (HEAD) {
+                    // reduce-scatter over the four lanes of the tile (lane bits 5 and 4): bit 5 keeps pixel row (kq >> 1), bit 4
+                    // pixel column (kq & 1); lane kq ends up with the complete logits of pixel (kq >> 1, kq & 1)
+                    const bool hi = (kq & 2) != 0, odd = (kq & 1) != 0;
+                    f32x4 row[2], mine;
+#pragma unroll
+                    for (int x = 0; x < 2; ++x)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float keep = hi ? hl[1][x][c] : hl[0][x][c], give = hi ? hl[0][x][c] : hl[1][x][c];
+                            row[x][c] = keep + __shfl_xor(give, 32);
+                        }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float keep = odd ? row[1][c] : row[0][c], give = odd ? row[0][c] : row[1][c];
+                        mine[c] = keep + __shfl_xor(give, 16);
+                    }
+                    const f32x4 hb = *reinterpret_cast<const f32x4*>(p.head_b);
+                    float l[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) l[c] = mine[c] + hb[c];
+                    if (p.head_act == ECSEG_ACT_SOFTMAX) {
+                        float mx = l[0];
+#pragma unroll
+                        for (int c = 1; c < 4; ++c) if (c < p.head_k) mx = fmaxf(mx, l[c]);
+                        float sum = 0.f;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { l[c] = c < p.head_k ? expf(l[c] - mx) : 0.f; sum += l[c]; }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) l[c] = l[c] / sum;
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) l[c] = apply_act(l[c], p.head_act, p.alpha);
+                    }
+                    const int py = oy + (kq >> 1), px = ox + (kq & 1);
+                    if (py < H && px < W) {
+                        float* ho = p.head_out.p + (((size_t)img * H + py) * W + px) * p.head_out.cs;
+                        if (p.head_k == 4 && (p.head_out.cs & 3) == 0) *reinterpret_cast<f32x4*>(ho) = f32x4{l[0], l[1], l[2], l[3]};
+                        else {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) if (c < p.head_k) ho[c] = l[c];
+                        }
+                    }
+                }
+}
             W16_STAMP(4);                                    // [4] output stage
             asm volatile("s_barrier" ::: "memory");
             W16_STAMP(5);                                    // [5] barrier
@@ -264,8 +332,8 @@ bool conv_wino16_supported(const ConvParams& p) {
            p.out.h >= 16 && p.out.w >= 32 && p.in.cs % 4 == 0 && p.out.cs % 4 == 0 && p.zero != nullptr;
 }
 
-template <int KC, int NB, int NBUF>
-static hipError_t launch_conv_wino16_t(const ConvParams& p, hipStream_t s) {
+template <int KC, int NB, int NBUF, bool HEAD>
+static hipError_t launch_conv_wino16_tt(const ConvParams& p, hipStream_t s) {
     const int blocks_x = (p.out.w + 31) / 32, strips_y = (p.out.h + 15) / 16;
     int bpw = 8;                                             // blocks per workgroup walk: the filter load is amortised over them
     while (bpw > 1 && (size_t)p.n * strips_y * ((blocks_x + bpw - 1) / bpw) < 1024) bpw >>= 1;
@@ -273,15 +341,20 @@ static hipError_t launch_conv_wino16_t(const ConvParams& p, hipStream_t s) {
     const size_t grid = (size_t)p.n * strips_y * segs_x;
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    const size_t lds = ((size_t)NBUF * W16_HS + (size_t)16 * KC * NB * 64) * 16;
+    const size_t lds = ((size_t)NBUF * W16_HS + (size_t)16 * KC * NB * 64 + (HEAD ? 16 * NB : 0)) * 16;
     static DeviceOnce attr_set;                              // the attribute is per device (and per template instance)
     if (attr_set.first()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino16_kernel<KC, NB, NBUF>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino16_kernel<KC, NB, NBUF, HEAD>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { attr_set.reset(); return e; }
     }
-    hipLaunchKernelGGL((conv_wino16_kernel<KC, NB, NBUF>), dim3((unsigned)grid), dim3(512), lds, s, p, blocks_x, strips_y, segs_x, bpw);
+    hipLaunchKernelGGL((conv_wino16_kernel<KC, NB, NBUF, HEAD>), dim3((unsigned)grid), dim3(512), lds, s, p, blocks_x, strips_y, segs_x, bpw);
     return hipGetLastError();
+}
+
+template <int KC, int NB, int NBUF>
+static hipError_t launch_conv_wino16_t(const ConvParams& p, hipStream_t s) {
+    return p.head_w != nullptr ? launch_conv_wino16_tt<KC, NB, NBUF, true>(p, s) : launch_conv_wino16_tt<KC, NB, NBUF, false>(p, s);
 }
 
 hipError_t launch_conv_wino16(const ConvParams& p, hipStream_t s) {

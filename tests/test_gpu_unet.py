@@ -220,12 +220,12 @@ def test_winograd_f4x4_activations_and_no_bias(gpu, act, use_bias):
     assert np.abs(got - want).max() < 5e-4 * max(1.0, float(np.abs(want).max())), np.abs(got - want).max()
 
 
-@pytest.mark.parametrize('n_convs', [3, 4])
-def test_fused_head_on_plain_conv_stack(gpu, n_convs):
+@pytest.mark.parametrize('n_convs,ch', [(3, 64), (4, 64), (3, 16), (4, 16), (3, 32), (4, 32)])
+def test_fused_head_on_plain_conv_stack(gpu, n_convs, ch):
     """in -> conv64 x n -> 1x1 softmax head.  The liveness allocator used to hand the head the buffer the last
     3x3 convolution READS; with the head fused into that convolution's output stage this was a race.  Fused and unfused
-    runs must agree (and match the oracle)."""
-    cfg = synth.conv_stack_config(n_convs)
+    runs must agree (and match the oracle).  64 channels: conv_wino4_kernel's fused head; 16 / 32: conv_wino16_kernel's."""
+    cfg = synth.conv_stack_config(n_convs, ch=ch)
     weights = synth.unet_weights(cfg, seed=11)
     x = _patches(3, seed=2)
     want = oracle_unet.forward(cfg, weights, x)

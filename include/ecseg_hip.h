@@ -120,11 +120,15 @@ int ecseg_set_images_per_group(ecseg_ctx* h, int n);
  * 0 (default): everything on one stream - measured equal, the MFMA convs already fill the chip), "post_chunk"
  * (images per post-processing launch set), "images_per_group", "winograd" (3x3 / stride-1 / 'same'
  * convolutions: 2 (default) Winograd F(4x4,3x3) where the layer allows it (extents % 16, Cin % 4 and >= 8, Cout % 32), else
- * F(2x2,3x3); 1: F(2x2,3x3); 0: the direct implicit-GEMM kernel; all three are fp32 MFMA kernels), "fuse_pool" (1
+ * F(2x2,3x3); 1: F(2x2,3x3); 0: the direct implicit-GEMM kernel; all three are fp32 MFMA kernels), "wino16" (1 (default):
+ * F(2x2,3x3) layers with 16 or 32 input and output channels and extents >= 16 x 32 take conv_wino16_kernel - 16x16x4 MFMAs,
+ * register output stage; 0: the 32-wide F(2x2) kernels), "wino_resident" (1 (default): the remaining F(2x2) layers with <= 32
+ * input and <= 32 output channels keep their filter in registers and walk a tile row; 0: the streaming F(2x2) kernel - the
+ * results of the two are identical), "fuse_pool" (1
  * (default): a MaxPooling2D(2x2, stride 2) that directly follows a Winograd (F(4x4) or F(2x2)) convolution is written by that
  * convolution's output stage; 0: separate max-pool kernel), "fuse_head" (1 (default): a 1x1 convolution with <= 4 output channels that
- * is the only reader of a 64-channel F(4x4) convolution is computed by that convolution's output stage and the
- * 64-channel tensor is never written; 0: separate head kernel), "crop" (1 (default): in ecseg_segment_images the last
+ * is the only reader of a 64-channel F(4x4) convolution (or of a 16 / 32-channel conv_wino16_kernel convolution) is computed by
+ * that convolution's output stage and the feature tensor is never written; 0: separate head kernel), "crop" (1 (default): in ecseg_segment_images the last
  * full-resolution F(4x4) convolutions compute only the 16x16 regions of every window that the stitch (or the halo of the
  * convolutions behind them) reads - 72 % of them at 1040x1392; results are unchanged; 0: whole windows), "post_graph" (1: the
  * ~60 short kernels of meta_inference + count are captured once per (buffers, geometry) into a HIP graph and replayed;

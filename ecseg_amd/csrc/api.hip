@@ -99,6 +99,7 @@ struct ecseg_ctx {
     int crop = 1;             // segment path: skip output regions of the last full-resolution convolutions that the stitch never reads
     int fuse_head = 1;        // 1x1 head (<= 4 classes) computed by the output stage of the last F(4x4) convolution
     int use_winograd = 2;     // 0 direct, 1 Winograd F(2x2,3x3), 2 F(4x4,3x3) where eligible (else F(2x2))
+    int wino4_split = 1;      // F(4x4) layers with exactly 32 output channels: split-K over the channel-half waves
     int wino16 = 1;           // F(2x2) layers with 16 / 32 input and output channels: conv_wino16_kernel (16x16x4 MFMA, register output stage)
     int wino_resident = 1;    // F(2x2) layers with <= 32 input and output channels: filter-resident kernel (conv_wino_res_kernel)
 
@@ -406,7 +407,7 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                         }
                     };
                     if (wino4) {
-                        p.wt = o.wt_wino4; p.coutp = out.c;
+                        p.wt = o.wt_wino4; p.coutp = out.c; p.w4_split = h->wino4_split;
                         if (crop && h->crop && o.crop_ok && n % crop->n_pos == 0) {
                             const CropLut* cl = get_crop_lut(crop, o.crop_code);
                             if (cl->len > 0 && out.h == cl->size && out.w == cl->size) {
@@ -807,6 +808,7 @@ int ecseg_set_option(ecseg_ctx* h, const char* key, int value) {
     else if (k == "fuse_head") h->fuse_head = value != 0;
     else if (k == "wino_resident") h->wino_resident = value != 0;
     else if (k == "wino16") h->wino16 = value != 0;
+    else if (k == "wino4_split") h->wino4_split = value != 0;
     else if (k == "crop") h->crop = value != 0;
     else if (k == "winograd") h->use_winograd = value < 0 ? 0 : value > 2 ? 2 : (int)value;   // 0 direct, 1 F(2x2), 2 F(4x4)
     else if (k == "post_chunk" && value >= 1) h->post_chunk = value;

@@ -42,6 +42,9 @@ struct ConvParams {
     int force_tw;
     // conv_wino (F(2x2)): 1: layers with <= 32 input and <= 32 output channels take the filter-resident kernel
     int resident;
+    // conv_wino4: 1: a layer with exactly 32 output channels splits the input channels of every 8-channel group between the
+    // two channel-half waves of a transform row instead of multiplying zero padding
+    int w4_split;
     // filter image strides in floats: [tap][chunk][half][N padded][4] with padded chunk / tap pitches (power-of-two
     // pitches put the 16 transform points of a K-chunk on the same L2 channel and set)
     long wt_chunk_stride, wt_tap_stride;

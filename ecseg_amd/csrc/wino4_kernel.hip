@@ -74,7 +74,13 @@ __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {   
 // ABL: timing-only ablations for tools/w4_ablate.py (ECSEG_W4_ABL): 1 no halo LDS reads, 2 no filter DMA, 4 no halo DMA,
 // 8 no MFMA, 32 instruction mix of a (row, column-half) wave split, 64 instruction mix of a transform shared between
 // the two channel-half waves of a row through LDS, 128 halo pieces from consecutive addresses; STAMP (ECSEG_W4_ABL=100): s_memtime stamps
-template <int ABL, bool STAMP = false, bool HEAD = false>
+// SPLIT (a lone 32-channel output block, Cout == 32): the two channel-half waves of a transform row would otherwise
+// multiply real channels (ch = 0) and zero padding (ch = 1).  Instead both work on the SAME 32 outputs and split the 8
+// input channels of a group: wave (ch, xi) runs only filter stage ch (channels 2 ch, 2 ch + 1 of both halo planes) of every
+// group, from the ch = 0 slot of the unchanged filter image; the partial sums meet in the exchange image of the output
+// stage (ch = 0 writes, ch = 1 adds).  Per group a wave has two phases (T, S) instead of three; waves 4-11 run S one
+// group late (phase rotation).
+template <int ABL, bool STAMP = false, bool HEAD = false, bool SPLIT = false>
 __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_x, int regs_y, int npairs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* Hs = reinterpret_cast<f32x4*>(smem);              // [3][W4_HS]        halo ring (group g -> buffer g % 3)
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         }
         Hd[i * 768] = d;
     }
-    auto dma_halo_piece = [&](int grp, auto ii) {            // piece ii (0 | 1) of halo group grp (< ngroups)
+    auto dma_halo_piece = [&](int grp, auto ii) __attribute__((always_inline)) {            // piece ii (0 | 1) of halo group grp (< ngroups)
         if (ABL & 4) return;
         constexpr int i = decltype(ii)::value;
         unsigned long long d = Hd[i * 768];
@@ -165,9 +171,9 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         glds16<0>(src, lds_base + (unsigned)((grp % 3) * W4_HS + 64 * (wave + 12 * i)) * 16u);
     };
     // ---- filter DMA: wt4[nb][stage][wave][point nu][h][cout 32][k 2], 768 floats per wave and stage ----
-    const float* w_src = p.wt + ((size_t)nb * nstages * 12 + wave) * 768 + lane * 4;
+    const float* w_src = p.wt + ((size_t)nb * nstages * 12 + (SPLIT ? xi : wave)) * 768 + lane * 4;
     f32x4* Bw = Bs + wave * 2 * W4_BWS;
-    auto dma_filter_piece = [&](int stage, int buf, auto kk) {
+    auto dma_filter_piece = [&](int stage, int buf, auto kk) __attribute__((always_inline)) {
         if (ABL & 2) return;
         constexpr int k = decltype(kk)::value;
         const float* g = w_src + (size_t)stage * (12 * 768);
@@ -201,11 +207,16 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         for (int e = 0; e < 16; ++e) acc[v][e] = 0.f;
 
     f32x4 t[6];
+    if (SPLIT) {                                             // (components 2, 3 are never written in this mode: keep the vectors defined)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) t[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     // ---- row transform of group grp: t[j] for the six halo columns of the lane's tile, 4 channels each ----
     // Rows 1-4 of B^T end in +1 (t = c0 d[r0] + c1 d[r1] + c2 d[r2] + d[r3]: three fmas), rows 0 and 5 have only three
     // terms, the last with +1 (t = c0 d[r0] + c1 d[r1] + d[r2]: three reads, two fmas).
     const bool inner_row = xi >= 1 && xi <= 4;
-    auto transform = [&](int grp) {
+    auto transform = [&](int grp, auto c_src, auto c_num) __attribute__((always_inline)) {   // t[j][k] = row transform of channel c_src + k of the lane's slot, k < c_num (SPLIT: the wave's two channels, in components 0 and 1)
+        constexpr int CS = decltype(c_src)::value, CN = decltype(c_num)::value;
         const f32x4* A = Hs + (grp % 3) * W4_HS + a_lane;
         constexpr int cp[6] = {w4_cpos(0), w4_cpos(1), w4_cpos(2), w4_cpos(3), w4_cpos(4), w4_cpos(5)};
         if (ABL & 1) {
@@ -239,8 +250,8 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
                 if ((ABL & 32) && j == 5) { t[5] = t[4]; continue; }      // timing model of a (row, column-half) wave split
                 const f32x4 d0 = A[ro0 + cp[j]], d1 = A[ro1 + cp[j]], d2 = A[ro2 + cp[j]], d3 = A[ro3 + cp[j]];
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    t[j][c] = __builtin_fmaf(c0, d0[c], __builtin_fmaf(c1, d1[c], __builtin_fmaf(c2, d2[c], d3[c])));
+                for (int c = 0; c < CN; ++c)
+                    t[j][c] = __builtin_fmaf(c0, d0[CS + c], __builtin_fmaf(c1, d1[CS + c], __builtin_fmaf(c2, d2[CS + c], d3[CS + c])));
                 asm volatile("" : "+v"(t[j]));               // finish this column here: 16 transient registers, not 96
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -250,14 +261,14 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
                 if ((ABL & 32) && j == 5) { t[5] = t[4]; continue; }
                 const f32x4 d0 = A[ro0 + cp[j]], d1 = A[ro1 + cp[j]], d2 = A[ro2 + cp[j]];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) t[j][c] = __builtin_fmaf(c0, d0[c], __builtin_fmaf(c1, d1[c], d2[c]));
+                for (int c = 0; c < CN; ++c) t[j][c] = __builtin_fmaf(c0, d0[CS + c], __builtin_fmaf(c1, d1[CS + c], d2[CS + c]));
                 asm volatile("" : "+v"(t[j]));
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
     // ---- one filter stage (2 of the group's 4 channel pairs; buffer ss): column transform + 12 MFMAs ----
-    auto mfma_stage = [&](int ss, int next_stage, int halo_grp) {     // halo_grp: group to prefetch (stage 0), < 0: none
+    auto mfma_stage = [&](int ss, int fbuf, int next_stage, int halo_grp) __attribute__((always_inline)) {     // ss: channel pair of the group, fbuf: filter buffer; halo_grp: group to prefetch, < 0: none
         float V[6][2];
         if ((ABL & 64) && ss == 1) {
             // stage 1 of the shared-transform model: the 12 values come from the partner through LDS
@@ -289,7 +300,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             const f32x4 x0 = X[0], x1 = X[64], x2 = X[128];
             asm volatile("" :: "v"(x0), "v"(x1), "v"(x2));
         }
-        const f32x2* Bp = reinterpret_cast<const f32x2*>(Bw + ss * W4_BWS) + lane;
+        const f32x2* Bp = reinterpret_cast<const f32x2*>(Bw + fbuf * W4_BWS) + lane;
         f32x2 w2[6];
 #pragma unroll
         for (int v = 0; v < 6; ++v) w2[v] = Bp[v * 64];
@@ -304,9 +315,9 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
                 else acc[v] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[v][e], w2[v][e], acc[v], 0, 0, 0);
                 if (e == 0 && (v == 1 || v == 3 || v == 5)) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (v == 1) dma_filter_piece(next_stage, ss ^ 1, std::integral_constant<int, 0>{});
-                    if (v == 3) dma_filter_piece(next_stage, ss ^ 1, std::integral_constant<int, 1>{});
-                    if (v == 5) dma_filter_piece(next_stage, ss ^ 1, std::integral_constant<int, 2>{});
+                    if (v == 1) dma_filter_piece(next_stage, fbuf ^ 1, std::integral_constant<int, 0>{});
+                    if (v == 3) dma_filter_piece(next_stage, fbuf ^ 1, std::integral_constant<int, 1>{});
+                    if (v == 5) dma_filter_piece(next_stage, fbuf ^ 1, std::integral_constant<int, 2>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (e == 1 && (v == 1 || v == 3) && halo_grp >= 0) {       // behind MFMAs 8 and 10
@@ -333,12 +344,21 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
 #define W4_SB() __builtin_amdgcn_sched_barrier(0)
 // T(g): raised priority for the few long-latency instructions of the transform; afterwards the MFMA phases run at a
 // priority that orders the three waves of a SIMD (class 2 first): the wave that is latest in the rotation gets the pipe
-#define W4_T(g, PR) do { __builtin_amdgcn_s_setprio(3); transform(g); __builtin_amdgcn_s_setprio(W4_VARIANT == 12 ? (PR) + 1 : (PR)); } while (0)
+#define W4_T(g, PR) do { __builtin_amdgcn_s_setprio(3); transform(g, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}); __builtin_amdgcn_s_setprio(W4_VARIANT == 12 ? (PR) + 1 : (PR)); } while (0)
     // S0(g): filter stage 2g has landed (it is the youngest thing this wave issued) -> vmcnt(0); streams stage 2g+1 and
     // the halo of group g+2.  S1(g): only the two halo pieces issued after stage 2g+1 may still fly -> vmcnt(2).
-#define W4_S0(g) do { W4_SB(); W4_WAIT(0); W4_SB(); mfma_stage(0, 2 * (g) + 1, (g) + 2 < ngroups ? (g) + 2 : -1); } while (0)
+#define W4_S0(g) do { W4_SB(); W4_WAIT(0); W4_SB(); mfma_stage(0, 0, 2 * (g) + 1, (g) + 2 < ngroups ? (g) + 2 : -1); } while (0)
 #define W4_S1(g) do { W4_SB(); if ((g) + 2 < ngroups) W4_WAIT(2); else W4_WAIT(0); W4_SB(); \
-                      mfma_stage(1, (g) + 1 < ngroups ? 2 * (g) + 2 : 2 * (g), -1); } while (0)
+                      mfma_stage(1, 1, (g) + 1 < ngroups ? 2 * (g) + 2 : 2 * (g), -1); } while (0)
+// SPLIT: T(g) as above (all four channels of the slot: a two-channel transform made the register allocator spill ~100
+// registers; the wave uses channels 2 ch, 2 ch + 1); S(g) = its one filter stage of group g (stage 2 g + ch of the image, private
+// buffer g & 1): everything this wave issued has landed (vmcnt(0): the filter of this group and its halo pieces of group
+// g + 1); streams the filter of group g + 1 and the halo of group g + 2
+#define W4_TS(g, PR) do { __builtin_amdgcn_s_setprio(3); \
+                          transform(g, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}); \
+                          __builtin_amdgcn_s_setprio(PR); } while (0)
+#define W4_SS(g) do { W4_SB(); W4_WAIT(0); W4_SB(); \
+                      mfma_stage(CH, (g) & 1, ((g) + 1 < ngroups ? 2 * (g) + 2 : 2 * (g)) + CH, (g) + 2 < ngroups ? (g) + 2 : -1); } while (0)
     const int cls = wave >> 2;
     dma_halo_piece(0, std::integral_constant<int, 0>{});
     dma_halo_piece(0, std::integral_constant<int, 1>{});
@@ -346,11 +366,36 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         dma_halo_piece(1, std::integral_constant<int, 0>{});
         dma_halo_piece(1, std::integral_constant<int, 1>{});
     }
-    dma_filter_piece(0, 0, std::integral_constant<int, 0>{});
-    dma_filter_piece(0, 0, std::integral_constant<int, 1>{});
-    dma_filter_piece(0, 0, std::integral_constant<int, 2>{});
+    dma_filter_piece(SPLIT ? ch : 0, 0, std::integral_constant<int, 0>{});
+    dma_filter_piece(SPLIT ? ch : 0, 0, std::integral_constant<int, 1>{});
+    dma_filter_piece(SPLIT ? ch : 0, 0, std::integral_constant<int, 2>{});
     if (ngroups > 1) W4_WAIT(5); else W4_WAIT(3);            // halo group 0 has landed (group 1: before barrier 1, below)
-    if (cls == 0) {
+    if (SPLIT) {
+        // two phases per group.  Waves 0-3 run T(g) S(g) after barrier g; waves 4-11 run S(g - 1) T(g): while one class
+        // transforms, the other feeds the matrix pipe.  The late waves' halo pieces of group g + 1 go out in period g (inside
+        // S(g - 1)) and are waited for before barrier g + 1.
+        auto kloop = [&](auto chc) __attribute__((always_inline)) {      // (one copy of the loop per channel half: no branch inside)
+            constexpr int CH = decltype(chc)::value;
+            if (cls == 0) {
+                for (int grp = 0; grp < ngroups; ++grp) {
+                    W4_BARRIER();
+                    W4_TS(grp, 0);
+                    W4_SS(grp);
+                }
+            } else {
+                W4_BARRIER();
+                W4_TS(0, 1);
+                for (int grp = 1; grp < ngroups; ++grp) {
+                    W4_WAIT(0);
+                    W4_BARRIER();
+                    W4_SS(grp - 1);
+                    W4_TS(grp, 1);
+                }
+                W4_SS(ngroups - 1);
+            }
+        };
+        if (ch == 0) kloop(std::integral_constant<int, 0>{}); else kloop(std::integral_constant<int, 1>{});
+    } else if (cls == 0) {
         for (int grp = 0; grp < ngroups; ++grp) {
             WSTAMP(0);
             W4_BARRIER();
@@ -399,6 +444,8 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
 #undef W4_T
 #undef W4_S0
 #undef W4_S1
+#undef W4_TS
+#undef W4_SS
 #undef W4_SB
     if (STAMP && blockIdx.x == gridDim.x / 2 && lane == 0) {
         float* dbg = const_cast<float*>(p.zero) + 16 + wave * 10;
@@ -434,21 +481,32 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         bvp[0] = *reinterpret_cast<const f32x4*>(p.bias + nb * 64 + 4 * (tid & 7));
         if (nb * 64 + 32 < Cout) bvp[1] = *reinterpret_cast<const f32x4*>(p.bias + nb * 64 + 32 + 4 * (tid & 7));
     }
-    for (int pass = 0; pass < 2; ++pass) {
+    // fold the wave's own row (R = M[xi][:] A) into the exchange image; `add` (SPLIT, ch = 1): onto the partner's partial sums
+    auto write_R = [&](auto add_c) __attribute__((always_inline)) {
+        constexpr bool add = decltype(add_c)::value;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int tl = (e & 3) + 8 * (e >> 2) + 4 * lh;               // accumulator row = tile slot
+            const float m0 = acc[0][e], m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e], m5 = acc[5][e];
+            const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+            float* o = Rs + (xi * 4) * W4_RPLANE + tl * 32 + li;
+            const float r0 = m0 + s12 + s34, r1 = d12 + 2.f * d34, r2 = s12 + 4.f * s34, r3 = d12 + 8.f * d34 + m5;
+            if (add) {                                           // (this lane's four words: nobody else touches them in this phase)
+                o[0 * W4_RPLANE] += r0; o[1 * W4_RPLANE] += r1; o[2 * W4_RPLANE] += r2; o[3 * W4_RPLANE] += r3;
+            } else {
+                o[0 * W4_RPLANE] = r0; o[1 * W4_RPLANE] = r1; o[2 * W4_RPLANE] = r2; o[3 * W4_RPLANE] = r3;
+            }
+        }
+    };
+    for (int pass = 0; pass < (SPLIT ? 1 : 2); ++pass) {
         __syncthreads();                                     // main-loop LDS reads / previous pass's combine are done
         ESTAMP(0);                                           // [0] barrier (K-loop skew / previous combine)
-        if (ch == pass) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int tl = (e & 3) + 8 * (e >> 2) + 4 * lh;           // accumulator row = tile slot
-                const float m0 = acc[0][e], m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e], m5 = acc[5][e];
-                const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-                float* o = Rs + (xi * 4) * W4_RPLANE + tl * 32 + li;
-                o[0 * W4_RPLANE] = m0 + s12 + s34;
-                o[1 * W4_RPLANE] = d12 + 2.f * d34;
-                o[2 * W4_RPLANE] = s12 + 4.f * s34;
-                o[3 * W4_RPLANE] = d12 + 8.f * d34 + m5;
-            }
+        if (SPLIT) {
+            if (ch == 0) write_R(std::false_type{});
+            __syncthreads();
+            if (ch == 1) write_R(std::true_type{});
+        } else if (ch == pass) {
+            write_R(std::false_type{});
         }
         ESTAMP(1);                                           // [1] fold own row + write R to LDS
         __syncthreads();
@@ -589,6 +647,7 @@ hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s) {
     if (lds_epi > lds) lds = lds_epi;
     void (*kern)(ConvParams, int, int, int) = conv_wino4_kernel<0>;
     if (p.head_w != nullptr) kern = conv_wino4_kernel<0, false, true>;
+    else if (p.out.c == 32 && p.w4_split) kern = conv_wino4_kernel<0, false, false, true>;   // a lone 32-channel block: split K
 #ifdef ECSEG_DIAG
     // timing-only ablations / in-kernel cycle stamps: diagnostic builds only (tools/build_variants.sh -DECSEG_DIAG);
     // the shipped library has none of these kernels
@@ -608,8 +667,8 @@ hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s) {
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 #endif
-    static DeviceOnce attr_set[2];                          // the attribute is per device
-    const int which = p.head_w != nullptr ? 1 : 0;
+    static DeviceOnce attr_set[3];                          // the attribute is per device
+    const int which = p.head_w != nullptr ? 1 : (p.out.c == 32 && p.w4_split) ? 2 : 0;
     if (attr_set[which].first()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { attr_set[which].reset(); return e; }

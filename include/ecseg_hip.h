@@ -124,7 +124,9 @@ int ecseg_set_images_per_group(ecseg_ctx* h, int n);
  * F(2x2,3x3) layers with 16 or 32 input and output channels and extents >= 16 x 32 take conv_wino16_kernel - 16x16x4 MFMAs,
  * register output stage; 0: the 32-wide F(2x2) kernels), "wino_resident" (1 (default): the remaining F(2x2) layers with <= 32
  * input and <= 32 output channels keep their filter in registers and walk a tile row; 0: the streaming F(2x2) kernel - the
- * results of the two are identical), "fuse_pool" (1
+ * results of the two are identical), "wino4_split" (1 (default): an F(4x4) layer with exactly 32 output channels splits the 8 input
+ * channels of a group between the two channel-half waves of a transform row; 0: the upper waves multiply the zero padding
+ * of the 64-channel block), "fuse_pool" (1
  * (default): a MaxPooling2D(2x2, stride 2) that directly follows a Winograd (F(4x4) or F(2x2)) convolution is written by that
  * convolution's output stage; 0: separate max-pool kernel), "fuse_head" (1 (default): a 1x1 convolution with <= 4 output channels that
  * is the only reader of a 64-channel F(4x4) convolution (or of a 16 / 32-channel conv_wino16_kernel convolution) is computed by

@@ -315,3 +315,35 @@ def test_winograd_wino16_kernel(gpu, cin, cout, hw, n):
     sel = np.r_[0:k // 2, n - (k - k // 2):n]
     want = oracle_unet.forward(cfg, weights, x[sel])
     assert np.abs(w16[sel] - want).max() < 2e-4 * scale, np.abs(w16[sel] - want).max()
+
+
+@pytest.mark.parametrize('cin,hw,n', [(64, (32, 32), 3), (72, (16, 48), 5), (128, (48, 16), 2), (68, (16, 16), 1)])
+def test_winograd_f4x4_split_k_for_32_output_channels(gpu, cin, hw, n):
+    """A layer with exactly 32 output channels under F(4x4): the two channel-half waves of a transform row split the 8 input
+    channels of a group (option wino4_split) instead of multiplying the zero-padded upper half of a 64-channel block; both
+    modes against each other and the oracle (odd number of 16x16 regions, Cin % 8 == 4 tail, one K group more or less)."""
+    rng = np.random.default_rng(cin * 5 + 1)
+    H, W = hw
+    cout = 32
+    cfg = {'class_name': 'Functional', 'config': {'name': 'm', 'layers': [
+        {'class_name': 'InputLayer', 'name': 'in', 'config': {'name': 'in', 'batch_input_shape': [None, H, W, cin]},
+         'inbound_nodes': []},
+        {'class_name': 'Conv2D', 'name': 'c', 'config': {'name': 'c', 'filters': cout, 'kernel_size': [3, 3],
+                                                         'strides': [1, 1], 'padding': 'same', 'activation': 'relu',
+                                                         'use_bias': True}, 'inbound_nodes': [[['in', 0, 0, {}]]]}],
+        'input_layers': [['in', 0, 0]], 'output_layers': [['c', 0, 0]]}}
+    weights = {'c': [(rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin) / 64).astype(np.float32),
+                     rng.normal(size=cout).astype(np.float32)]}
+    x = rng.integers(0, 256, size=(n, H, W, cin), dtype=np.uint8)
+    want = oracle_unet.forward(cfg, weights, x)
+    try:
+        gpu.set_option('winograd', 2)
+        gpu.set_option('wino4_split', 1)
+        split, _ = _run(gpu, cfg, weights, x, fuse=True)
+        gpu.set_option('wino4_split', 0)
+        padded = gpu.forward_patches(x)
+    finally:
+        gpu.set_option('wino4_split', 1)
+    scale = max(1.0, float(np.abs(want).max()))
+    assert np.abs(split - padded).max() < 1e-4 * scale, float(np.abs(split - padded).max())
+    assert np.abs(split - want).max() < 5e-4 * scale, np.abs(split - want).max()

@@ -422,6 +422,14 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                     } else if (wino && h->wino16 && o.wt_wino16 && conv_wino16_supported(p)) {
                         w16 = true;
                         p.wt = o.wt_wino16;
+                        if (crop && h->crop && o.crop_ok && n % crop->n_pos == 0) {
+                            // cropped launch: only the 16 x 32 blocks some later stage reads
+                            const CropLut* cl = get_crop_lut(crop, o.crop_code, 16, 32);
+                            if (cl->len > 0 && out.h == cl->size && out.w == cl->size) {
+                                p.lut = cl->dev; p.lut_len = cl->len; p.per_image = crop->n_pos;
+                                computed = (double)cl->len / ((double)crop->n_pos * (out.h / 16) * (out.w / 32));
+                            }
+                        }
                         fuse_following_pool();
                         fuse_following_head(out.c);
                         e = launch_conv_wino16(p, s);

@@ -67,17 +67,34 @@ __global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(C
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int seg = bid % segs_x; bid /= segs_x;
-    const int by = bid % strips_y; bid /= strips_y;
-    const int img = bid;
-    const int bx0 = seg * bpw;
-    const int nblk = min(bpw, blocks_x - bx0);
-    const int oy0 = by * 16;
     const int H = p.in.h, W = p.in.w;                        // output extent == input extent
+    // The blocks (16 x 32 output pixels) of this workgroup: `bpw` consecutive blocks of a 16-row strip - or, in a cropped
+    // launch (p.lut: the regions some later stage reads, origins in 4-pixel units, the same list for every image), `bpw`
+    // consecutive entries of the region list
+    const bool use_lut = p.lut != nullptr;
+    int w_img = 0, w_y0 = 0, w_bx0 = 0, w_first = 0, nblk;
+    if (use_lut) {
+        w_first = (int)bid * bpw;
+        nblk = min(bpw, blocks_x - w_first);                 // (blocks_x = entries in all)
+    } else {
+        const int seg = bid % segs_x; bid /= segs_x;
+        w_y0 = (int)(bid % strips_y) * 16; bid /= strips_y;
+        w_img = (int)bid;
+        w_bx0 = seg * bpw;
+        nblk = min(bpw, blocks_x - w_bx0);
+    }
+    auto block_origin = [&](int blk, int& img, int& y0, int& x0) __attribute__((always_inline)) {      // all wave-uniform
+        if (use_lut) {
+            const int e = w_first + blk, i = e / p.lut_len, v = p.lut[e - i * p.lut_len];
+            img = i * p.per_image + (v >> 16); y0 = ((v >> 8) & 255) * 4; x0 = (v & 255) * 4;
+        } else {
+            img = w_img; y0 = w_y0; x0 = (w_bx0 + blk) * 32;
+        }
+    };
 
     // ---- DMA descriptors of this thread: slot q = (wave + 8 k) * 64 + lane of a halo buffer ----
-    long d_off[W16_NP];                                      // float offset of the piece for block 0, chunk 0 of the walk
-    int d_meta[W16_NP];                                      // halo column (0..33) | 0x100: padding slot / row outside the image
+    int d_rel[W16_NP];                                       // float offset of the piece relative to halo pixel (0, 0), channel 0 of the chunk
+    int d_meta[W16_NP];                                      // halo column (0..33) | halo row << 8 | 0x10000: padding slot
 #pragma unroll
     for (int k = 0; k < W16_NP; ++k) {
         const int q = (wave + 8 * k) * 64 + lane;
@@ -88,19 +105,21 @@ __global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(C
         else if (r >= 74 && r < 108) { cq = 2; rr = r - 74; }
         else if (r >= 114 && r < 148) { cq = 3; rr = r - 114; }
         const int par = rr >= 17 ? 1 : 0, x = 2 * (rr - 17 * par) + par;
-        const int iy = oy0 - 1 + y;
-        const bool ok = cq >= 0 && y < W16_ROWS && iy >= 0 && iy < H;
-        d_meta[k] = x | (ok ? 0 : 0x100);
-        d_off[k] = (((long)img * H + iy) * W + (long)(bx0 * 32 - 1 + x)) * p.in.cs + (cq < 0 ? 0 : cq) * 4;
+        const bool ok = cq >= 0 && y < W16_ROWS;
+        d_meta[k] = x | (y << 8) | (ok ? 0 : 0x10000);
+        d_rel[k] = (y * W + x) * p.in.cs + (cq < 0 ? 0 : cq) * 4;
     }
-    auto dma_halo = [&](int blk, int kc, int buf) {
+    auto dma_halo = [&](int blk, int kc, int buf) __attribute__((always_inline)) {
+        int img, y0, x0;
+        block_origin(blk, img, y0, x0);
+        const float* base = p.in.p + (((long)img * H + (y0 - 1)) * W + (x0 - 1)) * p.in.cs + kc * 16;      // halo pixel (0, 0); only dereferenced inside the image
 #pragma unroll
         for (int k = 0; k < W16_NP; ++k) {
             const int piece = wave + 8 * k;                  // wave-uniform
             if (piece < W16_PIECES) {
-                const int ix = (bx0 + blk) * 32 - 1 + (d_meta[k] & 0xff);
+                const int ix = x0 - 1 + (d_meta[k] & 0xff), iy = y0 - 1 + ((d_meta[k] >> 8) & 0xff);
                 const float* src = p.zero;
-                if (!(d_meta[k] & 0x100) && ix >= 0 && ix < W) src = p.in.p + d_off[k] + (long)blk * 32 * p.in.cs + kc * 16;
+                if (!(d_meta[k] & 0x10000) && ix >= 0 && ix < W && iy >= 0 && iy < H) src = base + d_rel[k];
                 w16_dma16(src, lds_base + (unsigned)(buf * W16_HS + piece * 64) * 16u);
             }
         }
@@ -215,7 +234,9 @@ __global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(C
             W16_STAMP(3);                                    // [3] wait for the DMA
             if (kc == KC - 1) {
                 // ---- output: Y = A^T M A + bias, activation, 16-byte stores (lane = 4 output channels of one tile) ----
-                const int oy = oy0 + 2 * TR, ox = (bx0 + blk) * 32 + 2 * TC;
+                int img, by0, bx0;
+                block_origin(blk, img, by0, bx0);
+                const int oy = by0 + 2 * TR, ox = bx0 + 2 * TC;
                 f32x4 hl[2][2];                                  // HEAD: partial logits [row][column] of the tile's pixels
 #pragma unroll
                 for (int yy = 0; yy < 2; ++yy)
@@ -334,11 +355,21 @@ bool conv_wino16_supported(const ConvParams& p) {
 
 template <int KC, int NB, int NBUF, bool HEAD>
 static hipError_t launch_conv_wino16_tt(const ConvParams& p, hipStream_t s) {
-    const int blocks_x = (p.out.w + 31) / 32, strips_y = (p.out.h + 15) / 16;
+    int blocks_x = (p.out.w + 31) / 32, strips_y = (p.out.h + 15) / 16;
     int bpw = 8;                                             // blocks per workgroup walk: the filter load is amortised over them
-    while (bpw > 1 && (size_t)p.n * strips_y * ((blocks_x + bpw - 1) / bpw) < 1024) bpw >>= 1;
-    const int segs_x = (blocks_x + bpw - 1) / bpw;
-    const size_t grid = (size_t)p.n * strips_y * segs_x;
+    int segs_x;
+    size_t grid;
+    if (p.lut != nullptr) {                                  // cropped launch: blocks_x = entries of the region list over all images
+        const size_t total = (size_t)(p.n / p.per_image) * p.lut_len;
+        if (total > 0x7fffffffull) return hipErrorInvalidValue;
+        while (bpw > 1 && (total + bpw - 1) / bpw < 1024) bpw >>= 1;
+        blocks_x = (int)total; segs_x = 1;
+        grid = (total + bpw - 1) / bpw;
+    } else {
+        while (bpw > 1 && (size_t)p.n * strips_y * ((blocks_x + bpw - 1) / bpw) < 1024) bpw >>= 1;
+        segs_x = (blocks_x + bpw - 1) / bpw;
+        grid = (size_t)p.n * strips_y * segs_x;
+    }
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     const size_t lds = ((size_t)NBUF * W16_HS + (size_t)16 * KC * NB * 64 + (HEAD ? 16 * NB : 0)) * 16;

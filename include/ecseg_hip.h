@@ -131,8 +131,9 @@ int ecseg_set_images_per_group(ecseg_ctx* h, int n);
  * convolution's output stage; 0: separate max-pool kernel), "fuse_head" (1 (default): a 1x1 convolution with <= 4 output channels that
  * is the only reader of a 64-channel F(4x4) convolution (or of a 16 / 32-channel conv_wino16_kernel convolution) is computed by
  * that convolution's output stage and the feature tensor is never written; 0: separate head kernel), "crop" (1 (default): in ecseg_segment_images the last
- * full-resolution F(4x4) convolutions compute only the 16x16 regions of every window that the stitch (or the halo of the
- * convolutions behind them) reads - 72 % of them at 1040x1392; results are unchanged; 0: whole windows), "post_graph" (1: the
+ * full-resolution convolutions (F(4x4): 16x16 regions; conv_wino16_kernel: 16x32 blocks; 2x2 up-convolutions: input tiles)
+ * compute only the parts of every window that the stitch (or the halo of the convolutions behind them) reads - 72 % of them
+ * at 1040x1392; results are unchanged; 0: whole windows), "post_graph" (1: the
  * ~60 short kernels of meta_inference + count are captured once per (buffers, geometry) into a HIP graph and replayed;
  * 0 (default): plain launches - measured equal, the asynchronous launch queue already hides the launch gaps). */
 int ecseg_set_option(ecseg_ctx* h, const char* key, int value);

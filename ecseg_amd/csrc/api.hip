@@ -75,7 +75,7 @@ struct ecseg_ctx {
     double flops_per_patch = 0.0, mfma_flops_per_patch = 0.0;
 
     // image pipeline
-    int images_per_group = 16;   // 560 windows per U-Net launch: ~46 GB of activations for the base-64 U-Net
+    int images_per_group = 0;    // images (of 35 windows) per U-Net launch; 0 = automatic: ~48 GB of activations (windows_per_group)
     std::map<std::pair<int, int>, StitchPlan> stitch;
     uint8_t* d_gray = nullptr; size_t d_gray_cap = 0;
     uint8_t* d_raw = nullptr; size_t d_raw_cap = 0;
@@ -276,6 +276,21 @@ int ensure_patches(ecseg_ctx* h, int n) {
     }
     h->cap_patches = n;
     return ECSEG_OK;
+}
+
+// Windows per U-Net launch group.  An explicit images_per_group counts 35-window images (1040 x 1392).  Automatic: as many
+// windows as fit ~48 GB of activations, between 16 and 64 such images - 16 for the canonical base-64 U-Net (82 MB per
+// window), 32 for base 32, 64 for base 16, whose short kernels gain 5-6 % from the longer launches (base-16 bench model:
+// 799 / 836 / 851 images/s at 16 / 32 / 64 images per group).
+int windows_per_group(const ecseg_ctx* h) {
+    if (h->images_per_group > 0) return h->images_per_group * 35;
+    size_t per_window = 0;
+    for (size_t f : h->buf_floats) per_window += std::max<size_t>(f, 4) * sizeof(float);
+    const size_t budget = (size_t)48 << 30;
+    size_t img = per_window ? budget / (per_window * 35) : 16;
+    int g = 16;
+    while (g < 64 && (size_t)(2 * g) <= img) g *= 2;
+    return g * 35;
 }
 
 hipEvent_t* prof_pair(ecseg_ctx* h) {
@@ -682,7 +697,8 @@ int segment_dev(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint
     hipStream_t s = h->stream, s2 = h->overlap_post ? h->stream2 : h->stream;
     // images per U-Net launch: images_per_group is calibrated for 35-window images (1040 x 1392); larger images have more
     // windows each, so the group shrinks to keep the activation memory (~82 MB per window for a base-64 U-Net) bounded
-    const int grp = std::max(1, std::min(h->images_per_group, std::max(1, h->images_per_group * 35 / sp->n_pos)));
+    const int wpg = windows_per_group(h);
+    const int grp = std::max(1, std::min(wpg / 35, std::max(1, wpg / sp->n_pos)));
     if ((rc = ensure_patches(h, std::min(grp, n_img) * sp->n_pos))) return rc;
     if ((rc = ensure_post(h, std::min(n_img, grp), px))) return rc;
     for (float& v : h->stage_ms) v = 0.f;
@@ -1031,7 +1047,7 @@ static int forward_host(ecseg_ctx* h, const void* patches, bool is_f32, int n, f
     const ecseg_tensor_desc& to = h->tensors[h->output_tensor];
     if (ti.c_stride != ti.c || ti.c_offset != 0) return fail(h, ECSEG_E_INVALID, "input tensor must be compact");
     const size_t in_per = (size_t)ti.h * ti.w * ti.c, out_per = (size_t)to.h * to.w * to.c;
-    const int chunk = std::max(1, h->images_per_group * 35);
+    const int chunk = std::max(1, windows_per_group(h));
     if ((rc = ensure_patches(h, std::min(n, chunk)))) return rc;
     if (!is_f32 && (rc = ensure(h, h->d_u8in, h->d_u8in_cap, in_per * std::min(n, chunk)))) return rc;
     hipStream_t s = h->stream;

@@ -114,7 +114,8 @@ int ecseg_segment_images(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, in
                          uint8_t* labels_raw, uint8_t* labels_post, int32_t* n_ec);
 int ecseg_segment_images_dev(ecseg_ctx* h, const uint8_t* gray_dev, int n_img, int H, int W,
                              uint8_t* labels_raw_dev, uint8_t* labels_post_dev, int32_t* n_ec_dev);
-/* Upper bound on images per internal U-Net launch group (default 16). */
+/* Upper bound on images (of 35 windows) per internal U-Net launch group.  Default: automatic - as many as fit ~48 GB of
+ * activations, between 16 and 64 (16 for the canonical base-64 U-Net, 32 for base 32, 64 for base 16). */
 int ecseg_set_images_per_group(ecseg_ctx* h, int n);
 /* Tuning knobs: "overlap_post" (1: clean-up + count of group g run on a second stream beside the U-Net of group g+1;
  * 0 (default): everything on one stream - measured equal, the MFMA convs already fill the chip), "post_chunk"

@@ -1,3 +1,6 @@
+#!/bin/bash
+# rocprofv3 kernel statistics of tools/post_bench.py, one run per input kind (--only speckle / synth): which kernels of
+# meta_inference + count take the time on speckled vs realistic label maps -> gpurun_out/pp_<kind>/
 R=$PWD
 for k in speckle synth; do
 mkdir -p $R/gpurun_out/pp_$k

@@ -1,3 +1,5 @@
+"""F(4x4) layers with exactly 32 output channels: the zero-padded 64-channel block (option wino4_split=0) against the split-K
+mode (1), for several K lengths and extents.  python tools/w4_split_probe.py (GPU box)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.getcwd())

@@ -63,13 +63,15 @@ def main():
         res['kernels'][name] = e
         for k in ('SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_INSTS_MFMA', 'GRBM_GUI_ACTIVE', '_ns'):
             tot[k] += c.get(k, 0.0)
+        # FLOP per wave-level MFMA instruction: v_mfma_f32_32x32x2_f32 4096, v_mfma_f32_16x16x4_f32 (conv_wino16_kernel) 2048
+        tot['_flop'] += c.get('SQ_INSTS_MFMA', 0.0) * (2048.0 if 'conv_wino16_kernel' in name else 4096.0)
     if tot['_ns']:
         cyc = tot['GRBM_GUI_ACTIVE'] / 8.0 * N_SIMD
         res['all_mfma_conv_kernels'] = {'total_ms_under_profiler': round(tot['_ns'] / 1e6, 3),
                                         'effective_clock_GHz': round(tot['GRBM_GUI_ACTIVE'] / 8.0 / tot['_ns'], 3),
                                         'mfma_busy_frac_of_simd_cycles': round(tot['SQ_VALU_MFMA_BUSY_CYCLES'] / cyc, 4),
-                                        'executed_tflops_from_SQ_INSTS_MFMA': round(tot['SQ_INSTS_MFMA'] * 64 * 2 * 32 * 32 * 2 / 64 / tot['_ns'] / 1e3, 2),
-                                        'note': 'executed TFLOP/s = SQ_INSTS_MFMA (wave-level v_mfma_f32_32x32x2_f32) x 4096 FLOP / time; '
+                                        'executed_tflops_from_SQ_INSTS_MFMA': round(tot['_flop'] / tot['_ns'] / 1e3, 2),
+                                        'note': 'executed TFLOP/s = SQ_INSTS_MFMA x FLOP per instruction (v_mfma_f32_32x32x2_f32 4096, conv_wino16_kernel\'s v_mfma_f32_16x16x4_f32 2048) / time; '
                                                 'mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)'}
     for k in res['kernels'].values():
         pass

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(C
                     const int py = oy + (kq >> 1), px = ox + (kq & 1);
                     if (py < H && px < W) {
                         float* ho = p.head_out.p + (((size_t)img * H + py) * W + px) * p.head_out.cs;
-                        if (p.head_k == 4 && (p.head_out.cs & 3) == 0) *reinterpret_cast<f32x4*>(ho) = f32x4{l[0], l[1], l[2], l[3]};
+                        if (p.head_k == 4 && (p.head_out.cs & 3) == 0 && (reinterpret_cast<size_t>(p.head_out.p) & 15) == 0) *reinterpret_cast<f32x4*>(ho) = f32x4{l[0], l[1], l[2], l[3]};
                         else {
 #pragma unroll
                             for (int c = 0; c < 4; ++c) if (c < p.head_k) ho[c] = l[c];

@@ -69,6 +69,19 @@ __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {   
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst), "n"(OFF) : "memory");
 }
 
+// (experiment builds: W4_VARIANT 50 = halo pieces with the nt cache policy, 51 = filter pieces nt, 52 = halo pieces sc1)
+template <int OFF>
+__device__ __forceinline__ void glds16_pol(const float* gsrc, unsigned lds_dst) {
+    unsigned keep;
+#if W4_VARIANT == 52
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%3 sc1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst), "n"(OFF) : "memory");
+#else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%3 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst), "n"(OFF) : "memory");
+#endif
+}
+
 }  // namespace
 
 // ABL: timing-only ablations for tools/w4_ablate.py (ECSEG_W4_ABL): 1 no halo LDS reads, 2 no filter DMA, 4 no halo DMA,
@@ -168,7 +181,11 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         // Cin % 8 == 4: the upper channel half of the last group does not exist - its lanes (bit 1) read the zero page
         if (tail4 && grp == ngroups - 1 && (d & 2ull)) d = (unsigned long long)(size_t)p.zero;
         const float* src = reinterpret_cast<const float*>((size_t)(d & ~3ull)) + (d & 1ull ? ((ABL & 128) ? grp * 6144 : grp * 8) : 0);
+#if W4_VARIANT == 50 || W4_VARIANT == 52
+        glds16_pol<0>(src, lds_base + (unsigned)((grp % 3) * W4_HS + 64 * (wave + 12 * i)) * 16u);
+#else
         glds16<0>(src, lds_base + (unsigned)((grp % 3) * W4_HS + 64 * (wave + 12 * i)) * 16u);
+#endif
     };
     // ---- filter DMA: wt4[nb][stage][wave][point nu][h][cout 32][k 2], 768 floats per wave and stage ----
     const float* w_src = p.wt + ((size_t)nb * nstages * 12 + (SPLIT ? xi : wave)) * 768 + lane * 4;
@@ -178,7 +195,11 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         constexpr int k = decltype(kk)::value;
         const float* g = w_src + (size_t)stage * (12 * 768);
         // the instruction offset advances the global AND the LDS address: one M0 for the three pieces
+#if W4_VARIANT == 51
+        glds16_pol<k * 1024>(g, lds_base + (unsigned)(3 * W4_HS + (wave * 2 + buf) * W4_BWS) * 16u);
+#else
         glds16<k * 1024>(g, lds_base + (unsigned)(3 * W4_HS + (wave * 2 + buf) * W4_BWS) * 16u);
+#endif
     };
 
     // ---- A-operand lane -> tile.  ds_read_b128 serves lanes {0-3,12-15,20-27} and {4-11,16-19,28-31} of each half

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void ccl_local_kernel(CclGeom g, const uint8_t
                                                         int32_t* __restrict__ L_all, uint32_t* __restrict__ area_all,
                                                         u64* __restrict__ sumy_all, u64* __restrict__ sumx_all,
                                                         uint32_t* __restrict__ flag_all, int stat, int sparse,
-                                                        uint8_t* __restrict__ tile_any) {
+                                                        uint8_t* __restrict__ tile_any, int allow_full) {
     __shared__ int Ls[CCL_BLOCK_ROWS * 64];
     __shared__ uint8_t Kl[4][64];                          // keys of every wave's last row (the next wave's "row above")
     int img, y0, cx;
@@ -158,12 +158,14 @@ __global__ __launch_bounds__(256) void ccl_local_kernel(CclGeom g, const uint8_t
     // The keys of the wave's 8 rows stay in registers: the neighbours above come from the previous row's register through
     // DPP wave shifts (one VALU instruction each) instead of byte reads from an LDS copy of the tile.
     int keys[CCL_ROWS], hpos[CCL_ROWS];                    // key, lane of the pixel's run head
+    int hole = 0;                                          // a valid pixel of this thread without a key
 #pragma unroll
     for (int r = 0; r < CCL_ROWS; ++r) {
         const int y = y0 + r, li = (wave * CCL_ROWS + r) * 64 + lane;
         const bool valid = y < g.H && x < g.W;
         const int key = valid ? key_of(img_all[base + (size_t)y * g.W + x], lut) : 0;
         keys[r] = key;
+        hole |= (valid && key == 0) ? 1 : 0;
         const int kprev = wave_from_left(key);
         const bool start = key != 0 && kprev != key;       // (lane 0: kprev = 0)
         const u64 S = __ballot(start);
@@ -180,8 +182,22 @@ __global__ __launch_bounds__(256) void ccl_local_kernel(CclGeom g, const uint8_t
     // The vote is also left in tile_any for the later kernels of this labelling: ccl_border, ccl_flatten and count_roots
     // skip a tile without a keyed pixel before they load anything of it.
     const int any = __syncthreads_or(mine);
-    if (threadIdx.x == 0) tile_any[tile_index(g, img)] = (uint8_t)(any != 0);
+    // FULL tiles (allow_full: binary keys, 4-connectivity, no statistics - the background labellings of fill_holes, where
+    // most tiles of a realistic image hold nothing but background): every valid pixel is keyed, so the tile is ONE
+    // component whose root is its first pixel.  Only that pixel gets a parent; ccl_border / ccl_flatten / apply_fill_tile
+    // stand in the tile root for any pixel of such a tile (tile_any == 2).
+    const int holes = allow_full ? __syncthreads_or(hole) : 1;
+    const bool full = allow_full && any && !holes;
+    if (threadIdx.x == 0) tile_any[tile_index(g, img)] = (uint8_t)(full ? 2 : (any != 0));
     if (!any && sparse) return;
+    if (full) {
+        if (threadIdx.x == 0) {
+            const size_t p0 = base + (size_t)yblk * g.W + cx * 64;
+            L_all[p0] = yblk * g.W + cx * 64;
+            flag_all[p0] = 0u;
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < CCL_ROWS; ++r) {
         const int ly = wave * CCL_ROWS + r, li = ly * 64 + lane;
@@ -238,13 +254,19 @@ __global__ __launch_bounds__(128) void ccl_border_kernel(CclGeom g, const uint8_
                                                          int32_t* __restrict__ L_all, const uint8_t* __restrict__ tile_any) {
     int img, y0, cx;
     if (!decode_block(g, img, y0, cx)) return;
-    if (!tile_any[tile_index(g, img)]) return;                    // no keyed pixel in this tile: nothing to unite from here
+    const size_t ti = tile_index(g, img);
+    const int ta = tile_any[ti];
+    if (!ta) return;                                               // no keyed pixel in this tile: nothing to unite from here
     const size_t base = (size_t)img * g.H * g.W;
     const uint8_t* im = img_all + base;
     int32_t* L = L_all + base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ytile = y0 - wave * CCL_ROWS;                        // first row of the tile
     const int W = g.W;
+    // full tiles (ccl_local, 4-connectivity only): only the tile's first pixel has a parent - it stands in for every pixel of
+    // the tile; two full tiles are united once, by one lane
+    const bool fullA = CONN == 4 && ta == 2;
+    const int rootA = ytile * W + cx * 64;
     if (wave == 0) {
         // first row of a tile that has a tile above it
         const int y = ytile, x = cx * 64 + lane;
@@ -253,7 +275,10 @@ __global__ __launch_bounds__(128) void ccl_border_kernel(CclGeom g, const uint8_
         const int key = key_of(im[p], lut);
         if (!key) return;
         const bool left = x > 0 && key_of(im[p - 1], lut) == key;
-        if (lane == 0 && left) uf_unite(L, p, p - 1);
+        const bool fullL = CONN == 4 && lane == 0 && cx > 0 && tile_any[ti - 1] == 2;
+        const bool fullU = CONN == 4 && tile_any[ti - g.chunks_x] == 2;
+        const int P = fullA ? rootA : p;
+        if (lane == 0 && left) uf_unite(L, P, fullL ? rootA - 64 : p - 1);
         const bool u0 = key_of(im[p - W], lut) == key;
         const bool ul = x > 0 && key_of(im[p - W - 1], lut) == key;
         const bool ur = x + 1 < W && key_of(im[p - W + 1], lut) == key;
@@ -264,7 +289,8 @@ __global__ __launch_bounds__(128) void ccl_border_kernel(CclGeom g, const uint8_
                 else if (ul) uf_unite(L, p, p - W - 1);
             }
         } else {
-            if (u0 && !(left && ul)) uf_unite(L, p, p - W);
+            if (fullA && fullU) { if (lane == 0) uf_unite(L, rootA, rootA - CCL_BLOCK_ROWS * W); }
+            else if (u0 && !(left && ul)) uf_unite(L, P, fullU ? rootA - CCL_BLOCK_ROWS * W : p - W);
         }
     } else {
         // first / last column of the rows that wave 0 does not cover (all rows of the image's first tile row)
@@ -275,6 +301,15 @@ __global__ __launch_bounds__(128) void ccl_border_kernel(CclGeom g, const uint8_
         const int key = key_of(im[p], lut);
         if (!key) return;
         if (side == 0) {
+            if (CONN == 4) {
+                const bool fullL = cx > 0 && tile_any[ti - 1] == 2;
+                if (x > 0 && key_of(im[p - 1], lut) == key) {
+                    // two full tiles: one union is enough - the first row this wave handles (row 1, or row 0 in the top strip)
+                    if (fullA && fullL) { if (r == (ytile > 0 ? 1 : 0)) uf_unite(L, rootA, rootA - 64); }
+                    else uf_unite(L, fullA ? rootA : p, fullL ? rootA - 64 : p - 1);
+                }
+                return;
+            }
             if (x > 0 && key_of(im[p - 1], lut) == key) uf_unite(L, p, p - 1);
             if (CONN == 8 && y > 0 && x > 0 && key_of(im[p - W - 1], lut) == key) uf_unite(L, p, p - W - 1);
         } else if (CONN == 8) {                                    // diagonal contact across the vertical tile border
@@ -313,7 +348,22 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8
     int img, y0, cx;
     if (!decode_block(g, img, y0, cx)) return;                 // block-uniform
     const int tid = threadIdx.x;
-    if (!tile_any[tile_index(g, img)]) return;                 // ccl_local's vote: no keyed pixel, nothing to accumulate or rewrite
+    const int ta_ = tile_any[tile_index(g, img)];
+    if (!ta_) return;                                          // ccl_local's vote: no keyed pixel, nothing to accumulate or rewrite
+    if (ta_ == 2) {
+        // full tile (fill_holes background labelling: no statistics, no counters): one component, only its root pixel holds a
+        // parent.  The root takes the global root and passes the tile's "touches the image border" bit on.
+        if (tid == 0) {
+            const int yt = y0, W_ = g.W;                       // (wave 0: y0 is the tile's first row)
+            const size_t base_ = (size_t)img * g.H * g.W;
+            const int p0 = yt * W_ + cx * 64;
+            const int gr = uf_find(L_all + base_, p0);
+            L_all[base_ + p0] = gr;
+            const bool edge = yt == 0 || yt + CCL_BLOCK_ROWS >= g.H || cx == 0 || cx * 64 + 64 >= W_;
+            if (aux_mode == AUX_BORDER && edge) atomicOr(flag_all + base_ + gr, 1u);
+        }
+        return;
+    }
     // all sixteen loads of the thread (pixel values and parents of its eight rows) go out together, before the LDS set-up;
     // stale parents of unkeyed pixels are read and ignored
     uint8_t vals[CCL_ROWS];
@@ -560,6 +610,7 @@ struct CclPass {
     int need;      // NEED_* counters this pass has to produce
     bool count_only = false;   // only NEED_NCOMP | NEED_NPX are wanted: count roots instead of flattening
     bool sparse = false;       // every consumer checks the key before it reads a parent: background parents are not written
+    bool allow_full = false;   // binary keys, 4-connectivity, no statistics / counters: tiles without an unkeyed pixel are one node (tile_any == 2)
     int32_t* list1 = nullptr;  // NEED_LISTS: per-image lists of class-1 roots / class-2 roots (first word of 16-byte slots)
     int32_t* list2 = nullptr;
     size_t list_cap = 0;
@@ -571,11 +622,12 @@ static hipError_t run_ccl_pass(PostWorkspace& ws, const CclGeom& g, const CclPas
     const unsigned grid = geom_grid(g);
     if (c.conn == 8) {
         hipLaunchKernelGGL(ccl_local_kernel<8>, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy,
-                           ws.sumx, ws.flag, c.stat, c.sparse ? 1 : 0, ws.tile_any);
+                           ws.sumx, ws.flag, c.stat, c.sparse ? 1 : 0, ws.tile_any, 0);
         hipLaunchKernelGGL(ccl_border_kernel<8>, dim3(grid), dim3(128), 0, s, g, c.key_img, c.lut, ws.L, ws.tile_any);
     } else {
         hipLaunchKernelGGL(ccl_local_kernel<4>, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy,
-                           ws.sumx, ws.flag, c.stat, c.sparse ? 1 : 0, ws.tile_any);
+                           ws.sumx, ws.flag, c.stat, c.sparse ? 1 : 0, ws.tile_any,
+                           (c.allow_full && c.stat == 0 && c.need == 0 && !c.count_only) ? 1 : 0);
         hipLaunchKernelGGL(ccl_border_kernel<4>, dim3(grid), dim3(128), 0, s, g, c.key_img, c.lut, ws.L, ws.tile_any);
     }
     if (c.count_only) {        // counts per key only: no per-pixel roots, no statistics
@@ -619,6 +671,38 @@ __global__ __launch_bounds__(256) void apply_fill_kernel(uint8_t* __restrict__ i
         if (!key_of(img[t], lut)) continue;                    // not part of the labelled background: its parent is stale
         const int r = L[t];
         if (!(flag[ib + r] & 1u)) img[t] = (uint8_t)c;
+    }
+}
+
+// The same per labelling tile (fill passes run with full-tile nodes): a full tile asks once - its root's component either
+// reaches the image border (nothing to do) or the whole tile lies inside a hole; a tile without a keyed pixel has nothing to
+// fill; the others go pixel by pixel.
+__global__ __launch_bounds__(256) void apply_fill_tile_kernel(CclGeom g, uint8_t* __restrict__ img_all, const int32_t* __restrict__ L_all,
+                                                              const uint32_t* __restrict__ flag_all, int c, uint32_t lut,
+                                                              const uint8_t* __restrict__ tile_any) {
+    int img, y0, cx;
+    if (!decode_block(g, img, y0, cx)) return;
+    const int ta = tile_any[tile_index(g, img)];
+    if (!ta) return;
+    const size_t base = (size_t)img * g.H * g.W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = cx * 64 + lane;
+    bool fill_all = false;
+    if (ta == 2) {
+        const int p0 = (y0 - wave * CCL_ROWS) * g.W + cx * 64;
+        const int r = L_all[base + p0];
+        if (flag_all[base + r] & 1u) return;                   // background connected to the image border
+        fill_all = true;
+    }
+#pragma unroll
+    for (int r = 0; r < CCL_ROWS; ++r) {
+        const int y = y0 + r;
+        if (y >= g.H || x >= g.W) continue;
+        const size_t t = base + (size_t)y * g.W + x;
+        if (fill_all) { img_all[t] = (uint8_t)c; continue; }
+        if (!key_of(img_all[t], lut)) continue;
+        const int root = L_all[t];
+        if (!(flag_all[base + root] & 1u)) img_all[t] = (uint8_t)c;
     }
 }
 
@@ -983,8 +1067,9 @@ hipError_t run_meta_inference(PostWorkspace& ws, uint8_t* img, int n_img, int H,
     for (int c = 1; c <= 2; ++c) {
         CclPass p{img, lut_ne(c), 4, 0, AUX_BORDER, 0, nullptr, 0};
         p.sparse = true;
+        p.allow_full = true;
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
-        hipLaunchKernelGGL(apply_fill_kernel, ig, dim3(256), 0, s, img, ws.L, ws.flag, n_img, px, c, lut_ne(c));
+        hipLaunchKernelGGL(apply_fill_tile_kernel, dim3(geom_grid(g)), dim3(256), 0, s, g, img, ws.L, ws.flag, c, lut_ne(c), ws.tile_any);
     }
     // 2-4. size_thresh
     {

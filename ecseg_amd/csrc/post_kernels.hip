@@ -342,9 +342,10 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8
     __shared__ uint32_t used_s[TP / 32];                       // bit per slot: some run accumulated into it
     __shared__ uint16_t own_s[TP];                             // compacted list of the slots in use
     extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
-    u64* sumy_s = reinterpret_cast<u64*>(dyn_smem);            // [TP] only when STAT_SUMS
-    u64* sumx_s = sumy_s + TP;
-    int16_t* lsl_s = reinterpret_cast<int16_t*>(dyn_smem + ((stat & STAT_SUMS) ? (size_t)TP * 16 : 0));   // [TP] only when NEED_LISTS: list position of owner k
+    // [TP] only when STAT_SUMS: coordinate sums of the slot RELATIVE to the tile origin, packed (sum of rows << 32 | sum of
+    // columns; each < 2^18 inside a 64 x 32 tile): one 64-bit LDS atomic per run instead of two, and half the LDS
+    u64* sum_s = reinterpret_cast<u64*>(dyn_smem);
+    int16_t* lsl_s = reinterpret_cast<int16_t*>(dyn_smem + ((stat & STAT_SUMS) ? (size_t)TP * 8 : 0));   // [TP] only when NEED_LISTS: list position of owner k
     int img, y0, cx;
     if (!decode_block(g, img, y0, cx)) return;                 // block-uniform
     const int tid = threadIdx.x;
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8
     if (tid < TP / 32) used_s[tid] = 0u;
     for (int i = tid; i < TP; i += 256) {
         af_s[i] = 0u;
-        if (stat & STAT_SUMS) { sumy_s[i] = 0ull; sumx_s[i] = 0ull; }
+        if (stat & STAT_SUMS) sum_s[i] = 0ull;
     }
     __syncthreads();
     const size_t base = (size_t)img * g.H * g.W;
@@ -453,16 +454,17 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8
             const u64 stop = (S | ~F) & above;
             const int len = stop ? (__ffsll((long long)stop) - 1 - lane) : (64 - lane);
             const u64 run = (len == 64) ? ~0ull : (((1ull << len) - 1ull) << lane);
-            atomicOr(&used_s[tr >> 5], 1u << (tr & 31));
+            // (with pixel counts the slot's count marks it as used: no separate bit)
+            if (!(stat & (STAT_AREA | STAT_SUMS))) atomicOr(&used_s[tr >> 5], 1u << (tr & 31));
             if (stat & STAT_SUMS) {
-                atomicAdd(&sumy_s[tr], (u64)y * (u64)len);
-                atomicAdd(&sumx_s[tr], (u64)x * (u64)len + (u64)len * (u64)(len - 1) / 2ull);
+                const unsigned ry = (unsigned)(y - yblk), rx = (unsigned)(x - cx * 64), ulen = (unsigned)len;
+                atomicAdd(&sum_s[tr], ((u64)(ry * ulen) << 32) | (u64)(rx * ulen + ulen * (ulen - 1) / 2u));
             }
             uint32_t fb = 0;
 #pragma unroll
             for (int b = 0; b < 5; ++b) if (B[b] & run) fb |= 1u << b;
             // pixel count and flag bits share a word (the count never carries into bit 16)
-            if (stat & STAT_AREA) atomicAdd(&af_s[tr], (uint32_t)len);
+            if (stat & (STAT_AREA | STAT_SUMS)) atomicAdd(&af_s[tr], (uint32_t)len);
             if (fb) atomicOr(&af_s[tr], fb << 16);
         }
     }
@@ -475,7 +477,7 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8
 #pragma unroll
     for (int r = 0; r < CCL_ROWS; ++r) {
         const int li = (wave * CCL_ROWS + r) * 64 + lane;
-        const bool own = (used_s[li >> 5] >> (li & 31)) & 1u;
+        const bool own = (stat & (STAT_AREA | STAT_SUMS)) ? (af_s[li] & 0xffffu) != 0u : ((used_s[li >> 5] >> (li & 31)) & 1u) != 0u;
         const u64 m = __ballot(own);
         if (!m) continue;                                      // wave-uniform
         int at = 0;
@@ -493,7 +495,11 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8
         groot_s[li] = gr;
         const uint32_t af = af_s[li];
         if (stat & STAT_AREA) atomicAdd(area_all + base + gr, af & 0xffffu);
-        if (stat & STAT_SUMS) { atomicAdd(sumy_all + base + gr, sumy_s[li]); atomicAdd(sumx_all + base + gr, sumx_s[li]); }
+        if (stat & STAT_SUMS) {
+            const u64 pk = sum_s[li], cnt = af & 0xffffu;
+            atomicAdd(sumy_all + base + gr, (pk >> 32) + (u64)yblk * cnt);
+            atomicAdd(sumx_all + base + gr, (pk & 0xffffffffull) + (u64)(cx * 64) * cnt);
+        }
         if (af >> 16) atomicOr(flag_all + base + gr, af >> 16);
         int16_t ls = -1;                                       // (class << 12 | index inside the block's range), -1 = none
         if (gr == p) {                                         // a global root lives in this tile
@@ -635,7 +641,7 @@ static hipError_t run_ccl_pass(PostWorkspace& ws, const CclGeom& g, const CclPas
         hipLaunchKernelGGL(reduce_g_kernel, dim3(g.n_img), dim3(G_STRIDE), 0, s, ws.g, g.n_img);
         return hipGetLastError();
     }
-    const size_t dyn = ((c.stat & STAT_SUMS) ? (size_t)CCL_BLOCK_ROWS * 64 * 16 : 0) + ((c.need & NEED_LISTS) ? (size_t)CCL_BLOCK_ROWS * 64 * 2 : 0);
+    const size_t dyn = ((c.stat & STAT_SUMS) ? (size_t)CCL_BLOCK_ROWS * 64 * 8 : 0) + ((c.need & NEED_LISTS) ? (size_t)CCL_BLOCK_ROWS * 64 * 2 : 0);
     hipLaunchKernelGGL(ccl_flatten_kernel, dim3(grid), dim3(256), dyn, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy,
                        ws.sumx, ws.flag, ws.g, c.stat, c.aux_mode, c.aux_c, c.aux_img, c.need, c.list1, c.list2, c.list_cap, ws.tile_any);
     if (c.need) hipLaunchKernelGGL(reduce_g_kernel, dim3(g.n_img), dim3(G_STRIDE), 0, s, ws.g, g.n_img);

@@ -17,8 +17,8 @@ test:
 # corpus; CPU only (GPU sanitizers are not available on the target pool)
 asan:
 	g++ -std=c++17 -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=all \
-	    ecseg_amd/csrc/host_codec.cpp tools/asan/codec_fuzz.cpp -o /tmp/ecseg_codec_fuzz
+	    ecseg_amd/csrc/host_codec.cpp ecseg_amd/csrc/host_io.cpp tools/asan/codec_fuzz.cpp -lz -o /tmp/ecseg_codec_fuzz
 	/tmp/ecseg_codec_fuzz
 
 clean:
-	rm -rf __pycache__ ecseg_amd/csrc/*.o ecseg_amd/libecseg_hip.so
+	rm -rf __pycache__ ecseg_amd/csrc/*.o ecseg_amd/libecseg_*.so

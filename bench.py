@@ -25,7 +25,6 @@ the CPU results of (4).
 import argparse
 import json
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -191,22 +190,35 @@ def self_launch(args):
     have = torch.cuda.device_count()
     if have < args.gpus:
         raise SystemExit('bench.py: --gpus %d but only %d HIP device(s) visible' % (args.gpus, have))
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
-           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: torch.distributed.run hosts its own c10d rendezvous store on a port the store itself binds (no
+    # bind-then-close race with other jobs on the node); --local-addr pins it to 127.0.0.1 (the hostname may not resolve)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1',
+           '--nproc-per-node', str(args.gpus), os.path.abspath(__file__)] + sys.argv[1:]
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: RCCL's intra-node transport shares device buffers between the rank processes through HIP
+    # IPC handles; this pool's host driver supports only the dmabuf flavour, and with the legacy mode left on
+    # hipIpcGetMemHandle fails with "invalid argument" as soon as a second rank joins
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+KIND_NAMES = ('conv_mfma_kernel', 'conv_wino_kernel F(2x2)', 'conv_wino4_kernel F(4x4)',
+              'conv_wino_res_kernel F(2x2), filter-resident', 'conv_wino16_kernel F(2x2), 16x16x4 MFMA')
+KIND_ISSUED = (1.0, 16.0 / 36.0, 0.25, 16.0 / 36.0, 16.0 / 36.0)      # multiplies issued / multiplies of the direct 3x3 convolution
+
+
+def aggregate(recs):
+    agg = {}
+    for r in recs:
+        a = agg.setdefault(r['op'], dict(kind=r['kind'] & 0xff, pool=bool(r['kind'] & 0x100), head=bool(r['kind'] & 0x200),
+                                         launches=0, ms=0.0, flops=0.0, executed=0.0))
+        a['launches'] += 1; a['ms'] += r['ms']; a['flops'] += r['flops']; a['executed'] += r['executed_flops']
+    return agg
 
 
 def layer_table(model, recs, steps):
     """Per-convolution table from the per-launch HIP-event records of the timed steps."""
     plan = model.plan
-    agg = {}
-    for r in recs:
-        a = agg.setdefault(r['op'], dict(kind=r['kind'], launches=0, ms=0.0, flops=0.0, executed=0.0))
-        a['launches'] += 1; a['ms'] += r['ms']; a['flops'] += r['flops']; a['executed'] += r['executed_flops']
+    agg = aggregate(recs)
     names = {v: k for k, v in plan.layer_tensor.items()}
     rows = []
     for op, a in sorted(agg.items()):
@@ -215,8 +227,7 @@ def layer_table(model, recs, steps):
         ms = a['ms'] / a['launches']
         rows.append({'op': op, 'layer': names.get(o['out'], '?'), 'type': 'conv%dx%d' % (o['kh'], o['kw']) if o['op'] == 1 else 'convT%dx%d' % (o['kh'], o['kw']),
                      'in': [ti['h'], ti['w'], ti['c']], 'out': [to['h'], to['w'], to['c']],
-                     'kernel': ('conv_mfma_kernel', 'conv_wino_kernel F(2x2)', 'conv_wino4_kernel F(4x4)',
-                                'conv_wino_res_kernel F(2x2), filter-resident', 'conv_wino16_kernel F(2x2), 16x16x4 MFMA')[a['kind']],
+                     'kernel': KIND_NAMES[a['kind']] + (' + fused 2x2 max-pool' if a['pool'] else '') + (' + fused 1x1 head' if a['head'] else ''),
                      'launches': a['launches'], 'avg_ms': round(ms, 4),
                      'algorithmic_gflop_per_launch': round(a['flops'] / a['launches'] / 1e9, 2),
                      'executed_gflop_per_launch': round(a['executed'] / a['launches'] / 1e9, 2),
@@ -226,6 +237,162 @@ def layer_table(model, recs, steps):
     return rows
 
 
+def roofline_8d(plan, recs, steps, patches_per_step, unet_ms_per_step):
+    """SURVEY 8d's mixed roofline of the whole U-Net: sum over its convolution layers of max(F_l / 157.3e12, B_l / 8.0e12)
+    divided by the measured U-Net time.  F_l = FLOPs the kernel EXECUTES for the layer (Winograd F(4x4) issues 36/144, F(2x2)
+    16/36 of a 3x3 convolution's multiplies; cropped launches count the regions computed; layers on VALU kernels - first
+    convolution, unfused head - count their direct FLOPs and are HBM-bound anyway); B_l = algorithmic fp32 bytes, every
+    tensor read / written once (4 N (Hin Win Cin + Hout Wout Cout) + the kernel), scaled by the computed fraction of a
+    cropped launch; a 1x1 head finished by the previous convolution's output stage counts neither its own bytes nor the
+    write of the tensor it would have read.  frac <= 1: the ideal schedule of the same layers on the same algorithms."""
+    agg = aggregate(recs)
+    fused_heads = {op + 1 for op, a in agg.items() if a['head']}
+    ideal_f = ideal_b = tot_f = tot_b = 0.0
+    for k, o in enumerate(plan.ops):
+        if o['op'] not in (1, 2) or k in fused_heads:
+            continue
+        ti, to = plan.tensors[o['in0']], plan.tensors[o['out']]
+        n = patches_per_step
+        px = to['h'] * to['w'] if o['op'] == 1 else ti['h'] * ti['w']
+        F = 2.0 * o['kh'] * o['kw'] * ti['c'] * to['c'] * px * n
+        b_in, b_out = 4.0 * n * ti['h'] * ti['w'] * ti['c'], 4.0 * n * to['h'] * to['w'] * to['c']
+        b_w = 4.0 * plan.weights[o['w0']].size
+        a = agg.get(k)
+        if a is not None:
+            issued = a['flops'] * KIND_ISSUED[a['kind']]
+            computed = min(1.0, a['executed'] / issued) if issued else 1.0
+            F = a['executed'] / steps
+            if a['head']:
+                b_out = 0.0
+            b_in, b_out = b_in * computed, b_out * computed
+        B = b_in + b_out + b_w
+        tf, tb = F / (PEAK_FP32_MFMA_TFLOPS * 1e12), B / (PEAK_HBM_GBS * 1e9)
+        tot_f += F; tot_b += B
+        if tf >= tb:
+            ideal_f += tf
+        else:
+            ideal_b += tb
+    ideal = ideal_f + ideal_b
+    return {'frac': round(ideal * 1e3 / unet_ms_per_step, 4), 'ideal_unet_ms_per_step': round(ideal * 1e3, 4),
+            'measured_unet_ms_per_step': round(unet_ms_per_step, 4),
+            'bound': 'mfma' if ideal_f >= ideal_b else 'hbm',
+            'ideal_ms_in_mfma_bound_layers': round(ideal_f * 1e3, 4), 'ideal_ms_in_hbm_bound_layers': round(ideal_b * 1e3, 4),
+            'executed_tflop_per_step': round(tot_f / 1e12, 4), 'algorithmic_gbyte_per_step': round(tot_b / 1e9, 3),
+            'peaks': {'fp32_mfma_tflops': PEAK_FP32_MFMA_TFLOPS, 'hbm_gbs': PEAK_HBM_GBS},
+            'definition': 'sum_l max(F_l / peak_mfma, B_l / peak_hbm) / t_unet; F_l executed FLOPs, B_l algorithmic bytes (SURVEY 8d)'}
+
+
+class DeviceRun:
+    """One synthetic model on this rank's GPU: inputs resident in HBM, `step()` = the whole device pipeline over B images."""
+
+    def __init__(self, base, B, group, local, rank, world, args, first_image=None):
+        import torch
+        from ecseg_amd import dist as edist
+        from ecseg_amd import synth
+        from ecseg_amd.model import MetasegModel
+        self.torch, self.edist = torch, edist
+        self.base, self.B, self.world = base, B, world
+        dev = torch.device('cuda', local)
+        cfg = synth.unet_config(base=base)
+        self.model = MetasegModel(cfg, synth.unet_weights(cfg, seed=0), device=local)
+        hnd = self.hnd = self.model.handle
+        hnd.set_images_per_group(group)
+        hnd.set_option('overlap_post', 1 if args.overlap else 0)
+        if args.wino is not None:
+            hnd.set_option('winograd', args.wino)
+        for kv in args.opt:
+            k, v = kv.split('=')
+            hnd.set_option(k, int(v))
+        total = B * world                              # weak scaling: per-GPU work fixed
+        self.total_images = total
+        start, stop, per = edist.shard_bounds(total, rank, world)
+        self.host = np.stack([synth.dapi_image(i, H, W) for i in range(start, stop)])
+        self.gray = torch.from_numpy(self.host).to(dev)
+        self.raw = torch.empty_like(self.gray)
+        self.post = torch.empty_like(self.gray)
+        self.nec = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.rec = torch.from_numpy(edist.make_records(start, stop - start, per)).to(dev)
+
+    def step(self):
+        self.hnd.segment_images_dev(self.gray.data_ptr(), self.B, H, W, self.raw.data_ptr(), self.post.data_ptr(), self.nec.data_ptr())
+        self.rec[:self.B, self.edist.F_NEC] = self.nec.to(self.torch.int64)
+        return self.edist.allgather_records(self.rec)
+
+    def barrier(self):
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def timed(self, steps, warmup, profile=True):
+        """W untimed + K timed steps bracketed by barrier + synchronize; MAX over ranks.  -> dict of raw measurements."""
+        import torch.distributed as dist
+        hnd = self.hnd
+        for _ in range(warmup):
+            self.step()
+        hnd.set_kernel_profiling(profile)
+        stage = {k: 0.0 for k in hnd.T_NAMES}
+        conv_ms = conv_flops = conv_exec = 0.0
+        conv_launches = 0
+        recs = []
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = self.step()
+            for k, v in hnd.timings().items():
+                stage[k] += v
+            ms, nl, fl = hnd.conv_profile()
+            conv_ms += ms; conv_launches += nl; conv_flops += fl
+            conv_exec += hnd.conv_executed_flops()
+            if profile:
+                recs += hnd.conv_launch_profile()
+        self.barrier()
+        dt = time.perf_counter() - t0
+        hnd.set_kernel_profiling(False)
+        tmax = self.torch.tensor([dt], dtype=self.torch.float64, device=self.gray.device)
+        if dist.is_initialized():
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return dict(dt=float(tmax.item()), stage=stage, conv_ms=conv_ms, conv_launches=conv_launches, conv_flops=conv_flops,
+                    conv_exec=conv_exec, recs=recs, out=out, steps=steps)
+
+    def single_image_latency(self, reps=10):
+        """BASELINE configs[1] read literally: ONE 1040x1392 image resident in HBM -> labels + count, synchronous."""
+        call = lambda: self.hnd.segment_images_dev(self.gray.data_ptr(), 1, H, W, self.raw.data_ptr(), self.post.data_ptr(), self.nec.data_ptr())
+        call(); call()
+        self.torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            call()
+            self.torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return {'median_ms': round(float(np.median(ts)), 3), 'min_ms': round(min(ts), 3), 'reps': reps,
+                'what': 'ecseg_segment_images_dev on ONE resident 1040x1392 image (35 windows): tile -> U-Net -> stitch/argmax -> '
+                        'meta_inference -> count, host-synchronous'}
+
+    def close(self):
+        self.hnd.close()
+        del self.gray, self.raw, self.post, self.nec, self.rec
+        self.torch.cuda.empty_cache()
+
+
+def model_summary(run, m):
+    """The per-model part of the JSON line (used for the headline model and for the narrow models)."""
+    steps, B = m['steps'], run.B
+    unet_ms_step = m['stage']['unet'] / steps
+    res = {'value': round(run.total_images * steps / m['dt'], 3), 'unit': 'images/s', 'images_per_gpu_per_step': B, 'steps': steps,
+           'ms_per_step': round(m['dt'] / steps * 1e3, 3), 'unet_base': run.base,
+           'gflop_per_patch': round(run.model.plan.flops_per_patch() / 1e9, 2),
+           'stage_ms_per_image': {k: round(v / (steps * B), 4) for k, v in m['stage'].items()},
+           'ccl_ms_per_image': round(m['stage']['post'] / (steps * B), 4)}
+    if m['conv_launches'] and m['recs']:
+        exe = m['conv_exec'] / (m['conv_ms'] * 1e-3) / 1e12
+        res['mfma_executed_tflops'] = round(exe, 2)
+        res['mfma_executed_frac_of_peak'] = round(exe / PEAK_FP32_MFMA_TFLOPS, 4)
+        res['roofline_8d'] = roofline_8d(run.model.plan, m['recs'], steps, B * 35, unet_ms_step)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -233,7 +400,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--images', type=int, default=16, help='images per GPU per step')
     ap.add_argument('--base', type=int, default=64, help='U-Net base width of the synthetic model')
-    ap.add_argument('--group', type=int, default=16, help='images per internal U-Net launch group')
+    ap.add_argument('--group', type=int, default=16, help='images per internal U-Net launch group (0: automatic)')
     ap.add_argument('--overlap', action='store_true', help='run post-processing on a second stream')
     ap.add_argument('--direct', action='store_true', help='direct implicit-GEMM 3x3 kernel instead of Winograd')
     ap.add_argument('--wino', type=int, default=None, help='3x3 kernel: 0 direct, 1 Winograd F(2x2,3x3), 2 F(4x4,3x3) where eligible (default: library default)')
@@ -241,22 +408,19 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument('--no-host-inclusive', action='store_true')
+    ap.add_argument('--no-narrow', action='store_true', help='skip the base-32 / base-16 legs and the single-image latency (N = 1 only)')
     ap.add_argument('--layer-table', default=None, help='write the per-layer roofline table (JSON) to this path')
     args = ap.parse_args()
 
     under_launcher = 'WORLD_SIZE' in os.environ and 'RANK' in os.environ
     if args.gpus > 1 and not under_launcher:
         self_launch(args)
-
     want_cpu = args.gpus <= 1 and int(os.environ.get('WORLD_SIZE', '1')) == 1 and not args.no_cpu_baseline
-    cpu_par = cpu_single = refs = None
     pools = cpu_pools_start() if want_cpu else None              # worker processes exist before this process initialises HIP
 
     import torch                      # first: libecseg_hip.so then binds to the HIP runtime torch already loaded
     import torch.distributed as dist
     from ecseg_amd import dist as edist
-    from ecseg_amd import synth
-    from ecseg_amd.model import MetasegModel
 
     rank, world = edist.init_process_group()
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -265,90 +429,33 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no HIP device visible); there is no CPU fallback')
     torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
-
-    cfg = synth.unet_config(base=args.base)
-    weights = synth.unet_weights(cfg, seed=0)
-    model = MetasegModel(cfg, weights, device=local)
-    hnd = model.handle
-    hnd.set_images_per_group(args.group)
-    hnd.set_option('overlap_post', 1 if args.overlap else 0)
     if args.direct:
         args.wino = 0
-    if args.wino is not None:
-        hnd.set_option('winograd', args.wino)
     wino_mode = 2 if args.wino is None else max(0, min(2, args.wino))
-    for kv in args.opt:
-        k, v = kv.split('=')
-        hnd.set_option(k, int(v))
     B = args.images
-    total_images = B * world                       # weak scaling: per-GPU work fixed
-    start, stop, per = edist.shard_bounds(total_images, rank, world)
 
-    # synthetic inputs, resident in HBM before the timed region
-    host = np.stack([synth.dapi_image(i, H, W) for i in range(start, stop)])
-    gray = torch.from_numpy(host).to(dev)
-    raw = torch.empty_like(gray)
-    post = torch.empty_like(gray)
-    nec = torch.zeros(B, dtype=torch.int32, device=dev)
-    rec = torch.from_numpy(edist.make_records(start, stop - start, per)).to(dev)
-
-    def step():
-        hnd.segment_images_dev(gray.data_ptr(), B, H, W, raw.data_ptr(), post.data_ptr(), nec.data_ptr())
-        rec[:B, edist.F_NEC] = nec.to(torch.int64)
-        return edist.allgather_records(rec)
-
-    def barrier():
-        if dist.is_initialized():
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    hnd.set_kernel_profiling(not args.no_kernel_profile)
-    stage = {k: 0.0 for k in hnd.T_NAMES}
-    conv_ms = conv_flops = conv_exec = 0.0
-    conv_launches = 0
-    launch_recs = []
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-        for k, v in hnd.timings().items():
-            stage[k] += v
-        ms, nl, fl = hnd.conv_profile()
-        conv_ms += ms; conv_launches += nl; conv_flops += fl
-        conv_exec += hnd.conv_executed_flops()
-        if not args.no_kernel_profile:
-            launch_recs += hnd.conv_launch_profile()
-    barrier()
-    dt = time.perf_counter() - t0
-    hnd.set_kernel_profiling(False)
-
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if dist.is_initialized():
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    run = DeviceRun(args.base, B, args.group, local, rank, world, args)
+    m = run.timed(args.steps, args.warmup, profile=not args.no_kernel_profile)
+    hnd, model = run.hnd, run.model
 
     if rank == 0:
-        counts = edist.compact_records(out)[:, edist.F_NEC]
-        assert len(counts) == total_images
-        value = total_images * args.steps / dt
-        gflop_patch = model.plan.flops_per_patch() / 1e9
+        counts = edist.compact_records(m['out'])[:, edist.F_NEC]
+        assert len(counts) == run.total_images
+        summ = model_summary(run, m)
         res = {
-            'metric': 'DAPI images/sec (1392x1040, 4-class metaseg)', 'value': round(value, 3), 'unit': 'images/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'metric': 'DAPI images/sec (1392x1040, 4-class metaseg)', 'value': summ['value'], 'unit': 'images/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': summ['ms_per_step'],
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1] + post-process: %d synthetic 1040x1392 uint8 DAPI images per GPU per '
                                    'step, 35 tiles of 256x256 each, canonical U-Net base %d (%.1f GFLOP/patch, seeded random '
                                    'weights) -> stitch/uint8-quantise/argmax -> meta_inference -> ecDNA count'
-                                   % (B, args.base, gflop_patch),
+                                   % (B, args.base, summ['gflop_per_patch']),
                        'images_per_gpu_per_step': B, 'unet_base': args.base, 'patches_per_image': 35,
                        'parallelism': 'image-parallel x%d, all-gather of 128-B records' % world},
-            'stage_ms_per_image': {k: round(v / (args.steps * B), 4) for k, v in stage.items()},
-            'ccl_ms_per_image': round(stage['post'] / (args.steps * B), 4),
+            'stage_ms_per_image': summ['stage_ms_per_image'], 'ccl_ms_per_image': summ['ccl_ms_per_image'],
         }
-        if conv_launches:
+        if m['conv_launches']:
+            conv_ms, conv_launches, conv_flops, conv_exec = m['conv_ms'], m['conv_launches'], m['conv_flops'], m['conv_exec']
             traffic = traffic_src = None
             try:        # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
                 tag = {0: 'direct', 1: 'f2x2', 2: 'f4x4'}[wino_mode]
@@ -361,7 +468,8 @@ def main():
                 traffic = None
             alg = conv_flops / (conv_ms * 1e-3) / 1e12
             exe = conv_exec / (conv_ms * 1e-3) / 1e12
-            res['roofline'] = {'bound': 'mfma',
+            r8 = summ.get('roofline_8d')
+            res['roofline'] = {'bound': r8['bound'] if r8 else 'mfma',
                                'kernel': {0: 'conv_mfma_kernel (direct implicit GEMM)',
                                           1: 'conv_wino_kernel (Winograd F(2x2,3x3)) + conv_mfma_kernel (2x2 up-convs)',
                                           2: 'conv_wino4_kernel (Winograd F(4x4,3x3)) + conv_mfma_kernel (2x2 up-convs)'}[wino_mode] +
@@ -378,23 +486,39 @@ def main():
                                        'layers count only the 16x16 regions computed) / HIP-event time of every MFMA-conv launch '
                                        'on the handle\'s stream / fp32 MFMA peak, so frac <= 1 is matrix-pipe utilisation.  '
                                        'algorithmic_tflops = direct-convolution FLOPs of whole 256x256 windows (SURVEY 8d) / the '
-                                       'same time; it exceeds the direct-convolution roof by the Winograd and cropping factors'}
-            if args.layer_table and launch_recs:
-                rows = layer_table(model, launch_recs, args.steps)
+                                       'same time; it exceeds the direct-convolution roof by the Winograd and cropping factors.  '
+                                       'bound = the term that dominates roofline_8d for this model'}
+            if r8:
+                res['roofline_8d'] = r8
+            if args.layer_table and m['recs']:
+                rows = layer_table(model, m['recs'], args.steps)
                 json.dump({'command': ' '.join(sys.argv), 'patches_per_launch': B * 35, 'peak_tflops': PEAK_FP32_MFMA_TFLOPS,
                            'layers': rows}, open(args.layer_table, 'w'), indent=1)
         if world == 1 and not args.no_host_inclusive:
             # host arrays in (pageable numpy), labels + counts back on the host: H2D + device pipeline + D2H per call
             n_hi = 2
-            hnd.segment_images(host, want_raw=False)
+            hnd.segment_images(run.host, want_raw=False)
             t1 = time.perf_counter()
             for _ in range(n_hi):
-                hnd.segment_images(host, want_raw=False)
+                hnd.segment_images(run.host, want_raw=False)
             hi = (time.perf_counter() - t1) / n_hi
             res['host_inclusive'] = {'value': round(B / hi, 3), 'unit': 'images/s', 'ms_per_image': round(hi / B * 1e3, 3),
                                      'what': 'ecseg_segment_images: %d uint8 images from pageable host memory (H2D), device '
                                              'pipeline, post-processed labels + counts back to host memory (D2H), synchronous'
                                              % B}
+        if world == 1 and not args.no_narrow:
+            res['single_image_latency_ms'] = run.single_image_latency()
+            # "also run base 32 and 16" - the same pipeline on the narrower canonical models with the automatic
+            # launch-group size (as many images per U-Net launch as fit ~48 GB of activations: 32 / 64 images), one step =
+            # that many images; before the CPU legs (all-core CPU load right before a GPU timing costs it 1.5 - 3 %)
+            narrow = {}
+            for nb, nimg in ((32, 32), (16, 64)):
+                if nb == args.base:
+                    continue
+                r2 = DeviceRun(nb, nimg, 0, local, rank, world, args)
+                narrow['base%d' % nb] = model_summary(r2, r2.timed(5, 1, profile=True))
+                r2.close()
+            res['narrow_models'] = narrow
         if pools is not None:
             cpu_par, cpu_single, refs = cpu_baseline(args.base, pools)    # after the timed region, on the idle workers
             res['cpu_baseline'] = cpu_par

@@ -16,6 +16,7 @@ EXPORTS = [
     'ecseg_stitch_argmax', 'ecseg_meta_inference', 'ecseg_meta_inference_dev', 'ecseg_count_cc', 'ecseg_ccl_labels',
     'ecseg_count_colocalization', 'ecseg_count_hsr', 'ecseg_overlay', 'ecseg_get_timings',
     'ecseg_set_kernel_profiling', 'ecseg_get_conv_profile', 'ecseg_get_conv_executed_flops', 'ecseg_get_conv_launch_profile', 'ecseg_debug_peek', 'ecseg_lzw_decode', 'ecseg_lzw_encode',
+    'ecseg_npy_write_i64', 'ecseg_png_write_labels', 'ecseg_png_write', 'ecseg_tiff_write_gray8', 'ecseg_tiff_info', 'ecseg_tiff_read',
 ]
 
 
@@ -25,6 +26,8 @@ class EcsegError(RuntimeError):
 
 
 E_NOMEM = -4
+E_UNSUPPORTED, E_IO = -5, -6
+ABI_VERSION = 2           # ECSEG_ABI_VERSION of include/ecseg_hip.h this binding was written for
 
 
 class TensorDesc(C.Structure):
@@ -55,6 +58,9 @@ def load_library():
         raise EcsegError('cannot load %s: %s' % (LIB_PATH, e))
     vp, i32, u8p = C.c_void_p, C.c_int, C.c_void_p
     lib.ecseg_abi_version.restype = C.c_int
+    if lib.ecseg_abi_version() != ABI_VERSION:
+        raise EcsegError('%s has ABI version %d, this binding was written for %d: rebuild it with `python -m ecseg_amd.build --force`'
+                         % (LIB_PATH, lib.ecseg_abi_version(), ABI_VERSION))
     lib.ecseg_create.argtypes = [C.POINTER(vp), i32]
     lib.ecseg_destroy.argtypes = [vp]; lib.ecseg_destroy.restype = None
     lib.ecseg_last_error.argtypes = [vp]; lib.ecseg_last_error.restype = C.c_char_p
@@ -89,6 +95,12 @@ def load_library():
     for fn in (lib.ecseg_lzw_decode, lib.ecseg_lzw_encode):
         fn.argtypes = [vp, C.c_longlong, vp, C.c_longlong]
         fn.restype = C.c_longlong
+    lib.ecseg_npy_write_i64.argtypes = [C.c_char_p, vp, i32, i32]
+    lib.ecseg_png_write_labels.argtypes = [C.c_char_p, vp, i32, i32]
+    lib.ecseg_png_write.argtypes = [C.c_char_p, vp, i32, i32, i32, i32]
+    lib.ecseg_tiff_write_gray8.argtypes = [C.c_char_p, vp, i32, i32, i32]
+    lib.ecseg_tiff_info.argtypes = [C.c_char_p, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    lib.ecseg_tiff_read.argtypes = [C.c_char_p, vp, C.c_longlong]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ('ecseg_abi_version',):
@@ -125,6 +137,7 @@ class Handle:
         self.h = h
         self.device = int(device)
         self.plan = None
+        self.images_per_group = 0          # 0: automatic (ecseg_set_images_per_group)
 
     def close(self):
         if getattr(self, 'h', None):
@@ -175,6 +188,7 @@ class Handle:
 
     def set_images_per_group(self, n):
         self._check(self.lib.ecseg_set_images_per_group(self.h, int(n)), 'ecseg_set_images_per_group')
+        self.images_per_group = int(n)
 
     def set_option(self, key, value):
         self._check(self.lib.ecseg_set_option(self.h, key.encode(), int(value)), 'ecseg_set_option(%s)' % key)

@@ -222,8 +222,12 @@ std::vector<float> winograd_filter(const float* w, int cin, int cout) {
 // of conv_wino4_kernel: wt4[cout block of 64][stage = 4 input channels][wave = half * 6 + xi][nu][h][cout 32][e], where
 // stage s of 8-channel group s / 2 holds input channels 8 (s / 2) + 4 h + 2 (s % 2) + e.
 std::vector<float> winograd4_filter(const float* w, int cin, int cout) {
-    static const double G[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    // G row of a finite point p: [1, p, p^2] / prod_{q != p} (p - q) over the finite points {0, +-a, +-b}; infinity: [0, 0, 1]
+    // (textbook values for a = 1, b = 2: 1/4, -1/6, 1/24)
+    const double a = W4_PA, b = W4_PB, a2 = a * a, b2 = b * b;
+    const double n0 = a2 * b2, na = 2 * a2 * (a2 - b2), nb_ = 2 * b2 * (b2 - a2);
+    const double G[6][3] = {{1 / n0, 0, 0},           {1 / na, a / na, a2 / na},   {1 / na, -a / na, a2 / na},
+                            {1 / nb_, b / nb_, b2 / nb_}, {1 / nb_, -b / nb_, b2 / nb_}, {0, 0, 1}};
     // zero padded to whole 64-channel output blocks and whole 8-channel input groups (Cout % 64 == 32: the second
     // channel-half waves of the last block multiply zeros; Cin % 8 == 4: the second half of the last group is zero)
     const int nblk = (cout + 63) / 64, nstages = 2 * ((cin + 7) / 8);
@@ -477,7 +481,9 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                         const double ex = o.flops * n * computed * (wino4 ? 0.25 : wino ? 16.0 / 36.0 : 1.0);   // multiplies actually issued
                         h->prof_exec_flops += ex;
                         const bool res = wino && p.resident && p.coutp == 32 && p.cin_chunks <= 4;
-                        h->prof_recs.push_back({(int)oi_first, wino4 ? 2 : w16 ? 4 : res ? 3 : wino ? 1 : 0, o.flops * n, ex, 0.f});
+                        // kind: bits 0-7 the kernel, bit 8: the following 2x2 max-pool was written by this launch, bit 9: the following 1x1 head was
+                        h->prof_recs.push_back({(int)oi_first, (wino4 ? 2 : w16 ? 4 : res ? 3 : wino ? 1 : 0) | (p.pool.p != nullptr ? 0x100 : 0) |
+                                                (p.head_w != nullptr ? 0x200 : 0), o.flops * n, ex, 0.f});
                     }
                 } else if (o.path == PATH_SMALL_CIN) {
                     e = launch_conv_small_cin(in, out, o.wt, o.bias, n, d.kh, d.kw, d.pad_top, d.pad_left, act, d.alpha, s);
@@ -819,7 +825,7 @@ int ecseg_device_name(ecseg_ctx* h, char* buf, int buflen) {
 void* ecseg_stream(ecseg_ctx* h) { return h ? (void*)h->stream : nullptr; }
 
 int ecseg_set_images_per_group(ecseg_ctx* h, int n) {
-    if (!h || n < 1) return ECSEG_E_INVALID;
+    if (!h || n < 0) return ECSEG_E_INVALID;               // 0: automatic (windows_per_group)
     h->images_per_group = n;
     return ECSEG_OK;
 }
@@ -837,7 +843,7 @@ int ecseg_set_option(ecseg_ctx* h, const char* key, int value) {
     else if (k == "winograd") h->use_winograd = value < 0 ? 0 : value > 2 ? 2 : (int)value;   // 0 direct, 1 F(2x2), 2 F(4x4)
     else if (k == "post_chunk" && value >= 1) h->post_chunk = value;
     else if (k == "post_graph") { h->post_graph = value != 0; if (!h->post_graph) drop_post_graphs(h); }
-    else if (k == "images_per_group" && value >= 1) h->images_per_group = value;
+    else if (k == "images_per_group" && value >= 0) h->images_per_group = value;     // 0: automatic
     else return fail(h, ECSEG_E_INVALID, "unknown option or bad value: " + k);
     return ECSEG_OK;
 }

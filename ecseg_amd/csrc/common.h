@@ -50,6 +50,20 @@ struct ConvParams {
     long wt_chunk_stride, wt_tap_stride;
 };
 
+// Winograd F(4x4,3x3) interpolation points {0, +-W4_PA, +-W4_PB, inf}, shared by the host filter transform (api.hip:
+// winograd4_filter) and the kernel's input / output transforms (wino4_kernel.hip).  The textbook set is {0, +-1, +-2, inf};
+// the rounding error of the result is dominated by the float32 channel sum of the transformed products on the matrix cores,
+// whose magnitude the points set: tools/wino_points.py replays the kernel's arithmetic on the CPU and measures, against a
+// float64 convolution, 4.4x the error of a sequential float32 direct convolution for {1, 2} and 2.0x for {5/8, 3/2} (the
+// best pair on a 1/16 grid; both dyadic, so every constant of B^T and A^T stays exact in float32) - at the same number of
+// VALU instructions (the +-1 rows' additions become fmas).
+// (-DECSEG_W4_PA=1 -DECSEG_W4_PB=2 rebuilds the textbook kernel for A/B measurements: tools/build_variants.sh points12)
+#ifndef ECSEG_W4_PA
+#define ECSEG_W4_PA 0.625
+#define ECSEG_W4_PB 1.5
+#endif
+constexpr double W4_PA = ECSEG_W4_PA, W4_PB = ECSEG_W4_PB;
+
 // pitches used by relayout_* (api.hip) and the kernels
 inline long wt_chunk_pitch(int np_total) { return (long)2 * np_total * 4 + 32; }
 inline long wt_tap_pitch(int np_total, int chunks) { return wt_chunk_pitch(np_total) * chunks + 96; }

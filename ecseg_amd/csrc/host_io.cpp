@@ -1,0 +1,352 @@
+// Host-side file I/O of `make metaseg` / `make meta_overlay` (no GPU work): the readers and writers that stand in for
+// skimage.io.imread -> tifffile (reference src/utils.py:110), cv2.imwrite of dapi/<name>.tif (src/utils.py:122-123),
+// plt.imsave of labels/<stem>.png (src/metaseg.py:47-52) and np.save of labels/<stem>.npy (src/metaseg.py:53), as whole-file
+// C entry points.  They are called through ctypes, which drops the GIL for the duration of the call, so the decoder /
+// encoder threads of ecseg_amd/metaseg.py run in parallel on the host cores instead of time-slicing one interpreter lock
+// (round 2: the Python-side strip loops, gathers and widenings held `make metaseg` at 1/8 of the device rate on the
+// base-16 model).  Exotic TIFF layouts (tiles, BigTIFF, PackBits, float samples, planar) return ECSEG_E_UNSUPPORTED and
+// are read by the pure-Python reader in ecseg_amd/image_io.py.
+#include <zlib.h>
+
+#include <cerrno>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ecseg_hip.h"
+
+namespace {
+
+struct File {
+    FILE* f = nullptr;
+    explicit File(const char* path, const char* mode) : f(std::fopen(path, mode)) {}
+    ~File() { if (f) std::fclose(f); }
+    bool put(const void* p, size_t n) { return n == 0 || std::fwrite(p, 1, n, f) == n; }
+    bool close() { const bool ok = std::fclose(f) == 0; f = nullptr; return ok; }
+};
+
+inline void put_le16(std::vector<uint8_t>& v, uint32_t x) { v.push_back((uint8_t)x); v.push_back((uint8_t)(x >> 8)); }
+inline void put_le32(std::vector<uint8_t>& v, uint32_t x) { for (int i = 0; i < 4; ++i) v.push_back((uint8_t)(x >> (8 * i))); }
+inline void put_be32(uint8_t* p, uint32_t x) { p[0] = (uint8_t)(x >> 24); p[1] = (uint8_t)(x >> 16); p[2] = (uint8_t)(x >> 8); p[3] = (uint8_t)x; }
+
+// one PNG chunk: length, tag, data, CRC-32 of tag + data
+bool png_chunk(File& out, const char tag[4], const uint8_t* data, size_t n) {
+    uint8_t head[8], tail[4];
+    put_be32(head, (uint32_t)n);
+    std::memcpy(head + 4, tag, 4);
+    uLong c = crc32(0L, reinterpret_cast<const Bytef*>(tag), 4);
+    size_t off = 0;
+    while (off < n) {                                   // (crc32 takes a 32-bit length)
+        const size_t k = n - off < (1u << 30) ? n - off : (1u << 30);
+        c = crc32(c, data + off, (uInt)k);
+        off += k;
+    }
+    put_be32(tail, (uint32_t)c);
+    return out.put(head, 8) && out.put(data, n) && out.put(tail, 4);
+}
+
+// rows: H scan lines of `stride` bytes, each starting with its filter byte
+int png_write_rows(const char* path, const std::vector<uint8_t>& rows, int H, int W, int color_type, int level) {
+    uLongf cap = compressBound((uLong)rows.size());
+    std::vector<uint8_t> z(cap);
+    if (compress2(z.data(), &cap, rows.data(), (uLong)rows.size(), level) != Z_OK) return ECSEG_E_INVALID;
+    File out(path, "wb");
+    if (!out.f) return ECSEG_E_IO;
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    uint8_t ihdr[13];
+    put_be32(ihdr, (uint32_t)W); put_be32(ihdr + 4, (uint32_t)H);
+    ihdr[8] = 8; ihdr[9] = (uint8_t)color_type; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
+    const bool ok = out.put(sig, 8) && png_chunk(out, "IHDR", ihdr, 13) && png_chunk(out, "IDAT", z.data(), cap) &&
+                    png_chunk(out, "IEND", nullptr, 0);
+    return ok && out.close() ? ECSEG_OK : ECSEG_E_IO;
+}
+
+// ---- TIFF reading -----------------------------------------------------------------------------------------------
+struct Reader {
+    const uint8_t* b; size_t n; bool le;
+    bool ok(size_t off, size_t len) const { return off <= n && len <= n - off; }
+    uint32_t u16(size_t o) const { return le ? (uint32_t)b[o] | ((uint32_t)b[o + 1] << 8) : ((uint32_t)b[o] << 8) | b[o + 1]; }
+    uint32_t u32(size_t o) const {
+        return le ? (uint32_t)b[o] | ((uint32_t)b[o + 1] << 8) | ((uint32_t)b[o + 2] << 16) | ((uint32_t)b[o + 3] << 24)
+                  : ((uint32_t)b[o] << 24) | ((uint32_t)b[o + 1] << 16) | ((uint32_t)b[o + 2] << 8) | b[o + 3];
+    }
+};
+
+struct TiffInfo {
+    uint32_t W = 0, H = 0, bits = 8, spp = 1, comp = 1, planar = 1, pred = 1, fmt = 1, rps = 0;
+    std::vector<uint32_t> off, cnt;
+    bool le = true;
+};
+
+// values of one IFD entry (types BYTE / SHORT / LONG only) -> vector; false when the entry is malformed
+bool entry_values(const Reader& r, size_t e, std::vector<uint32_t>* out) {
+    const uint32_t typ = r.u16(e + 2), cnt = r.u32(e + 4);
+    const size_t sz = typ == 1 ? 1 : typ == 3 ? 2 : typ == 4 ? 4 : 0;
+    if (sz == 0 || cnt > (1u << 26)) return false;
+    size_t voff = e + 8;
+    if (sz * cnt > 4) { voff = r.u32(e + 8); if (!r.ok(voff, sz * cnt)) return false; }
+    out->resize(cnt);
+    for (uint32_t i = 0; i < cnt; ++i)
+        (*out)[i] = sz == 1 ? r.b[voff + i] : sz == 2 ? r.u16(voff + 2 * i) : r.u32(voff + 4 * i);
+    return true;
+}
+
+// ECSEG_OK, ECSEG_E_UNSUPPORTED (a valid layout this reader leaves to the Python one) or ECSEG_E_INVALID (corrupt)
+int parse_tiff(const uint8_t* buf, size_t n, TiffInfo* t) {
+    if (n < 8) return ECSEG_E_INVALID;
+    if (buf[0] == 'I' && buf[1] == 'I') t->le = true;
+    else if (buf[0] == 'M' && buf[1] == 'M') t->le = false;
+    else return ECSEG_E_INVALID;
+    Reader r{buf, n, t->le};
+    const uint32_t magic = r.u16(2);
+    if (magic == 43) return ECSEG_E_UNSUPPORTED;          // BigTIFF
+    if (magic != 42) return ECSEG_E_INVALID;
+    const size_t ifd = r.u32(4);
+    if (!r.ok(ifd, 2)) return ECSEG_E_INVALID;
+    const uint32_t ne = r.u16(ifd);
+    if (!r.ok(ifd + 2, (size_t)ne * 12)) return ECSEG_E_INVALID;
+    bool have_w = false, have_h = false, tiled = false;
+    std::vector<uint32_t> v;
+    for (uint32_t i = 0; i < ne; ++i) {
+        const size_t e = ifd + 2 + (size_t)i * 12;
+        const uint32_t tag = r.u16(e);
+        const bool wanted = tag == 256 || tag == 257 || tag == 258 || tag == 259 || tag == 273 || tag == 277 || tag == 278 ||
+                            tag == 279 || tag == 284 || tag == 317 || tag == 339 || tag == 322;
+        if (!wanted) continue;
+        if (tag == 322) { tiled = true; continue; }
+        if (!entry_values(r, e, &v) || v.empty()) return ECSEG_E_INVALID;
+        switch (tag) {
+            case 256: t->W = v[0]; have_w = true; break;
+            case 257: t->H = v[0]; have_h = true; break;
+            case 258: t->bits = v[0]; for (uint32_t x : v) if (x != v[0]) return ECSEG_E_UNSUPPORTED; break;
+            case 259: t->comp = v[0]; break;
+            case 273: t->off = v; break;
+            case 277: t->spp = v[0]; break;
+            case 278: t->rps = v[0]; break;
+            case 279: t->cnt = v; break;
+            case 284: t->planar = v[0]; break;
+            case 317: t->pred = v[0]; break;
+            case 339: t->fmt = v[0]; for (uint32_t x : v) if (x != v[0]) return ECSEG_E_UNSUPPORTED; break;
+        }
+    }
+    if (!have_w || !have_h || t->W == 0 || t->H == 0 || t->spp == 0 || t->W > (1u << 20) || t->H > (1u << 20) || t->spp > 16)
+        return ECSEG_E_INVALID;
+    if (tiled || (t->bits != 8 && t->bits != 16) || t->fmt != 1 || (t->planar != 1 && t->spp > 1) ||
+        (t->comp != 1 && t->comp != 5 && t->comp != 8 && t->comp != 32946) || (t->pred != 1 && t->pred != 2))
+        return ECSEG_E_UNSUPPORTED;
+    if (t->off.empty()) return ECSEG_E_INVALID;
+    if (t->cnt.empty()) {
+        if (t->off.size() != 1 || t->off[0] > n) return ECSEG_E_INVALID;
+        t->cnt.assign(1, (uint32_t)(n - t->off[0]));
+    }
+    if (t->cnt.size() != t->off.size()) return ECSEG_E_INVALID;
+    if (t->rps == 0 || t->rps > t->H) t->rps = t->H;
+    return ECSEG_OK;
+}
+
+bool read_file(const char* path, std::vector<uint8_t>* out) {
+    File f(path, "rb");
+    if (!f.f) return false;
+    if (std::fseek(f.f, 0, SEEK_END) != 0) return false;
+    const long sz = std::ftell(f.f);
+    if (sz < 0 || std::fseek(f.f, 0, SEEK_SET) != 0) return false;
+    out->resize((size_t)sz);
+    return sz == 0 || std::fread(out->data(), 1, (size_t)sz, f.f) == (size_t)sz;
+}
+
+}  // namespace
+
+extern "C" {
+
+// labels/<stem>.npy: np.save(path, labels.astype('int64')) (src/metaseg.py:53), byte for byte what numpy's format 1.0
+// writer produces (header dict, padded with spaces to a multiple of 64 bytes, '\n' last).
+int ecseg_npy_write_i64(const char* path, const uint8_t* labels, int H, int W) {
+    if (!path || !labels || H < 0 || W < 0) return ECSEG_E_INVALID;
+    std::string hdr = "{'descr': '<i8', 'fortran_order': False, 'shape': (" + std::to_string(H) + ", " + std::to_string(W) + "), }";
+    const size_t hlen = hdr.size() + 1;                                   // + '\n'
+    const size_t pad = 64 - ((8 + 2 + hlen) % 64);
+    hdr.append(pad, ' ');
+    hdr.push_back('\n');
+    const size_t npx = (size_t)H * W;
+    std::vector<uint8_t> buf(10 + hdr.size() + npx * 8);
+    static const uint8_t magic[8] = {0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0};
+    std::memcpy(buf.data(), magic, 8);
+    buf[8] = (uint8_t)(hdr.size() & 255); buf[9] = (uint8_t)(hdr.size() >> 8);
+    std::memcpy(buf.data() + 10, hdr.data(), hdr.size());
+    uint8_t* d = buf.data() + 10 + hdr.size();                            // (not 8-byte aligned in general: byte stores)
+    std::memset(d, 0, npx * 8);
+    for (size_t i = 0; i < npx; ++i) d[8 * i] = labels[i];                // little-endian int64 of a value 0..255
+    File out(path, "wb");
+    if (!out.f) return ECSEG_E_IO;
+    return out.put(buf.data(), buf.size()) && out.close() ? ECSEG_OK : ECSEG_E_IO;
+}
+
+// labels/<stem>.png: plt.imsave(path, I.astype('uint8'), cmap=ListedColormap(['#386cb0', '#ffff99', '#7fc97f', '#f0027f']),
+// vmin=0, vmax=4) (src/metaseg.py:47-52): class k -> colour k (values above 3 clip to 3), 8-bit RGBA, filter type 0 on
+// every scan line, zlib level 1 (the pixels are the contract, not the compressed bytes).
+int ecseg_png_write_labels(const char* path, const uint8_t* labels, int H, int W) {
+    if (!path || !labels || H <= 0 || W <= 0) return ECSEG_E_INVALID;
+    static const uint8_t pal[4][4] = {{0x38, 0x6c, 0xb0, 255}, {0xff, 0xff, 0x99, 255}, {0x7f, 0xc9, 0x7f, 255}, {0xf0, 0x02, 0x7f, 255}};
+    uint32_t pal32[4];
+    for (int k = 0; k < 4; ++k) std::memcpy(&pal32[k], pal[k], 4);
+    const size_t stride = 1 + (size_t)W * 4;
+    std::vector<uint8_t> rows((size_t)H * stride);
+    for (int y = 0; y < H; ++y) {
+        uint8_t* r = rows.data() + (size_t)y * stride;
+        *r++ = 0;
+        const uint8_t* l = labels + (size_t)y * W;
+        for (int x = 0; x < W; ++x) { const uint32_t c = pal32[l[x] > 3 ? 3 : l[x]]; std::memcpy(r + 4 * x, &c, 4); }
+    }
+    return png_write_rows(path, rows, H, W, 6, 1);
+}
+
+// 8-bit PNG of a (H, W, channels) image, channels 1 (gray), 3 (RGB) or 4 (RGBA): the red/ green/ channel images of
+// split_FISH_channels (src/image_tools.py:136-146).
+int ecseg_png_write(const char* path, const uint8_t* px, int H, int W, int channels, int level) {
+    if (!path || !px || H <= 0 || W <= 0 || (channels != 1 && channels != 3 && channels != 4) || level < 0 || level > 9) return ECSEG_E_INVALID;
+    const size_t line = (size_t)W * channels, stride = 1 + line;
+    std::vector<uint8_t> rows((size_t)H * stride);
+    for (int y = 0; y < H; ++y) {
+        rows[(size_t)y * stride] = 0;
+        std::memcpy(rows.data() + (size_t)y * stride + 1, px + (size_t)y * line, line);
+    }
+    return png_write_rows(path, rows, H, W, channels == 1 ? 0 : channels == 3 ? 2 : 6, level);
+}
+
+// dapi/<name>.tif: cv2.imwrite of an 8-bit gray image (src/utils.py:122-123): LZW + horizontal predictor, strips of
+// 8192 / width rows (the tags OpenCV 4.6 wrote into example_ecSeg/dapi.jpeg's sibling files).  invert != 0 writes 255 - img
+// (the caller holds the pre-processed image, the file holds cv2.bitwise_not of it: src/utils.py:112).
+int ecseg_tiff_write_gray8(const char* path, const uint8_t* img, int H, int W, int invert) {
+    if (!path || !img || H <= 0 || W <= 0) return ECSEG_E_INVALID;
+    int rps = 8192 / W; if (rps < 1) rps = 1; if (rps > H) rps = H;
+    const int nstrips = (H + rps - 1) / rps;
+    std::vector<uint8_t> diff((size_t)rps * W), enc((size_t)2 * rps * W + 64), data;
+    std::vector<uint32_t> offs(nstrips), cnts(nstrips);
+    data.reserve((size_t)H * W / 2 + 4096);
+    const uint8_t flip = invert ? 0xff : 0;
+    size_t pos = 8;
+    for (int s = 0; s < nstrips; ++s) {
+        const int r0 = s * rps, rows = r0 + rps <= H ? rps : H - r0;
+        for (int y = 0; y < rows; ++y) {
+            const uint8_t* src = img + (size_t)(r0 + y) * W;
+            uint8_t* d = diff.data() + (size_t)y * W;
+            d[0] = src[0] ^ flip;
+            for (int x = 1; x < W; ++x) d[x] = (uint8_t)((src[x] ^ flip) - (src[x - 1] ^ flip));   // horizontal differencing (mod 256)
+        }
+        const long long m = ecseg_lzw_encode(diff.data(), (long long)rows * W, enc.data(), (long long)enc.size());
+        if (m < 0) return ECSEG_E_INVALID;
+        offs[s] = (uint32_t)pos; cnts[s] = (uint32_t)m;
+        data.insert(data.end(), enc.begin(), enc.begin() + m);
+        if (m & 1) data.push_back(0);
+        pos += (size_t)m + (m & 1);
+    }
+    std::vector<uint8_t> extra;
+    const size_t extra_off = pos;
+    uint32_t so = offs[0], sc = cnts[0];
+    if (nstrips > 1) {
+        so = (uint32_t)(extra_off + extra.size()); for (uint32_t v : offs) put_le32(extra, v);
+        sc = (uint32_t)(extra_off + extra.size()); for (uint32_t v : cnts) put_le32(extra, v);
+    }
+    size_t ifd_off = extra_off + extra.size();
+    const bool pad = ifd_off & 1;
+    ifd_off += pad;
+    std::vector<uint8_t> ifd;
+    auto entry = [&](uint32_t tag, uint32_t typ, uint32_t count, uint32_t value) { put_le16(ifd, tag); put_le16(ifd, typ); put_le32(ifd, count); put_le32(ifd, value); };
+    put_le16(ifd, 12);
+    entry(256, 4, 1, (uint32_t)W); entry(257, 4, 1, (uint32_t)H); entry(258, 3, 1, 8); entry(259, 3, 1, 5);
+    entry(262, 3, 1, 1); entry(273, 4, (uint32_t)nstrips, so); entry(277, 3, 1, 1); entry(278, 4, 1, (uint32_t)rps);
+    entry(279, 4, (uint32_t)nstrips, sc); entry(284, 3, 1, 1); entry(317, 3, 1, 2); entry(339, 3, 1, 1);
+    put_le32(ifd, 0);
+    std::vector<uint8_t> head = {'I', 'I'};
+    put_le16(head, 42); put_le32(head, (uint32_t)ifd_off);
+    File out(path, "wb");
+    if (!out.f) return ECSEG_E_IO;
+    const uint8_t zero = 0;
+    const bool ok = out.put(head.data(), head.size()) && out.put(data.data(), data.size()) && out.put(extra.data(), extra.size()) &&
+                    (!pad || out.put(&zero, 1)) && out.put(ifd.data(), ifd.size());
+    return ok && out.close() ? ECSEG_OK : ECSEG_E_IO;
+}
+
+// imread of a baseline TIFF (src/utils.py:110): first image of the file; strips; 8 / 16-bit unsigned samples, gray or
+// interleaved RGB(A); uncompressed, LZW or Deflate; horizontal predictor; either byte order.  ecseg_tiff_info reports the
+// shape (ECSEG_E_UNSUPPORTED: a valid file this reader leaves to the Python reader; ECSEG_E_INVALID: not a TIFF / corrupt;
+// ECSEG_E_IO: cannot be opened), ecseg_tiff_read decodes into dst as native-endian samples, (H, W, spp) row-major; strips
+// that end early are zero-filled, as the Python reader does.
+int ecseg_tiff_info(const char* path, int* H, int* W, int* spp, int* bits) {
+    if (!path || !H || !W || !spp || !bits) return ECSEG_E_INVALID;
+    std::vector<uint8_t> buf;
+    if (!read_file(path, &buf)) return ECSEG_E_IO;
+    TiffInfo t;
+    const int rc = parse_tiff(buf.data(), buf.size(), &t);
+    if (rc != ECSEG_OK) return rc;
+    *H = (int)t.H; *W = (int)t.W; *spp = (int)t.spp; *bits = (int)t.bits;
+    return ECSEG_OK;
+}
+
+int ecseg_tiff_read(const char* path, void* dst, long long dst_bytes) {
+    if (!path || !dst || dst_bytes < 0) return ECSEG_E_INVALID;
+    std::vector<uint8_t> buf;
+    if (!read_file(path, &buf)) return ECSEG_E_IO;
+    TiffInfo t;
+    const int rc = parse_tiff(buf.data(), buf.size(), &t);
+    if (rc != ECSEG_OK) return rc;
+    const size_t bpp = t.bits / 8, line = (size_t)t.W * t.spp * bpp, total = line * t.H;
+    if ((unsigned long long)dst_bytes < total) return ECSEG_E_INVALID;
+    uint8_t* out = static_cast<uint8_t*>(dst);
+    for (size_t k = 0; k < t.off.size(); ++k) {
+        const size_t r0 = k * (size_t)t.rps;
+        if (r0 >= t.H) break;
+        const size_t rows = r0 + t.rps <= t.H ? t.rps : t.H - r0, want = rows * line;
+        uint8_t* d = out + r0 * line;
+        if (t.off[k] > buf.size()) return ECSEG_E_INVALID;
+        const size_t have = std::min<size_t>(t.cnt[k], buf.size() - t.off[k]);
+        const uint8_t* src = buf.data() + t.off[k];
+        size_t got = 0;
+        if (t.comp == 1) {
+            got = std::min(have, want);
+            std::memcpy(d, src, got);
+        } else if (t.comp == 5) {
+            const long long m = ecseg_lzw_decode(src, (long long)have, d, (long long)want);
+            if (m < 0) return ECSEG_E_INVALID;
+            got = (size_t)m;
+        } else {
+            uLongf cap = (uLongf)want;
+            const int z = uncompress(d, &cap, src, (uLong)have);
+            if (z != Z_OK && z != Z_BUF_ERROR) return ECSEG_E_INVALID;
+            got = z == Z_OK ? (size_t)cap : 0;
+            if (z == Z_BUF_ERROR) {                                   // more data than the strip holds: keep what fits
+                z_stream zs; std::memset(&zs, 0, sizeof zs);
+                if (inflateInit(&zs) != Z_OK) return ECSEG_E_INVALID;
+                zs.next_in = const_cast<Bytef*>(src); zs.avail_in = (uInt)have; zs.next_out = d; zs.avail_out = (uInt)want;
+                const int zr = inflate(&zs, Z_FINISH);
+                got = want - zs.avail_out;
+                inflateEnd(&zs);
+                if (zr != Z_STREAM_END && zr != Z_BUF_ERROR && zr != Z_OK) return ECSEG_E_INVALID;
+            }
+        }
+        if (got < want) std::memset(d + got, 0, want - got);
+        // samples to native (little-endian) order, then undo the horizontal predictor per sample channel
+        if (bpp == 2) {
+            uint16_t* p = reinterpret_cast<uint16_t*>(d);
+            const size_t ns = rows * (size_t)t.W * t.spp;
+            if (!t.le) for (size_t i = 0; i < ns; ++i) p[i] = (uint16_t)((p[i] << 8) | (p[i] >> 8));
+            if (t.pred == 2)
+                for (size_t y = 0; y < rows; ++y) {
+                    uint16_t* q = p + y * (size_t)t.W * t.spp;
+                    for (size_t i = t.spp; i < (size_t)t.W * t.spp; ++i) q[i] = (uint16_t)(q[i] + q[i - t.spp]);
+                }
+        } else if (t.pred == 2) {
+            for (size_t y = 0; y < rows; ++y) {
+                uint8_t* q = d + y * line;
+                for (size_t i = t.spp; i < line; ++i) q[i] = (uint8_t)(q[i] + q[i - t.spp]);
+            }
+        }
+    }
+    const size_t covered = std::min<size_t>(t.off.size() * (size_t)t.rps, t.H);
+    if (covered < t.H) std::memset(out + covered * line, 0, (t.H - covered) * line);
+    return ECSEG_OK;
+}
+
+}  // extern "C"

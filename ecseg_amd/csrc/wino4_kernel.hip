@@ -35,10 +35,6 @@
 #include "common.h"
 #include "device_util.h"
 
-#ifndef W4_VARIANT
-#define W4_VARIANT 0
-#endif
-
 namespace ecseg {
 
 namespace {
@@ -69,37 +65,53 @@ __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {   
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst), "n"(OFF) : "memory");
 }
 
-// (experiment builds: W4_VARIANT 50 = halo pieces with the nt cache policy, 51 = filter pieces nt, 52 = halo pieces sc1)
-template <int OFF>
-__device__ __forceinline__ void glds16_pol(const float* gsrc, unsigned lds_dst) {
-    unsigned keep;
-#if W4_VARIANT == 52
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%3 sc1\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst), "n"(OFF) : "memory");
-#else
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%3 nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst), "n"(OFF) : "memory");
-#endif
-}
+// Interpolation points {0, +-a, +-b, inf} (common.h: W4_PA, W4_PB) and the constants of B^T and A^T they give:
+//   B^T rows (monic Lagrange numerators): p = 0: [a2b2, 0, -(a2+b2), 0, 1, 0]      p = inf: [0, a2b2, 0, -(a2+b2), 0, 1]
+//                                         p = +-a: [0, -+a b2, -b2, +-a, 1, 0]     p = +-b: [0, -+a2 b, -a2, +-b, 1, 0]
+//   A^T = [1 1 1 1 1 0; 0 a -a b -b 0; 0 a2 a2 b2 b2 0; 0 a3 -a3 b3 -b3 1]
+// All constants are exact in float32 for the dyadic points chosen.
+constexpr float KA = (float)W4_PA, KB = (float)W4_PB, KA2 = KA * KA, KB2 = KB * KB, KA3 = KA2 * KA, KB3 = KB2 * KB;
+constexpr float KP = KA2 * KB2, KS = -(KA2 + KB2);
+static_assert((double)KA2 == W4_PA * W4_PA && (double)KB3 == W4_PB * W4_PB * W4_PB && (double)KP == W4_PA * W4_PA * W4_PB * W4_PB &&
+              (double)KA3 == W4_PA * W4_PA * W4_PA && (double)(KA * KB2) == W4_PA * W4_PB * W4_PB && (double)(KA2 * KB) == W4_PA * W4_PA * W4_PB,
+              "the Winograd points must keep every transform constant exact in float32");
 
 }  // namespace
 
-// ABL: timing-only ablations for tools/w4_ablate.py (ECSEG_W4_ABL): 1 no halo LDS reads, 2 no filter DMA, 4 no halo DMA,
-// 8 no MFMA, 32 instruction mix of a (row, column-half) wave split, 64 instruction mix of a transform shared between
-// the two channel-half waves of a row through LDS, 128 halo pieces from consecutive addresses; STAMP (ECSEG_W4_ABL=100): s_memtime stamps
+// Diagnostics (timing-only ablations, in-kernel cycle stamps) live in wino4_diag.inc and exist only in the -DECSEG_DIAG
+// build (tools/build_variants.sh diag); the product translation unit has ONE code path: every hook below is empty.
+#ifdef ECSEG_DIAG
+#include "wino4_diag.inc"
+#else
+#define W4_TEMPLATE template <bool HEAD = false, bool SPLIT = false>
+#define W4_DIAG_ENTRY()
+#define W4_DIAG_SKIP_HALO_DMA()
+#define W4_DIAG_SKIP_FILTER_DMA()
+#define W4_DIAG_FAKE_TRANSFORM(grp)
+#define W4_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A, B, ACC, 0, 0, 0)
+#define W4_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define W4_KSTAMP_BEGIN()
+#define WSTAMP(i)
+#define W4_KSTAMP_DUMP()
+#define W4_ESTAMP_BEGIN()
+#define ESTAMP(i)
+#define W4_ESTAMP_DUMP()
+#define W4_DIAG_SELECT(kern, p, lds)
+#endif
+
 // SPLIT (a lone 32-channel output block, Cout == 32): the two channel-half waves of a transform row would otherwise
 // multiply real channels (ch = 0) and zero padding (ch = 1).  Instead both work on the SAME 32 outputs and split the 8
 // input channels of a group: wave (ch, xi) runs only filter stage ch (channels 2 ch, 2 ch + 1 of both halo planes) of every
 // group, from the ch = 0 slot of the unchanged filter image; the partial sums meet in the exchange image of the output
 // stage (ch = 0 writes, ch = 1 adds).  Per group a wave has two phases (T, S) instead of three; waves 4-11 run S one
 // group late (phase rotation).
-template <int ABL, bool STAMP = false, bool HEAD = false, bool SPLIT = false>
+W4_TEMPLATE
 __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_x, int regs_y, int npairs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* Hs = reinterpret_cast<f32x4*>(smem);              // [3][W4_HS]        halo ring (group g -> buffer g % 3)
     f32x4* Bs = Hs + 3 * W4_HS;                              // [12][2][W4_BWS]   per-wave filter stages
 
-    const unsigned long long t_entry = STAMP ? __builtin_amdgcn_s_memtime() : 0;
+    W4_DIAG_ENTRY();
     const unsigned lds_base = (unsigned)(size_t)(lptr_t)smem;   // LDS byte address of the dynamic segment
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -111,12 +123,8 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
     // workgroups running together on an XCD then share each input halo in L2 between G of them and keep only G filter
     // slabs streaming (spatial position fastest alone re-read the input Cout / 64 times from the Infinity Cache: 11-13x
     // the algorithmic bytes on the Cin = 1024 layers; channel block fastest alone streams Cout / 64 slabs at once): +1.4 %.
-#if W4_VARIANT == 44
-    const unsigned G = 1u;
-#else
     const unsigned nblk_all = gridDim.x / (unsigned)npairs;
     const unsigned G = (nblk_all & 3u) == 0 ? 4u : (nblk_all & 1u) == 0 ? 2u : 1u;
-#endif
     const unsigned lo = bid % G, rest = bid / G;
     const int pair = (int)(rest % (unsigned)npairs);
     const int nb = (int)((rest / (unsigned)npairs) * G + lo);
@@ -165,41 +173,26 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             if (img >= 0 && iy >= 0 && iy < H && ix >= 0 && ix < W)
                 d = (unsigned long long)(size_t)(p.in.p + (((size_t)img * H + iy) * W + ix) * p.in.cs + 4 * h) | 1ull | (h ? 2ull : 0ull);
         }
-        if (ABL & 128) {
-            // timing model of a channel-blocked activation layout: the 64 lanes of a piece read 1 KB of consecutive
-            // addresses (distinct per workgroup and group, wrong data)
-            const size_t tensor = (size_t)p.n * H * W * p.in.cs;
-            const size_t off = (((size_t)pair * 4099u) % (tensor / 8192 > 201 ? tensor / 8192 - 200 : 1)) * 8192 + (size_t)a * 4;
-            d = (unsigned long long)(size_t)(p.in.p + off) | 1ull;
-        }
         Hd[i * 768] = d;
     }
     auto dma_halo_piece = [&](int grp, auto ii) __attribute__((always_inline)) {            // piece ii (0 | 1) of halo group grp (< ngroups)
-        if (ABL & 4) return;
+        W4_DIAG_SKIP_HALO_DMA();
         constexpr int i = decltype(ii)::value;
         unsigned long long d = Hd[i * 768];
         // Cin % 8 == 4: the upper channel half of the last group does not exist - its lanes (bit 1) read the zero page
         if (tail4 && grp == ngroups - 1 && (d & 2ull)) d = (unsigned long long)(size_t)p.zero;
-        const float* src = reinterpret_cast<const float*>((size_t)(d & ~3ull)) + (d & 1ull ? ((ABL & 128) ? grp * 6144 : grp * 8) : 0);
-#if W4_VARIANT == 50 || W4_VARIANT == 52
-        glds16_pol<0>(src, lds_base + (unsigned)((grp % 3) * W4_HS + 64 * (wave + 12 * i)) * 16u);
-#else
+        const float* src = reinterpret_cast<const float*>((size_t)(d & ~3ull)) + (d & 1ull ? grp * 8 : 0);
         glds16<0>(src, lds_base + (unsigned)((grp % 3) * W4_HS + 64 * (wave + 12 * i)) * 16u);
-#endif
     };
     // ---- filter DMA: wt4[nb][stage][wave][point nu][h][cout 32][k 2], 768 floats per wave and stage ----
     const float* w_src = p.wt + ((size_t)nb * nstages * 12 + (SPLIT ? xi : wave)) * 768 + lane * 4;
     f32x4* Bw = Bs + wave * 2 * W4_BWS;
     auto dma_filter_piece = [&](int stage, int buf, auto kk) __attribute__((always_inline)) {
-        if (ABL & 2) return;
+        W4_DIAG_SKIP_FILTER_DMA();
         constexpr int k = decltype(kk)::value;
         const float* g = w_src + (size_t)stage * (12 * 768);
         // the instruction offset advances the global AND the LDS address: one M0 for the three pieces
-#if W4_VARIANT == 51
-        glds16_pol<k * 1024>(g, lds_base + (unsigned)(3 * W4_HS + (wave * 2 + buf) * W4_BWS) * 16u);
-#else
         glds16<k * 1024>(g, lds_base + (unsigned)(3 * W4_HS + (wave * 2 + buf) * W4_BWS) * 16u);
-#endif
     };
 
     // ---- A-operand lane -> tile.  ds_read_b128 serves lanes {0-3,12-15,20-27} and {4-11,16-19,28-31} of each half
@@ -209,15 +202,15 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
     const int ty = (q8 == 0 || q8 == 1) ? 0 : (q8 == 2 || q8 == 3) ? 1 : (q8 == 4 || q8 == 5) ? 2 : 3;
     const int a_lane = (tg * 18 + ty) * 36 + lh * 18 + tx;       // slot of halo pixel (4 ty, 4 tx) of the lane's tile
 
-    // row transform of wave xi: t = c0 d[r0] + c1 d[r1] + c2 d[r2] + c3 d[r3]
-    int rr0, rr1, rr2, rr3; float c0, c1, c2, c3;
+    // row transform of wave xi (row xi of B^T): t = c0 d[r0] + c1 d[r1] + c2 d[r2] + d[r3]  (rows 0 and 5: three terms)
+    int rr0, rr1, rr2, rr3; float c0, c1, c2;
     switch (xi) {
-        case 0:  rr0 = 0; rr1 = 2; rr2 = 4; rr3 = 4; c0 = 4.f;  c1 = -5.f; c2 = 1.f;  c3 = 0.f; break;
-        case 1:  rr0 = 1; rr1 = 2; rr2 = 3; rr3 = 4; c0 = -4.f; c1 = -4.f; c2 = 1.f;  c3 = 1.f; break;
-        case 2:  rr0 = 1; rr1 = 2; rr2 = 3; rr3 = 4; c0 = 4.f;  c1 = -4.f; c2 = -1.f; c3 = 1.f; break;
-        case 3:  rr0 = 1; rr1 = 2; rr2 = 3; rr3 = 4; c0 = -2.f; c1 = -1.f; c2 = 2.f;  c3 = 1.f; break;
-        case 4:  rr0 = 1; rr1 = 2; rr2 = 3; rr3 = 4; c0 = 2.f;  c1 = -1.f; c2 = -2.f; c3 = 1.f; break;
-        default: rr0 = 1; rr1 = 3; rr2 = 5; rr3 = 5; c0 = 4.f;  c1 = -5.f; c2 = 1.f;  c3 = 0.f; break;
+        case 0:  rr0 = 0; rr1 = 2; rr2 = 4; rr3 = 4; c0 = KP;        c1 = KS;   c2 = 1.f; break;
+        case 1:  rr0 = 1; rr1 = 2; rr2 = 3; rr3 = 4; c0 = -KA * KB2; c1 = -KB2; c2 = KA;  break;
+        case 2:  rr0 = 1; rr1 = 2; rr2 = 3; rr3 = 4; c0 = KA * KB2;  c1 = -KB2; c2 = -KA; break;
+        case 3:  rr0 = 1; rr1 = 2; rr2 = 3; rr3 = 4; c0 = -KA2 * KB; c1 = -KA2; c2 = KB;  break;
+        case 4:  rr0 = 1; rr1 = 2; rr2 = 3; rr3 = 4; c0 = KA2 * KB;  c1 = -KA2; c2 = -KB; break;
+        default: rr0 = 1; rr1 = 3; rr2 = 5; rr3 = 5; c0 = KP;        c1 = KS;   c2 = 1.f; break;
     }
     const int ro0 = 36 * w4_pos(rr0), ro1 = 36 * w4_pos(rr1), ro2 = 36 * w4_pos(rr2), ro3 = 36 * w4_pos(rr3);
 
@@ -234,41 +227,18 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
     }
     // ---- row transform of group grp: t[j] for the six halo columns of the lane's tile, 4 channels each ----
     // Rows 1-4 of B^T end in +1 (t = c0 d[r0] + c1 d[r1] + c2 d[r2] + d[r3]: three fmas), rows 0 and 5 have only three
-    // terms, the last with +1 (t = c0 d[r0] + c1 d[r1] + d[r2]: three reads, two fmas).
+    // terms, the last with +1 (t = c0 d[r0] + c1 d[r1] + d[r2]: three reads, two fmas) - for any point set of this shape.
     const bool inner_row = xi >= 1 && xi <= 4;
     auto transform = [&](int grp, auto c_src, auto c_num) __attribute__((always_inline)) {   // t[j][k] = row transform of channel c_src + k of the lane's slot, k < c_num (SPLIT: the wave's two channels, in components 0 and 1)
         constexpr int CS = decltype(c_src)::value, CN = decltype(c_num)::value;
         const f32x4* A = Hs + (grp % 3) * W4_HS + a_lane;
         constexpr int cp[6] = {w4_cpos(0), w4_cpos(1), w4_cpos(2), w4_cpos(3), w4_cpos(4), w4_cpos(5)};
-        if (ABL & 1) {
-#pragma unroll
-            for (int j = 0; j < 6; ++j) t[j] = f32x4{c0, c1, c2, c3} * (float)(j + grp);
-            return;
-        }
+        W4_DIAG_FAKE_TRANSFORM(grp);
         // scalar fmas on purpose (file is built with -fno-slp-vectorize): packed f32 VALU ops (v_pk_fma_f32) stall the
         // SIMD beside MFMAs, single v_fma_f32 hide in the matrix pipe's shadow
-        if (ABL & 64) {
-            // timing model of a transform shared by the two channel-half waves of a row: each wave transforms 2 of the 4
-            // channels per lane (b64 halo reads, half the fmas), the column transform of ONE stage, and hands its 12
-            // values to the partner through LDS (3 b128 writes here, 3 + 3 b128 reads in the MFMA stages)
-            const f32x2* A2 = reinterpret_cast<const f32x2*>(A) + ch;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const f32x2 d0 = A2[2 * (ro0 + cp[j])], d1 = A2[2 * (ro1 + cp[j])], d2 = A2[2 * (ro2 + cp[j])], d3 = A2[2 * (ro3 + cp[j])];
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-                    t[j][c] = inner_row ? __builtin_fmaf(c0, d0[c], __builtin_fmaf(c1, d1[c], __builtin_fmaf(c2, d2[c], d3[c])))
-                                        : __builtin_fmaf(c0, d0[c], __builtin_fmaf(c1, d1[c], d2[c]));
-                t[j][2] = t[j][0]; t[j][3] = t[j][1];
-                asm volatile("" : "+v"(t[j]));
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            return;
-        }
         if (inner_row) {
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                if ((ABL & 32) && j == 5) { t[5] = t[4]; continue; }      // timing model of a (row, column-half) wave split
                 const f32x4 d0 = A[ro0 + cp[j]], d1 = A[ro1 + cp[j]], d2 = A[ro2 + cp[j]], d3 = A[ro3 + cp[j]];
 #pragma unroll
                 for (int c = 0; c < CN; ++c)
@@ -279,7 +249,6 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         } else {
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                if ((ABL & 32) && j == 5) { t[5] = t[4]; continue; }
                 const f32x4 d0 = A[ro0 + cp[j]], d1 = A[ro1 + cp[j]], d2 = A[ro2 + cp[j]];
 #pragma unroll
                 for (int c = 0; c < CN; ++c) t[j][c] = __builtin_fmaf(c0, d0[CS + c], __builtin_fmaf(c1, d1[CS + c], d2[CS + c]));
@@ -288,38 +257,40 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             }
         }
     };
+#if defined(W4_CT) && W4_CT == 1
+    float sNB2, sNA2, sP, sS, sA, sNA, sB, sNB;
+    asm volatile("s_mov_b32 %0, %1" : "=s"(sNB2) : "s"(-KB2)); asm volatile("s_mov_b32 %0, %1" : "=s"(sNA2) : "s"(-KA2));
+    asm volatile("s_mov_b32 %0, %1" : "=s"(sP) : "s"(KP)); asm volatile("s_mov_b32 %0, %1" : "=s"(sS) : "s"(KS));
+    asm volatile("s_mov_b32 %0, %1" : "=s"(sA) : "s"(KA)); asm volatile("s_mov_b32 %0, %1" : "=s"(sNA) : "s"(-KA));
+    asm volatile("s_mov_b32 %0, %1" : "=s"(sB) : "s"(KB)); asm volatile("s_mov_b32 %0, %1" : "=s"(sNB) : "s"(-KB));
+#endif
     // ---- one filter stage (2 of the group's 4 channel pairs; buffer ss): column transform + 12 MFMAs ----
     auto mfma_stage = [&](int ss, int fbuf, int next_stage, int halo_grp) __attribute__((always_inline)) {     // ss: channel pair of the group, fbuf: filter buffer; halo_grp: group to prefetch, < 0: none
         float V[6][2];
-        if ((ABL & 64) && ss == 1) {
-            // stage 1 of the shared-transform model: the 12 values come from the partner through LDS
-            f32x4* X = Hs + 3 * W4_HS + (wave * 2 + 1) * W4_BWS + 3 * 64 + lane;     // (scratch behind the wave's own filter stage)
-            const f32x4 x0 = X[0], x1 = X[1], x2 = X[2];
-            asm volatile("" :: "v"(x0), "v"(x1), "v"(x2));
-#pragma unroll
-            for (int v = 0; v < 6; ++v) { V[v][0] = t[v][0]; V[v][1] = t[v][1]; }
-        } else
 #pragma unroll
         for (int e = 0; e < 2; ++e) {   // V[nu] = sum_j B^T[nu][j] t[j], scalar ops (see transform)
             const int c = 2 * ss + e;
             const float u0 = t[0][c], u1 = t[1][c], u2 = t[2][c], u3 = t[3][c], u4 = t[4][c], u5 = t[5][c];
-            const float a42 = __builtin_fmaf(-4.f, u2, u4), a31 = __builtin_fmaf(-4.f, u1, u3);
-            const float b42 = u4 - u2, b31 = 2.f * (u3 - u1);
-            V[0][e] = __builtin_fmaf(4.f, u0, __builtin_fmaf(-5.f, u2, u4));
-            V[1][e] = a42 + a31;
-            V[2][e] = a42 - a31;
-            if (ABL & 32) { V[3][e] = V[0][e]; V[4][e] = V[1][e]; V[5][e] = V[2][e]; continue; }
-            V[3][e] = b42 + b31;
-            V[4][e] = b42 - b31;
-            V[5][e] = __builtin_fmaf(4.f, u1, __builtin_fmaf(-5.f, u3, u5));
-        }
-        if ((ABL & 64) && ss == 0) {
-            f32x4* X = Hs + (halo_grp >= 0 ? 0 : 0) + 3 * W4_HS + 12 * 2 * W4_BWS - 3 * 64 * 12 + wave * 3 * 64 + lane;   // scratch: tail of the filter area (timing only)
-            X[0] = f32x4{V[0][0], V[0][1], V[1][0], V[1][1]};
-            X[64] = f32x4{V[2][0], V[2][1], V[3][0], V[3][1]};
-            X[128] = f32x4{V[4][0], V[4][1], V[5][0], V[5][1]};
-            const f32x4 x0 = X[0], x1 = X[64], x2 = X[128];
-            asm volatile("" :: "v"(x0), "v"(x1), "v"(x2));
+            // points +-a share an even part (u4 - b2 u2) and an odd part (u3 - b2 u1), points +-b likewise with a2
+#if defined(W4_CT) && W4_CT == 1
+            const float ea = __builtin_fmaf(sNB2, u2, u4), oa = __builtin_fmaf(sNB2, u1, u3);
+            const float eb = __builtin_fmaf(sNA2, u2, u4), ob = __builtin_fmaf(sNA2, u1, u3);
+            V[0][e] = __builtin_fmaf(sP, u0, __builtin_fmaf(sS, u2, u4));
+            V[1][e] = __builtin_fmaf(sA, oa, ea);
+            V[2][e] = __builtin_fmaf(sNA, oa, ea);
+            V[3][e] = __builtin_fmaf(sB, ob, eb);
+            V[4][e] = __builtin_fmaf(sNB, ob, eb);
+            V[5][e] = __builtin_fmaf(sP, u1, __builtin_fmaf(sS, u3, u5));
+#else
+            const float ea = __builtin_fmaf(-KB2, u2, u4), oa = __builtin_fmaf(-KB2, u1, u3);
+            const float eb = __builtin_fmaf(-KA2, u2, u4), ob = __builtin_fmaf(-KA2, u1, u3);
+            V[0][e] = __builtin_fmaf(KP, u0, __builtin_fmaf(KS, u2, u4));
+            V[1][e] = __builtin_fmaf(KA, oa, ea);
+            V[2][e] = __builtin_fmaf(-KA, oa, ea);
+            V[3][e] = __builtin_fmaf(KB, ob, eb);
+            V[4][e] = __builtin_fmaf(-KB, ob, eb);
+            V[5][e] = __builtin_fmaf(KP, u1, __builtin_fmaf(KS, u3, u5));
+#endif
         }
         const f32x2* Bp = reinterpret_cast<const f32x2*>(Bw + fbuf * W4_BWS) + lane;
         f32x2 w2[6];
@@ -332,8 +303,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         for (int e = 0; e < 2; ++e)
 #pragma unroll
             for (int v = 0; v < 6; ++v) {
-                if (ABL & 8) acc[v][0] += V[v][e] * w2[v][e];
-                else acc[v] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[v][e], w2[v][e], acc[v], 0, 0, 0);
+                W4_MFMA(acc[v], V[v][e], w2[v][e]);
                 if (e == 0 && (v == 1 || v == 3 || v == 5)) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (v == 1) dma_filter_piece(next_stage, fbuf ^ 1, std::integral_constant<int, 0>{});
@@ -349,12 +319,9 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
                 }
             }
     };
-#define W4_WAIT(n) do { if (ABL & 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); } while (0)
 #define W4_BARRIER() asm volatile("s_barrier" ::: "memory")
 
-    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk0 = 0, tk = 0;
-#define WSTAMP(i) do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); st[i] += now - tk; tk = now; __builtin_amdgcn_sched_barrier(0); } } while (0)
-    if (STAMP) { tk0 = tk = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
+    W4_KSTAMP_BEGIN();
     // Phase rotation.  Per 8-channel group a wave has three phases: T (halo LDS reads + row transform, latency-bound),
     // S0 and S1 (12 MFMAs each).  The barrier would keep the three waves of a SIMD (w, w + 4, w + 8) in the same phase,
     // with the matrix pipe idle while all of them transform.  So the barrier sits at a different point of each wave's
@@ -365,7 +332,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
 #define W4_SB() __builtin_amdgcn_sched_barrier(0)
 // T(g): raised priority for the few long-latency instructions of the transform; afterwards the MFMA phases run at a
 // priority that orders the three waves of a SIMD (class 2 first): the wave that is latest in the rotation gets the pipe
-#define W4_T(g, PR) do { __builtin_amdgcn_s_setprio(3); transform(g, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}); __builtin_amdgcn_s_setprio(W4_VARIANT == 12 ? (PR) + 1 : (PR)); } while (0)
+#define W4_T(g, PR) do { __builtin_amdgcn_s_setprio(3); transform(g, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}); __builtin_amdgcn_s_setprio(PR); } while (0)
     // S0(g): filter stage 2g has landed (it is the youngest thing this wave issued) -> vmcnt(0); streams stage 2g+1 and
     // the halo of group g+2.  S1(g): only the two halo pieces issued after stage 2g+1 may still fly -> vmcnt(2).
 #define W4_S0(g) do { W4_SB(); W4_WAIT(0); W4_SB(); mfma_stage(0, 0, 2 * (g) + 1, (g) + 2 < ngroups ? (g) + 2 : -1); } while (0)
@@ -468,23 +435,14 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
 #undef W4_TS
 #undef W4_SS
 #undef W4_SB
-    if (STAMP && blockIdx.x == gridDim.x / 2 && lane == 0) {
-        float* dbg = const_cast<float*>(p.zero) + 16 + wave * 10;
-        for (int i = 0; i < 8; ++i) dbg[i] = (float)st[i];
-        dbg[8] = (float)(__builtin_amdgcn_s_memtime() - tk0);
-        dbg[9] = (float)ngroups;
-        dbg[6] = (float)(tk0 - t_entry);                     // prologue
-    }
-#undef WSTAMP
-#undef W4_WAIT
+    W4_KSTAMP_DUMP();
 #undef W4_BARRIER
 
     // ---- output stage: two passes (channel halves) through a [xi][x][tile][32 couts] exchange image ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the compiler does not see the asm LDS-DMAs
     float* Rs = reinterpret_cast<float*>(smem);
     const int Cout = p.out.c;
-    unsigned long long et[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ek = STAMP ? __builtin_amdgcn_s_memtime() : 0;
-#define ESTAMP(i) do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); et[i] += now - ek; ek = now; __builtin_amdgcn_sched_barrier(0); } } while (0)
+    W4_ESTAMP_BEGIN();
     // Work split of the combine step: per pass 2048 "half items" (channel quad q, column x, tile n, row pair yh) over the
     // 768 threads in three rounds (the last one 2/3 full) - with whole items (1024 over 768 threads) the first four
     // waves did two rounds of 4 rows while the others idled behind them.
@@ -511,7 +469,8 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             const float m0 = acc[0][e], m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e], m5 = acc[5][e];
             const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
             float* o = Rs + (xi * 4) * W4_RPLANE + tl * 32 + li;
-            const float r0 = m0 + s12 + s34, r1 = d12 + 2.f * d34, r2 = s12 + 4.f * s34, r3 = d12 + 8.f * d34 + m5;
+            const float r0 = m0 + s12 + s34, r1 = __builtin_fmaf(KA, d12, KB * d34), r2 = __builtin_fmaf(KA2, s12, KB2 * s34),
+                        r3 = __builtin_fmaf(KA3, d12, __builtin_fmaf(KB3, d34, m5));
             if (add) {                                           // (this lane's four words: nobody else touches them in this phase)
                 o[0 * W4_RPLANE] += r0; o[1 * W4_RPLANE] += r1; o[2 * W4_RPLANE] += r2; o[3 * W4_RPLANE] += r3;
             } else {
@@ -556,10 +515,10 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             f32x4 y[2];
             if (yh == 0) {
                 y[0] = qe + s12 + s34 + bv;
-                y[1] = d12 + 2.f * d34 + bv;
+                y[1] = KA * d12 + KB * d34 + bv;
             } else {
-                y[0] = s12 + 4.f * s34 + bv;
-                y[1] = d12 + 8.f * d34 + qe + bv;
+                y[0] = KA2 * s12 + KB2 * s34 + bv;
+                y[1] = KA3 * d12 + KB3 * d34 + qe + bv;
             }
             const int oy = (g ? r_y0[1] : r_y0[0]) + 4 * nty + 2 * yh, ox = (g ? r_x0[1] : r_x0[0]) + 4 * ntx + x;
             float* o = p.out.p + (((size_t)img * H + oy) * W + ox) * p.out.cs + co;
@@ -639,14 +598,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             }
         }
     }
-    if (STAMP && blockIdx.x == gridDim.x / 2 && lane == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        float* dbg = const_cast<float*>(p.zero) + 16 + wave * 10;
-        dbg[7] = (float)(__builtin_amdgcn_s_memtime() - t_entry);   // whole workgroup, output stores retired
-        float* dbe = const_cast<float*>(p.zero) + 16 + 120 + wave * 4;
-        for (int i = 0; i < 4; ++i) dbe[i] = (float)et[i];
-    }
-#undef ESTAMP
+    W4_ESTAMP_DUMP();
 }
 
 // Eligibility beyond "3x3, stride 1, pad 1, same size" (checked by the caller): extents multiples of 16, input channels
@@ -666,28 +618,10 @@ hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s) {
     size_t lds = (size_t)(3 * W4_HS + 12 * 2 * W4_BWS) * 16 + 2 * 768 * 8;
     const size_t lds_epi = (size_t)24 * W4_RPLANE * 4;
     if (lds_epi > lds) lds = lds_epi;
-    void (*kern)(ConvParams, int, int, int) = conv_wino4_kernel<0>;
-    if (p.head_w != nullptr) kern = conv_wino4_kernel<0, false, true>;
-    else if (p.out.c == 32 && p.w4_split) kern = conv_wino4_kernel<0, false, false, true>;   // a lone 32-channel block: split K
-#ifdef ECSEG_DIAG
-    // timing-only ablations / in-kernel cycle stamps: diagnostic builds only (tools/build_variants.sh -DECSEG_DIAG);
-    // the shipped library has none of these kernels
-    static const int abl = getenv("ECSEG_W4_ABL") ? atoi(getenv("ECSEG_W4_ABL")) : 0;
-    if (p.head_w == nullptr) switch (abl) {
-        case 1: kern = conv_wino4_kernel<1>; break;
-        case 2: kern = conv_wino4_kernel<2>; break;
-        case 3: kern = conv_wino4_kernel<3>; break;
-        case 6: kern = conv_wino4_kernel<6>; break;
-        case 7: kern = conv_wino4_kernel<7>; break;
-        case 8: kern = conv_wino4_kernel<8>; break;
-        case 32: kern = conv_wino4_kernel<32>; break;
-        case 64: kern = conv_wino4_kernel<64>; break;
-        case 128: kern = conv_wino4_kernel<128>; break;
-        case 100: kern = conv_wino4_kernel<0, true>; break;        // in-kernel cycle stamps (tools/w4_stamp_probe.py)
-        default: break;
-    }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-#endif
+    void (*kern)(ConvParams, int, int, int) = conv_wino4_kernel<false, false>;
+    if (p.head_w != nullptr) kern = conv_wino4_kernel<true, false>;
+    else if (p.out.c == 32 && p.w4_split) kern = conv_wino4_kernel<false, true>;   // a lone 32-channel block: split K
+    W4_DIAG_SELECT(kern, p, lds);
     static DeviceOnce attr_set[3];                          // the attribute is per device
     const int which = p.head_w != nullptr ? 1 : (p.out.c == 32 && p.w4_split) ? 2 : 0;
     if (attr_set[which].first()) {

@@ -37,8 +37,9 @@ def make_records(start, n_local, padded_len, n_ec=None, overlay=None, status=Non
     return rec
 
 
-def init_process_group(backend=None):
-    """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE / MASTER_*)."""
+def init_process_group(backend=None, device=None):
+    """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE / MASTER_*).  ``device``: the physical
+    GPU index this rank computes on (default LOCAL_RANK) - the RCCL communicator is bound to the same device."""
     import torch
     import torch.distributed as dist
     if dist.is_initialized():
@@ -53,7 +54,7 @@ def init_process_group(backend=None):
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
     kw = {}
     if backend == 'nccl':
-        local = int(os.environ.get('LOCAL_RANK', rank))
+        local = int(os.environ.get('LOCAL_RANK', rank)) if device is None else int(device)
         torch.cuda.set_device(local)
         try:
             kw['device_id'] = torch.device('cuda', local)

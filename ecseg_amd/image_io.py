@@ -9,12 +9,13 @@
 LZW runs in the native library (host code, csrc/host_codec.cpp); everything else is numpy / zlib.
 """
 import ctypes as C
+import os
 import struct
 import zlib
 
 import numpy as np
 
-from ._lib import load_library
+from ._lib import E_IO, E_UNSUPPORTED, load_library
 
 # class k -> RGBA of ListedColormap(['#386cb0', '#ffff99', '#7fc97f', '#f0027f']) with vmin=0, vmax=4
 # (reference src/metaseg.py:47,52)
@@ -96,8 +97,34 @@ def _read_ifd(buf, off, bo, big):
     return tags
 
 
-def read_tiff(path):
+def _native_tiff(path):
+    """Whole-file native reader (csrc/host_io.cpp, runs without the GIL): baseline strips, 8 / 16-bit unsigned, none / LZW /
+    Deflate, predictor 1 / 2.  -> array, or None when the layout is left to the Python reader below."""
+    lib = load_library()
+    H, W, spp, bits = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    enc = os.fsencode(path)
+    rc = lib.ecseg_tiff_info(enc, C.byref(H), C.byref(W), C.byref(spp), C.byref(bits))
+    if rc == E_UNSUPPORTED:
+        return None
+    if rc == E_IO:
+        raise OSError('cannot read %s' % path)
+    if rc != 0:
+        raise TiffError('%s is not a readable TIFF file' % path)
+    out = np.empty((H.value, W.value, spp.value), np.uint8 if bits.value == 8 else np.uint16)
+    rc = lib.ecseg_tiff_read(enc, out.ctypes.data_as(C.c_void_p), out.nbytes)
+    if rc == E_UNSUPPORTED:
+        return None
+    if rc != 0:
+        raise TiffError('corrupt TIFF file %s' % path)
+    return out[..., 0] if spp.value == 1 else out
+
+
+def read_tiff(path, native=True):
     """First image of a TIFF file -> numpy array (H, W) or (H, W, S), dtype uint8 / uint16 (or what the file holds)."""
+    if native:
+        a = _native_tiff(path)
+        if a is not None:
+            return a
     with open(path, 'rb') as f:
         buf = f.read()
     if buf[:2] == b'II':
@@ -186,6 +213,17 @@ def read_tiff(path):
     return out[..., 0] if spp == 1 else out
 
 
+def image_shape(path):
+    """Shape of what ``imread(path)`` returns, from the file header where possible (resume check of `make metaseg`)."""
+    if str(path).lower().endswith('.npy'):
+        return np.load(path, mmap_mode='r').shape
+    lib = load_library()
+    H, W, spp, bits = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    if lib.ecseg_tiff_info(os.fsencode(path), C.byref(H), C.byref(W), C.byref(spp), C.byref(bits)) == 0:
+        return (H.value, W.value) if spp.value == 1 else (H.value, W.value, spp.value)
+    return read_tiff(path).shape
+
+
 def imread(path):
     """``skimage.io.imread`` stand-in for the inputs ``get_imgs`` globs (``*.tif`` and ``*.npy``, src/utils.py:105-110)."""
     if str(path).lower().endswith('.npy'):
@@ -197,11 +235,26 @@ def _ifd_entry(tag, typ, count, value):
     return struct.pack('<HHII', tag, typ, count, value)
 
 
-def write_tiff_gray8(path, img):
-    """8-bit grayscale TIFF, LZW + horizontal predictor, strips of 8192 // width rows (OpenCV imwrite defaults)."""
+def _check_write(rc, path):
+    if rc == E_IO:
+        raise OSError('cannot write %s' % path)
+    if rc != 0:
+        raise ValueError('could not encode %s (status %d)' % (path, rc))
+
+
+def write_tiff_gray8(path, img, invert=False, native=True):
+    """8-bit grayscale TIFF, LZW + horizontal predictor, strips of 8192 // width rows (OpenCV imwrite defaults).
+    ``invert``: store 255 - img (``cv2.bitwise_not``, src/utils.py:112).  The native writer (csrc/host_io.cpp) and the
+    Python one below produce the same bytes (tests/test_io_fixtures.py)."""
     img = np.ascontiguousarray(img, np.uint8)
     if img.ndim != 2:
         raise ValueError('write_tiff_gray8 takes a 2-D uint8 image')
+    if native and img.size:
+        _check_write(load_library().ecseg_tiff_write_gray8(os.fsencode(path), img.ctypes.data_as(C.c_void_p), img.shape[0],
+                                                           img.shape[1], int(bool(invert))), path)
+        return
+    if invert:
+        img = ~img
     H, W = img.shape
     rps = max(1, min(H, 8192 // max(W, 1)))
     diff = img.copy()
@@ -243,7 +296,7 @@ def write_tiff_gray8(path, img):
         f.write(struct.pack('<H', len(entries)) + b''.join(entries) + struct.pack('<I', 0))
 
 
-def write_png(path, img, level=6):
+def write_png(path, img, level=6, native=True):
     """8-bit PNG: (H, W) gray, (H, W, 3) RGB or (H, W, 4) RGBA."""
     img = np.ascontiguousarray(img, np.uint8)
     if img.ndim == 2:
@@ -255,6 +308,9 @@ def write_png(path, img, level=6):
     else:
         raise ValueError('unsupported PNG shape %s' % (img.shape,))
     H, W = img.shape[:2]
+    if native and img.size:
+        _check_write(load_library().ecseg_png_write(os.fsencode(path), img.ctypes.data_as(C.c_void_p), H, W, ch, int(level)), path)
+        return
     rows = np.empty((H, 1 + W * ch), np.uint8)           # filter type 0 on every scan line
     rows[:, 0] = 0
     rows[:, 1:] = img.reshape(H, W * ch)
@@ -272,7 +328,7 @@ def write_png(path, img, level=6):
 _LABEL_COLORS_U32 = None
 
 
-def write_label_png(path, labels):
+def write_label_png(path, labels, native=True):
     """``plt.imsave(path, I.astype('uint8'), cmap=ListedColormap([...4 colours...]), vmin=0, vmax=4)``
     (src/metaseg.py:47-52): class k -> colour k, RGBA.  The four colours compress to almost nothing at any zlib level;
     level 1 keeps the encoder off the critical path of `make metaseg` (pixels, not bytes, are the contract)."""
@@ -282,5 +338,24 @@ def write_label_png(path, labels):
     lab = np.asarray(labels)
     if lab.dtype != np.uint8:
         lab = np.clip(lab, 0, 3).astype(np.uint8)
+    if native and lab.ndim == 2 and lab.size:
+        lab = np.ascontiguousarray(lab)
+        _check_write(load_library().ecseg_png_write_labels(os.fsencode(path), lab.ctypes.data_as(C.c_void_p), lab.shape[0],
+                                                           lab.shape[1]), path)
+        return
     rgba = np.take(_LABEL_COLORS_U32, lab, mode='clip')              # one 32-bit gather per pixel
-    write_png(path, rgba.view(np.uint8).reshape(lab.shape[0], lab.shape[1], 4), level=1)
+    write_png(path, rgba.view(np.uint8).reshape(lab.shape[0], lab.shape[1], 4), level=1, native=False)
+
+
+def write_npy_int64(path, labels):
+    """``np.save(path, labels.astype('int64'))`` (src/metaseg.py:53) for a uint8 label image: the widening and the write
+    happen in csrc/host_io.cpp, byte-identical to numpy's file (tests/test_io_fixtures.py).  ``path`` is taken as given (no
+    ``.npy`` is appended)."""
+    lab = np.asarray(labels)
+    if lab.dtype == np.uint8 and lab.ndim == 2:
+        lab = np.ascontiguousarray(lab)
+        _check_write(load_library().ecseg_npy_write_i64(os.fsencode(path), lab.ctypes.data_as(C.c_void_p), lab.shape[0],
+                                                        lab.shape[1]), path)
+        return
+    with open(path, 'wb') as f:
+        np.save(f, lab.astype(np.int64))

@@ -15,7 +15,6 @@ Optional config keys (defaults keep the reference's behaviour): ``batch_images``
 import concurrent.futures as cf
 import os
 import queue
-import socket
 import subprocess
 import sys
 import threading
@@ -37,47 +36,97 @@ def _outputs_of(p):
     return stem + '.npy', stem + '.png', os.path.join(path_split[0], 'dapi', path_split[1])
 
 
+def _resume_probe(p):
+    """Optional resume ("checkpoint / resume"): an image whose three outputs exist, whose stored labels load and
+    have the input image's shape is not segmented again; its count is taken from the stored labels (count_cc(I == 3) on the
+    device, as src/metaseg.py:46 does).  ANY doubt - a truncated .npy of a killed run, a wrong shape or dtype, an unreadable
+    header - returns None and the image is segmented again (the .npy is written last and atomically, see _write_outputs)."""
+    try:
+        outs = _outputs_of(p)
+        if not all(os.path.exists(o) and os.path.getsize(o) > 0 for o in outs):
+            return None
+        lab = np.load(outs[0])
+        if lab.ndim != 2 or lab.dtype != np.int64 or tuple(lab.shape) != tuple(image_io.image_shape(p)[:2]):
+            return None
+        return ('done', np.ascontiguousarray(lab == 3))
+    except Exception:
+        return None
+
+
 def _read(p, resume=False):
     if resume:
-        # optional resume ("checkpoint / resume"): an image whose three outputs already exist is not segmented
-        # again; its count is taken from the stored labels (count_cc(I == 3) on the device, as src/metaseg.py:46 does)
-        outs = _outputs_of(p)
-        if all(os.path.exists(o) and os.path.getsize(o) > 0 for o in outs):
-            lab = np.load(outs[0])
-            if lab.ndim == 2 and lab.dtype == np.int64:
-                return ('done', np.ascontiguousarray(lab == 3))
+        done = _resume_probe(p)
+        if done is not None:
+            return done
     img = image_io.imread(p)
     if img.dtype not in (np.uint8, np.uint16) or img.ndim not in (2, 3):
         raise ValueError('unsupported image array %s %s' % (img.dtype, img.shape))
     return img
 
 
-def _write_outputs(p, gray_inv, post, log):
+def _replace_into(path, write):
+    """Write through a temporary name in the same directory and rename: a killed run never leaves a truncated output."""
+    tmp = '%s.tmp%d' % (path, os.getpid())
+    try:
+        write(tmp)
+        os.replace(tmp, path)
+    except BaseException:
+        try:
+            os.unlink(tmp)
+        except OSError:
+            pass
+        raise
+
+
+def _write_outputs(p, gray, post, log):
+    """gray: the pre-processed image; dapi/<name> holds cv2.bitwise_not of it (src/utils.py:112,122-123)."""
     path_split = os.path.split(p)
-    save_img(gray_inv, path_split, 'dapi')                               # cv2.bitwise_not(I) (src/utils.py:112)
+    dapi = os.path.join(path_split[0], 'dapi', path_split[1])
+    if dapi.lower().endswith(('.tif', '.tiff')):
+        _replace_into(dapi, lambda t: image_io.write_tiff_gray8(t, gray, invert=True))
+    else:
+        save_img(~gray, path_split, 'dapi')
     outpath = os.path.join(path_split[0], 'labels', path_split[1][:-4])
     log("Saving labels: ", p, " to ", outpath)
-    image_io.write_label_png(outpath + '.png', post)
-    np.save(outpath, post.astype(np.int64))                               # int64 .npy (src/metaseg.py:53)
+    _replace_into(outpath + '.png', lambda t: image_io.write_label_png(t, post))
+    # int64 .npy (src/metaseg.py:53), LAST: its presence is the resume marker
+    _replace_into(outpath + '.npy', lambda t: image_io.write_npy_int64(t, post))
+
+
+def _segment_group(model, imgs):
+    gray, _ = model.handle.preprocess(imgs)
+    post, nec = model.segment(gray)
+    return gray, post, nec
 
 
 def _segment_with_retry(model, imgs, log):
-    """GPU part of one batch; on an out-of-memory status the internal launch group is halved (down to one image)."""
+    """GPU part of one batch.  On an out-of-memory status the internal launch group is halved, starting below what the failed
+    attempt used (down to one image per launch); if that still does not fit, the batch itself is split by images (allocations
+    that scale with the batch: post-processing workspace, input staging).  The handle's setting is restored afterwards, so
+    one oversized batch does not slow every later one."""
     h = model.handle
-    group = None
-    while True:
-        try:
-            gray, _ = h.preprocess(imgs)
-            post, nec = model.segment(gray)
-            return gray, post, nec
-        except EcsegError as e:
-            if e.code != E_NOMEM:
-                raise
-            group = 8 if group is None else group // 2
-            if group < 1:
-                raise
-            log("Out of device memory for a batch of shape %s: retrying with %d image(s) per launch group" % (imgs.shape, group))
-            h.set_images_per_group(group)
+    before = h.images_per_group
+    try:
+        group = min(before, len(imgs)) if before > 0 else len(imgs)
+        while True:
+            try:
+                return _segment_group(model, imgs)
+            except EcsegError as e:
+                if e.code != E_NOMEM:
+                    raise
+                group //= 2
+                if group < 1:
+                    break
+                log("Out of device memory for a batch of shape %s: retrying with %d image(s) per launch group" % (imgs.shape, group))
+                h.set_images_per_group(group)
+        if len(imgs) < 2:
+            raise EcsegError('out of device memory for a single image of shape %s' % (imgs.shape[1:],))
+        half = len(imgs) // 2
+        log("Out of device memory for a batch of shape %s: splitting it into %d + %d image(s)" % (imgs.shape, half, len(imgs) - half))
+        a, b = _segment_with_retry(model, imgs[:half], log), _segment_with_retry(model, imgs[half:], log)
+        return tuple(np.concatenate([x, y]) for x, y in zip(a, b))
+    finally:
+        h.set_images_per_group(before)
 
 
 def run(inpath, model, image_paths, rank=0, world=1, batch_images=8, io_threads=None, log=print, stats=None, resume=False):
@@ -138,7 +187,7 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
             for j, k in enumerate(group):
                 n_ec[k] = int(nec[j])
                 pending_writes.acquire()
-                f = writers.submit(_write_outputs, mine[k], ~gray[j], post[j], log)
+                f = writers.submit(_write_outputs, mine[k], gray[j], post[j], log)
                 f.add_done_callback(lambda _f: pending_writes.release())
                 write_futs.append((k, f))
 
@@ -207,15 +256,15 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
 
 def _self_launch(device_ids):
     """``device_ids`` with more than one GPU outside a launcher: one rank per listed GPU (this parent never touches HIP)."""
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))          # the ranks import ecseg_amd from here
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: RCCL shares device buffers between the rank processes through HIP IPC handles, and this
+    # pool's host driver only supports the dmabuf flavour (hipIpcGetMemHandle: invalid argument otherwise)
     env = dict(os.environ, ECSEG_DEVICE_IDS=','.join(str(int(d)) for d in device_ids),
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'),
                PYTHONPATH=root + (os.pathsep + os.environ['PYTHONPATH'] if os.environ.get('PYTHONPATH') else ''))
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(len(device_ids)),
-           '--master-addr', '127.0.0.1', '--master-port', str(port), '-m', 'ecseg_amd.metaseg']
+    # --standalone: torch.distributed.run binds its own rendezvous port (no bind-then-close race with other jobs on the node)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1',
+           '--nproc-per-node', str(len(device_ids)), '-m', 'ecseg_amd.metaseg']
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
@@ -234,12 +283,12 @@ def main(argv=None):
     device_ids = var.get('device_ids')
     if device_ids and len(device_ids) > 1 and not under_launcher:
         _self_launch(device_ids)
-    rank, world = dist.init_process_group() if under_launcher else (0, 1)
-    device = None
-    if os.environ.get('ECSEG_DEVICE_IDS'):
-        device = int(os.environ['ECSEG_DEVICE_IDS'].split(',')[int(os.environ.get('LOCAL_RANK', '0'))])
-    elif device_ids:
-        device = int(device_ids[0])
+    # the physical GPU of this rank: entry LOCAL_RANK of the device list (from the self-launching parent's environment, or
+    # from config.yaml when an external launcher - torchrun - started the ranks)
+    ids = [int(d) for d in os.environ['ECSEG_DEVICE_IDS'].split(',')] if os.environ.get('ECSEG_DEVICE_IDS') else \
+        [int(d) for d in device_ids] if device_ids else None
+    device = ids[int(os.environ.get('LOCAL_RANK', '0')) % len(ids)] if ids else None
+    rank, world = dist.init_process_group(device=device) if under_launcher else (0, 1)     # RCCL on the same physical GPU
     model = load_model(MODEL_NAME, device=device)
     print(model.handle.device_name)
     image_paths = get_imgs(inpath)

@@ -27,7 +27,10 @@
 extern "C" {
 #endif
 
-#define ECSEG_ABI_VERSION 1
+/* 2 (round 3): ecseg_get_conv_launch_profile kinds 3 / 4 and fusion bits, images_per_group 0 = automatic, op code 9
+ * (GLOBALPOOL), MAXPOOL honours `mode`, CONV accepts stride != 1, ecseg_npy_write_i64 / ecseg_png_write* /
+ * ecseg_tiff_* / ecseg_allgather_records added.  ecseg_amd/_lib.py refuses a library whose version differs from the one it was written for. */
+#define ECSEG_ABI_VERSION 2
 
 #define ECSEG_OK             0
 #define ECSEG_E_INVALID     -1   /* bad argument / shape / plan */
@@ -35,6 +38,7 @@ extern "C" {
 #define ECSEG_E_NOMODEL     -3   /* a model-dependent call before ecseg_model_load */
 #define ECSEG_E_NOMEM       -4
 #define ECSEG_E_UNSUPPORTED -5
+#define ECSEG_E_IO          -6   /* a file could not be opened / read / written (host I/O entry points) */
 
 typedef struct ecseg_ctx ecseg_ctx;
 
@@ -114,8 +118,8 @@ int ecseg_segment_images(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, in
                          uint8_t* labels_raw, uint8_t* labels_post, int32_t* n_ec);
 int ecseg_segment_images_dev(ecseg_ctx* h, const uint8_t* gray_dev, int n_img, int H, int W,
                              uint8_t* labels_raw_dev, uint8_t* labels_post_dev, int32_t* n_ec_dev);
-/* Upper bound on images (of 35 windows) per internal U-Net launch group.  Default: automatic - as many as fit ~48 GB of
- * activations, between 16 and 64 (16 for the canonical base-64 U-Net, 32 for base 32, 64 for base 16). */
+/* Upper bound on images (of 35 windows) per internal U-Net launch group.  Default and n == 0: automatic - as many as fit
+ * ~48 GB of activations, between 16 and 64 (16 for the canonical base-64 U-Net, 32 for base 32, 64 for base 16). */
 int ecseg_set_images_per_group(ecseg_ctx* h, int n);
 /* Tuning knobs: "overlap_post" (1: clean-up + count of group g run on a second stream beside the U-Net of group g+1;
  * 0 (default): everything on one stream - measured equal, the MFMA convs already fill the chip), "post_chunk"
@@ -198,9 +202,12 @@ int ecseg_get_conv_profile(ecseg_ctx* h, double* total_ms, int64_t* launches, do
 /* FLOPs the matrix cores actually executed in those launches (Winograd F(2x2,3x3) issues 16/36 of the algorithmic
  * multiplies of a 3x3 convolution; the direct kernel issues all of them). */
 int ecseg_get_conv_executed_flops(ecseg_ctx* h, double* flops);
-/* Per-launch records of the same profile, in launch order: plan operator index, kernel family (0 direct implicit GEMM,
- * 1 Winograd F(2x2,3x3), 2 Winograd F(4x4,3x3)), duration, algorithmic and executed FLOPs.  Returns the number of
- * records written (<= max_records) or a negative error. */
+/* Per-launch records of the same profile, in launch order: plan operator index, kind, duration, algorithmic and executed
+ * FLOPs.  kind bits 0-7 = kernel family (0 direct implicit GEMM conv_mfma_kernel, 1 Winograd F(2x2,3x3) conv_wino_kernel,
+ * 2 Winograd F(4x4,3x3) conv_wino4_kernel, 3 filter-resident F(2x2) conv_wino_res_kernel, 4 F(2x2) on 16x16x4 MFMAs
+ * conv_wino16_kernel); bit 8 (0x100): the launch also wrote the 2x2 max-pool that follows in the plan; bit 9 (0x200): it
+ * also finished the 1x1 head that follows (the convolution's own output was not written).  Returns the number of records
+ * written (<= max_records) or a negative error. */
 int ecseg_get_conv_launch_profile(ecseg_ctx* h, int max_records, int32_t* op_index, int32_t* kind, float* ms,
                                   double* flops, double* executed_flops);
 /* Diagnostics only (-DECSEG_DIAG builds; ECSEG_E_UNSUPPORTED otherwise): up to 240 floats of in-kernel cycle stamps written by the ECSEG_WINO_STAMP build of the conv kernel. */
@@ -211,6 +218,24 @@ int ecseg_debug_peek(ecseg_ctx* h, float* out, int n);
  * dapi/<name>.tif written by cv2.imwrite (src/utils.py:122-123).  Return bytes written, or -1 on error. */
 long long ecseg_lzw_decode(const uint8_t* src, long long n, uint8_t* dst, long long dst_cap);
 long long ecseg_lzw_encode(const uint8_t* src, long long n, uint8_t* dst, long long dst_cap);
+
+/* ---- whole-file readers / writers of `make metaseg` / `make meta_overlay` (host only; thread-safe, no handle) --------
+ * Called through ctypes they run without the interpreter lock, so the I/O threads of ecseg_amd/metaseg.py scale over the
+ * host cores.  Return ECSEG_OK, ECSEG_E_INVALID (bad argument / corrupt file), ECSEG_E_IO, or - readers only -
+ * ECSEG_E_UNSUPPORTED for a valid TIFF layout that is left to the Python reader (tiles, BigTIFF, PackBits, float). */
+/* np.save(labels/<stem>.npy, I.astype(int64)) (src/metaseg.py:53): byte-identical to numpy's format-1.0 writer. */
+int ecseg_npy_write_i64(const char* path, const uint8_t* labels, int H, int W);
+/* plt.imsave(labels/<stem>.png, I, cmap=ListedColormap([4 colours]), vmin=0, vmax=4) (src/metaseg.py:47-52): RGBA. */
+int ecseg_png_write_labels(const char* path, const uint8_t* labels, int H, int W);
+/* 8-bit gray / RGB / RGBA PNG (channels 1 / 3 / 4; zlib level 0..9): red/ and green/ of split_FISH_channels
+ * (src/image_tools.py:136-146). */
+int ecseg_png_write(const char* path, const uint8_t* pixels, int H, int W, int channels, int level);
+/* cv2.imwrite(dapi/<name>.tif, gray) (src/utils.py:122-123): LZW + predictor 2, strips of 8192 / W rows; invert != 0
+ * stores 255 - img (cv2.bitwise_not, src/utils.py:112). */
+int ecseg_tiff_write_gray8(const char* path, const uint8_t* img, int H, int W, int invert);
+/* skimage.io.imread of a baseline TIFF (src/utils.py:110): shape first, then the samples as native-endian (H, W, spp). */
+int ecseg_tiff_info(const char* path, int* H, int* W, int* samples_per_pixel, int* bits_per_sample);
+int ecseg_tiff_read(const char* path, void* dst, long long dst_bytes);
 
 #ifdef __cplusplus
 }

@@ -104,9 +104,14 @@ def _tfop(L, lc, a):
     raise NotImplementedError('TFOpLambda %s' % fn)
 
 
-def forward(model_config, weights, x_nhwc, lambda_fns=None):
+def forward(model_config, weights, x_nhwc, lambda_fns=None, dtype=np.float32):
     """``model_config``: dict (or JSON text) of a Keras Functional/Sequential model; ``weights``: {layer name:
-    [arrays in Keras order]}; ``x_nhwc``: (N, H, W, C) any dtype.  Returns float32 NHWC output of the model."""
+    [arrays in Keras order]}; ``x_nhwc``: (N, H, W, C) any dtype.  Returns float32 NHWC output of the model.
+
+    ``dtype=np.float64`` evaluates the same graph with the same float32 weights in double precision and returns float64:
+    the adjudicator between two float32 evaluations that disagree (tools/label_mismatch.py, tests/test_gpu_configs.py) -
+    its rounding error is 2^-29 of a float32 evaluation's, so ``float32(forward(..., dtype=float64))`` is what an exactly
+    rounded float32 network would return."""
     if isinstance(model_config, (str, bytes)):
         model_config = json.loads(model_config)
     cfg = model_config['config']
@@ -116,7 +121,7 @@ def forward(model_config, weights, x_nhwc, lambda_fns=None):
     x_nhwc = np.ascontiguousarray(x_nhwc)
     if x_nhwc.ndim == 3:                      # (N, H, W): a model whose InputLayer has no channel axis
         x_nhwc = x_nhwc[..., None]
-    x = torch.from_numpy(x_nhwc.astype(np.float32)).permute(0, 3, 1, 2).contiguous()
+    x = torch.from_numpy(x_nhwc.astype(dtype)).permute(0, 3, 1, 2).contiguous()
     prev = None
     with torch.no_grad():
         for L in layers:
@@ -138,7 +143,7 @@ def forward(model_config, weights, x_nhwc, lambda_fns=None):
                 if node and isinstance(node[0], str):
                     node = [node]
                 ins = [vals[n[0]] for n in node]
-            w = weights.get(name, [])
+            w = [np.asarray(v, dtype) for v in weights.get(name, [])]
             a = ins[0]
             if cls == 'Conv2D':
                 y = _conv2d(a, lc, w)

@@ -85,8 +85,64 @@ def device_modes(base, weights, n, refs):
     return out
 
 
+def adjudicate(truth_path):
+    """Device vs float32 oracle vs float64 adjudicator on the cached CPU results of tools/label_truth.py.  For every 3x3
+    kernel: raw-label pixels differing from the oracle / from the truth, who is right where device and oracle disagree,
+    the decision margin (float64) of the device's wrong pixels, max |dp| against the float64 probabilities, and the
+    consequences after clean-up (labels, n_ec, CSV rows)."""
+    from ecseg_amd import synth
+    from ecseg_amd._lib import LIB_PATH
+    from ecseg_amd.model import MetasegModel
+    from oracle import tiling
+    from tools import label_truth
+    z = np.load(truth_path)
+    base, seed0, n = int(z['base']), int(z['seed0']), len(z['raw32'])
+    cfg, weights = label_truth.model_weights(str(z['model']), base)
+    raw32, raw64, post64, nec32, nec64, margin = z['raw32'], z['raw64'], z['post64'], z['nec32'], z['nec64'], z['margin64']
+    model = MetasegModel(cfg, weights, device=0)
+    imgs = np.stack([synth.dapi_image(seed0 + i, H, W) for i in range(n)])
+    pos = tiling.patch_positions(H, W)
+    win = tiling.extract_patches(imgs[0][..., None], pos)[:len(z['p64'])]
+    o_wrong = raw32 != raw64
+    out = {'library': os.path.basename(LIB_PATH), 'images': n, 'pixels': int(n * H * W), 'unet_base': base, 'model': str(z['model']),
+           'oracle_float32_vs_float64': {
+               'raw_px_wrong': int(o_wrong.sum()), 'raw_px_wrong_per_100_images': round(100.0 * o_wrong.sum() / n, 1),
+               'images_with_n_ec_difference': int((nec32 != nec64).sum()), 'max_abs_dp': float(z['p32err'].max()),
+               'post_px_differing': int((z['post32'] != post64).sum())},
+           'kernels': {}}
+    for mode, tag in ((0, 'direct'), (1, 'winograd_f2x2'), (2, 'winograd_f4x4')):
+        model.handle.set_option('winograd', mode)
+        raw, post, nec = model.handle.segment_images(imgs, want_raw=True)
+        d_wrong = raw != raw64
+        dis = raw != raw32
+        probs = model.predict_on_batch(win)
+        out['kernels'][tag] = {
+            'raw_px_differing_from_oracle32': int(dis.sum()), 'per_100_images_vs_oracle32': round(100.0 * dis.sum() / n, 1),
+            'raw_px_wrong_vs_float64': int(d_wrong.sum()), 'per_100_images_vs_float64': round(100.0 * d_wrong.sum() / n, 1),
+            'where_device_and_oracle32_disagree': {'device_agrees_with_float64': int((dis & ~d_wrong).sum()),
+                                                   'oracle32_agrees_with_float64': int((dis & ~o_wrong).sum()),
+                                                   'neither': int((dis & d_wrong & o_wrong).sum())},
+            'both_wrong_same_label': int((d_wrong & o_wrong & ~dis).sum()),
+            'margin_of_device_wrong_px_1e-7': {'max': int(margin[d_wrong].max()) if d_wrong.any() else 0,
+                                               'p50': float(np.median(margin[d_wrong])) if d_wrong.any() else 0.0},
+            'max_abs_dp_vs_float64': float(np.abs(probs.astype(np.float64) - z['p64']).max()),
+            'rms_dp_vs_float64': float(np.sqrt(((probs.astype(np.float64) - z['p64']) ** 2).mean())),
+            'post_px_differing_from_float64': int((post != post64).sum()),
+            'images_with_n_ec_difference_vs_float64': int((np.asarray(nec) != nec64).sum()),
+            'images_with_n_ec_difference_vs_oracle32': int((np.asarray(nec) != nec32).sum()),
+            'worst_image_raw_px_vs_oracle32': int(dis.sum(axis=(1, 2)).max()),
+            'worst_image_raw_px_vs_float64': int(d_wrong.sum(axis=(1, 2)).max())}
+    p32 = None
+    out['oracle_float32_vs_float64']['margin_of_wrong_px_1e-7'] = {'max': int(margin[o_wrong].max()) if o_wrong.any() else 0}
+    model.handle.set_option('winograd', 2)
+    model.handle.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--truth', action='append', default=[], help='cache file of tools/label_truth.py: adjudicate against its '
+                    'float64 evaluation instead of fitting / running the CPU oracle here (repeatable)')
     ap.add_argument('--base', type=int, default=64)
     ap.add_argument('--fit-steps', type=int, default=150)
     ap.add_argument('--images', type=int, default=16)
@@ -95,6 +151,14 @@ def main():
     ap.add_argument('--fit-device', default='cpu', help="'cuda': fit in a child process with torch on the GPU")
     ap.add_argument('--fit-batch', type=int, default=2)
     a = ap.parse_args()
+    if a.truth:
+        res = {'image_size': [H, W], 'what': 'device vs float32 CPU oracle vs float64 CPU evaluation (tools/label_truth.py)',
+               'models': {os.path.splitext(os.path.basename(t))[0]: adjudicate(t) for t in a.truth}}
+        text = json.dumps(res, indent=1)
+        if a.out:
+            open(a.out, 'w').write(text)
+        print(text)
+        return
     from ecseg_amd import synth
     from tools import fit_smooth_model
     res = {'image_size': [H, W], 'pixels_per_image': H * W, 'images': a.images, 'unet_base': a.base, 'models': {}}

@@ -312,10 +312,53 @@ class DeviceRun:
         self.post = torch.empty_like(self.gray)
         self.nec = torch.zeros(B, dtype=torch.int32, device=dev)
         self.rec = torch.from_numpy(edist.make_records(start, stop - start, per)).to(dev)
+        self.comm, self.gathered, self.allgather_via = None, None, 'none (1 rank)'
+        if world > 1 or (os.environ.get('ECSEG_BENCH_FORCE_COMM') and torch.distributed.is_initialized()):   # (the latter: 1-GPU test of the same code)
+            self._setup_c_abi_collective(local, rank, world)
+
+    def _setup_c_abi_collective(self, local, rank, world):
+        """The record all-gather through the C ABI (ecseg_allgather_records_dev: RCCL resolved by the library itself) instead
+        of torch.distributed; the unique id travels over the torch process group that the launcher contract provides anyway.
+        Verified once against torch's all_gather; every rank must agree, otherwise all fall back to torch (and say so)."""
+        import torch.distributed as dist
+        from ecseg_amd._lib import Comm
+        torch = self.torch
+        ok, why = 1, ''
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = Comm.unique_id()
+            except Exception as e:                                           # librccl not loadable, ...
+                why = str(e)
+        dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            ok = 0
+        else:
+            try:
+                self.comm = Comm(box[0], rank, world, local)
+                self.gathered = torch.empty((world * self.rec.shape[0], self.rec.shape[1]), dtype=torch.int64, device=self.rec.device)
+                torch.cuda.synchronize()
+                self.comm.allgather_records_dev(self.rec.data_ptr(), self.rec.shape[0], self.gathered.data_ptr())
+                want = self.edist.allgather_records(self.rec)
+                ok = int(bool(torch.equal(self.gathered, want)))
+                why = '' if ok else 'result differs from torch.distributed.all_gather_into_tensor'
+            except Exception as e:
+                ok, why = 0, str(e)
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.rec.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            self.allgather_via = 'ecseg_allgather_records_dev (C ABI; RCCL loaded by libecseg_hip.so), checked against torch.distributed once'
+        else:
+            self.comm = None
+            self.allgather_via = 'torch.distributed.all_gather_into_tensor (C-ABI collective unavailable: %s)' % (why or 'another rank failed')
 
     def step(self):
         self.hnd.segment_images_dev(self.gray.data_ptr(), self.B, H, W, self.raw.data_ptr(), self.post.data_ptr(), self.nec.data_ptr())
         self.rec[:self.B, self.edist.F_NEC] = self.nec.to(self.torch.int64)
+        if self.comm is not None:
+            self.comm.allgather_records_dev(self.rec.data_ptr(), self.rec.shape[0], self.gathered.data_ptr(),
+                                            stream=self.torch.cuda.current_stream().cuda_stream)
+            return self.gathered
         return self.edist.allgather_records(self.rec)
 
     def barrier(self):
@@ -371,6 +414,8 @@ class DeviceRun:
                         'meta_inference -> count, host-synchronous'}
 
     def close(self):
+        if self.comm is not None:
+            self.comm.close()
         self.hnd.close()
         del self.gray, self.raw, self.post, self.nec, self.rec
         self.torch.cuda.empty_cache()
@@ -451,7 +496,7 @@ def main():
                                    'weights) -> stitch/uint8-quantise/argmax -> meta_inference -> ecDNA count'
                                    % (B, args.base, summ['gflop_per_patch']),
                        'images_per_gpu_per_step': B, 'unet_base': args.base, 'patches_per_image': 35,
-                       'parallelism': 'image-parallel x%d, all-gather of 128-B records' % world},
+                       'parallelism': 'image-parallel x%d, all-gather of 128-B records' % world, 'allgather': run.allgather_via},
             'stage_ms_per_image': summ['stage_ms_per_image'], 'ccl_ms_per_image': summ['ccl_ms_per_image'],
         }
         if m['conv_launches']:

@@ -16,6 +16,7 @@ EXPORTS = [
     'ecseg_stitch_argmax', 'ecseg_meta_inference', 'ecseg_meta_inference_dev', 'ecseg_count_cc', 'ecseg_ccl_labels',
     'ecseg_count_colocalization', 'ecseg_count_hsr', 'ecseg_overlay', 'ecseg_get_timings',
     'ecseg_set_kernel_profiling', 'ecseg_get_conv_profile', 'ecseg_get_conv_executed_flops', 'ecseg_get_conv_launch_profile', 'ecseg_debug_peek', 'ecseg_lzw_decode', 'ecseg_lzw_encode',
+    'ecseg_comm_unique_id', 'ecseg_comm_create', 'ecseg_comm_destroy', 'ecseg_comm_last_error', 'ecseg_allgather_records', 'ecseg_allgather_records_dev',
     'ecseg_npy_write_i64', 'ecseg_png_write_labels', 'ecseg_png_write', 'ecseg_tiff_write_gray8', 'ecseg_tiff_info', 'ecseg_tiff_read',
 ]
 
@@ -95,6 +96,12 @@ def load_library():
     for fn in (lib.ecseg_lzw_decode, lib.ecseg_lzw_encode):
         fn.argtypes = [vp, C.c_longlong, vp, C.c_longlong]
         fn.restype = C.c_longlong
+    lib.ecseg_comm_unique_id.argtypes = [vp, i32]
+    lib.ecseg_comm_create.argtypes = [C.POINTER(vp), vp, i32, i32, i32]
+    lib.ecseg_comm_destroy.argtypes = [vp]; lib.ecseg_comm_destroy.restype = None
+    lib.ecseg_comm_last_error.restype = C.c_char_p
+    lib.ecseg_allgather_records.argtypes = [vp, vp, i32, vp]
+    lib.ecseg_allgather_records_dev.argtypes = [vp, vp, i32, vp, vp]
     lib.ecseg_npy_write_i64.argtypes = [C.c_char_p, vp, i32, i32]
     lib.ecseg_png_write_labels.argtypes = [C.c_char_p, vp, i32, i32]
     lib.ecseg_png_write.argtypes = [C.c_char_p, vp, i32, i32, i32, i32]
@@ -364,3 +371,58 @@ class Handle:
         fl = C.c_double()
         self._check(self.lib.ecseg_get_conv_executed_flops(self.h, C.byref(fl)), 'ecseg_get_conv_executed_flops')
         return fl.value
+
+
+class Comm:
+    """RCCL communicator of the C ABI (csrc/comm.hip): the record all-gather without torch.distributed.  Rank 0 creates the
+    id with ``Comm.unique_id()`` and hands the 128 bytes to the other ranks; then every rank constructs its ``Comm``."""
+
+    @staticmethod
+    def unique_id():
+        lib = load_library()
+        buf = C.create_string_buffer(128)
+        rc = lib.ecseg_comm_unique_id(buf, 128)
+        if rc != 0:
+            e = EcsegError('ecseg_comm_unique_id failed (%d): %s' % (rc, lib.ecseg_comm_last_error().decode()))
+            e.code = rc
+            raise e
+        return buf.raw
+
+    def __init__(self, unique_id, rank, world, device):
+        self.lib = load_library()
+        c = C.c_void_p()
+        rc = self.lib.ecseg_comm_create(C.byref(c), C.c_char_p(bytes(unique_id)), int(rank), int(world), int(device))
+        if rc != 0:
+            e = EcsegError('ecseg_comm_create(rank %d of %d, device %d) failed (%d): %s'
+                           % (rank, world, device, rc, self.lib.ecseg_comm_last_error().decode()))
+            e.code = rc
+            raise e
+        self.c, self.rank, self.world = c, int(rank), int(world)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            e = EcsegError('%s failed (%d): %s' % (what, rc, self.lib.ecseg_comm_last_error().decode()))
+            e.code = rc
+            raise e
+
+    def allgather_records(self, rec):
+        """rec: int64 (padded_len, 16) host array -> (world * padded_len, 16), rank-major."""
+        a = np.ascontiguousarray(rec, np.int64)
+        out = np.empty((self.world * a.shape[0], a.shape[1]), np.int64)
+        self._check(self.lib.ecseg_allgather_records(self.c, _ptr(a), a.shape[0], _ptr(out)), 'ecseg_allgather_records')
+        return out
+
+    def allgather_records_dev(self, send_ptr, n_records, recv_ptr, stream=None):
+        self._check(self.lib.ecseg_allgather_records_dev(self.c, C.c_void_p(send_ptr), int(n_records), C.c_void_p(recv_ptr),
+                                                         C.c_void_p(stream) if stream else None), 'ecseg_allgather_records_dev')
+
+    def close(self):
+        if getattr(self, 'c', None):
+            self.lib.ecseg_comm_destroy(self.c)
+            self.c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

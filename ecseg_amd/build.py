@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libecseg_hip.so')
-SOURCES = ['api.hip', 'unet_kernels.hip', 'wino4_kernel.hip', 'wino16_kernel.hip', 'post_kernels.hip', 'host_codec.cpp', 'host_io.cpp']
+SOURCES = ['api.hip', 'unet_kernels.hip', 'wino4_kernel.hip', 'wino16_kernel.hip', 'post_kernels.hip', 'host_codec.cpp', 'host_io.cpp', 'comm.hip']
 # packed f32 VALU ops stall the SIMD beside MFMAs: keep the transform arithmetic of the Winograd kernels scalar
 EXTRA_FLAGS = {'wino4_kernel.hip': ['-fno-slp-vectorize']}
 HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'device_util.h'), os.path.join(HERE, '..', 'include', 'ecseg_hip.h')]
@@ -44,7 +44,7 @@ def build(force=False, verbose=True):
     for p, cmd in procs:
         if p.wait() != 0:
             raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
-    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-lz']     # zlib: PNG / Deflate-TIFF in host_io.cpp
+    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-lz', '-ldl']     # zlib: PNG / Deflate-TIFF in host_io.cpp; dl: RCCL is loaded on first use (comm.hip)
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)

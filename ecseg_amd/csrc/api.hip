@@ -952,7 +952,7 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
                 o.flops = 2.0 * d.kh * d.kw * cin * cout * (double)ti.h * ti.w;
                 if (d.kh == d.kw && d.kh == d.stride && in_al && cin >= 8 && cout >= 16 && d.pad_top == 0 && d.pad_left == 0) {
                     o.path = PATH_MFMA;
-                    const int bn = conv_mfma_ntile(cout);
+                    const int bn = cout <= 16 && d.kh == 2 ? 16 : conv_mfma_ntile(cout);   // 2x2, <= 16 channels: all four phases in one 64-column tile
                     o.coutp = (cout + bn - 1) / bn * bn;
                     o.cin_chunks = (cin + 7) / 8;
                     if ((rc = upload(h, relayout_convt(kw, d.kh, cin, cout, o.cin_chunks, o.coutp), &o.wt))) return rc;

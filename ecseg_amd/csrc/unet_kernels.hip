@@ -170,15 +170,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p, int tiles_
     const int quad = lane & 7;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        int co_base = n0 + nt * 32, oa = 0, ob = 0;
-        if (p.convt) {                                        // N index = (a * kT + b) * coutp + co
-            const int ab = co_base / p.coutp;
-            co_base -= ab * p.coutp;
+        int co = n0 + nt * 32 + 4 * quad, oa = 0, ob = 0;
+        if (p.convt) {
+            // N index = (a * kT + b) * coutp + co, decoded per lane: with coutp = 16 a 32-column tile holds BOTH column phases
+            // b = 0, 1 of one row phase a, i.e. the two output pixels (2x, 2x + 1) a lane octet writes are neighbours in memory
+            const int ab = co / p.coutp;
+            co -= ab * p.coutp;
             oa = ab / p.kT; ob = ab - oa * p.kT;
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) Xs[((e & 3) + 8 * (e >> 2) + 4 * lh) * 32 + li] = acc[nt][e];
-        const int co = co_base + 4 * quad;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if (p.bias != nullptr) {
 #pragma unroll
@@ -659,7 +660,11 @@ static hipError_t launch_conv_mfma_rs(const ConvParams& p, hipStream_t s) {
 }
 
 hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
-    const int bn = conv_mfma_ntile(p.out.c);
+    // transposed convolutions whose kT x kT phases x padded channels fit one 128-column tile (Cout <= 32 at 2x2): ONE workgroup
+    // computes every output phase of its input tile - the tile is staged once instead of once per phase, and the per-thread
+    // staging descriptors / prologue of these short-K layers are amortised over 2 - 4x the work
+    const int np_t = p.convt ? p.kT * p.kT * p.coutp : 0;
+    const int bn = (p.convt && np_t <= 128 && np_t % 32 == 0) ? np_t : conv_mfma_ntile(p.out.c);
     const bool wide = p.force_tw ? p.force_tw == 32 : (p.convt ? p.in.w : p.out.w) >= 32;
     if (bn == 128) return wide ? launch_conv_mfma_rs<4, 32>(p, s) : launch_conv_mfma_rs<4, 16>(p, s);
     if (bn == 64) return wide ? launch_conv_mfma_rs<2, 32>(p, s) : launch_conv_mfma_rs<2, 16>(p, s);
@@ -706,53 +711,60 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(TView in, TView out
     }
 }
 
-// First layer of the U-Net (Cin = 1, 3x3, 4.4 flop/B: HBM-bound on its 64-channel output).  Thread = 4 output channels
-// x 8 consecutive pixels of one row: the nine filter taps live in registers, the 3 x 10 input window is read once, and
-// 16 lanes (64 channels) complete one pixel's 256-byte line, so the stores of a wave are four full 256-B segments.
+// First layer of the U-Net (Cin = 1, 3x3, 4.4 flop/B: HBM-bound on its output).  Thread = 4 output channels x 8 consecutive
+// ROWS of one pixel column: consecutive lanes are the channel quads of a pixel, then the next pixel of the row, so that every
+// store instruction of a wave writes 1 KiB of CONTIGUOUS output (16 pixels x 64 B at 16 channels, 4 pixels x 256 B at 64) -
+// with the 8 pixels of a thread along the row instead (rounds 1-2) a store instruction wrote 16 separate 64-byte pieces
+// 512 bytes apart at 16 channels and the layer ran at 2.1 - 2.5 TB/s.  The nine filter taps live in registers; the 10 x 3
+// input window streams through three registers per row (lanes of one pixel read the same address: one broadcast fetch).
 __global__ __launch_bounds__(256) void conv_first_kernel(TView in, TView out, const float* __restrict__ w,
                                                          const float* __restrict__ bias, size_t total, int pad_top,
                                                          int pad_left, int act, float alpha) {
-    constexpr int PX = 8;
+    constexpr int PY = 8;
     const int quads = out.c >> 2;
-    const int gx = (out.w + PX - 1) / PX;
+    const int gy = (out.h + PY - 1) / PY;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
         const int q = (int)(t % quads);
         size_t g = t / quads;
-        const int x0 = (int)(g % gx) * PX; g /= gx;
-        const int oy = (int)(g % out.h);
-        const size_t img = g / out.h;
+        const int ox = (int)(g % out.w); g /= out.w;
+        const int y0 = (int)(g % gy) * PY;
+        const size_t img = g / gy;
         f32x4 wt[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) wt[k] = *reinterpret_cast<const f32x4*>(w + (size_t)k * out.c + q * 4);
-        f32x4 acc[PX];
+        f32x4 acc[PY];
         const f32x4 b4 = bias ? *reinterpret_cast<const f32x4*>(bias + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < PX; ++i) acc[i] = b4;
+        for (int i = 0; i < PY; ++i) acc[i] = b4;
+        const float* col = in.p + (img * in.h * in.w) * in.cs;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int iy = oy - pad_top + r;
-            float v[PX + 2];
+        for (int r = 0; r < PY + 2; ++r) {                   // input row r of the window feeds output rows r - 2 .. r
+            const int iy = y0 - pad_top + r;
+            float v[3];
 #pragma unroll
-            for (int i = 0; i < PX + 2; ++i) {
-                const int ix = x0 - pad_left + i;
-                v[i] = (iy >= 0 && iy < in.h && ix >= 0 && ix < in.w) ? in.p[((img * in.h + iy) * in.w + ix) * in.cs] : 0.f;
+            for (int sx = 0; sx < 3; ++sx) {
+                const int ix = ox - pad_left + sx;
+                v[sx] = (iy >= 0 && iy < in.h && ix >= 0 && ix < in.w) ? col[((size_t)iy * in.w + ix) * in.cs] : 0.f;
             }
 #pragma unroll
-            for (int s = 0; s < 3; ++s)
+            for (int kr = 0; kr < 3; ++kr) {
+                const int i = r - kr;                         // output row of the thread that sees this input row as tap row kr
+                if (i < 0 || i >= PY) continue;
 #pragma unroll
-                for (int i = 0; i < PX; ++i) {
-                    const f32x4 k4 = wt[r * 3 + s];
-                    acc[i][0] = fmaf(v[i + s], k4[0], acc[i][0]); acc[i][1] = fmaf(v[i + s], k4[1], acc[i][1]);
-                    acc[i][2] = fmaf(v[i + s], k4[2], acc[i][2]); acc[i][3] = fmaf(v[i + s], k4[3], acc[i][3]);
+                for (int sx = 0; sx < 3; ++sx) {
+                    const f32x4 k4 = wt[kr * 3 + sx];
+                    acc[i][0] = fmaf(v[sx], k4[0], acc[i][0]); acc[i][1] = fmaf(v[sx], k4[1], acc[i][1]);
+                    acc[i][2] = fmaf(v[sx], k4[2], acc[i][2]); acc[i][3] = fmaf(v[sx], k4[3], acc[i][3]);
                 }
+            }
         }
 #pragma unroll
-        for (int i = 0; i < PX; ++i) {
-            if (x0 + i < out.w) {
+        for (int i = 0; i < PY; ++i) {
+            if (y0 + i < out.h) {
                 f32x4 o;
                 o[0] = acc[i][0]; o[1] = acc[i][1]; o[2] = acc[i][2]; o[3] = acc[i][3];
                 o = apply_act4(o, act, alpha);
-                __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(out.p + ((img * out.h + oy) * out.w + x0 + i) * out.cs + q * 4));
+                __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(out.p + ((img * out.h + y0 + i) * out.w + ox) * out.cs + q * 4));
             }
         }
     }
@@ -761,7 +773,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(TView in, TView out, co
 hipError_t launch_conv_small_cin(const TView& in, const TView& out, const float* w, const float* bias, int n, int R, int S,
                                  int pad_top, int pad_left, int act, float alpha, hipStream_t s) {
     if (in.c == 1 && R == 3 && S == 3) {
-        const size_t tot = (size_t)n * out.h * ((out.w + 7) / 8) * (out.c / 4);
+        const size_t tot = (size_t)n * ((out.h + 7) / 8) * out.w * (out.c / 4);
         if (!tot) return hipSuccess;
         const unsigned g = (unsigned)((tot + 255) / 256 > 65536 * 16 ? 65536 * 16 : (tot + 255) / 256);
         hipLaunchKernelGGL(conv_first_kernel, dim3(g), dim3(256), 0, s, in, out, w, bias, tot, pad_top, pad_left, act, alpha);

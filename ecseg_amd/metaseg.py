@@ -254,6 +254,34 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
     return rec
 
 
+def finish(inpath, image_paths, rec, rank, seconds=None, gpu_seconds=0.0, log=print):
+    """After the all-gather every rank holds the records of the whole job; rank 0 writes ``ec_quantification.csv`` (one row
+    per successfully processed image, in sorted-path order: src/metaseg.py:44-46,56-57) and lists what failed.  Returns the
+    failed records (same on every rank)."""
+    failed = [r for r in rec if r[dist.F_STATUS] != 0]
+    if rank != 0:
+        return failed
+    rows = [[os.path.split(image_paths[int(r[dist.F_INDEX])])[1], int(r[dist.F_NEC])]
+            for r in rec if r[dist.F_STATUS] == 0]
+    out = os.path.join(inpath, 'ec_quantification.csv')
+    log("Saving ec quantification to", out)
+    text = csvio.csv_text(csvio.METASEG_COLUMNS, rows)
+    for name in ('ec_quantification.csv', 'ec_quantifications.csv'):       # the second is the name README.md:86 uses
+        tmp = os.path.join(inpath, name + '.tmp%d' % os.getpid())
+        with open(tmp, 'w') as f:
+            f.write(text)
+        os.replace(tmp, os.path.join(inpath, name))
+    if image_paths and seconds:
+        log("%d image(s) in %.2f s (%.1f images/s; device calls %.2f s on rank 0)"
+            % (len(image_paths), seconds, len(image_paths) / seconds, gpu_seconds))
+    if failed:
+        why = {1: 'could not be read', 2: 'failed on the device', 3: 'outputs could not be written'}
+        log("%d image(s) were NOT processed and are missing from the CSV:" % len(failed))
+        for r in failed:
+            log("  ", image_paths[int(r[dist.F_INDEX])], "-", why.get(int(r[dist.F_STATUS]), 'failed'))
+    return failed
+
+
 def _self_launch(device_ids):
     """``device_ids`` with more than one GPU outside a launcher: one rank per listed GPU (this parent never touches HIP)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))          # the ranks import ecseg_amd from here
@@ -297,26 +325,7 @@ def main(argv=None):
     stats = {}
     rec = run(inpath, model, image_paths, rank, world, batch_images=int(var.get('batch_images', 8)),
               io_threads=var.get('io_threads'), stats=stats, resume=bool(var.get('resume', False)))
-    failed = [r for r in rec if r[dist.F_STATUS] != 0]
-    if rank == 0:
-        rows = [[os.path.split(image_paths[int(r[dist.F_INDEX])])[1], int(r[dist.F_NEC])]
-                for r in rec if r[dist.F_STATUS] == 0]
-        out = os.path.join(inpath, 'ec_quantification.csv')
-        print("Saving ec quantification to", out)
-        text = csvio.csv_text(csvio.METASEG_COLUMNS, rows)
-        with open(out, 'w') as f:
-            f.write(text)
-        with open(os.path.join(inpath, 'ec_quantifications.csv'), 'w') as f:   # the name README.md:86 uses
-            f.write(text)
-        dt = time.perf_counter() - t0
-        if image_paths:
-            print("%d image(s) in %.2f s (%.1f images/s; device calls %.2f s on rank 0)"
-                  % (len(image_paths), dt, len(image_paths) / dt, stats.get('gpu_seconds', 0.0)))
-        if failed:
-            why = {1: 'could not be read', 2: 'failed on the device', 3: 'outputs could not be written'}
-            print("%d image(s) were NOT processed and are missing from the CSV:" % len(failed))
-            for r in failed:
-                print("  ", image_paths[int(r[dist.F_INDEX])], "-", why.get(int(r[dist.F_STATUS]), 'failed'))
+    failed = finish(inpath, image_paths, rec, rank, seconds=time.perf_counter() - t0, gpu_seconds=stats.get('gpu_seconds', 0.0))
     if world > 1:
         import torch.distributed as td
         td.barrier()

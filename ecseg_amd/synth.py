@@ -165,11 +165,19 @@ def classifier_weights(config, seed=0):
     return weights
 
 
-def unet_weights(config, seed=0, input_scale=1.0 / 255.0, head_gain=6.0):
+def unet_weights(config, seed=0, input_scale=1.0 / 255.0, head_gain=6.0, smooth=False):
     """Seeded He-normal kernels.  The first convolution is scaled by ``input_scale`` because the reference feeds raw
     0..255 pixel values (no normalisation anywhere in src/utils.py:109-120); the head is scaled up so that the
-    softmax is decisive rather than uniform."""
+    softmax is decisive rather than uniform.
+
+    ``smooth=True``: a SMOOTH-OUTPUT model from the same seed without any training - every 3x3 kernel is a seeded
+    He-normal channel-mixing matrix times the binomial low-pass stencil [1 2 1] x [1 2 1] / 16 (plus 3 % of the ordinary
+    random kernel), every 2x2 up-convolution the same mixing matrix on all four taps: the network is a cascade of blurs
+    and channel mixes, its label maps are blobs with smooth boundaries like a trained model's instead of the speckle
+    of ``smooth=False``, and it still executes every multiply of the architecture with generic float32 values.  Used
+    where a realistic tie density matters (label-mismatch measurements, tests) and 124 MB of fitted weights cannot travel."""
     rng = np.random.default_rng(seed)
+    stencil = np.outer([1.0, 2.0, 1.0], [1.0, 2.0, 1.0]) / 16.0
     weights = {}
     first = True
     layers = config['config']['layers']
@@ -185,6 +193,8 @@ def unet_weights(config, seed=0, input_scale=1.0 / 255.0, head_gain=6.0):
             kh, kw = lc['kernel_size']
             co = lc['filters']
             k = rng.normal(size=(kh, kw, c_in, co)) * np.sqrt(2.0 / (kh * kw * c_in))
+            if smooth and (kh, kw) == (3, 3):
+                k = 0.03 * k + (rng.normal(size=(c_in, co)) * np.sqrt(2.0 / c_in))[None, None] * stencil[:, :, None, None]
             if first:
                 k *= input_scale
                 first = False
@@ -196,6 +206,8 @@ def unet_weights(config, seed=0, input_scale=1.0 / 255.0, head_gain=6.0):
             kh, kw = lc['kernel_size']
             co = lc['filters']
             k = rng.normal(size=(kh, kw, co, c_in)) * np.sqrt(1.0 / c_in)
+            if smooth:
+                k = 0.03 * k + (rng.normal(size=(co, c_in)) * np.sqrt(1.0 / c_in))[None, None]
             weights[name] = [k.astype(np.float32), (rng.normal(size=co) * 0.05).astype(np.float32)]
             cin[name] = co
         elif cls == 'BatchNormalization':

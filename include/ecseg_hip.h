@@ -237,6 +237,26 @@ int ecseg_tiff_write_gray8(const char* path, const uint8_t* img, int H, int W, i
 int ecseg_tiff_info(const char* path, int* H, int* W, int* samples_per_pixel, int* bits_per_sample);
 int ecseg_tiff_read(const char* path, void* dst, long long dst_bytes);
 
+/* ---- the path's one exchange step: all-gather of per-image result records over RCCL (xGMI) ---------------------------
+ * Image-parallel sharding needs no data-path collective (every image is independent: src/metaseg.py:42 is a serial loop);
+ * at the end every rank contributes its block of fixed-size records and rank 0 writes ec_quantification.csv
+ * (src/metaseg.py:44-57).  Record = ECSEG_RECORD_INT64 int64: [0] global image index (-1 = padding of the last shard)
+ * [1] status (0 ok) [2] n_ec [3..14] the twelve fields of ecseg_overlay [15] reserved.  Shards are padded to equal length.
+ * librccl.so is loaded on first use (no link-time dependency); ECSEG_E_UNSUPPORTED when it is not installed.
+ * Rendezvous: rank 0 obtains ECSEG_COMM_ID_BYTES from ecseg_comm_unique_id and hands them to the other ranks by any channel
+ * of the host's (file, environment, socket); then every rank calls ecseg_comm_create (collective).  One process per GPU. */
+#define ECSEG_RECORD_INT64  16
+#define ECSEG_COMM_ID_BYTES 128
+typedef struct ecseg_comm ecseg_comm;
+int         ecseg_comm_unique_id(void* out, int out_bytes);
+int         ecseg_comm_create(ecseg_comm** out, const void* unique_id, int rank, int world, int device_id);
+void        ecseg_comm_destroy(ecseg_comm* c);
+const char* ecseg_comm_last_error(void);          /* text of the calling thread's last failed ecseg_comm_* / all-gather call */
+/* host buffers: n_records records in, world * n_records out (rank-major); synchronous */
+int ecseg_allgather_records(ecseg_comm* c, const int64_t* send, int n_records, int64_t* recv);
+/* device buffers; stream (hipStream_t as void*) non-null: returns once enqueued on it; null: own stream, synchronous */
+int ecseg_allgather_records_dev(ecseg_comm* c, const int64_t* send_dev, int n_records, int64_t* recv_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,11 +24,15 @@ from oracle import unet as oracle_unet
 
 pytestmark = pytest.mark.gpu
 H, W = 1040, 1392
-# Measured on MI355X over 32 full-size images per model and kernel (profiles/r02_label_mismatch.json, tools/label_mismatch.py):
-# random-weight bench model (speckled output, 16-17 k components per image): 2.4 - 5.3 raw-label pixels per image differ
-# from the CPU oracle (max 12 in one image), all of them ties of the uint8-quantised probabilities; a fitted,
-# smooth-output model: 1 pixel in 1 - 2 images of 32, ec_quantification.csv rows differing in 0 - 1 image of 32.
-MAX_RAW_MISMATCH_PX_PER_IMAGE = 24              # 2 x the worst image measured for the random-weight model
+# Measured on MI355X over 32 full-size images per model and kernel against a float64 evaluation of the same network
+# (tools/label_truth.py + tools/label_mismatch.py --truth -> profiles/r03_label_mismatch.json).  Random-weight bench model
+# (speckle: 16-17 k components per image): raw-label pixels that differ from the float64 label per image - float32 CPU oracle
+# 2.4 on average (worst image 6); device direct 2.3 (6), F(2x2) 1.2 (4), F(4x4) 2.3 (5; 4.4 (10) with the textbook
+# interpolation points of rounds 1-2).  Every differing pixel lies within 2.5e-6 of a point where the quantised argmax
+# changes; "hard" pixels below are all those within 2.55e-5 (~0.08 % of an image).
+MAX_WRONG_PX_PER_IMAGE = {0: 12, 1: 8, 2: 10}     # kernel -> 2 x the worst image measured vs float64 (direct, F(2x2), F(4x4))
+MAX_WRONG_PX_PER_IMAGE_SMOOTH = {0: 4, 1: 4, 2: 4}
+MAX_RAW_MISMATCH_PX_PER_IMAGE = 14                # device F(4x4) vs the float32 ORACLE: 2 x the worst image measured (7)
 MAX_RAW_MISMATCH_PX_PER_IMAGE_SMOOTH = 3
 
 
@@ -231,3 +235,52 @@ def test_config4_overlay_1024_fish_images(gpu):
     again = gpu.overlay(labs_post[:4], first_call[0], 85)  # batch-position / batch-size invariance
     assert np.array_equal(again, first_call[1])
     assert sum(len(r) for r in rows.values()) == n
+
+
+def _truth_fixture(golden_dir, tag):
+    z = np.load(os.path.join(golden_dir, 'label_truth_%s.npz' % tag))
+    cfg = synth.unet_config(base=int(z['base']))
+    weights = synth.unet_weights(cfg, seed=0, smooth=str(z['model']) == 'smooth', head_gain=float(z['head_gain']))
+    return z, cfg, weights
+
+
+@pytest.mark.parametrize('tag', ['random_base64', 'smooth_base64'])
+def test_labels_vs_float64_adjudicator(golden_dir, tag):
+    """Who is right where float32 evaluations disagree.  tests/golden/label_truth_<tag>.npz holds, for two
+    full-size images of a seeded base-64 model, every pixel whose FLOAT64 probabilities lie within 2.55e-5 of a change of the
+    quantised argmax, with the float64 label (tools/label_truth.py, tools/make_label_fixture.py; the largest float32 error
+    measured anywhere is 1.5e-5).  (a) Off those pixels the device - all three 3x3 kernels - and the float32 CPU oracle must
+    agree EXACTLY.  (b) On them the device may be wrong in no more pixels than measured per kernel, and in no more than the
+    float32 oracle itself plus a small allowance: the device is no further from the truth than the thing it is compared with."""
+    if not os.path.exists(os.path.join(golden_dir, 'label_truth_%s.npz' % tag)):
+        pytest.skip('fixture %s not built' % tag)
+    from ecseg_amd._lib import Handle
+    z, cfg, weights = _truth_fixture(golden_dir, tag)
+    n = int(z['images'])
+    imgs = np.stack([synth.dapi_image(int(z['seed0']) + i) for i in range(n)])
+    refs = [oracle_pipeline.segment_gray(cfg, weights, im, batch=7, return_intermediate=True)[1] for im in imgs]
+    bound = MAX_WRONG_PX_PER_IMAGE_SMOOTH if tag.startswith('smooth') else MAX_WRONG_PX_PER_IMAGE
+    hnd = Handle(0)
+    try:
+        hnd.load_plan(keras_plan.build_plan(cfg, weights))
+        oracle_wrong = 0
+        hard, truth = [], []
+        for i in range(n):
+            hard.append(z['idx_%d' % i].astype(np.int64)); truth.append(z['truth_%d' % i])
+            oracle_wrong += int((refs[i].ravel()[hard[i]] != truth[i]).sum())
+        for mode in (2, 1, 0):
+            hnd.set_option('winograd', mode)
+            raw, post, nec = hnd.segment_images(imgs, want_raw=True)
+            wrong = 0
+            for i in range(n):
+                easy = np.ones(raw[i].size, bool)
+                easy[hard[i]] = False
+                assert np.array_equal(raw[i].ravel()[easy], refs[i].ravel()[easy]), (tag, mode, i, 'device != oracle off the hard pixels')
+                w = int((raw[i].ravel()[hard[i]] != truth[i]).sum())
+                assert w <= bound[mode], (tag, mode, i, w)
+                wrong += w
+                assert np.array_equal(post[i], postproc.meta_inference(raw[i]))          # integer stages: exact on the device's labels
+            assert wrong <= oracle_wrong + 2 + n, (tag, mode, wrong, oracle_wrong)
+    finally:
+        hnd.set_option('winograd', 2)
+        hnd.close()

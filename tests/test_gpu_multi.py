@@ -1,5 +1,7 @@
 """More than one rank on real GPUs (skipped on 1-GPU boxes): `bench.py --gpus 2` starts its own two ranks, RCCL carries
-the all-gather of the per-image records, and the JSON line reports n_gpus == 2."""
+the all-gather of the per-image records, and the JSON line reports n_gpus == 2.  On any box: the C-ABI collective
+(ecseg_comm_* / ecseg_allgather_records*, csrc/comm.hip) with a one-rank communicator, and bench.py's use of it under a
+one-rank process group (the code path the multi-GPU runs take)."""
 import json
 import os
 import subprocess
@@ -45,3 +47,48 @@ def test_two_handles_in_one_process_on_two_gpus():
         finally:
             h.close()
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_c_abi_record_allgather_one_rank():
+    """ecseg_comm_unique_id / ecseg_comm_create / ecseg_allgather_records (host and device buffers) on a 1-rank RCCL
+    communicator: the gathered block is the rank's own block, padding rows included."""
+    import numpy as np
+    import torch
+    from ecseg_amd import dist as edist
+    from ecseg_amd._lib import Comm
+    uid = Comm.unique_id()
+    assert len(uid) == 128
+    c = Comm(uid, 0, 1, 0)
+    try:
+        rec = edist.make_records(5, 3, 4, n_ec=[7, 8, 9], status=[0, 1, 0])             # 3 real rows + 1 padding row
+        out = c.allgather_records(rec)
+        assert out.shape == (4, 16) and np.array_equal(out, rec)
+        d = torch.from_numpy(rec).to('cuda:0')
+        g = torch.zeros_like(d)
+        c.allgather_records_dev(d.data_ptr(), 4, g.data_ptr())
+        assert torch.equal(g, d)
+        s = torch.cuda.Stream()
+        g.zero_()
+        with torch.cuda.stream(s):
+            c.allgather_records_dev(d.data_ptr(), 4, g.data_ptr(), stream=s.cuda_stream)
+        s.synchronize()
+        assert torch.equal(g, d)
+        assert np.array_equal(edist.compact_records(out)[:, edist.F_NEC], [7, 8, 9])
+    finally:
+        c.close()
+
+
+def test_bench_uses_the_c_abi_collective_under_a_process_group():
+    """bench.py under torch.distributed.run with ONE rank and a forced process group: the C-ABI all-gather is set up, checked
+    against torch's and used in the timed steps - the code the N > 1 runs execute, on the one GPU this box has."""
+    env = dict(os.environ, ECSEG_FORCE_PROCESS_GROUP='1', ECSEG_BENCH_FORCE_COMM='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1',
+                          '--nproc-per-node', '1', os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
+                          '--images', '2', '--base', '16', '--no-cpu-baseline', '--no-narrow', '--no-host-inclusive'],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert res['n_gpus'] == 1 and res['value'] > 0
+    assert res['config']['allgather'].startswith('ecseg_allgather_records_dev'), res['config']['allgather']

@@ -1,0 +1,191 @@
+"""The sharded `make metaseg` path on the CPU: two gloo ranks drive ``ecseg_amd.metaseg.run`` with a stub model (no GPU)
+over 7 and 8 generated TIFF files, one of them corrupt - per-rank outputs, padded records, statuses and the rank-0 CSV must
+equal a 1-rank run over the same files (reference: the serial loop of src/metaseg.py:42-57).  Also: resume after
+a killed run (truncated .npy), atomic outputs and the out-of-memory retry of the device part."""
+import os
+import shutil
+import socket
+
+import numpy as np
+import pytest
+
+from ecseg_amd import dist as edist
+from ecseg_amd import image_io, metaseg
+from ecseg_amd._lib import E_NOMEM, EcsegError
+from ecseg_amd.utils import get_imgs
+from oracle import postproc
+
+H, W = 96, 128
+
+
+class StubHandle:
+    """What metaseg.run needs of a Handle, computed on the CPU: deterministic functions of the pixels."""
+    device = 0
+
+    def __init__(self, fail_above=None):
+        self.images_per_group = 0
+        self.fail_above = fail_above           # simulate E_NOMEM for launch groups / batches above this many images
+        self.calls = []
+
+    def set_images_per_group(self, n):
+        self.images_per_group = int(n)
+
+    def preprocess(self, imgs):
+        a = np.asarray(imgs)
+        gray = a[..., 2] if a.ndim == 4 else a
+        return np.ascontiguousarray(gray, np.uint8), np.zeros(len(a), np.int32)
+
+    def count_cc(self, masks):
+        m = np.asarray(masks).astype(bool)
+        return np.array([postproc.count_cc(x)[0] for x in m], np.int32), np.array([int(x.sum()) for x in m], np.int64)
+
+
+class StubModel:
+    def __init__(self, **kw):
+        self.handle = StubHandle(**kw)
+
+    def segment(self, gray):
+        h = self.handle
+        grp = h.images_per_group if h.images_per_group > 0 else len(gray)
+        h.calls.append((len(gray), h.images_per_group))
+        if h.fail_above is not None and min(grp, len(gray)) > h.fail_above:
+            e = EcsegError('simulated out of memory')
+            e.code = E_NOMEM
+            raise e
+        post = (np.asarray(gray) >> 6).astype(np.uint8)                    # labels 0..3
+        return post, np.array([postproc.count_cc(p == 3)[0] for p in post], np.int32)
+
+
+def make_inputs(folder, n, corrupt=None):
+    from PIL import Image
+    os.makedirs(folder, exist_ok=True)
+    rng = np.random.default_rng(n)
+    for i in range(n):
+        img = np.zeros((H, W, 3), np.uint8)
+        img[..., 2] = rng.integers(0, 64, (H, W))
+        for _ in range(3 + i):                                               # a few bright blobs -> class 3 components
+            y, x = rng.integers(4, H - 8), rng.integers(4, W - 8)
+            img[y:y + 3, x:x + 4, 2] = 250
+        p = os.path.join(folder, 'img%02d.tif' % i)
+        if i == corrupt:
+            open(p, 'wb').write(b'II*\x00' + bytes(rng.integers(0, 255, 300, dtype=np.uint8)))
+        else:
+            Image.fromarray(img).save(p, compression='tiff_lzw')
+    for sub in ('dapi', 'labels'):
+        os.makedirs(os.path.join(folder, sub), exist_ok=True)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, folder, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), LOCAL_RANK=str(rank))
+    import torch
+    r, w = edist.init_process_group('gloo')
+    paths = get_imgs(folder)
+    rec = metaseg.run(folder, StubModel(), paths, r, w, batch_images=3, io_threads=2, log=lambda *a: None)
+    failed = metaseg.finish(folder, paths, rec, r, log=lambda *a: None)
+    q.put((rank, rec.tolist(), len(failed)))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def _snapshot(folder):
+    out = {}
+    for sub in ('dapi', 'labels', ''):
+        d = os.path.join(folder, sub)
+        for f in sorted(os.listdir(d)):
+            p = os.path.join(d, f)
+            if os.path.isfile(p) and not f.startswith('img') or sub:
+                out[os.path.join(sub, f)] = open(p, 'rb').read()
+    return out
+
+
+@pytest.mark.parametrize('n_images', [7, 8])
+def test_sharded_run_equals_single_rank(tmp_path, n_images):
+    import torch.multiprocessing as mp
+    one, two = str(tmp_path / 'one'), str(tmp_path / 'two')
+    make_inputs(one, n_images, corrupt=2)
+    shutil.copytree(one, two)
+    # 1 rank
+    paths = get_imgs(one)
+    rec1 = metaseg.run(one, StubModel(), paths, 0, 1, batch_images=3, io_threads=2, log=lambda *a: None)
+    failed1 = metaseg.finish(one, paths, rec1, 0, log=lambda *a: None)
+    assert len(rec1) == n_images and [int(r[edist.F_STATUS]) for r in rec1] == [1 if i == 2 else 0 for i in range(n_images)]
+    assert len(failed1) == 1
+    # 2 gloo ranks
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, two, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, rec, n_failed in res:                                          # every rank holds the whole job's records
+        assert np.array_equal(np.array(rec), rec1), 'records of rank %d differ from the 1-rank run' % rank
+        assert n_failed == 1
+    a, b = _snapshot(one), _snapshot(two)
+    assert sorted(a) == sorted(b)
+    for k in a:
+        assert a[k] == b[k], k
+    csv = a['ec_quantification.csv'].decode()
+    assert csv.count('\n') == n_images and 'img02.tif' not in csv and a['ec_quantifications.csv'] == a['ec_quantification.csv']
+    # outputs of rank 1's shard exist and hold what the stub computed
+    stem = 'img%02d' % (n_images - 1)
+    lab = np.load(os.path.join(two, 'labels', stem + '.npy'))
+    assert lab.dtype == np.int64 and lab.shape == (H, W)
+    gray = image_io.imread(os.path.join(two, stem + '.tif'))[..., 2]
+    assert np.array_equal(lab, gray >> 6)
+    assert np.array_equal(image_io.imread(os.path.join(two, 'dapi', stem + '.tif')), ~gray)
+    assert not [f for d in ('dapi', 'labels', '') for f in os.listdir(os.path.join(two, d)) if '.tmp' in f]
+
+
+def test_resume_survives_a_truncated_npy(tmp_path):
+    """a run killed while writing leaves a truncated labels/<stem>.npy; resume must re-segment that image
+    instead of dropping it, and must not trust stored labels of the wrong shape."""
+    folder = str(tmp_path / 'in')
+    make_inputs(folder, 4)
+    paths = get_imgs(folder)
+    rec = metaseg.run(folder, StubModel(), paths, 0, 1, batch_images=2, io_threads=2, log=lambda *a: None)
+    want = rec[:, edist.F_NEC].copy()
+    good = open(os.path.join(folder, 'labels', 'img01.npy'), 'rb').read()
+    open(os.path.join(folder, 'labels', 'img01.npy'), 'wb').write(good[:len(good) // 3])           # killed mid-write
+    np.save(os.path.join(folder, 'labels', 'img02.npy'), np.zeros((5, 7), np.int64))                # stale, wrong shape
+    model = StubModel()
+    logs = []
+    rec2 = metaseg.run(folder, model, paths, 0, 1, batch_images=2, io_threads=2, log=lambda *a: logs.append(' '.join(map(str, a))),
+                       resume=True)
+    assert (rec2[:, edist.F_STATUS] == 0).all() and np.array_equal(rec2[:, edist.F_NEC], want)
+    assert sum(n for n, _ in model.handle.calls) == 2                          # exactly the two damaged images were segmented again
+    assert sum('Keeping existing outputs' in l for l in logs) == 2
+    assert open(os.path.join(folder, 'labels', 'img01.npy'), 'rb').read() == good
+    assert np.load(os.path.join(folder, 'labels', 'img02.npy')).shape == (H, W)
+
+
+def test_oom_retry_halves_below_the_failed_group_and_restores_the_setting(tmp_path):
+    imgs = np.zeros((8, H, W), np.uint8)
+    model = StubModel(fail_above=2)
+    model.handle.set_images_per_group(8)
+    logs = []
+    gray, post, nec = metaseg._segment_with_retry(model, imgs, lambda *a: logs.append(a))
+    assert post.shape == (8, H, W) and len(nec) == 8
+    assert [g for _, g in model.handle.calls] == [8, 4, 2]                     # first retry is BELOW the group that failed
+    assert model.handle.images_per_group == 8                                  # restored for the next batch
+    # a batch that does not fit even with one image per group is split by images
+    class PerBatch(StubModel):
+        def segment(self, gray):
+            if len(gray) > 3:
+                e = EcsegError('simulated'); e.code = E_NOMEM
+                self.handle.calls.append((len(gray), self.handle.images_per_group))
+                raise e
+            return StubModel.segment(self, gray)
+    m2 = PerBatch()
+    gray, post, nec = metaseg._segment_with_retry(m2, imgs, lambda *a: None)
+    assert post.shape == (8, H, W) and m2.handle.images_per_group == 0
+    assert [n for n, _ in m2.handle.calls if n <= 3] == [2, 2, 2, 2]

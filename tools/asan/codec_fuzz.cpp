@@ -10,6 +10,9 @@
 
 extern "C" long long ecseg_lzw_decode(const uint8_t* src, long long n, uint8_t* dst, long long dst_cap);
 extern "C" long long ecseg_lzw_encode(const uint8_t* src, long long n, uint8_t* dst, long long dst_cap);
+extern "C" int ecseg_tiff_write_gray8(const char* path, const uint8_t* img, int H, int W, int invert);
+extern "C" int ecseg_tiff_info(const char* path, int* H, int* W, int* spp, int* bits);
+extern "C" int ecseg_tiff_read(const char* path, void* dst, long long dst_bytes);
 
 static uint64_t s = 0x9e3779b97f4a7c15ull;
 static uint32_t rnd() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (uint32_t)(s >> 11); }
@@ -47,6 +50,48 @@ int main() {
         (void)ecseg_lzw_decode(junk.data(), (long long)junk.size(), out.data(), (long long)out.size());
     }
     (void)ecseg_lzw_decode(nullptr, 0, nullptr, 0);
+    // ---- whole-file TIFF reader (csrc/host_io.cpp): files written by our own writer, then truncated / bit-flipped /
+    //      overwritten with random tag values; the reader must return a status and never touch memory outside dst ----
+    long long files = 0;
+    const char* path = "/tmp/ecseg_codec_fuzz.tif";
+    for (int round = 0; round < 300; ++round) {
+        const int H = 1 + (int)(rnd() % 40), W = 1 + (int)(rnd() % 300);
+        std::vector<uint8_t> img((size_t)H * W);
+        for (auto& b : img) b = (uint8_t)(rnd() % (round % 3 ? 4 : 256));
+        if (ecseg_tiff_write_gray8(path, img.data(), H, W, round & 1) != 0) { std::printf("tiff write failed\n"); return 1; }
+        int h = 0, w = 0, spp = 0, bits = 0;
+        if (ecseg_tiff_info(path, &h, &w, &spp, &bits) != 0 || h != H || w != W || spp != 1 || bits != 8) { std::printf("tiff info mismatch\n"); return 1; }
+        std::vector<uint8_t> back((size_t)H * W + 1, 0xCD);
+        if (ecseg_tiff_read(path, back.data(), (long long)H * W) != 0) { std::printf("tiff read failed\n"); return 1; }
+        for (size_t i = 0; i < img.size(); ++i)
+            if (back[i] != (uint8_t)((round & 1) ? 255 - img[i] : img[i])) { std::printf("tiff round trip mismatch\n"); return 1; }
+        if (back[img.size()] != 0xCD) { std::printf("tiff reader wrote past its destination\n"); return 1; }
+        std::vector<uint8_t> file;
+        { FILE* f = std::fopen(path, "rb"); std::fseek(f, 0, SEEK_END); file.resize((size_t)std::ftell(f)); std::fseek(f, 0, SEEK_SET); if (std::fread(file.data(), 1, file.size(), f) != file.size()) return 1; std::fclose(f); }
+        for (int t = 0; t < 12; ++t) {
+            std::vector<uint8_t> bad = file;
+            if (t % 3 == 0) bad.resize(rnd() % (bad.size() + 1));
+            const int flips = 1 + rnd() % 8;
+            for (int k = 0; k < flips && !bad.empty(); ++k) {
+                const size_t at = t % 3 == 2 ? bad.size() - 1 - rnd() % (bad.size() < 160 ? bad.size() : 160) : rnd() % bad.size();   // t % 3 == 2: aim at the IFD
+                bad[at] = (uint8_t)rnd();
+            }
+            { FILE* f = std::fopen(path, "wb"); if (!bad.empty() && std::fwrite(bad.data(), 1, bad.size(), f) != bad.size()) return 1; std::fclose(f); }
+            int hh = 0, ww = 0, ss = 0, bb = 0;
+            if (ecseg_tiff_info(path, &hh, &ww, &ss, &bb) == 0) {
+                const size_t need = (size_t)hh * ww * ss * (bb / 8);
+                if (need <= (64u << 20)) {
+                    std::vector<uint8_t> out(need + 1, 0xEF);
+                    (void)ecseg_tiff_read(path, out.data(), (long long)need);
+                    if (out[need] != 0xEF) { std::printf("tiff reader wrote past its destination (corrupt file)\n"); return 1; }
+                    if (need > 16) (void)ecseg_tiff_read(path, out.data(), (long long)need / 2);     // too small a destination: must refuse
+                }
+            }
+            ++files;
+        }
+    }
+    std::remove(path);
+    std::printf("tiff_fuzz ok: %lld corrupt files\n", files);
     std::printf("codec_fuzz ok: %lld corrupt streams\n", checked);
     return 0;
 }

@@ -23,11 +23,11 @@ done
 wait
 for v in "$@"; do
   if [ "$v" = diag ]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libecseg_diag.so /tmp/w4/api_diag.o unet_kernels.o /tmp/w4/wino4_diag.o /tmp/w4/wino16_diag.o post_kernels.o host_codec.o host_io.o -lz
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libecseg_diag.so /tmp/w4/api_diag.o unet_kernels.o /tmp/w4/wino4_diag.o /tmp/w4/wino16_diag.o post_kernels.o host_codec.o host_io.o comm.o -lz -ldl
   elif [ "$v" = points12 ]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libecseg_points12.so /tmp/w4/api_p12.o unet_kernels.o /tmp/w4/wino4_p12.o wino16_kernel.o post_kernels.o host_codec.o host_io.o -lz
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libecseg_points12.so /tmp/w4/api_p12.o unet_kernels.o /tmp/w4/wino4_p12.o wino16_kernel.o post_kernels.o host_codec.o host_io.o comm.o -lz -ldl
   else
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libecseg_v$v.so api.o unet_kernels.o /tmp/w4/wino4_v$v.o wino16_kernel.o post_kernels.o host_codec.o host_io.o -lz
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libecseg_v$v.so api.o unet_kernels.o /tmp/w4/wino4_v$v.o wino16_kernel.o post_kernels.o host_codec.o host_io.o comm.o -lz -ldl
   fi
 done
 ls -la ../libecseg_*.so

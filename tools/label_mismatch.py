@@ -97,7 +97,10 @@ def adjudicate(truth_path):
     from tools import label_truth
     z = np.load(truth_path)
     base, seed0, n = int(z['base']), int(z['seed0']), len(z['raw32'])
-    cfg, weights = label_truth.model_weights(str(z['model']), base)
+    mname = str(z['model'])
+    if mname not in ('random', 'smooth') and not os.path.isabs(mname):
+        mname = os.path.join(ROOT, mname)
+    cfg, weights = label_truth.model_weights(mname, base)
     raw32, raw64, post64, nec32, nec64, margin = z['raw32'], z['raw64'], z['post64'], z['nec32'], z['nec64'], z['margin64']
     model = MetasegModel(cfg, weights, device=0)
     imgs = np.stack([synth.dapi_image(seed0 + i, H, W) for i in range(n)])

@@ -15,6 +15,7 @@ under build/label_truth/<tag>.npz (git-ignored; travels to the GPU box with the 
 code except the synthetic generators.  tools/label_mismatch.py consumes the cache on the GPU box.
 
     python tools/label_truth.py --model random --base 64 --images 32 --procs 6
+    python tools/label_truth.py --model smooth --base 64 --images 32
     python tools/label_truth.py --model build/label_truth/fit64_600.npz --tag fit64_600 --images 32
 """
 import argparse
@@ -29,6 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 H, W = 1040, 1392
 SEED0 = 5000
+SMOOTH_HEAD_GAIN = 150.0          # softmax as decisive as a trained model's (mean top probability 0.97)
 CACHE = os.path.join(ROOT, 'build', 'label_truth')
 
 
@@ -44,7 +46,11 @@ def load_weights(path):
 def model_weights(model, base):
     from ecseg_amd import synth
     cfg = synth.unet_config(base=base)
-    return cfg, (synth.unet_weights(cfg, seed=0) if model == 'random' else load_weights(model))
+    if model == 'random':
+        return cfg, synth.unet_weights(cfg, seed=0)
+    if model == 'smooth':                       # seeded smooth-output model (synth.unet_weights docstring)
+        return cfg, synth.unet_weights(cfg, seed=0, smooth=True, head_gain=SMOOTH_HEAD_GAIN)
+    return cfg, load_weights(model)
 
 
 def decision_margin(p):
@@ -86,14 +92,14 @@ def _worker(job):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--model', default='random', help="'random' (seed-0 bench weights) or a weights .npz (tools/fit_smooth_model.py)")
+    ap.add_argument('--model', default='random', help="'random' (seed-0 bench weights), 'smooth' (seeded smooth-output model) or a weights .npz (tools/fit_smooth_model.py)")
     ap.add_argument('--tag', default=None)
     ap.add_argument('--base', type=int, default=64)
     ap.add_argument('--images', type=int, default=32)
     ap.add_argument('--procs', type=int, default=6)
     ap.add_argument('--windows', type=int, default=6, help='float64 probability windows of image 0 to keep')
     a = ap.parse_args()
-    tag = a.tag or ('random_base%d' % a.base if a.model == 'random' else os.path.splitext(os.path.basename(a.model))[0])
+    tag = a.tag or ('%s_base%d' % (a.model, a.base) if a.model in ('random', 'smooth') else os.path.splitext(os.path.basename(a.model))[0])
     os.makedirs(CACHE, exist_ok=True)
     import multiprocessing as mp
     ctx = mp.get_context('spawn')

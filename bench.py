@@ -45,13 +45,13 @@ CPU_SEED0 = 900                    # synthetic image indices of the CPU-baseline
 # ---------------------------------------------------------------------------------------------------------------------
 def _cpu_worker(job):
     """One image (or a patch sample of one image) through the oracle with a fixed number of torch threads."""
-    base, idx, threads, n_patches = job
+    base, idx, threads, n_patches, up = job
     import torch
     torch.set_num_threads(threads)
     from ecseg_amd import synth
     from oracle import pipeline as op
     from oracle import postproc, tiling, unet
-    cfg = synth.unet_config(base=base)
+    cfg = synth.unet_config(base=base, up=up)
     weights = synth.unet_weights(cfg, seed=0)
     im = synth.dapi_image(idx, H, W)
     pos = tiling.patch_positions(H, W)
@@ -130,11 +130,11 @@ def cpu_pools_start():
     return {'pool': pool, 'nproc': nproc, 'threads': threads, 'ncpu': ncpu}
 
 
-def cpu_baseline(base, pools):
+def cpu_baseline(base, pools, up='transpose'):
     """(i) image-parallel workers over the host cores, one full image each; (ii) one thread on a bounded patch sample.
     Returns (cpu_baseline dict, single-thread dict, reference outputs for the parity check)."""
     pool, nproc, threads, ncpu = pools['pool'], pools['nproc'], pools['threads'], pools['ncpu']
-    out = pool.map(_cpu_worker, [(base, CPU_SEED0 + i, threads, 0) for i in range(nproc)], chunksize=1)
+    out = pool.map(_cpu_worker, [(base, CPU_SEED0 + i, threads, 0, up) for i in range(nproc)], chunksize=1)
     dt = max(o[3] + o[4] for o in out)                            # the workers run side by side; input synthesis is untimed
     refs = [(o[0], o[1], o[2]) for o in out]
     par = {'value': nproc / dt, 'unit': 'images/s', 'cores': nproc * threads, 'kind': 'port',
@@ -143,7 +143,7 @@ def cpu_baseline(base, pools):
                      'meta_inference+count via numpy/scipy: %.2f s/image), wall %.1f s'
                      % (nproc, nproc, threads, ncpu, float(np.mean([o[3] for o in out])), float(np.mean([o[4] for o in out])), dt)}
     n_sample = 2 if base >= 64 else 6 if base >= 32 else 18
-    o = pool.map(_cpu_worker, [(base, CPU_SEED0, 1, n_sample)])[0]       # one worker busy, the others idle
+    o = pool.map(_cpu_worker, [(base, CPU_SEED0, 1, n_sample, up)])[0]       # one worker busy, the others idle
     t_img = o[3] * 35.0 / n_sample + o[4]
     single = {'value': 1.0 / t_img, 'unit': 'images/s', 'cores': 1, 'kind': 'port',
               'sample': 'one thread: U-Net on %d of the 35 windows of one image (%.1f s, scaled x35/%d) + stitch/argmax/'
@@ -285,7 +285,7 @@ def roofline_8d(plan, recs, steps, patches_per_step, unet_ms_per_step):
 class DeviceRun:
     """One synthetic model on this rank's GPU: inputs resident in HBM, `step()` = the whole device pipeline over B images."""
 
-    def __init__(self, base, B, group, local, rank, world, args, first_image=None):
+    def __init__(self, base, B, group, local, rank, world, args):
         import torch
         from ecseg_amd import dist as edist
         from ecseg_amd import synth
@@ -293,7 +293,7 @@ class DeviceRun:
         self.torch, self.edist = torch, edist
         self.base, self.B, self.world = base, B, world
         dev = torch.device('cuda', local)
-        cfg = synth.unet_config(base=base)
+        cfg = synth.unet_config(base=base, up=args.up)
         self.model = MetasegModel(cfg, synth.unet_weights(cfg, seed=0), device=local)
         hnd = self.hnd = self.model.handle
         hnd.set_images_per_group(group)
@@ -445,6 +445,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--images', type=int, default=16, help='images per GPU per step')
     ap.add_argument('--base', type=int, default=64, help='U-Net base width of the synthetic model')
+    ap.add_argument('--up', default='transpose', help="decoder up-sampler of the synthetic U-Net: transpose (2x2 / stride 2, the canonical model), transpose3 / transpose4 (3x3 / 4x4 at stride 2), upsample")
     ap.add_argument('--group', type=int, default=16, help='images per internal U-Net launch group (0: automatic)')
     ap.add_argument('--overlap', action='store_true', help='run post-processing on a second stream')
     ap.add_argument('--direct', action='store_true', help='direct implicit-GEMM 3x3 kernel instead of Winograd')
@@ -492,9 +493,9 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': summ['ms_per_step'],
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1] + post-process: %d synthetic 1040x1392 uint8 DAPI images per GPU per '
-                                   'step, 35 tiles of 256x256 each, canonical U-Net base %d (%.1f GFLOP/patch, seeded random '
+                                   'step, 35 tiles of 256x256 each, canonical U-Net base %d%s (%.1f GFLOP/patch, seeded random '
                                    'weights) -> stitch/uint8-quantise/argmax -> meta_inference -> ecDNA count'
-                                   % (B, args.base, summ['gflop_per_patch']),
+                                   % (B, args.base, '' if args.up == 'transpose' else ' with %s up-convolutions' % args.up, summ['gflop_per_patch']),
                        'images_per_gpu_per_step': B, 'unet_base': args.base, 'patches_per_image': 35,
                        'parallelism': 'image-parallel x%d, all-gather of 128-B records' % world, 'allgather': run.allgather_via},
             'stage_ms_per_image': summ['stage_ms_per_image'], 'ccl_ms_per_image': summ['ccl_ms_per_image'],
@@ -565,7 +566,7 @@ def main():
                 r2.close()
             res['narrow_models'] = narrow
         if pools is not None:
-            cpu_par, cpu_single, refs = cpu_baseline(args.base, pools)    # after the timed region, on the idle workers
+            cpu_par, cpu_single, refs = cpu_baseline(args.base, pools, args.up)    # after the timed region, on the idle workers
             res['cpu_baseline'] = cpu_par
             res['cpu_baseline_single_thread'] = cpu_single
             res['parity_vs_cpu'] = parity_vs_cpu(hnd, refs)

@@ -37,6 +37,7 @@ struct OpRt {                 // run-time form of one plan operator
     float* scale = nullptr;   // AFFINE
     float* shift = nullptr;
     int cin_chunks = 0, coutp = 0;
+    int subpixel = 0;         // CONVT kh x kw / stride 2 with k in {3, 4} as a 2x2-tap convolution over the input (relayout_convt_subpixel)
     double flops = 0.0;       // algorithmic 2*MAC per patch
 };
 enum { PATH_MFMA = 1, PATH_SMALL_CIN = 2, PATH_HEAD = 3, PATH_GENERIC = 4, PATH_OTHER = 5 };
@@ -268,6 +269,31 @@ std::vector<float> relayout_convt(const float* w, int kT, int cin, int cout, int
     return o;
 }
 
+// Keras Conv2DTranspose kernel (k, k, out, in), stride 2, k in {3, 4}, as the filter of a 2x2-tap convolution over the INPUT
+// that produces all four output phases of a 2x2 output block at once: output (2 i + a, 2 j + b) of the full (uncropped)
+// result sums w[a - 2 d][b - 2 e] x in(i + d, j + e) over d, e in {-1, 0} (taps with kernel index outside [0, k) are zero:
+// 5 of 16 at k = 3, none at k = 4).  Layout as relayout_conv with tap t = (d + 1) * 2 + (e + 1) and N = (a * 2 + b) * coutp + co.
+std::vector<float> relayout_convt_subpixel(const float* w, int k, int cin, int cout, int chunks, int coutp) {
+    const int np = 4 * coutp;
+    const size_t cp = (size_t)wt_chunk_pitch(np), tp = (size_t)wt_tap_pitch(np, chunks);
+    std::vector<float> o((size_t)4 * tp, 0.f);
+    for (int d = -1; d <= 0; ++d)
+        for (int e = -1; e <= 0; ++e)
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 2; ++b) {
+                    const int kh = a - 2 * d, kw = b - 2 * e;
+                    if (kh >= k || kw >= k) continue;
+                    const int t = (d + 1) * 2 + (e + 1);
+                    for (int co = 0; co < cout; ++co)
+                        for (int ci = 0; ci < cin; ++ci) {
+                            const int chunk = ci / 8, hh = (ci % 8) / 4, ee = ci % 4;
+                            o[(size_t)t * tp + (size_t)chunk * cp + ((size_t)hh * np + (size_t)(a * 2 + b) * coutp + co) * 4 + ee] =
+                                w[((size_t)(kh * k + kw) * cout + co) * cin + ci];
+                        }
+                }
+    return o;
+}
+
 int ensure_patches(ecseg_ctx* h, int n) {
     if (n <= h->cap_patches) return ECSEG_OK;
     for (float*& p : h->bufs) { if (p) (void)hipFree(p); p = nullptr; }
@@ -380,7 +406,12 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                     }
                     p.act = act; p.alpha = d.alpha; p.cin_chunks = o.cin_chunks; p.coutp = o.coutp; p.zero = h->zero_page;
                     if (d.op == ECSEG_OP_CONV) {
-                        p.R = d.kh; p.S = d.kw; p.pad_top = d.pad_top; p.pad_left = d.pad_left; p.convt = 0;
+                        p.R = d.kh; p.S = d.kw; p.pad_top = d.pad_top; p.pad_left = d.pad_left; p.convt = 0; p.stride = d.stride;
+                    } else if (o.subpixel) {
+                        // 2x2 taps over input rows / columns (i - 1, i); tiles walk one position past the input (the last output
+                        // row / column of the full result comes from tap d = -1 alone)
+                        p.R = 2; p.S = 2; p.pad_top = 1; p.pad_left = 1; p.convt = 1; p.kT = 2; p.convt_ext = 1;
+                        p.crop_top = d.pad_top; p.crop_left = d.pad_left;
                     } else {
                         p.R = 1; p.S = 1; p.pad_top = 0; p.pad_left = 0; p.convt = 1; p.kT = d.kh;
                         p.crop_top = d.pad_top; p.crop_left = d.pad_left;
@@ -388,7 +419,7 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                     hipEvent_t* ev = h->profile_kernels ? prof_pair(h) : nullptr;
                     if (ev) (void)hipEventRecord(ev[0], s);
                     double computed = 1.0;                     // fraction of the layer a cropped launch really computes
-                    const bool wino4 = h->use_winograd >= 2 && o.wt_wino4 && conv_wino4_supported(p);
+                    const bool wino4 = h->use_winograd >= 2 && o.wt_wino4 && conv_wino4_supported(p);   // (wt_wino* exist only for stride-1 3x3 'same' layers)
                     const bool wino = !wino4 && h->use_winograd && o.wt_wino && out.h >= 4 && out.w >= 8;
                     bool w16 = false;
                     {
@@ -478,7 +509,8 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                     if (ev) {
                         (void)hipEventRecord(ev[1], s);
                         h->prof_flops += o.flops * n;
-                        const double ex = o.flops * n * computed * (wino4 ? 0.25 : wino ? 16.0 / 36.0 : 1.0);   // multiplies actually issued
+                        // multiplies actually issued (sub-pixel transposed convolution: 4 taps x 4 phases per input pixel, zeros included)
+                        const double ex = o.flops * n * computed * (wino4 ? 0.25 : wino ? 16.0 / 36.0 : o.subpixel ? 16.0 / (d.kh * d.kw) : 1.0);
                         h->prof_exec_flops += ex;
                         const bool res = wino && p.resident && p.coutp == 32 && p.cin_chunks <= 4;
                         // kind: bits 0-7 the kernel, bit 8: the following 2x2 max-pool was written by this launch, bit 9: the following 1x1 head was
@@ -908,9 +940,19 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
                 o.flops = 2.0 * d.kh * d.kw * cin * cout * (double)to.h * to.w;
                 const bool taps_ok = d.kh == d.kw && (d.kh == 1 || d.kh == 2 || d.kh == 3);
                 if (d.stride != 1) {
-                    // strided convolutions (classifier stems) take the generic kernel; the MFMA kernels are stride 1
-                    o.path = PATH_GENERIC;
-                    if ((rc = upload(h, std::vector<float>(kw, kw + (size_t)d.kh * d.kw * cin * cout), &o.wt))) return rc;
+                    // strided convolutions (classifier stems, down-sampling convolutions): the direct MFMA kernel gathers a
+                    // strided halo (stride 2, 1x1 / 2x2 / 3x3 taps); anything else takes the generic kernel
+                    if (d.stride == 2 && taps_ok && in_al && cin >= 8) {
+                        o.path = PATH_MFMA;
+                        const int bn = conv_mfma_ntile(cout);
+                        o.coutp = (cout + bn - 1) / bn * bn;
+                        o.cin_chunks = (cin + 7) / 8;
+                        if ((rc = upload(h, relayout_conv(kw, d.kh, d.kw, cin, cout, o.cin_chunks, o.coutp), &o.wt))) return rc;
+                        h->mfma_flops_per_patch += o.flops;
+                    } else {
+                        o.path = PATH_GENERIC;
+                        if ((rc = upload(h, std::vector<float>(kw, kw + (size_t)d.kh * d.kw * cin * cout), &o.wt))) return rc;
+                    }
                 } else if (cin <= 4 && cout % 4 == 0 && out_al) {
                     o.path = PATH_SMALL_CIN;
                     if ((rc = upload(h, std::vector<float>(kw, kw + (size_t)d.kh * d.kw * cin * cout), &o.wt))) return rc;
@@ -925,7 +967,9 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
                         if ((rc = upload(h, w4, &o.head_w4))) return rc;
                         if ((rc = upload(h, b4, &o.head_b4))) return rc;
                     }
-                } else if (taps_ok && in_al && cin >= 8 && cout >= 16) {
+                } else if (taps_ok && in_al && cin >= 8 && (cout >= 16 || (d.kh >= 2 && cin >= 16))) {
+                    // (a 2x2 / 3x3 convolution to a FEW channels - NuSeT's 3x3 'final' layer, src/model_layers/models.py:134 - still
+                    // belongs on the matrix cores: a mostly empty 32-column tile beats the scalar kernel by an order of magnitude)
                     o.path = PATH_MFMA;
                     const int bn = conv_mfma_ntile(cout);
                     o.coutp = (cout + bn - 1) / bn * bn;
@@ -956,6 +1000,16 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
                     o.coutp = (cout + bn - 1) / bn * bn;
                     o.cin_chunks = (cin + 7) / 8;
                     if ((rc = upload(h, relayout_convt(kw, d.kh, cin, cout, o.cin_chunks, o.coutp), &o.wt))) return rc;
+                    h->mfma_flops_per_patch += o.flops;
+                } else if (d.kh == d.kw && (d.kh == 3 || d.kh == 4) && d.stride == 2 && in_al && cin >= 8 && d.pad_top >= 0 && d.pad_left >= 0) {
+                    // k x k / stride 2, k != stride (a common Keras up-sampler; NuSeT's U-Net: src/model_layers/models.py:78-80):
+                    // four sub-pixel convolutions as ONE 2x2-tap convolution over the input with N = 4 x Cout
+                    o.path = PATH_MFMA;
+                    o.subpixel = 1;
+                    const int bn = cout <= 16 ? 16 : conv_mfma_ntile(cout);
+                    o.coutp = (cout + bn - 1) / bn * bn;
+                    o.cin_chunks = (cin + 7) / 8;
+                    if ((rc = upload(h, relayout_convt_subpixel(kw, d.kh, cin, cout, o.cin_chunks, o.coutp), &o.wt))) return rc;
                     h->mfma_flops_per_patch += o.flops;
                 } else {
                     o.path = PATH_GENERIC;

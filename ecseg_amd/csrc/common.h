@@ -28,6 +28,8 @@ struct ConvParams {
     // transposed-conv mode (R = S = 1 in the GEMM, kT x kT stride-kT scatter in the epilogue)
     int convt;          // 0 | 1
     int kT, crop_top, crop_left;
+    int convt_ext;      // transposed mode: tiles walk the input extent + convt_ext (sub-pixel form of k x k / stride 2: 1)
+    int stride;         // forward convolution: output stride (0 / 1: dense; 2: conv_mfma gathers a strided halo)
     const float* zero;  // >= 16 bytes of zeros in device memory (LDS-DMA source for padding / out-of-image pixels)
     TView pool;         // pool.p != null: also write MaxPooling2D(2x2, stride 2) of the activated output (conv_wino4 only)
     // fused 1x1 head (conv_wino4 only, Cout == 64): head_w != null: logits = act(out) . head_w[64][4] + head_b[4] (classes

@@ -22,12 +22,13 @@
 
 namespace ecseg {
 
-template <int NT, int TW, int R, int S, int KCH = 1>
+template <int NT, int TW, int R, int S, int KCH = 1, int ST = 1>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p, int tiles_x, int tiles_y, int nblk_n, int np_total) {
     // KCH = 8-channel K-chunks staged per barrier interval (4 for 1x1 taps: a single tap gives a wave only 4*NT MFMAs
-    // per chunk, too few to amortise the barrier / staging cost)
+    // per chunk, too few to amortise the barrier / staging cost).  ST = output stride (2: strided convolutions - the halo
+    // tile covers (TH - 1) ST + R rows and a lane's A operand sits ST halo pixels from its neighbour's).
     constexpr int TH = 128 / TW;
-    constexpr int HH = TH + R - 1, HW = TW + S - 1;
+    constexpr int HH = (TH - 1) * ST + R, HW = (TW - 1) * ST + S;
     constexpr int NPIX = HH * HW;
     constexpr int BN = NT * 32;
     constexpr int A_PIECES = NPIX * 2;
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p, int tiles_
             const int kc = q / A_PIECES, qq = q - kc * A_PIECES;
             const int pix = qq >> 1, h = qq & 1;
             const int hy = pix / HW, hx = pix - hy * HW;
-            const int iy = ty0 - p.pad_top + hy, ix = tx0 - p.pad_left + hx;
+            const int iy = ty0 * ST - p.pad_top + hy, ix = tx0 * ST - p.pad_left + hx;
             a_lds[k] = (kc * 2 + h) * NPIX + pix;
             a_ch[k] = kc * 8 + h * 4;
             if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win)
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p, int tiles_
     const int li = lane & 31, lh = lane >> 5;
     int ty, tx;
     if (TW == 32) { ty = wave; tx = li; } else { ty = 2 * wave + (li >> 4); tx = li & 15; }
-    const f32x4* Ap = As + lh * NPIX + ty * HW + tx;
+    const f32x4* Ap = As + lh * NPIX + ty * ST * HW + tx * ST;
     const f32x4* Bp = Bs + lh * BN + li;
 
     f32x16 acc[NT];
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p, int tiles_
     //      (the K loop's last barrier has retired the staging buffers) so that a lane finishes 4 consecutive channels of
     //      one pixel: bias + activation, one 16-byte store; a wave instruction writes 8 pixels x 128 B instead of 64 x 4 B ----
     const int Hout = p.out.h, Wout = p.out.w, Cout = p.out.c;
-    const int Ht = p.convt ? Hin : Hout, Wt = p.convt ? Win : Wout;   // extent the tiles walk over
+    const int Ht = p.convt ? Hin + p.convt_ext : Hout, Wt = p.convt ? Win + p.convt_ext : Wout;   // extent the tiles walk over
     float* Xs = reinterpret_cast<float*>(smem) + wave * 1024;
     const bool vec_ok = (p.out.cs % 4 == 0) && (Cout % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.out.p) & 15) == 0);
     const int quad = lane & 7;
@@ -634,26 +635,31 @@ bool conv_mfma_supported(const ConvParams& p) {
     return taps_ok && align_ok && p.in.c >= 8 && p.out.c >= 16;
 }
 
-template <int NT, int TW, int R, int S, int KCH = 1>
+template <int NT, int TW, int R, int S, int KCH = 1, int ST = 1>
 static hipError_t launch_conv_mfma_t(const ConvParams& p, hipStream_t s) {
     constexpr int TH = 128 / TW;
     constexpr int BN = NT * 32;
-    const int ext_h = p.convt ? p.in.h : p.out.h, ext_w = p.convt ? p.in.w : p.out.w;
+    const int ext_h = p.convt ? p.in.h + p.convt_ext : p.out.h, ext_w = p.convt ? p.in.w + p.convt_ext : p.out.w;
     const int tiles_x = (ext_w + TW - 1) / TW, tiles_y = (ext_h + TH - 1) / TH;
     const int np_total = p.convt ? p.kT * p.kT * p.coutp : p.coutp;
     const int nblk_n = np_total / BN;
-    size_t lds = (size_t)KCH * (2 * (TH + R - 1) * (TW + S - 1) + R * S * 2 * BN) * 16;
+    size_t lds = (size_t)KCH * (2 * ((TH - 1) * ST + R) * ((TW - 1) * ST + S) + R * S * 2 * BN) * 16;
     if (lds < 4 * 4096) lds = 4 * 4096;                       // the output stage needs a 4-KB exchange tile per wave
     const size_t grid = (p.lut != nullptr ? (size_t)(p.n / p.per_image) * p.lut_len : (size_t)p.n * tiles_x * tiles_y) * nblk_n;
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((conv_mfma_kernel<NT, TW, R, S, KCH>), dim3((unsigned)grid), dim3(256), lds, s, p, tiles_x, tiles_y,
+    hipLaunchKernelGGL((conv_mfma_kernel<NT, TW, R, S, KCH, ST>), dim3((unsigned)grid), dim3(256), lds, s, p, tiles_x, tiles_y,
                        nblk_n, np_total);
     return hipGetLastError();
 }
 
 template <int NT, int TW>
 static hipError_t launch_conv_mfma_rs(const ConvParams& p, hipStream_t s) {
+    if (p.stride == 2 && !p.convt) {                          // strided halo gather (classifier stems, down-sampling convolutions)
+        if (p.R == 3) return launch_conv_mfma_t<NT, TW, 3, 3, 1, 2>(p, s);
+        if (p.R == 2) return launch_conv_mfma_t<NT, TW, 2, 2, 1, 2>(p, s);
+        return launch_conv_mfma_t<NT, TW, 1, 1, 2, 2>(p, s);
+    }
     if (p.R == 3) return launch_conv_mfma_t<NT, TW, 3, 3>(p, s);
     if (p.R == 2) return launch_conv_mfma_t<NT, TW, 2, 2>(p, s);
     return launch_conv_mfma_t<NT, TW, 1, 1, 2>(p, s);      // K-chunks per barrier: 1 / 2 / 4 / 8 measured 0 / +0.2 / -0.2 / -1.5 % (A/B)

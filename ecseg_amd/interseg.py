@@ -63,12 +63,14 @@ def classify_crops(ecseg_i_model, crops, ecseg_c_model=None, centromeric_quality
         j = 0
         for a, k in enumerate(live):
             r = rows[k]
-            r['pred_no_amp'], r['pred_ec'], r['pred_hsr'] = (float(v) for v in pi[a])
+            # np.float32 scalars, as the reference keeps them (src/interseg.py:156-158,169-170): a CSV written from these
+            # rows prints 0.3, not float64(float32(0.3)) = 0.30000001192092896
+            r['pred_no_amp'], r['pred_ec'], r['pred_hsr'] = (np.float32(v) for v in pi[a])
             i_label = ECSEG_I_LABEL_MAP[int(np.argmax(pi[a]))]
             r['ecSeg-i_label'] = i_label
             if run_c[a]:
-                v = float(pc[j]); j += 1
-                r['pred_no_focal_amp'], r['pred_focal_amp'] = 1 - v, v
+                v = np.float32(pc[j]); j += 1
+                r['pred_no_focal_amp'], r['pred_focal_amp'] = np.float32(1) - v, v        # float32 complement
                 c_label = ECSEG_C_LABEL_MAP[int(v > 0.5)]
                 r['ecSeg-c_label'] = c_label
                 r['interSeg_label'] = INTERSEG_LABEL_MAP[(c_label, i_label)]

@@ -6,7 +6,8 @@ import numpy as np
 def unet_config(base=64, depth=4, in_ch=1, n_classes=4, up='transpose', batchnorm=False, name='metaseg_synth'):
     """Keras-2 functional ``model_config`` of the classic U-Net: (conv3-relu x2, pool) x depth, bottleneck,
     (2x2 up-conv, concat skip, conv3-relu x2) x depth, 1x1 softmax head.  ``up='transpose'`` uses Conv2DTranspose
-    2x2/s2, ``up='upsample'`` uses UpSampling2D + Conv2D 2x2 'same' (both occur in public Keras U-Nets)."""
+    2x2/s2 (``'transpose3'`` / ``'transpose4'``: 3x3 / 4x4 kernels at stride 2), ``up='upsample'`` uses UpSampling2D +
+    Conv2D 2x2 'same' (all occur in public Keras U-Nets)."""
     layers = []
     counter = {}
 
@@ -44,8 +45,9 @@ def unet_config(base=64, depth=4, in_ch=1, n_classes=4, up='transpose', batchnor
     x = conv(conv(x, f), f)
     for d in range(depth):
         f //= 2
-        if up == 'transpose':
-            u = L('Conv2DTranspose', 'conv2d_transpose', [x], filters=f, kernel_size=[2, 2], strides=[2, 2], padding='same',
+        if up.startswith('transpose'):                       # 'transpose' 2x2, 'transpose3' 3x3 (NuSeT: src/model_layers/models.py:78-80), 'transpose4' 4x4
+            kt = int(up[len('transpose'):] or 2)
+            u = L('Conv2DTranspose', 'conv2d_transpose', [x], filters=f, kernel_size=[kt, kt], strides=[2, 2], padding='same',
                   data_format='channels_last', dilation_rate=[1, 1], activation='linear', use_bias=True, output_padding=None)
         else:
             u = L('UpSampling2D', 'up_sampling2d', [x], size=[2, 2], data_format='channels_last', interpolation='nearest')

@@ -347,3 +347,83 @@ def test_winograd_f4x4_split_k_for_32_output_channels(gpu, cin, hw, n):
     scale = max(1.0, float(np.abs(want).max()))
     assert np.abs(split - padded).max() < 1e-4 * scale, float(np.abs(split - padded).max())
     assert np.abs(split - want).max() < 5e-4 * scale, np.abs(split - want).max()
+
+
+def _one_layer(cls, cin, hw, **cfg):
+    return {'class_name': 'Functional', 'config': {'name': 'm', 'layers': [
+        {'class_name': 'InputLayer', 'name': 'in', 'config': {'name': 'in', 'batch_input_shape': [None, hw[0], hw[1], cin]}, 'inbound_nodes': []},
+        {'class_name': cls, 'name': 'c', 'config': dict(cfg, name='c'), 'inbound_nodes': [[['in', 0, 0, {}]]]}],
+        'input_layers': [['in', 0, 0]], 'output_layers': [['c', 0, 0]]}}
+
+
+def _mfma_ops(gpu, x):
+    """Plan operators that ran on an MFMA kernel in a profiled forward pass."""
+    gpu.set_kernel_profiling(True)
+    try:
+        gpu.forward_patches(x)
+        return {r['op'] for r in gpu.conv_launch_profile()}
+    finally:
+        gpu.set_kernel_profiling(False)
+
+
+@pytest.mark.parametrize('cin,cout,k,padding,hw', [(32, 16, 3, 'same', (32, 48)), (64, 64, 3, 'same', (16, 16)), (16, 8, 4, 'same', (24, 40)),
+                                                   (24, 40, 3, 'valid', (17, 23)), (128, 128, 4, 'valid', (8, 8)), (8, 200, 3, 'same', (9, 33))])
+def test_transposed_conv_kernel_larger_than_stride_on_mfma(gpu, cin, cout, k, padding, hw):
+    """Conv2DTranspose k x k / stride 2 with k in {3, 4} (NuSeT's up-sampler, src/model_layers/models.py:78-80):
+    four sub-pixel convolutions as one 2x2-tap MFMA convolution with a scatter epilogue - against the oracle, and NOT on the
+    generic kernel."""
+    rng = np.random.default_rng(cin + 7 * cout + k)
+    cfg = _one_layer('Conv2DTranspose', cin, hw, filters=cout, kernel_size=[k, k], strides=[2, 2], padding=padding, activation='relu', use_bias=True)
+    weights = {'c': [(rng.normal(size=(k, k, cout, cin)) / np.sqrt(cin) / 64).astype(np.float32), rng.normal(size=cout).astype(np.float32)]}
+    x = rng.integers(0, 256, size=(3, hw[0], hw[1], cin), dtype=np.uint8)
+    got, plan = _run(gpu, cfg, weights, x, fuse=True)
+    want = oracle_unet.forward(cfg, weights, x)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < TOL * max(1.0, np.abs(want).max()), np.abs(got - want).max()
+    assert _mfma_ops(gpu, x) == {k_ for k_, o in enumerate(plan.ops) if o['op'] == keras_plan.OP_CONVT}
+
+
+@pytest.mark.parametrize('cin,cout,k,padding,hw', [(16, 32, 3, 'same', (64, 96)), (32, 64, 1, 'valid', (33, 47)), (8, 16, 2, 'valid', (32, 32)),
+                                                   (64, 48, 3, 'valid', (31, 45)), (24, 24, 3, 'same', (15, 20))])
+def test_strided_conv_on_mfma(gpu, cin, cout, k, padding, hw):
+    """Conv2D with stride 2 (classifier stems, down-sampling convolutions) on the direct MFMA kernel's strided halo gather."""
+    rng = np.random.default_rng(cin + 3 * cout + k)
+    cfg = _one_layer('Conv2D', cin, hw, filters=cout, kernel_size=[k, k], strides=[2, 2], padding=padding, activation='relu', use_bias=True)
+    weights = {'c': [(rng.normal(size=(k, k, cin, cout)) / np.sqrt(k * k * cin) / 64).astype(np.float32), rng.normal(size=cout).astype(np.float32)]}
+    x = rng.integers(0, 256, size=(3, hw[0], hw[1], cin), dtype=np.uint8)
+    got, plan = _run(gpu, cfg, weights, x, fuse=True)
+    want = oracle_unet.forward(cfg, weights, x)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < TOL * max(1.0, np.abs(want).max()), np.abs(got - want).max()
+    assert _mfma_ops(gpu, x) == {0}
+
+
+@pytest.mark.parametrize('cin,cout,k', [(64, 2, 3), (32, 3, 3), (16, 5, 2), (128, 1, 3)])
+def test_conv_to_a_few_channels_on_mfma(gpu, cin, cout, k):
+    """A 3x3 / 2x2 convolution to fewer than 16 channels (NuSeT's 'final' layer, src/model_layers/models.py:134) runs on the MFMA
+    kernel with a mostly empty column tile instead of the scalar fall-back."""
+    rng = np.random.default_rng(cin + cout)
+    cfg = _one_layer('Conv2D', cin, (48, 64), filters=cout, kernel_size=[k, k], strides=[1, 1], padding='same', activation='linear', use_bias=False)
+    weights = {'c': [(rng.normal(size=(k, k, cin, cout)) / np.sqrt(k * k * cin) / 64).astype(np.float32)]}
+    x = rng.integers(0, 256, size=(2, 48, 64, cin), dtype=np.uint8)
+    got, plan = _run(gpu, cfg, weights, x, fuse=True)
+    want = oracle_unet.forward(cfg, weights, x)
+    assert np.abs(got - want).max() < TOL * max(1.0, np.abs(want).max()), np.abs(got - want).max()
+    assert _mfma_ops(gpu, x) == {0}
+
+
+@pytest.mark.parametrize('base,up', [(16, 'transpose3'), (32, 'transpose4')])
+def test_unet_with_3x3_and_4x4_up_convolutions(gpu, base, up):
+    """A U-Net whose decoder up-samples with 3x3 / 4x4 stride-2 transposed convolutions: probabilities vs the oracle, and every
+    convolution except the 1-channel first layer and the 1x1 head on an MFMA kernel (none on conv_generic / convt_generic)."""
+    cfg = synth.unet_config(base=base, depth=3, up=up)
+    weights = synth.unet_weights(cfg, seed=3)
+    x = _patches(2, seed=5)
+    got, plan = _run(gpu, cfg, weights, x, fuse=True)
+    want = oracle_unet.forward(cfg, weights, x)
+    assert np.abs(got - want).max() < TOL, np.abs(got - want).max()
+    convs = [k for k, o in enumerate(plan.ops) if o['op'] in (keras_plan.OP_CONV, keras_plan.OP_CONVT)]
+    ran = _mfma_ops(gpu, x)
+    missing = [k for k in convs[1:-1] if k not in ran]
+    # (a 1x1 head or 2x2 pool fused into the previous convolution's output stage is not launched at all)
+    assert not missing, [(k, plan.ops[k]) for k in missing]

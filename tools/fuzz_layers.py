@@ -78,9 +78,10 @@ def random_graph(rng, seed_kind=0, wide=False):
         h2, w2, c2 = shape[prev]
         if rng.random() < 0.6:
             cu = int(rng.choice(CH))
-            layers.append(_L('Conv2DTranspose', 'up', [prev], filters=cu, kernel_size=[2, 2], strides=[2, 2], padding='same',
+            kt = int(rng.choice((2, 2, 3, 4)))                  # 3 / 4: kernel larger than the stride (sub-pixel MFMA form)
+            layers.append(_L('Conv2DTranspose', 'up', [prev], filters=cu, kernel_size=[kt, kt], strides=[2, 2], padding='same',
                              activation=str(rng.choice(('linear', 'relu'))), use_bias=True))
-            weights['up'] = [(rng.normal(size=(2, 2, cu, c2)) / np.sqrt(c2)).astype(np.float32),
+            weights['up'] = [(rng.normal(size=(kt, kt, cu, c2)) / np.sqrt(c2)).astype(np.float32),
                              (rng.normal(size=cu) * 0.1).astype(np.float32)]
             shape['up'] = (h2 * 2, w2 * 2, cu)
         else:

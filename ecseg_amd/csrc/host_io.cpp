@@ -7,12 +7,18 @@
 // base-16 model).  Exotic TIFF layouts (tiles, BigTIFF, PackBits, float samples, planar) return ECSEG_E_UNSUPPORTED and
 // are read by the pure-Python reader in ecseg_amd/image_io.py.
 #include <zlib.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include <cerrno>
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/ecseg_hip.h"
@@ -59,6 +65,237 @@ int png_write_rows(const char* path, const std::vector<uint8_t>& rows, int H, in
     put_be32(ihdr, (uint32_t)W); put_be32(ihdr + 4, (uint32_t)H);
     ihdr[8] = 8; ihdr[9] = (uint8_t)color_type; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
     const bool ok = out.put(sig, 8) && png_chunk(out, "IHDR", ihdr, 13) && png_chunk(out, "IDAT", z.data(), cap) &&
+                    png_chunk(out, "IEND", nullptr, 0);
+    return ok && out.close() ? ECSEG_OK : ECSEG_E_IO;
+}
+
+// ---- deflate for 4-colour label images ---------------------------------------------------------------------------
+// A label PNG is RGBA rows of at most four distinct pixels; zlib (level 1) spends 10 - 50 ms per 1040 x 1392 image finding
+// that out byte by byte.  This encoder works on the LABELS: every scan line is run-length coded at pixel granularity - the
+// first pixel of a run as 4 literals, the rest as matches of distance 4 (one pixel back) and length 4 m <= 256 - and the
+// token stream goes out as ONE dynamic-Huffman block whose code is built from the image's own token counts.  Adler-32 of
+// the never-materialised RGBA rows is advanced in closed form per run.  Any inflate reproduces the rows exactly (the
+// pixels are the contract); realistic label maps come out as small as zlib's, speckled ones ~2.5x larger, both in a
+// fraction of zlib's time.
+struct BitWriter {                                        // branch-free: speckled label maps make every data-dependent branch a coin flip
+    uint8_t* p;                                           // into a buffer sized for the worst case (+ 8 bytes of slack) by the caller
+    uint64_t acc = 0;
+    int n = 0;                                            // < 8 between calls
+    explicit BitWriter(uint8_t* dst) : p(dst) {}
+    inline void put(uint64_t bits, int len) {             // LSB-first; len <= 56
+        acc |= bits << n;
+        n += len;
+        std::memcpy(p, &acc, 8);                          // little-endian host (x86-64 / the GPU boxes); whole bytes are kept below
+        p += n >> 3;
+        acc >>= (n & ~7);
+        n &= 7;
+    }
+    uint8_t* finish() {
+        if (n > 0) { *p++ = (uint8_t)acc; }
+        acc = 0; n = 0;
+        return p;
+    }
+};
+
+// code lengths (<= 15) of a Huffman code for the given counts; symbols with count 0 get length 0; a lone used symbol gets 1
+void huffman_lengths(const uint32_t* freq, int nsym, uint8_t* len) {
+    std::vector<uint64_t> f(freq, freq + nsym);
+    for (;;) {
+        struct Node { uint64_t w; int l, r; };
+        std::vector<Node> nodes;
+        std::vector<int> live;
+        for (int i = 0; i < nsym; ++i) { len[i] = 0; if (f[i]) { nodes.push_back({f[i], -1 - i, 0}); live.push_back((int)nodes.size() - 1); } }
+        if (live.empty()) return;
+        if (live.size() == 1) { len[-1 - nodes[live[0]].l] = 1; return; }
+        while (live.size() > 1) {                             // (tens of symbols: a quadratic merge is fine)
+            int a = 0, b = 1;
+            if (nodes[live[b]].w < nodes[live[a]].w) std::swap(a, b);
+            for (int k = 2; k < (int)live.size(); ++k) {
+                if (nodes[live[k]].w < nodes[live[a]].w) { b = a; a = k; }
+                else if (nodes[live[k]].w < nodes[live[b]].w) b = k;
+            }
+            nodes.push_back({nodes[live[a]].w + nodes[live[b]].w, live[a], live[b]});
+            const int hi = std::max(a, b), lo = std::min(a, b);
+            live.erase(live.begin() + hi);
+            live[lo] = (int)nodes.size() - 1;
+        }
+        int maxlen = 0;
+        std::vector<std::pair<int, int>> stack{{live[0], 0}};
+        while (!stack.empty()) {
+            const auto [id, d] = stack.back();
+            stack.pop_back();
+            if (nodes[id].l < 0) { len[-1 - nodes[id].l] = (uint8_t)d; maxlen = std::max(maxlen, d); }
+            else { stack.push_back({nodes[id].l, d + 1}); stack.push_back({nodes[id].r, d + 1}); }
+        }
+        if (maxlen <= 15) return;
+        for (auto& v : f) if (v) v = (v + 1) / 2;              // flatten the distribution and try again
+    }
+}
+
+// canonical codes, bit-reversed for deflate's LSB-first packing
+void canonical_codes(const uint8_t* len, int nsym, uint16_t* code) {
+    int count[16] = {0}, next[16] = {0};
+    for (int i = 0; i < nsym; ++i) ++count[len[i]];
+    count[0] = 0;
+    int c = 0;
+    for (int b = 1; b < 16; ++b) { c = (c + count[b - 1]) << 1; next[b] = c; }
+    for (int i = 0; i < nsym; ++i) {
+        if (!len[i]) { code[i] = 0; continue; }
+        int v = next[len[i]]++, r = 0;
+        for (int k = 0; k < len[i]; ++k) { r = (r << 1) | (v & 1); v >>= 1; }
+        code[i] = (uint16_t)r;
+    }
+}
+
+struct LenCode { uint16_t sym; uint8_t extra_bits; uint8_t extra; };
+inline LenCode length_code(int L) {                          // deflate length 3..258 -> symbol 257.. + extra bits
+    static const int base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const int ebits[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    int i = 28;
+    while (base[i] > L) --i;
+    return LenCode{(uint16_t)(257 + i), (uint8_t)ebits[i], (uint8_t)(L - base[i])};
+}
+
+// zlib stream (header, one dynamic block, Adler-32) of the RGBA scan lines (filter byte 0 each) of an H x W label image
+void deflate_labels(const uint8_t* labels, int H, int W, const uint8_t pal[4][4], std::vector<uint8_t>* z) {
+    // pass 1: run-length tokens (colour in the top 2 bits, run length below; 0xffffffff = start of a scan line) + counts
+    uint32_t flit[4] = {0, 0, 0, 0};                          // runs per colour (each contributes its 4 literal bytes)
+    uint32_t flen[65] = {0};                                  // matches of 4 m bytes, m = 1..64
+    // run starts of a scan line as bit masks over 64-pixel blocks (one compare per pixel, no data-dependent branch), then one
+    // token per set bit
+    std::unique_ptr<uint32_t[]> tok(new uint32_t[(size_t)H * ((size_t)W + 1)]);     // (uninitialised: only the tokens written are touched)
+    size_t nt = 0;
+    std::vector<uint64_t> starts(((size_t)W + 63) / 64 + 1);
+    for (int y = 0; y < H; ++y) {
+        const uint8_t* l = labels + (size_t)y * W;
+        tok[nt++] = 0xffffffffu;
+        const size_t nblk = ((size_t)W + 63) / 64;
+        for (size_t bl = 0; bl < nblk; ++bl) {
+            const int x0 = (int)(bl * 64), nx = W - x0 < 64 ? W - x0 : 64;
+            uint64_t m = 0;
+            int i = 0;
+#if defined(__SSE2__)
+            if (x0 > 0 && nx == 64) {                         // whole block with a left neighbour: 4 x 16 pixels per compare
+                const __m128i three = _mm_set1_epi8(3);
+                for (; i < 64; i += 16) {
+                    const __m128i cur = _mm_min_epu8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(l + x0 + i)), three);
+                    const __m128i prev = _mm_min_epu8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(l + x0 + i - 1)), three);
+                    m |= (uint64_t)(uint16_t)~_mm_movemask_epi8(_mm_cmpeq_epi8(cur, prev)) << i;
+                }
+            }
+#endif
+            for (; i < nx; ++i) {
+                const int x = x0 + i;
+                const uint8_t cur = l[x] > 3 ? 3 : l[x], prev = x ? (l[x - 1] > 3 ? 3 : l[x - 1]) : 255;
+                m |= (uint64_t)(cur != prev) << i;
+            }
+            starts[bl] = m;
+        }
+        int run_x = 0;                                        // start of the run being measured (pixel 0 always starts one)
+        uint8_t run_c = l[0] > 3 ? 3 : l[0];
+        for (size_t bl = 0; bl < nblk; ++bl) {
+            uint64_t m = starts[bl];
+            if (bl == 0) m &= ~1ull;
+            while (m) {
+                const int x = (int)(bl * 64) + __builtin_ctzll(m);
+                m &= m - 1;
+                const int k = x - run_x;
+                tok[nt++] = ((uint32_t)run_c << 30) | (uint32_t)k;
+                ++flit[run_c];
+                flen[64] += (uint32_t)((k - 1) >> 6);
+                ++flen[(k - 1) & 63];                         // (slot 0 collects the runs without a remainder match; ignored below)
+                run_x = x; run_c = l[x] > 3 ? 3 : l[x];
+            }
+        }
+        const int k = W - run_x;
+        tok[nt++] = ((uint32_t)run_c << 30) | (uint32_t)k;
+        ++flit[run_c];
+        flen[64] += (uint32_t)((k - 1) >> 6);
+        ++flen[(k - 1) & 63];
+    }
+    uint32_t freq[286] = {0};
+    freq[0] += (uint32_t)H;                                   // filter bytes
+    for (int c = 0; c < 4; ++c) for (int k = 0; k < 4; ++k) freq[pal[c][k]] += flit[c];
+    freq[256] = 1;
+    bool any_match = false;
+    for (int m = 1; m <= 64; ++m) if (flen[m]) { freq[length_code(4 * m).sym] += flen[m]; any_match = true; }
+    uint8_t llen[286], dlen[4] = {0, 0, 0, 0};
+    uint16_t lcode[286];
+    huffman_lengths(freq, 286, llen);
+    canonical_codes(llen, 286, lcode);
+    if (any_match) dlen[3] = 1;                               // distance 4 = distance code 3, the only one: a single 1-bit code (bit 0)
+    // code-length alphabet: a fixed complete code (13 symbols of 4 bits, 6 of 5 bits); lengths are sent one by one
+    uint8_t cl_len[19];
+    uint16_t cl_code[19];
+    for (int i = 0; i < 19; ++i) cl_len[i] = i < 13 ? 4 : 5;
+    canonical_codes(cl_len, 19, cl_code);
+    // worst case: every run costs its four literals (<= 60 bits) plus one match code (<= 21 bits) per started 64 pixels
+    size_t worst_bits = 4096 + 16 * (size_t)H + 64;
+    for (size_t i = 0; i < nt; ++i) if (const uint32_t t = tok[i]; t != 0xffffffffu) worst_bits += 60 + 21 * (size_t)(((t & 0x3fffffffu) + 62) / 64);
+    std::unique_ptr<uint8_t[]> buf(new uint8_t[worst_bits / 8 + 32]);
+    buf[0] = 0x78; buf[1] = 0x01;
+    BitWriter bw(buf.get() + 2);
+    bw.put(1, 1); bw.put(2, 2);                               // BFINAL, BTYPE = dynamic
+    bw.put(286 - 257, 5); bw.put(4 - 1, 5); bw.put(19 - 4, 4);
+    static const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    for (int i = 0; i < 19; ++i) bw.put(cl_len[order[i]], 3);
+    for (int i = 0; i < 286; ++i) bw.put(cl_code[llen[i]], cl_len[llen[i]]);
+    for (int i = 0; i < 4; ++i) bw.put(cl_code[dlen[i]], cl_len[dlen[i]]);
+    // per colour: the bit string of its four literals; per match length 4 m: length code + extra bits + the 1-bit distance code
+    uint64_t cbits[4]; int cn[4];
+    for (int c = 0; c < 4; ++c) {
+        cbits[c] = 0; cn[c] = 0;
+        for (int k = 0; k < 4; ++k) { cbits[c] |= (uint64_t)lcode[pal[c][k]] << cn[c]; cn[c] += llen[pal[c][k]]; }
+    }
+    uint32_t mbits[65]; int mn[65];
+    mbits[0] = 0; mn[0] = 0;                                  // "no remainder match": zero bits
+    for (int m = 1; m <= 64; ++m) {
+        const LenCode lc = length_code(4 * m);
+        mbits[m] = (uint32_t)lcode[lc.sym] | ((uint32_t)lc.extra << llen[lc.sym]);
+        mn[m] = llen[lc.sym] + lc.extra_bits + 1;             // + distance code "0"
+    }
+    // pass 2: bits + Adler-32 in closed form (per run of k pixels with byte sum S and weighted sum T = 4 p0 + 3 p1 + 2 p2 + p3:
+    // b += 4 k a + 2 k (k - 1) S + k T; a += k S)
+    uint64_t S[4], T[4];
+    for (int c = 0; c < 4; ++c) { S[c] = pal[c][0] + pal[c][1] + pal[c][2] + pal[c][3]; T[c] = 4 * pal[c][0] + 3 * pal[c][1] + 2 * pal[c][2] + pal[c][3]; }
+    uint64_t a = 1, b = 0;
+    const uint64_t M = 65521;
+    for (size_t i = 0; i < nt; ++i) {
+        const uint32_t t = tok[i];
+        if (t == 0xffffffffu) { bw.put(lcode[0], llen[0]); b += a; continue; }
+        const int c = (int)(t >> 30);
+        const uint64_t k = t & 0x3fffffffu;
+        bw.put(cbits[c] & 0xffffffffu, cn[c] < 32 ? cn[c] : 32);
+        bw.put(cbits[c] >> 32, cn[c] < 32 ? 0 : cn[c] - 32);
+        uint64_t rest = k - 1;
+        for (; rest >= 64; rest -= 64) bw.put(mbits[64], mn[64]);
+        bw.put(mbits[rest], mn[rest]);
+        // (64-bit moduli are the most expensive thing in this loop: a and b are reduced lazily - short runs add < 2^30 each)
+        if (k > 256) {
+            a %= M; b %= M;
+            b += 4 * k * a + 2 * k * (k - 1) % M * S[c] + k * T[c];
+        } else {
+            if ((a | b) >> 36) { a %= M; b %= M; }
+            b += 4 * k * a + 2 * k * (k - 1) * S[c] + k * T[c];
+        }
+        a += k * S[c];
+    }
+    a %= M; b %= M;
+    bw.put(lcode[256], llen[256]);
+    uint8_t* end = bw.finish();
+    const uint32_t adler = (uint32_t)((b << 16) | a);
+    *end++ = (uint8_t)(adler >> 24); *end++ = (uint8_t)(adler >> 16); *end++ = (uint8_t)(adler >> 8); *end++ = (uint8_t)adler;
+    z->assign(buf.get(), end);
+}
+
+int png_write_stream(const char* path, const std::vector<uint8_t>& z, int H, int W, int color_type) {
+    File out(path, "wb");
+    if (!out.f) return ECSEG_E_IO;
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    uint8_t ihdr[13];
+    put_be32(ihdr, (uint32_t)W); put_be32(ihdr + 4, (uint32_t)H);
+    ihdr[8] = 8; ihdr[9] = (uint8_t)color_type; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
+    const bool ok = out.put(sig, 8) && png_chunk(out, "IHDR", ihdr, 13) && png_chunk(out, "IDAT", z.data(), z.size()) &&
                     png_chunk(out, "IEND", nullptr, 0);
     return ok && out.close() ? ECSEG_OK : ECSEG_E_IO;
 }
@@ -185,21 +422,14 @@ int ecseg_npy_write_i64(const char* path, const uint8_t* labels, int H, int W) {
 
 // labels/<stem>.png: plt.imsave(path, I.astype('uint8'), cmap=ListedColormap(['#386cb0', '#ffff99', '#7fc97f', '#f0027f']),
 // vmin=0, vmax=4) (src/metaseg.py:47-52): class k -> colour k (values above 3 clip to 3), 8-bit RGBA, filter type 0 on
-// every scan line, zlib level 1 (the pixels are the contract, not the compressed bytes).
+// every scan line, compressed by deflate_labels above (the pixels are the contract, not the compressed bytes).
 int ecseg_png_write_labels(const char* path, const uint8_t* labels, int H, int W) {
     if (!path || !labels || H <= 0 || W <= 0) return ECSEG_E_INVALID;
     static const uint8_t pal[4][4] = {{0x38, 0x6c, 0xb0, 255}, {0xff, 0xff, 0x99, 255}, {0x7f, 0xc9, 0x7f, 255}, {0xf0, 0x02, 0x7f, 255}};
-    uint32_t pal32[4];
-    for (int k = 0; k < 4; ++k) std::memcpy(&pal32[k], pal[k], 4);
-    const size_t stride = 1 + (size_t)W * 4;
-    std::vector<uint8_t> rows((size_t)H * stride);
-    for (int y = 0; y < H; ++y) {
-        uint8_t* r = rows.data() + (size_t)y * stride;
-        *r++ = 0;
-        const uint8_t* l = labels + (size_t)y * W;
-        for (int x = 0; x < W; ++x) { const uint32_t c = pal32[l[x] > 3 ? 3 : l[x]]; std::memcpy(r + 4 * x, &c, 4); }
-    }
-    return png_write_rows(path, rows, H, W, 6, 1);
+    if (W >= (1 << 30)) return ECSEG_E_INVALID;
+    std::vector<uint8_t> z;
+    deflate_labels(labels, H, W, pal, &z);
+    return png_write_stream(path, z, H, W, 6);
 }
 
 // 8-bit PNG of a (H, W, channels) image, channels 1 (gray), 3 (RGB) or 4 (RGBA): the red/ green/ channel images of

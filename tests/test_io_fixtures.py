@@ -153,3 +153,82 @@ def test_truncated_and_corrupt_h5_files_raise_cleanly(golden_dir, tmp_path):
             hdf5_min.load_keras_h5(p)
         except Exception:
             pass
+
+
+def test_native_and_python_tiff_readers_agree_on_every_fixture(golden_dir, tmp_path):
+    """Round 3: imread goes through the whole-file native reader (csrc/host_io.cpp) where the layout allows; the pure-Python
+    reader stays for the rest.  Both must return the stored pixels, and the native one must leave tiled / PackBits / ... files
+    to the Python one instead of failing."""
+    files, px = _fixtures(golden_dir)
+    native = 0
+    for name, b64 in files.items():
+        path = str(tmp_path / (name + '.tif'))
+        open(path, 'wb').write(base64.b64decode(b64))
+        a = image_io._native_tiff(path)
+        b = image_io.read_tiff(path, native=False)
+        assert np.array_equal(b, px[name]) and b.dtype == px[name].dtype, name
+        if a is not None:
+            native += 1
+            assert a.dtype == px[name].dtype and np.array_equal(a, px[name]), name
+        assert image_io.image_shape(path) == px[name].shape, name
+    assert native >= 8, native                                   # strips + none / LZW / Deflate + predictor: the common files
+    bad = str(tmp_path / 'bad.tif')
+    open(bad, 'wb').write(b'II*\x00' + bytes(range(200)))
+    with pytest.raises(ValueError):
+        image_io.imread(bad)
+    with pytest.raises(OSError):
+        image_io.imread(str(tmp_path / 'missing.tif'))
+
+
+@pytest.mark.parametrize('hw', [(1040, 1392), (37, 52), (5, 9000), (64, 1), (1, 1)])
+def test_native_writers_equal_the_python_ones_byte_for_byte(tmp_path, hw):
+    rng = np.random.default_rng(hw[1])
+    img = rng.integers(0, 256, hw, dtype=np.uint8)
+    img[: hw[0] // 2] //= 64                                     # compressible half
+    a, b = str(tmp_path / 'a.tif'), str(tmp_path / 'b.tif')
+    for inv in (False, True):
+        image_io.write_tiff_gray8(a, img, invert=inv)
+        image_io.write_tiff_gray8(b, img, invert=inv, native=False)
+        assert open(a, 'rb').read() == open(b, 'rb').read()
+        assert np.array_equal(np.array(Image.open(a)), ~img if inv else img)
+    lab = (img >> 6).astype(np.uint8)
+    image_io.write_npy_int64(a, lab)
+    import io
+    ref = io.BytesIO()
+    np.save(ref, lab.astype(np.int64))
+    assert open(a, 'rb').read() == ref.getvalue()                # np.save(labels.astype('int64')), src/metaseg.py:53
+    rgb = rng.integers(0, 256, hw + (3,), dtype=np.uint8)
+    image_io.write_png(a, rgb)
+    image_io.write_png(b, rgb, native=False)
+    assert open(a, 'rb').read() == open(b, 'rb').read()
+    assert np.array_equal(np.array(Image.open(a)), rgb)
+
+
+def test_label_png_run_length_deflate_decodes_everywhere(tmp_path):
+    """labels/<stem>.png is compressed by a purpose-built deflate encoder (runs of equal pixels as distance-4 matches, one
+    dynamic-Huffman block, Adler-32 in closed form): libpng (PIL) and zlib must reproduce the RGBA rows exactly for speckle,
+    flat images, single rows / columns, runs longer than one match (> 64 pixels) and values above 3 (clipped like vmax=4)."""
+    import struct
+    import zlib
+    rng = np.random.default_rng(7)
+    cases = [rng.integers(0, 4, (97, 211)), np.zeros((64, 80)), np.full((3, 70000), 1), rng.integers(0, 4, (50, 1)),
+             rng.integers(0, 4, (1, 300)), np.full((1, 1), 2), np.tile(np.array([0, 1, 2, 3]), (37, 91)), rng.integers(0, 9, (40, 50)),
+             (rng.random((300, 500)) < 0.01) * 3, rng.integers(0, 2, (5, 63)), rng.integers(0, 2, (5, 64)), rng.integers(0, 2, (5, 65)),
+             np.repeat(rng.integers(0, 4, (8, 40)), 67, axis=1)]
+    path = str(tmp_path / 'l.png')
+    for k, lab in enumerate(cases):
+        lab = lab.astype(np.uint8)
+        image_io.write_label_png(path, lab)
+        want = image_io.LABEL_COLORS[np.minimum(lab, 3)]
+        assert np.array_equal(np.array(Image.open(path)), want), k
+        raw = open(path, 'rb').read()
+        pos, idat = 8, b''
+        while pos < len(raw):                                    # chunk CRCs + the zlib stream itself (Adler-32 is checked by zlib)
+            n, tag = struct.unpack('>I4s', raw[pos:pos + 8])
+            body = raw[pos + 8:pos + 8 + n]
+            assert struct.unpack('>I', raw[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + body) & 0xffffffff
+            if tag == b'IDAT':
+                idat += body
+            pos += 12 + n
+        rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(lab.shape[0], 1 + 4 * lab.shape[1])
+        assert not rows[:, 0].any() and np.array_equal(rows[:, 1:].reshape(want.shape), want), k

@@ -44,7 +44,8 @@ def main():
     in_bytes = sum(os.path.getsize(os.path.join(inp, f)) for f in os.listdir(inp))
     cfg = synth.unet_config(base=a.base)
     model = MetasegModel(cfg, synth.unet_weights(cfg, seed=0), device=0)
-    model.handle.set_images_per_group(16)
+    if a.base >= 64:
+        model.handle.set_images_per_group(16)          # narrower models: the automatic launch-group size
     with open(os.path.join(work, 'config.yaml'), 'w') as f:
         yaml.safe_dump({'metaseg': {'inpath': inp, 'batch_images': a.batch, **({'io_threads': a.io_threads} if a.io_threads else {})}}, f)
     os.chdir(work)

@@ -1,6 +1,12 @@
 """Image-parallel sharding across the GPUs of one node and the one exchange step of the path: an all-gather of
 fixed-size per-image result records (RCCL over xGMI when the tensors live on GPUs; gloo on CPU in the tests).
 
+Two transports carry the exchange: ``torch.distributed`` (bench.py's launcher contract; gloo in the CPU tests) and - so that
+`make metaseg` on several GPUs needs no PyTorch at all ("PyTorch only as optional oracle / allocator") - the
+library's own RCCL communicator (``_lib.Comm`` -> csrc/comm.hip) with a file rendezvous: rank 0 writes the 128-byte
+communicator id next to the input folder, the other ranks pick it up (``ECSEG_DIST=native``; chosen by itself when torch
+cannot be imported).
+
 The reference's only parallelism is ``tf.distribute.MirroredStrategy`` around ``load_model``
 (src/metaseg.py:33-36), which splits one image's patch batch over replicas; images themselves are processed in a
 serial loop (src/metaseg.py:42).  Every image is independent, so here whole images are sharded and nothing but the
@@ -82,3 +88,86 @@ def compact_records(gathered):
     g = gathered.cpu().numpy() if hasattr(gathered, 'cpu') else np.asarray(gathered)
     g = g[g[:, F_INDEX] >= 0]
     return g[np.argsort(g[:, F_INDEX], kind='stable')]
+
+
+# ---- the library's own communicator (no torch) ----------------------------------------------------------------------
+_native = None          # _lib.Comm of this process, once native_init has run
+
+
+def want_native():
+    """ECSEG_DIST=native | torch; default: torch when it can be imported (the tested launcher path), else native."""
+    mode = os.environ.get('ECSEG_DIST', '').lower()
+    if mode in ('native', 'torch'):
+        return mode == 'native'
+    try:
+        import torch.distributed    # noqa: F401
+        return False
+    except Exception:
+        return True
+
+
+def write_rendezvous(path, payload):
+    """Rank 0: publish the communicator id atomically (temporary name + rename: a reader never sees half a file)."""
+    tmp = '%s.tmp%d' % (path, os.getpid())
+    with open(tmp, 'wb') as f:
+        f.write(payload)
+    os.replace(tmp, path)
+
+
+def read_rendezvous(path, nbytes, timeout=300.0, poll=0.05):
+    """Other ranks: wait for rank 0's file."""
+    import time
+    t0 = time.time()
+    while True:
+        try:
+            with open(path, 'rb') as f:
+                b = f.read()
+            if len(b) == nbytes:
+                return b
+        except OSError:
+            pass
+        if time.time() - t0 > timeout:
+            raise TimeoutError('no communicator id at %s after %.0f s (did rank 0 start?)' % (path, timeout))
+        time.sleep(poll)
+
+
+def native_init(rank, world, device, rdzv_path):
+    """One RCCL communicator over the ranks of this job without torch: rank 0 creates the id and publishes it at
+    ``rdzv_path`` (a file every rank can see), everybody joins.  -> (rank, world)."""
+    global _native
+    from ._lib import Comm
+    if rank == 0:
+        uid = Comm.unique_id()
+        write_rendezvous(rdzv_path, uid)
+    else:
+        uid = read_rendezvous(rdzv_path, 128)
+    _native = Comm(uid, rank, world, device)
+    return rank, world
+
+
+def native_close(rdzv_path=None, rank=0):
+    global _native
+    if _native is not None:
+        _native.close()
+        _native = None
+    if rdzv_path and rank == 0:
+        try:
+            os.unlink(rdzv_path)
+        except OSError:
+            pass
+
+
+def gather_all(rec, device=0):
+    """``rec``: this rank's int64 (padded_len, RECORD_INT64) numpy block -> the whole job's records, compacted (padding rows
+    dropped, ordered by global image index), over whichever transport this process initialised; 1 rank: just compacted."""
+    if _native is not None:
+        return compact_records(_native.allgather_records(rec))
+    try:
+        import torch
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dev = torch.device('cuda', device) if torch.cuda.is_available() else torch.device('cpu')
+            return compact_records(allgather_records(torch.from_numpy(np.ascontiguousarray(rec)).to(dev)))
+    except ImportError:
+        pass
+    return compact_records(rec)

@@ -245,13 +245,7 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
     if stats is not None:
         stats['gpu_seconds'] = t_gpu
     rec = dist.make_records(start, len(mine), per, n_ec=n_ec, status=status)
-    if world > 1:
-        import torch
-        dev = torch.device('cuda', model.handle.device) if torch.cuda.is_available() else torch.device('cpu')
-        rec = dist.compact_records(dist.allgather_records(torch.from_numpy(rec).to(dev)))
-    else:
-        rec = dist.compact_records(rec)
-    return rec
+    return dist.gather_all(rec, device=model.handle.device)        # the path's one exchange (identity for one rank)
 
 
 def finish(inpath, image_paths, rec, rank, seconds=None, gpu_seconds=0.0, log=print):
@@ -290,6 +284,16 @@ def _self_launch(device_ids):
     env = dict(os.environ, ECSEG_DEVICE_IDS=','.join(str(int(d)) for d in device_ids),
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'),
                PYTHONPATH=root + (os.pathsep + os.environ['PYTHONPATH'] if os.environ.get('PYTHONPATH') else ''))
+    if dist.want_native():
+        # no torch: plain child processes, the library's own RCCL communicator, rendezvous through a file in the job's folder
+        import tempfile
+        rdzv = os.path.join(tempfile.gettempdir(), 'ecseg_rdzv_%d_%d' % (os.getpid(), int(time.time() * 1e3) & 0xffffff))
+        n = len(device_ids)
+        procs = [subprocess.Popen([sys.executable, '-m', 'ecseg_amd.metaseg'],
+                                  env=dict(env, ECSEG_DIST='native', ECSEG_RDZV=rdzv, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n)))
+                 for r in range(n)]
+        codes = [p.wait() for p in procs]
+        sys.exit(max(abs(c) for c in codes))
     # --standalone: torch.distributed.run binds its own rendezvous port (no bind-then-close race with other jobs on the node)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1',
            '--nproc-per-node', str(len(device_ids)), '-m', 'ecseg_amd.metaseg']
@@ -316,7 +320,12 @@ def main(argv=None):
     ids = [int(d) for d in os.environ['ECSEG_DEVICE_IDS'].split(',')] if os.environ.get('ECSEG_DEVICE_IDS') else \
         [int(d) for d in device_ids] if device_ids else None
     device = ids[int(os.environ.get('LOCAL_RANK', '0')) % len(ids)] if ids else None
-    rank, world = dist.init_process_group(device=device) if under_launcher else (0, 1)     # RCCL on the same physical GPU
+    native = under_launcher and os.environ.get('ECSEG_DIST', '').lower() == 'native' and os.environ.get('ECSEG_RDZV')
+    if native:                                                     # RCCL through the C ABI, no torch (rank / world from the environment)
+        rank, world = dist.native_init(int(os.environ['RANK']), int(os.environ['WORLD_SIZE']),
+                                       device if device is not None else int(os.environ.get('LOCAL_RANK', '0')), os.environ['ECSEG_RDZV'])
+    else:
+        rank, world = dist.init_process_group(device=device) if under_launcher else (0, 1)     # RCCL on the same physical GPU
     model = load_model(MODEL_NAME, device=device)
     print(model.handle.device_name)
     image_paths = get_imgs(inpath)
@@ -326,7 +335,9 @@ def main(argv=None):
     rec = run(inpath, model, image_paths, rank, world, batch_images=int(var.get('batch_images', 8)),
               io_threads=var.get('io_threads'), stats=stats, resume=bool(var.get('resume', False)))
     failed = finish(inpath, image_paths, rec, rank, seconds=time.perf_counter() - t0, gpu_seconds=stats.get('gpu_seconds', 0.0))
-    if world > 1:
+    if native:
+        dist.native_close(os.environ['ECSEG_RDZV'], rank)          # (the all-gather was the last thing every rank waited for)
+    elif world > 1:
         import torch.distributed as td
         td.barrier()
         td.destroy_process_group()

@@ -92,3 +92,20 @@ def test_bench_uses_the_c_abi_collective_under_a_process_group():
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
     assert res['n_gpus'] == 1 and res['value'] > 0
     assert res['config']['allgather'].startswith('ecseg_allgather_records_dev'), res['config']['allgather']
+
+
+def test_native_transport_one_rank(tmp_path):
+    """dist.native_init / gather_all / native_close: the library's RCCL communicator behind the `make metaseg` exchange
+    (ECSEG_DIST=native), with the one rank this box has."""
+    import numpy as np
+    from ecseg_amd import dist as edist
+    path = str(tmp_path / 'rdzv')
+    assert edist.native_init(0, 1, 0, path) == (0, 1)
+    try:
+        assert len(open(path, 'rb').read()) == 128
+        rec = edist.make_records(10, 3, 5, n_ec=[1, 2, 3], status=[0, 2, 0])
+        out = edist.gather_all(rec)
+        assert out.shape == (3, 16) and np.array_equal(out[:, edist.F_NEC], [1, 2, 3]) and out[1, edist.F_STATUS] == 2
+    finally:
+        edist.native_close(path, 0)
+    assert not os.path.exists(path) and edist._native is None

@@ -189,3 +189,30 @@ def test_oom_retry_halves_below_the_failed_group_and_restores_the_setting(tmp_pa
     gray, post, nec = metaseg._segment_with_retry(m2, imgs, lambda *a: None)
     assert post.shape == (8, H, W) and m2.handle.images_per_group == 0
     assert [n for n, _ in m2.handle.calls if n <= 3] == [2, 2, 2, 2]
+
+
+def test_native_rendezvous_file_and_transport_choice(tmp_path, monkeypatch):
+    """The torch-free transport of `make metaseg` (ECSEG_DIST=native): rank 0 publishes the 128-byte communicator id through a
+    file, late and early readers both get exactly those bytes; one rank without any transport: gather_all = compaction."""
+    import threading
+    import time
+    path = str(tmp_path / 'rdzv')
+    payload = bytes(range(128))
+    got = []
+    t = threading.Thread(target=lambda: got.append(edist.read_rendezvous(path, 128, timeout=20)))
+    t.start()                                                     # reader first: polls until the writer's rename
+    time.sleep(0.2)
+    open(path, 'wb').write(b'short')                              # a partial / foreign file is not accepted
+    time.sleep(0.2)
+    edist.write_rendezvous(path, payload)
+    t.join(timeout=30)
+    assert got == [payload] and edist.read_rendezvous(path, 128, timeout=1) == payload
+    with pytest.raises(TimeoutError):
+        edist.read_rendezvous(str(tmp_path / 'nobody'), 128, timeout=0.3)
+    monkeypatch.setenv('ECSEG_DIST', 'native')
+    assert edist.want_native()
+    monkeypatch.setenv('ECSEG_DIST', 'torch')
+    assert not edist.want_native()
+    rec = edist.make_records(3, 2, 4, n_ec=[5, 6])
+    out = edist.gather_all(rec)
+    assert out.shape == (2, edist.RECORD_INT64) and out[:, edist.F_INDEX].tolist() == [3, 4]

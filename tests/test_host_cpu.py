@@ -226,3 +226,21 @@ def test_plan_of_classifier_graphs(kind, golden_dir):
     ops = [o['op'] for o in plan.ops]
     assert keras_plan.OP_GLOBALPOOL in ops if kind == 'interseg' else keras_plan.OP_GLOBALPOOL not in ops
     assert any(o['op'] == keras_plan.OP_CONV and o['stride'] == 2 for o in plan.ops)
+
+
+def test_shipped_library_has_no_diagnostic_kernels():
+    """the timing-only ablations and cycle stamps of conv_wino4_kernel live in csrc/wino4_diag.inc and exist
+    only in the -DECSEG_DIAG build; the product source contains one code path and the shipped library exactly the three
+    instantiations <HEAD, SPLIT> it launches."""
+    import re
+    import shutil
+    import subprocess
+    from ecseg_amd._lib import LIB_PATH
+    nm = shutil.which('nm') or '/opt/rocm/lib/llvm/bin/llvm-nm'
+    out = subprocess.run([nm, '-C', LIB_PATH], capture_output=True, text=True, check=True).stdout
+    inst = sorted(set(re.findall(r' ecseg::conv_wino4_kernel<([^>]*)>\(', out)))
+    assert inst == ['false, false', 'false, true', 'true, false'], inst
+    src = open(os.path.join(ROOT, 'ecseg_amd', 'csrc', 'wino4_kernel.hip')).read()
+    product = src.split('#ifdef ECSEG_DIAG')[0] + src.split('#endif', 1)[1]          # everything but the hook definitions
+    for word in ('ABL', 'STAMP', 'W4_VARIANT', 's_memtime'):
+        assert word not in product.replace('W4_KSTAMP', '').replace('W4_ESTAMP', '').replace('WSTAMP', '').replace('ESTAMP', ''), word

@@ -17,10 +17,15 @@
 //     filter (16 KB per 16 x 16 channels) is loaded into LDS once per workgroup; the input halo (18 x 34 pixels x 16
 //     channels) arrives by LDS-DMA into a double buffer, one stage (block, 16-channel chunk) ahead; one s_barrier per stage.
 //
-// LDS halo image (16-byte slots = 4 channels of a pixel): slot(y, x, cq) = y * 152 + OFF[cq][x & 1] + (x >> 1) with
-// OFF = {0, 17 | 40, 57 | 74, 91 | 114, 131}: the four 16-lane groups of a ds_read_b128 hold 8 tiles of channel quad kq
-// and the other 8 tiles of quad kq ^ 1; OFF[kq ^ 1] - OFF[kq] = 40 = 8 (mod 16) and two tile rows are 304 = 0 (mod 16)
-// slots apart, so the 16 lanes of a group land on 16 different 16-byte bank columns: conflict-free.
+// LDS halo image (16-byte slots = 4 channels of a pixel), round 3: slot(y, x, cq) = 138 y + 4 x + (cq ^ (((x >> 2) & 1) << 1)) -
+// a pixel's four channel quads sit next to each other (in an order that flips with bit 2 of x) and a halo row is 34 pixels =
+// 136 slots + 2 of padding.  A 64-slot LDS-DMA piece is then 16 CONSECUTIVE pixels of a halo row with all their channels: 1 KiB of
+// contiguous global memory at 16 input channels (8 cache lines; 16 half lines at 32 channels) instead of 64 pieces of 16 bytes
+// from 64 different lines (rounds 1-2: slot = 152 y + OFF[cq][x & 1] + (x >> 1), 370-540 issue cycles per piece against 55-100
+// for a contiguous one), and a buffer needs 39 instead of 43 pieces.  Conflict-free all the same: the hardware serves a
+// ds_read_b128 in the lane groups {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} (+32), i.e. 8 tiles of quad kq and the other 8
+// tiles of quad kq ^ 1; for every halo offset (i, j) their 16 slots are distinct modulo 16 (138 = 10 mod 16 separates the two
+// tile rows by 4, the quad flip separates tiles 4 apart; verified exhaustively by tools/w16_layout_check.py).
 #include <type_traits>
 
 #include "common.h"
@@ -30,11 +35,11 @@ namespace ecseg {
 
 namespace {
 
-constexpr int W16_PITCH = 152;       // slots per halo row (136 used)
+constexpr int W16_PITCH = 138;       // slots per halo row (136 used)
 constexpr int W16_ROWS = 18;
-constexpr int W16_PIECES = 43;       // 64-slot DMA pieces per halo buffer (18 * 152 = 2736 slots, padded to 2752)
+constexpr int W16_PIECES = 39;       // 64-slot DMA pieces per halo buffer (18 * 138 = 2484 slots, padded to 2496)
 constexpr int W16_HS = W16_PIECES * 64;
-constexpr int W16_NP = 6;            // pieces per thread and stage: piece = wave + 8 k
+constexpr int W16_NP = 5;            // pieces per thread and stage: piece = wave + 8 k
 
 typedef __attribute__((address_space(3))) void* w16_lptr_t;
 
@@ -99,15 +104,10 @@ __global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(C
     for (int k = 0; k < W16_NP; ++k) {
         const int q = (wave + 8 * k) * 64 + lane;
         const int y = q / W16_PITCH, r = q - y * W16_PITCH;
-        int cq = -1, rr = 0;
-        if (r < 34) { cq = 0; rr = r; }
-        else if (r >= 40 && r < 74) { cq = 1; rr = r - 40; }
-        else if (r >= 74 && r < 108) { cq = 2; rr = r - 74; }
-        else if (r >= 114 && r < 148) { cq = 3; rr = r - 114; }
-        const int par = rr >= 17 ? 1 : 0, x = 2 * (rr - 17 * par) + par;
-        const bool ok = cq >= 0 && y < W16_ROWS;
-        d_meta[k] = x | (y << 8) | (ok ? 0 : 0x10000);
-        d_rel[k] = (y * W + x) * p.in.cs + (cq < 0 ? 0 : cq) * 4;
+        const int x = r >> 2, cq = (r & 3) ^ (((x >> 2) & 1) << 1);
+        const bool ok = r < 136 && y < W16_ROWS;
+        d_meta[k] = (ok ? x : 0) | (y << 8) | (ok ? 0 : 0x10000);
+        d_rel[k] = ok ? (y * W + x) * p.in.cs + cq * 4 : 0;
     }
     auto dma_halo = [&](int blk, int kc, int buf) __attribute__((always_inline)) {
         int img, y0, x0;
@@ -136,8 +136,9 @@ __global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(C
     // ---- lane geometry: tile (tr, tc) of the wave's 2 x 8 tiles, channel quad kq ----
     const int m = lane & 15, kq = lane >> 4;
     const int TR = 2 * (wave & 3) + (m >> 3), TC = 8 * (wave >> 2) + (m & 7);
-    const int off_a = (2 * TR) * W16_PITCH + TC + 40 * (kq & 1) + 74 * (kq >> 1);   // even halo columns of the tile
-    const int off_b = off_a + 17;                                                    // odd halo columns
+    // halo pixel (2 TR + i, 2 TC + j), quad kq: columns j = 0, 1 share bit 2 of x (off_a), columns 2, 3 may have crossed it (off_b)
+    const int off_a = (2 * TR) * W16_PITCH + 8 * TC + (kq ^ ((((2 * TC) >> 2) & 1) << 1));
+    const int off_b = (2 * TR) * W16_PITCH + 8 * TC + 8 + (kq ^ ((((2 * TC + 2) >> 2) & 1) << 1));
 
     f32x4 bv[NB];
 #pragma unroll
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(C
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) d[i][j] = Hb[((j & 1) ? off_b : off_a) + i * W16_PITCH + (j >> 1)];
+                for (int j = 0; j < 4; ++j) d[i][j] = Hb[((j & 2) ? off_b : off_a) + i * W16_PITCH + 4 * (j & 1)];
             // V = B^T d B per channel (k-step) s: 32 adds
             float V[4][16];
 #pragma unroll

@@ -60,6 +60,44 @@ def unet_config(base=64, depth=4, in_ch=1, n_classes=4, up='transpose', batchnor
                        'output_layers': [[out, 0, 0]]}}
 
 
+def nuset_unet_config(base=64, n_classes=2, in_ch=1, hw=256):
+    """The shape of NuSeT's U-Net (reference src/model_layers/models.py:5-136, a TF1-layers graph; SURVEY 8(f)4: "the same conv
+    kernels can serve ... NuSeT's U-Net") written as a Keras functional ``model_config``: four (conv3-relu x2, 2x2 pool) levels of
+    base .. 8 x base channels, a 16 x base bottleneck, four 3x3 / stride-2 ``Conv2DTranspose`` + ReLU up-samplers of which the
+    FIRST is not concatenated with its skip (models.py:78-94) and the other three are, and a final 3x3 convolution to
+    ``n_classes`` feature maps without bias or activation (models.py:134).  Only the architecture is taken from the reference -
+    weights are seeded like every other synthetic model here."""
+    layers = []
+
+    def L(cls, name, inbound, **cfg):
+        layers.append({'class_name': cls, 'name': name, 'config': dict(cfg, name=name),
+                       'inbound_nodes': [[[i, 0, 0, {}] for i in inbound]] if inbound else []})
+        return name
+
+    def conv(name, x, filters, act='relu', bias=True):
+        return L('Conv2D', name, [x], filters=filters, kernel_size=[3, 3], strides=[1, 1], padding='same', activation=act,
+                 use_bias=bias, dilation_rate=[1, 1], groups=1)
+
+    x = L('InputLayer', 'input', [], batch_input_shape=[None, hw, hw, in_ch], dtype='float32')
+    skips = []
+    for lv in range(4):
+        f = base << lv
+        x = conv('conv%d-2' % (lv + 1), conv('conv%d-1' % (lv + 1), x, f), f)
+        skips.append(x)
+        x = L('MaxPooling2D', 'pool%d' % (lv + 1), [x], pool_size=[2, 2], strides=[2, 2], padding='valid')
+    x = conv('conv5-2', conv('conv5-1', x, base << 4), base << 4)
+    for lv in (3, 2, 1, 0):
+        f = base << lv
+        x = L('Conv2DTranspose', 'up%d' % (lv + 1), [x], filters=f, kernel_size=[3, 3], strides=[2, 2], padding='same',
+              activation='relu', use_bias=True, dilation_rate=[1, 1], output_padding=None)
+        if lv != 3:
+            x = L('Concatenate', 'cat%d' % (lv + 1), [skips[lv], x], axis=3)
+        x = conv('conv%d-4' % (lv + 1), conv('conv%d-3' % (lv + 1), x, f), f)
+    out = conv('final', x, n_classes, act='linear', bias=False)
+    return {'class_name': 'Functional', 'config': {'name': 'nuset_unet_synth', 'layers': layers,
+                                                   'input_layers': [['input', 0, 0]], 'output_layers': [[out, 0, 0]]}}
+
+
 def conv_stack_config(n_convs=3, ch=64, n_classes=4, in_ch=1):
     """Plain stack: input -> (conv3-relu) x n_convs -> 1x1 softmax head (no pooling, no skips)."""
     def L(cls, name, inb, **c):

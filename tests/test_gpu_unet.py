@@ -427,3 +427,20 @@ def test_unet_with_3x3_and_4x4_up_convolutions(gpu, base, up):
     missing = [k for k in convs[1:-1] if k not in ran]
     # (a 1x1 head or 2x2 pool fused into the previous convolution's output stage is not launched at all)
     assert not missing, [(k, plan.ops[k]) for k in missing]
+
+
+def test_nuset_shaped_unet_runs_on_mfma_kernels(gpu):
+    """SURVEY 8(f)4 / VERDICT r02 #6: the architecture of NuSeT's U-Net (src/model_layers/models.py:5-136: 3x3 stride-2 transposed
+    convolutions, a first up-sampler without skip, a bias-free 3x3 'final' layer to 2 feature maps) with seeded weights - output
+    within 1e-3 of the oracle and every convolution but the 1-channel first layer on an MFMA kernel."""
+    cfg = synth.nuset_unet_config(base=16)
+    weights = synth.unet_weights(cfg, seed=4)
+    x = _patches(2, seed=9)
+    got, plan = _run(gpu, cfg, weights, x, fuse=True)
+    want = oracle_unet.forward(cfg, weights, x)
+    assert got.shape == want.shape == (2, 256, 256, 2)
+    assert np.abs(got - want).max() < TOL * max(1.0, np.abs(want).max()), np.abs(got - want).max()
+    convs = [k for k, o in enumerate(plan.ops) if o['op'] in (keras_plan.OP_CONV, keras_plan.OP_CONVT)]
+    ran = _mfma_ops(gpu, x)
+    missing = [k for k in convs[1:] if k not in ran]
+    assert not missing, [(k, plan.ops[k]) for k in missing]

@@ -53,7 +53,7 @@ def main():
         depth = int(rng.choice((3, 4, 4))) if a.deep else int(rng.choice((1, 2, 2, 3)))
         if a.deep:
             base = 8
-        up = str(rng.choice(('transpose', 'transpose', 'upsample')))
+        up = str(rng.choice(('transpose', 'transpose', 'upsample', 'transpose3', 'transpose4')))
         bn = bool(rng.random() < 0.25)
         cfg = synth.unet_config(base=base, depth=depth, up=up, batchnorm=bn)
         w = synth.unet_weights(cfg, seed=int(rng.integers(0, 1000)))

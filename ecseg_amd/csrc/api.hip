@@ -410,7 +410,10 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                     } else if (o.subpixel) {
                         // 2x2 taps over input rows / columns (i - 1, i); tiles walk one position past the input (the last output
                         // row / column of the full result comes from tap d = -1 alone)
-                        p.R = 2; p.S = 2; p.pad_top = 1; p.pad_left = 1; p.convt = 1; p.kT = 2; p.convt_ext = 1;
+                        p.R = 2; p.S = 2; p.pad_top = 1; p.pad_left = 1; p.convt = 1; p.kT = 2;
+                        // (that position only matters when a kept output row / column lies at or beyond 2 x the input extent:
+                        // 4x4 'same' and every 'valid' layer, not 3x3 'same' - whose 16 x 16 inputs then tile exactly)
+                        p.convt_ext = (out.h + d.pad_top > 2 * in.h || out.w + d.pad_left > 2 * in.w) ? 1 : 0;
                         p.crop_top = d.pad_top; p.crop_left = d.pad_left;
                     } else {
                         p.R = 1; p.S = 1; p.pad_top = 0; p.pad_left = 0; p.convt = 1; p.kT = d.kh;

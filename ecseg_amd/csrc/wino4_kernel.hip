@@ -257,13 +257,6 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             }
         }
     };
-#if defined(W4_CT) && W4_CT == 1
-    float sNB2, sNA2, sP, sS, sA, sNA, sB, sNB;
-    asm volatile("s_mov_b32 %0, %1" : "=s"(sNB2) : "s"(-KB2)); asm volatile("s_mov_b32 %0, %1" : "=s"(sNA2) : "s"(-KA2));
-    asm volatile("s_mov_b32 %0, %1" : "=s"(sP) : "s"(KP)); asm volatile("s_mov_b32 %0, %1" : "=s"(sS) : "s"(KS));
-    asm volatile("s_mov_b32 %0, %1" : "=s"(sA) : "s"(KA)); asm volatile("s_mov_b32 %0, %1" : "=s"(sNA) : "s"(-KA));
-    asm volatile("s_mov_b32 %0, %1" : "=s"(sB) : "s"(KB)); asm volatile("s_mov_b32 %0, %1" : "=s"(sNB) : "s"(-KB));
-#endif
     // ---- one filter stage (2 of the group's 4 channel pairs; buffer ss): column transform + 12 MFMAs ----
     auto mfma_stage = [&](int ss, int fbuf, int next_stage, int halo_grp) __attribute__((always_inline)) {     // ss: channel pair of the group, fbuf: filter buffer; halo_grp: group to prefetch, < 0: none
         float V[6][2];
@@ -272,16 +265,6 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             const int c = 2 * ss + e;
             const float u0 = t[0][c], u1 = t[1][c], u2 = t[2][c], u3 = t[3][c], u4 = t[4][c], u5 = t[5][c];
             // points +-a share an even part (u4 - b2 u2) and an odd part (u3 - b2 u1), points +-b likewise with a2
-#if defined(W4_CT) && W4_CT == 1
-            const float ea = __builtin_fmaf(sNB2, u2, u4), oa = __builtin_fmaf(sNB2, u1, u3);
-            const float eb = __builtin_fmaf(sNA2, u2, u4), ob = __builtin_fmaf(sNA2, u1, u3);
-            V[0][e] = __builtin_fmaf(sP, u0, __builtin_fmaf(sS, u2, u4));
-            V[1][e] = __builtin_fmaf(sA, oa, ea);
-            V[2][e] = __builtin_fmaf(sNA, oa, ea);
-            V[3][e] = __builtin_fmaf(sB, ob, eb);
-            V[4][e] = __builtin_fmaf(sNB, ob, eb);
-            V[5][e] = __builtin_fmaf(sP, u1, __builtin_fmaf(sS, u3, u5));
-#else
             const float ea = __builtin_fmaf(-KB2, u2, u4), oa = __builtin_fmaf(-KB2, u1, u3);
             const float eb = __builtin_fmaf(-KA2, u2, u4), ob = __builtin_fmaf(-KA2, u1, u3);
             V[0][e] = __builtin_fmaf(KP, u0, __builtin_fmaf(KS, u2, u4));
@@ -290,7 +273,6 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             V[3][e] = __builtin_fmaf(KB, ob, eb);
             V[4][e] = __builtin_fmaf(-KB, ob, eb);
             V[5][e] = __builtin_fmaf(KP, u1, __builtin_fmaf(KS, u3, u5));
-#endif
         }
         const f32x2* Bp = reinterpret_cast<const f32x2*>(Bw + fbuf * W4_BWS) + lane;
         f32x2 w2[6];

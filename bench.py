@@ -178,8 +178,11 @@ def parity_vs_cpu(hnd, refs):
             'n_ec_device': [int(v) for v in g_nec], 'n_ec_cpu': [int(r[2]) for r in refs],
             'integer_stages_bit_exact_on_device_raw_labels': bool(exact),
             'note': 'raw labels differ only where fp32 summation order moves a uint8-quantised probability across an '
-                    'argmax tie (random-weight model = speckled, tie-rich output; see profiles/*label_mismatch* for a '
-                    'smooth-output model); clean-up and counting are bit-exact functions of the raw labels'}
+                    'argmax tie (random-weight model = speckled, tie-rich output).  Both sides of this comparison are float32 '
+                    'evaluations: against a float64 evaluation of the same network (profiles/r03_label_mismatch.json, 32 images) '
+                    'this CPU oracle is wrong in 2.4 pixels per image and the device in 2.3, and where the two disagree float64 '
+                    'sides with the device as often as with the oracle; on smooth-output / fitted models the counts are 0.4 vs 0.3 '
+                    'and 0 vs 0.  Clean-up and counting are bit-exact functions of the raw labels'}
 
 
 # ---------------------------------------------------------------------------------------------------------------------

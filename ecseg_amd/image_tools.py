@@ -55,8 +55,8 @@ def split_FISH_channels(I, image_path, sensitivity, handle=None):
         print(image_path, " isn't an RGB image. Therefore, no FISH signals could be identified. Skipping...")
         return 0
     I = u16_to_u8(I, handle=handle)
-    image_io.write_png(os.path.join(path_split[0], 'red', path_split[1] + '.png'), ~np.uint8(I[..., 0]))
-    image_io.write_png(os.path.join(path_split[0], 'green', path_split[1] + '.png'), ~np.uint8(I[..., 1]))
+    image_io.write_png(os.path.join(path_split[0], 'red', path_split[1] + '.png'), ~np.uint8(I[..., 0]), level=1)
+    image_io.write_png(os.path.join(path_split[0], 'green', path_split[1] + '.png'), ~np.uint8(I[..., 1]), level=1)
     return (np.array(I[..., 0]) > sensitivity), (np.array(I[..., 1]) > sensitivity)
 
 

@@ -56,8 +56,8 @@ def _load(p):
 
 def _write_channels(p, I8):
     path_split = os.path.split(p)
-    image_io.write_png(os.path.join(path_split[0], 'red', path_split[1] + '.png'), ~np.uint8(I8[..., 0]))
-    image_io.write_png(os.path.join(path_split[0], 'green', path_split[1] + '.png'), ~np.uint8(I8[..., 1]))
+    image_io.write_png(os.path.join(path_split[0], 'red', path_split[1] + '.png'), ~np.uint8(I8[..., 0]), level=1)
+    image_io.write_png(os.path.join(path_split[0], 'green', path_split[1] + '.png'), ~np.uint8(I8[..., 1]), level=1)
 
 
 def run(inpath, handle, image_paths, sensitivity, batch_images=8, io_threads=None, log=print):

@@ -438,6 +438,9 @@ def model_summary(run, m):
         res['mfma_executed_tflops'] = round(exe, 2)
         res['mfma_executed_frac_of_peak'] = round(exe / PEAK_FP32_MFMA_TFLOPS, 4)
         res['roofline_8d'] = roofline_8d(run.model.plan, m['recs'], steps, B * 35, unet_ms_step)
+        res['roofline'] = {'bound': res['roofline_8d']['bound'], 'achieved': round(exe, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                           'frac': round(exe / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                           'kernel': 'all MFMA-convolution launches of the step (HIP events on the handle\'s stream), executed FLOPs'}
     return res
 
 

@@ -135,7 +135,6 @@ def adjudicate(truth_path):
             'images_with_n_ec_difference_vs_oracle32': int((np.asarray(nec) != nec32).sum()),
             'worst_image_raw_px_vs_oracle32': int(dis.sum(axis=(1, 2)).max()),
             'worst_image_raw_px_vs_float64': int(d_wrong.sum(axis=(1, 2)).max())}
-    p32 = None
     out['oracle_float32_vs_float64']['margin_of_wrong_px_1e-7'] = {'max': int(margin[o_wrong].max()) if o_wrong.any() else 0}
     model.handle.set_option('winograd', 2)
     model.handle.close()

@@ -316,6 +316,7 @@ class DeviceRun:
         self.nec = torch.zeros(B, dtype=torch.int32, device=dev)
         self.rec = torch.from_numpy(edist.make_records(start, stop - start, per)).to(dev)
         self.comm, self.gathered, self.allgather_via = None, None, 'none (1 rank)'
+        self.ag_events = []
         if world > 1 or (os.environ.get('ECSEG_BENCH_FORCE_COMM') and torch.distributed.is_initialized()):   # (the latter: 1-GPU test of the same code)
             self._setup_c_abi_collective(local, rank, world)
 
@@ -358,11 +359,20 @@ class DeviceRun:
     def step(self):
         self.hnd.segment_images_dev(self.gray.data_ptr(), self.B, H, W, self.raw.data_ptr(), self.post.data_ptr(), self.nec.data_ptr())
         self.rec[:self.B, self.edist.F_NEC] = self.nec.to(self.torch.int64)
+        timed_ag = self.world > 1 or self.comm is not None   # the all-gather as its own stage (events on torch's current stream)
+        if timed_ag:
+            e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+            e0.record()
         if self.comm is not None:
             self.comm.allgather_records_dev(self.rec.data_ptr(), self.rec.shape[0], self.gathered.data_ptr(),
                                             stream=self.torch.cuda.current_stream().cuda_stream)
-            return self.gathered
-        return self.edist.allgather_records(self.rec)
+            out = self.gathered
+        else:
+            out = self.edist.allgather_records(self.rec)
+        if timed_ag:
+            e1.record()
+            self.ag_events.append((e0, e1))
+        return out
 
     def barrier(self):
         import torch.distributed as dist
@@ -377,6 +387,7 @@ class DeviceRun:
         for _ in range(warmup):
             self.step()
         hnd.set_kernel_profiling(profile)
+        self.ag_events = []
         stage = {k: 0.0 for k in hnd.T_NAMES}
         conv_ms = conv_flops = conv_exec = 0.0
         conv_launches = 0
@@ -398,6 +409,8 @@ class DeviceRun:
         tmax = self.torch.tensor([dt], dtype=self.torch.float64, device=self.gray.device)
         if dist.is_initialized():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        if self.ag_events:                                    # (after the closing barrier + synchronize: every event has completed)
+            stage = dict(stage, allgather=sum(a.elapsed_time(b) for a, b in self.ag_events))
         return dict(dt=float(tmax.item()), stage=stage, conv_ms=conv_ms, conv_launches=conv_launches, conv_flops=conv_flops,
                     conv_exec=conv_exec, recs=recs, out=out, steps=steps)
 

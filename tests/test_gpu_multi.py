@@ -92,6 +92,7 @@ def test_bench_uses_the_c_abi_collective_under_a_process_group():
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
     assert res['n_gpus'] == 1 and res['value'] > 0
     assert res['config']['allgather'].startswith('ecseg_allgather_records_dev'), res['config']['allgather']
+    assert res['stage_ms_per_image']['allgather'] > 0                       # the exchange is reported as its own stage
 
 
 def test_native_transport_one_rank(tmp_path):

@@ -521,26 +521,39 @@ def main():
         }
         if m['conv_launches']:
             conv_ms, conv_launches, conv_flops, conv_exec = m['conv_ms'], m['conv_launches'], m['conv_flops'], m['conv_exec']
+            # HBM bytes per launch from a committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary (tools/profile_round.sh) - only
+            # one of THIS configuration (base, up-sampler, 3x3 kernel) measured on THESE kernel sources; anything else is stale
             traffic = traffic_src = None
-            try:        # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-                tag = {0: 'direct', 1: 'f2x2', 2: 'f4x4'}[wino_mode]
-                pmc = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_pmc_traffic.json')
-                             and tag in f)
-                if pmc and args.base == 64:
-                    traffic = json.load(open(os.path.join(ROOT, 'profiles', pmc[-1])))['conv_mfma_all']['hbm_bytes_per_launch']
-                    traffic_src = 'profiles/' + pmc[-1] + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, read from the committed summary, not measured in this run)'
+            traffic_stale = False
+            try:
+                from ecseg_amd.build import source_hash
+                want = {'base': str(args.base), 'up': args.up, 'wino': str(wino_mode)}
+                cur = source_hash()
+                for f in sorted((f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_pmc_traffic.json')), reverse=True):
+                    d = json.load(open(os.path.join(ROOT, 'profiles', f)))
+                    if d.get('config') != want:
+                        continue
+                    if d.get('kernel_source_sha256') != cur:
+                        traffic_stale = True
+                        continue
+                    traffic = d['conv_mfma_all']['hbm_bytes_per_launch']
+                    traffic_src = 'profiles/' + f + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on these kernel sources, read from the committed summary, not measured in this run)'
+                    traffic_stale = False
+                    break
             except Exception:
                 traffic = None
+            up_desc = {'transpose': '2x2 up-convs', 'transpose3': '3x3 / stride-2 up-convs, sub-pixel form', 'transpose4': '4x4 / stride-2 up-convs, sub-pixel form',
+                       'upsample': 'no up-convs: UpSampling2D'}.get(args.up, args.up)
             alg = conv_flops / (conv_ms * 1e-3) / 1e12
             exe = conv_exec / (conv_ms * 1e-3) / 1e12
             r8 = summ.get('roofline_8d')
             res['roofline'] = {'bound': r8['bound'] if r8 else 'mfma',
                                'kernel': {0: 'conv_mfma_kernel (direct implicit GEMM)',
-                                          1: 'conv_wino_kernel (Winograd F(2x2,3x3)) + conv_mfma_kernel (2x2 up-convs)',
-                                          2: 'conv_wino4_kernel (Winograd F(4x4,3x3)) + conv_mfma_kernel (2x2 up-convs)'}[wino_mode] +
+                                          1: 'conv_wino_kernel (Winograd F(2x2,3x3)) + conv_mfma_kernel (%s)' % up_desc,
+                                          2: 'conv_wino4_kernel (Winograd F(4x4,3x3)) + conv_mfma_kernel (%s)' % up_desc}[wino_mode] +
                                          ', fp32 v_mfma_f32_32x32x2_f32',
                                'achieved': round(exe, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': round(exe / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
+                               'frac': round(exe / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_stale': traffic_stale, 'traffic_source': traffic_src,
                                'avg_launch_ms': round(conv_ms / conv_launches, 4), 'launches': int(conv_launches),
                                'executed_flop_per_launch_avg': conv_exec / conv_launches,
                                'algorithmic_flop_per_launch_avg': conv_flops / conv_launches,

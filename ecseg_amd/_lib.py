@@ -199,6 +199,8 @@ class Handle:
 
     def set_option(self, key, value):
         self._check(self.lib.ecseg_set_option(self.h, key.encode(), int(value)), 'ecseg_set_option(%s)' % key)
+        if key == 'images_per_group':        # the same knob as set_images_per_group: keep the mirror the OOM retry restores from
+            self.images_per_group = int(value)
 
     def forward_patches(self, patches):
         """uint8 (or float32) (N, H, W, C) -> float32 (N, H', W', K): ``model.predict_on_batch`` (reference

@@ -12,6 +12,19 @@ EXTRA_FLAGS = {'wino4_kernel.hip': ['-fno-slp-vectorize']}
 HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'device_util.h'), os.path.join(HERE, '..', 'include', 'ecseg_hip.h')]
 
 
+def source_hash():
+    """sha256 over the device-side sources of the library: ties a committed PMC summary (tools/pmc_summary.py) to the kernels
+    it was measured on - bench.py reports a summary of other sources as stale instead of quoting it."""
+    import hashlib
+    h = hashlib.sha256()
+    names = sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.h', '.inc')))
+    for f in names:
+        h.update(f.encode() + b'\0')
+        with open(os.path.join(CSRC, f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def _hipcc():
     for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):

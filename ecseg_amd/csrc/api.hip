@@ -247,7 +247,11 @@ std::vector<float> winograd4_filter(const float* w, int cin, int cout) {
             for (int a = 0; a < 6; ++a)
                 for (int b = 0; b < 6; ++b) {
                     const double u = t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2];
+#if ECSEG_W4_FREG
+                    const size_t idx = (((size_t)nb * nstages + stage) * 12 + (half * 6 + a)) * 768 + ((((size_t)(b >> 1) * 64 + hh * 32 + m) * 2 + (b & 1)) * 2) + e;
+#else
                     const size_t idx = (((size_t)nb * nstages + stage) * 12 + (half * 6 + a)) * 768 + (((size_t)b * 2 + hh) * 32 + m) * 2 + e;
+#endif
                     o[idx] = (float)u;
                 }
         }

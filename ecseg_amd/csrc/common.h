@@ -65,6 +65,13 @@ struct ConvParams {
 #define ECSEG_W4_PB 1.5
 #endif
 constexpr double W4_PA = ECSEG_W4_PA, W4_PB = ECSEG_W4_PB;
+// ECSEG_W4_FREG=1 (round-4 experiment, tools/build_variants.sh freg): the F(4x4) kernel loads its filter fragments from global
+// memory straight into registers (double-buffered, no LDS stage buffers) - the filter image then holds, per (block, stage,
+// wave), three 1-KiB pieces [piece k][lane][point 2k + {0, 1}][channel e] so that one dwordx4 load per lane and piece
+// delivers the B operands of four MFMAs.  0: LDS-DMA into private per-wave stage buffers, image [point][lane][e].
+#ifndef ECSEG_W4_FREG
+#define ECSEG_W4_FREG 0
+#endif
 
 // pitches used by relayout_* (api.hip) and the kernels
 inline long wt_chunk_pitch(int np_total) { return (long)2 * np_total * 4 + 32; }

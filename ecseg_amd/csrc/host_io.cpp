@@ -317,17 +317,20 @@ struct TiffInfo {
     bool le = true;
 };
 
-// values of one IFD entry (types BYTE / SHORT / LONG only) -> vector; false when the entry is malformed
-bool entry_values(const Reader& r, size_t e, std::vector<uint32_t>* out) {
+// values of one IFD entry (types BYTE / SHORT / LONG only) -> vector; ECSEG_E_INVALID when the entry is malformed,
+// ECSEG_E_UNSUPPORTED for a structurally valid entry of another TIFF 6.0 / BigTIFF type (RATIONAL, LONG8, ...): the Python
+// reader decodes those (image_io._TYPE_FMT)
+int entry_values(const Reader& r, size_t e, std::vector<uint32_t>* out) {
     const uint32_t typ = r.u16(e + 2), cnt = r.u32(e + 4);
     const size_t sz = typ == 1 ? 1 : typ == 3 ? 2 : typ == 4 ? 4 : 0;
-    if (sz == 0 || cnt > (1u << 26)) return false;
+    if (sz == 0) return (typ >= 1 && typ <= 18) ? ECSEG_E_UNSUPPORTED : ECSEG_E_INVALID;
+    if (cnt > (1u << 26)) return ECSEG_E_INVALID;
     size_t voff = e + 8;
-    if (sz * cnt > 4) { voff = r.u32(e + 8); if (!r.ok(voff, sz * cnt)) return false; }
+    if (sz * cnt > 4) { voff = r.u32(e + 8); if (!r.ok(voff, sz * cnt)) return ECSEG_E_INVALID; }
     out->resize(cnt);
     for (uint32_t i = 0; i < cnt; ++i)
         (*out)[i] = sz == 1 ? r.b[voff + i] : sz == 2 ? r.u16(voff + 2 * i) : r.u32(voff + 4 * i);
-    return true;
+    return ECSEG_OK;
 }
 
 // ECSEG_OK, ECSEG_E_UNSUPPORTED (a valid layout this reader leaves to the Python one) or ECSEG_E_INVALID (corrupt)
@@ -353,7 +356,8 @@ int parse_tiff(const uint8_t* buf, size_t n, TiffInfo* t) {
                             tag == 279 || tag == 284 || tag == 317 || tag == 339 || tag == 322;
         if (!wanted) continue;
         if (tag == 322) { tiled = true; continue; }
-        if (!entry_values(r, e, &v) || v.empty()) return ECSEG_E_INVALID;
+        if (const int rc = entry_values(r, e, &v)) return rc;
+        if (v.empty()) return ECSEG_E_INVALID;
         switch (tag) {
             case 256: t->W = v[0]; have_w = true; break;
             case 257: t->H = v[0]; have_h = true; break;

@@ -78,6 +78,11 @@ static_assert((double)KA2 == W4_PA * W4_PA && (double)KB3 == W4_PB * W4_PB * W4_
 
 }  // namespace
 
+// Row-transform pipeline depth (slots of in-flight halo reads beside the six direct ones; 0: rounds 1-3, column by column)
+#ifndef ECSEG_W4_TSLOTS
+#define ECSEG_W4_TSLOTS 4
+#endif
+
 // Diagnostics (timing-only ablations, in-kernel cycle stamps) live in wino4_diag.inc and exist only in the -DECSEG_DIAG
 // build (tools/build_variants.sh diag); the product translation unit has ONE code path: every hook below is empty.
 #ifdef ECSEG_DIAG
@@ -159,7 +164,11 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
     //      ring: nobody ever waits for a halo piece to land).  The per-lane source pointers are computed once and parked
     //      in LDS (bit 0 = "advance with the channel group"; padding / out-of-image lanes point at the zero page and do
     //      not advance): no registers held during the K loop ----
+#if ECSEG_W4_FREG
+    unsigned long long* Hd = reinterpret_cast<unsigned long long*>(Bs) + tid;                      // [2][768] (no filter stages in LDS)
+#else
     unsigned long long* Hd = reinterpret_cast<unsigned long long*>(Bs + 12 * 2 * W4_BWS) + tid;   // [2][768]
+#endif
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int a = 64 * (wave + 12 * i) + lane;
@@ -186,6 +195,22 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
     };
     // ---- filter DMA: wt4[nb][stage][wave][point nu][h][cout 32][k 2], 768 floats per wave and stage ----
     const float* w_src = p.wt + ((size_t)nb * nstages * 12 + (SPLIT ? xi : wave)) * 768 + lane * 4;
+#if ECSEG_W4_FREG
+    // filter fragments global -> registers: two stage buffers of three dwordx4 pieces; the loads are issued through inline asm
+    // like the LDS-DMAs (the counted vmcnt waits of the K loop are the only ordering); W4_WAITF ties the buffer it releases
+    f32x4 wq[2][3];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wq[b][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto dma_filter_piece = [&](int stage, auto bufc, auto kk) __attribute__((always_inline)) {
+        W4_DIAG_SKIP_FILTER_DMA();
+        constexpr int k = decltype(kk)::value, buf = decltype(bufc)::value;
+        const float* g = w_src + (size_t)stage * (12 * 768);
+        f32x4& dst = wq[buf][k];
+        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(g), "n"(k * 1024) : "memory");
+    };
+#else
     f32x4* Bw = Bs + wave * 2 * W4_BWS;
     auto dma_filter_piece = [&](int stage, int buf, auto kk) __attribute__((always_inline)) {
         W4_DIAG_SKIP_FILTER_DMA();
@@ -194,6 +219,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         // the instruction offset advances the global AND the LDS address: one M0 for the three pieces
         glds16<k * 1024>(g, lds_base + (unsigned)(3 * W4_HS + (wave * 2 + buf) * W4_BWS) * 16u);
     };
+#endif
 
     // ---- A-operand lane -> tile.  ds_read_b128 serves lanes {0-3,12-15,20-27} and {4-11,16-19,28-31} of each half
     //      in separate LDS cycles; give each of those groups the 16 tiles of ONE region ----
@@ -236,6 +262,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         W4_DIAG_FAKE_TRANSFORM(grp);
         // scalar fmas on purpose (file is built with -fno-slp-vectorize): packed f32 VALU ops (v_pk_fma_f32) stall the
         // SIMD beside MFMAs, single v_fma_f32 hide in the matrix pipe's shadow
+#if ECSEG_W4_TSLOTS == 0
         if (inner_row) {
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
@@ -256,9 +283,60 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#else
+        // Software-pipelined (round 4): the phase used to be six LDS round trips behind each other (one per halo column:
+        // 3 - 4 reads, wait, 12 fmas) and took 2200 - 3200 cycles per group - the three transforms of a SIMD's waves add up to the
+        // group period (in-kernel stamps).  Now the LAST term of every column is read straight into t[j] (it enters the
+        // chain with coefficient 1), the other reads go through NS rotating slots: each step waits for ONE read, accumulates it
+        // into its column (four fmas) and re-issues the slot, so NS reads are always in flight.  The fma chain of a column runs in
+        // the same order as before (innermost term first): results are bit-identical.
+        constexpr int NS = ECSEG_W4_TSLOTS;
+        static_assert(CS == 0 && CN == 4, "whole slots only");
+        f32x4 sl[NS];
+        if (inner_row) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) t[j] = A[ro3 + cp[j]];
+#define W4_TRD(i) A[((i) % 3 == 0 ? ro2 : (i) % 3 == 1 ? ro1 : ro0) + cp[(i) / 3]]
+#pragma unroll
+            for (int k = 0; k < NS; ++k) sl[k] = W4_TRD(k);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 18; ++i) {
+                const float cf = i % 3 == 0 ? c2 : i % 3 == 1 ? c1 : c0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) t[i / 3][c] = __builtin_fmaf(cf, sl[i % NS][c], t[i / 3][c]);
+                if (i + NS < 18) sl[i % NS] = W4_TRD(i + NS);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef W4_TRD
+        } else {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) t[j] = A[ro2 + cp[j]];
+#define W4_TRD(i) A[((i) % 2 == 0 ? ro1 : ro0) + cp[(i) / 2]]
+#pragma unroll
+            for (int k = 0; k < NS; ++k) sl[k] = W4_TRD(k);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const float cf = i % 2 == 0 ? c1 : c0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) t[i / 2][c] = __builtin_fmaf(cf, sl[i % NS][c], t[i / 2][c]);
+                if (i + NS < 12) sl[i % NS] = W4_TRD(i + NS);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef W4_TRD
+        }
+#endif
     };
     // ---- one filter stage (2 of the group's 4 channel pairs; buffer ss): column transform + 12 MFMAs ----
+#if ECSEG_W4_FREG
+    auto mfma_stage = [&](int ss, auto fbufc, int next_stage, int halo_grp) __attribute__((always_inline)) {     // ss: channel pair of the group, fbuf: filter buffer; halo_grp: group to prefetch, < 0: none
+        constexpr int fbuf = decltype(fbufc)::value;
+        constexpr std::integral_constant<int, fbuf ^ 1> nbuf{};
+#else
     auto mfma_stage = [&](int ss, int fbuf, int next_stage, int halo_grp) __attribute__((always_inline)) {     // ss: channel pair of the group, fbuf: filter buffer; halo_grp: group to prefetch, < 0: none
+        const int nbuf = fbuf ^ 1;
+#endif
         float V[6][2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {   // V[nu] = sum_j B^T[nu][j] t[j], scalar ops (see transform)
@@ -274,10 +352,15 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             V[4][e] = __builtin_fmaf(-KB, ob, eb);
             V[5][e] = __builtin_fmaf(KP, u1, __builtin_fmaf(KS, u3, u5));
         }
-        const f32x2* Bp = reinterpret_cast<const f32x2*>(Bw + fbuf * W4_BWS) + lane;
         f32x2 w2[6];
+#if ECSEG_W4_FREG
+#pragma unroll
+        for (int v = 0; v < 6; ++v) w2[v] = f32x2{wq[fbuf][v >> 1][(v & 1) * 2], wq[fbuf][v >> 1][(v & 1) * 2 + 1]};
+#else
+        const f32x2* Bp = reinterpret_cast<const f32x2*>(Bw + fbuf * W4_BWS) + lane;
 #pragma unroll
         for (int v = 0; v < 6; ++v) w2[v] = Bp[v * 64];
+#endif
         // 12 MFMAs, channel-major: consecutive MFMAs hit different accumulators (dependency distance 6), so even a lone
         // wave keeps the matrix pipe full.  The next stage's three filter pieces go out one at a time behind MFMAs 2, 4
         // and 6 (pinned): the wave's issue slot is free while the pipe works, and the load path never sees a burst.
@@ -286,11 +369,11 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
 #pragma unroll
             for (int v = 0; v < 6; ++v) {
                 W4_MFMA(acc[v], V[v][e], w2[v][e]);
-                if (e == 0 && (v == 1 || v == 3 || v == 5)) {
+                if (e == 0 && (v == 1 || v == 3 || v == 5) && (!ECSEG_W4_FREG || next_stage >= 0)) {   // (registers: no dummy load whose result nobody waits for)
                     __builtin_amdgcn_sched_barrier(0);
-                    if (v == 1) dma_filter_piece(next_stage, fbuf ^ 1, std::integral_constant<int, 0>{});
-                    if (v == 3) dma_filter_piece(next_stage, fbuf ^ 1, std::integral_constant<int, 1>{});
-                    if (v == 5) dma_filter_piece(next_stage, fbuf ^ 1, std::integral_constant<int, 2>{});
+                    if (v == 1) dma_filter_piece(next_stage, nbuf, std::integral_constant<int, 0>{});
+                    if (v == 3) dma_filter_piece(next_stage, nbuf, std::integral_constant<int, 1>{});
+                    if (v == 5) dma_filter_piece(next_stage, nbuf, std::integral_constant<int, 2>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (e == 1 && (v == 1 || v == 3) && halo_grp >= 0) {       // behind MFMAs 8 and 10
@@ -314,21 +397,57 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
 #define W4_SB() __builtin_amdgcn_sched_barrier(0)
 // T(g): raised priority for the few long-latency instructions of the transform; afterwards the MFMA phases run at a
 // priority that orders the three waves of a SIMD (class 2 first): the wave that is latest in the rotation gets the pipe
-#define W4_T(g, PR) do { __builtin_amdgcn_s_setprio(3); transform(g, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}); __builtin_amdgcn_s_setprio(PR); } while (0)
+// Priorities (round 4, A/B on one box, per-layer tables in gpurun_out/r04_ab1): the MATRIX phases run above the transform
+// (transform 0, matrix phases 1 / 2 / 3 by rotation class): 1024 -> 512 at 32x32 13.83 -> 13.35 ms, 512 -> 512 6.92-7.11 -> 6.73-6.78,
+// every other layer +-0.5 %; the transform is latency-bound on its LDS reads and loses nothing at priority 0, a ready MFMA
+// no longer waits behind another wave's burst of 12 transform fmas.  (ECSEG_W4_PRIO=0: rounds 1-3, transform at 3, matrix
+// phases 0 / 1 / 2; =2: no priorities at all, -6 %.)
+#ifndef ECSEG_W4_PRIO
+#define ECSEG_W4_PRIO 1
+#endif
+#if ECSEG_W4_PRIO == 0
+#define W4_PT 3
+#define W4_PS(PR) (PR)
+#elif ECSEG_W4_PRIO == 1
+#define W4_PT 0
+#define W4_PS(PR) ((PR) + 1)
+#else
+#define W4_PT 0
+#define W4_PS(PR) 0
+#endif
+#define W4_T(g, PR) do { __builtin_amdgcn_s_setprio(W4_PT); transform(g, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}); __builtin_amdgcn_s_setprio(W4_PS(PR)); } while (0)
     // S0(g): filter stage 2g has landed (it is the youngest thing this wave issued) -> vmcnt(0); streams stage 2g+1 and
     // the halo of group g+2.  S1(g): only the two halo pieces issued after stage 2g+1 may still fly -> vmcnt(2).
-#define W4_S0(g) do { W4_SB(); W4_WAIT(0); W4_SB(); mfma_stage(0, 0, 2 * (g) + 1, (g) + 2 < ngroups ? (g) + 2 : -1); } while (0)
-#define W4_S1(g) do { W4_SB(); if ((g) + 2 < ngroups) W4_WAIT(2); else W4_WAIT(0); W4_SB(); \
-                      mfma_stage(1, 1, (g) + 1 < ngroups ? 2 * (g) + 2 : 2 * (g), -1); } while (0)
+#if ECSEG_W4_FREG
+#define W4_TIE(b) asm volatile("" : "+v"(wq[b][0]), "+v"(wq[b][1]), "+v"(wq[b][2]))      /* the loads into buffer b have landed: later reads stay behind the wait */
+#else
+#define W4_TIE(b)
+#endif
+#if ECSEG_W4_FREG
+#define W4_C0 std::integral_constant<int, 0>{}
+#define W4_C1 std::integral_constant<int, 1>{}
+#else
+#define W4_C0 0
+#define W4_C1 1
+#endif
+#define W4_S0(g) do { W4_SB(); W4_WAIT(0); W4_TIE(0); W4_SB(); mfma_stage(0, W4_C0, 2 * (g) + 1, (g) + 2 < ngroups ? (g) + 2 : -1); } while (0)
+#define W4_S1(g) do { W4_SB(); if ((g) + 2 < ngroups) W4_WAIT(2); else W4_WAIT(0); W4_TIE(1); W4_SB(); \
+                      mfma_stage(1, W4_C1, (g) + 1 < ngroups ? 2 * (g) + 2 : (ECSEG_W4_FREG ? -1 : 2 * (g)), -1); } while (0)
 // SPLIT: T(g) as above (all four channels of the slot: a two-channel transform made the register allocator spill ~100
 // registers; the wave uses channels 2 ch, 2 ch + 1); S(g) = its one filter stage of group g (stage 2 g + ch of the image, private
 // buffer g & 1): everything this wave issued has landed (vmcnt(0): the filter of this group and its halo pieces of group
 // g + 1); streams the filter of group g + 1 and the halo of group g + 2
-#define W4_TS(g, PR) do { __builtin_amdgcn_s_setprio(3); \
+#define W4_TS(g, PR) do { __builtin_amdgcn_s_setprio(W4_PT); \
                           transform(g, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}); \
-                          __builtin_amdgcn_s_setprio(PR); } while (0)
+                          __builtin_amdgcn_s_setprio(W4_PS(PR)); } while (0)
+#if ECSEG_W4_FREG
+#define W4_SS(g) do { W4_SB(); W4_WAIT(0); W4_TIE(0); W4_TIE(1); W4_SB(); \
+                      if ((g) & 1) mfma_stage(CH, W4_C1, (g) + 1 < ngroups ? 2 * (g) + 2 + CH : -1, (g) + 2 < ngroups ? (g) + 2 : -1); \
+                      else mfma_stage(CH, W4_C0, (g) + 1 < ngroups ? 2 * (g) + 2 + CH : -1, (g) + 2 < ngroups ? (g) + 2 : -1); } while (0)
+#else
 #define W4_SS(g) do { W4_SB(); W4_WAIT(0); W4_SB(); \
                       mfma_stage(CH, (g) & 1, ((g) + 1 < ngroups ? 2 * (g) + 2 : 2 * (g)) + CH, (g) + 2 < ngroups ? (g) + 2 : -1); } while (0)
+#endif
     const int cls = wave >> 2;
     dma_halo_piece(0, std::integral_constant<int, 0>{});
     dma_halo_piece(0, std::integral_constant<int, 1>{});
@@ -336,9 +455,9 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         dma_halo_piece(1, std::integral_constant<int, 0>{});
         dma_halo_piece(1, std::integral_constant<int, 1>{});
     }
-    dma_filter_piece(SPLIT ? ch : 0, 0, std::integral_constant<int, 0>{});
-    dma_filter_piece(SPLIT ? ch : 0, 0, std::integral_constant<int, 1>{});
-    dma_filter_piece(SPLIT ? ch : 0, 0, std::integral_constant<int, 2>{});
+    dma_filter_piece(SPLIT ? ch : 0, W4_C0, std::integral_constant<int, 0>{});
+    dma_filter_piece(SPLIT ? ch : 0, W4_C0, std::integral_constant<int, 1>{});
+    dma_filter_piece(SPLIT ? ch : 0, W4_C0, std::integral_constant<int, 2>{});
     if (ngroups > 1) W4_WAIT(5); else W4_WAIT(3);            // halo group 0 has landed (group 1: before barrier 1, below)
     if (SPLIT) {
         // two phases per group.  Waves 0-3 run T(g) S(g) after barrier g; waves 4-11 run S(g - 1) T(g): while one class
@@ -416,6 +535,9 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
 #undef W4_S1
 #undef W4_TS
 #undef W4_SS
+#undef W4_TIE
+#undef W4_C0
+#undef W4_C1
 #undef W4_SB
     W4_KSTAMP_DUMP();
 #undef W4_BARRIER
@@ -597,7 +719,7 @@ hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s) {
     const size_t grid = npairs * (size_t)((p.out.c + 63) / 64);
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    size_t lds = (size_t)(3 * W4_HS + 12 * 2 * W4_BWS) * 16 + 2 * 768 * 8;
+    size_t lds = (size_t)(3 * W4_HS + (ECSEG_W4_FREG ? 0 : 12 * 2 * W4_BWS)) * 16 + 2 * 768 * 8;
     const size_t lds_epi = (size_t)24 * W4_RPLANE * 4;
     if (lds_epi > lds) lds = lds_epi;
     void (*kern)(ConvParams, int, int, int) = conv_wino4_kernel<false, false>;

@@ -3,9 +3,10 @@ fixed-size per-image result records (RCCL over xGMI when the tensors live on GPU
 
 Two transports carry the exchange: ``torch.distributed`` (bench.py's launcher contract; gloo in the CPU tests) and - so that
 `make metaseg` on several GPUs needs no PyTorch at all ("PyTorch only as optional oracle / allocator") - the
-library's own RCCL communicator (``_lib.Comm`` -> csrc/comm.hip) with a file rendezvous: rank 0 writes the 128-byte
-communicator id next to the input folder, the other ranks pick it up (``ECSEG_DIST=native``; chosen by itself when torch
-cannot be imported).
+library's own RCCL communicator (``_lib.Comm`` -> csrc/comm.hip) with a file rendezvous: rank 0 writes the job's nonce +
+the 128-byte communicator id to ``ECSEG_RDZV`` (the self-launcher puts it into a private ``mkdtemp`` directory), the
+other ranks pick it up and reject a file that carries another job's nonce (``ECSEG_DIST=native``; chosen by itself when
+torch cannot be imported).
 
 The reference's only parallelism is ``tf.distribute.MirroredStrategy`` around ``load_model``
 (src/metaseg.py:33-36), which splits one image's patch batch over replicas; images themselves are processed in a
@@ -106,28 +107,52 @@ def want_native():
         return True
 
 
-def write_rendezvous(path, payload):
-    """Rank 0: publish the communicator id atomically (temporary name + rename: a reader never sees half a file)."""
+NONCE_BYTES = 16
+
+
+def job_nonce():
+    """The per-job nonce every rank got from its launcher (``ECSEG_RDZV_NONCE``, hex); empty when the launcher set none."""
+    h = os.environ.get('ECSEG_RDZV_NONCE', '')
+    try:
+        b = bytes.fromhex(h)
+    except ValueError:
+        b = h.encode()
+    return (b + b'\0' * NONCE_BYTES)[:NONCE_BYTES] if b else b''
+
+
+def write_rendezvous(path, payload, nonce=b''):
+    """Rank 0: publish nonce + communicator id atomically.  The temporary file is created exclusively with mode 0600 (no
+    following of a symlink somebody planted at a predictable name) and renamed over ``path``: a reader never sees half a
+    file, and a stale file of a crashed job is replaced, never appended to."""
     tmp = '%s.tmp%d' % (path, os.getpid())
-    with open(tmp, 'wb') as f:
-        f.write(payload)
+    try:
+        os.unlink(tmp)
+    except OSError:
+        pass
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, 'O_NOFOLLOW', 0), 0o600)
+    with os.fdopen(fd, 'wb') as f:
+        f.write(nonce + payload)
     os.replace(tmp, path)
 
 
-def read_rendezvous(path, nbytes, timeout=300.0, poll=0.05):
-    """Other ranks: wait for rank 0's file."""
+def read_rendezvous(path, nbytes, timeout=300.0, poll=0.05, nonce=b'', alive=None):
+    """Other ranks: wait for rank 0's file.  A file whose leading nonce is not this job's (left behind by a crashed job at a
+    user-supplied ``ECSEG_RDZV``) is ignored until rank 0 has replaced it.  ``alive()`` (optional) lets the caller give up
+    early, e.g. when its launcher has gone."""
     import time
     t0 = time.time()
     while True:
         try:
             with open(path, 'rb') as f:
                 b = f.read()
-            if len(b) == nbytes:
-                return b
+            if len(b) == len(nonce) + nbytes and b[:len(nonce)] == nonce:
+                return b[len(nonce):]
         except OSError:
             pass
         if time.time() - t0 > timeout:
-            raise TimeoutError('no communicator id at %s after %.0f s (did rank 0 start?)' % (path, timeout))
+            raise TimeoutError('no communicator id of this job at %s after %.0f s (did rank 0 start?)' % (path, timeout))
+        if alive is not None and not alive():
+            raise RuntimeError('the launcher of this rank has gone: giving up the rendezvous at %s' % path)
         time.sleep(poll)
 
 
@@ -136,11 +161,15 @@ def native_init(rank, world, device, rdzv_path):
     ``rdzv_path`` (a file every rank can see), everybody joins.  -> (rank, world)."""
     global _native
     from ._lib import Comm
+    nonce = job_nonce()
     if rank == 0:
         uid = Comm.unique_id()
-        write_rendezvous(rdzv_path, uid)
+        write_rendezvous(rdzv_path, uid, nonce)
     else:
-        uid = read_rendezvous(rdzv_path, 128)
+        ppid = os.getppid()
+        # (a rank whose launcher died is re-parented: stop polling instead of spinning for the whole timeout)
+        uid = read_rendezvous(rdzv_path, 128, nonce=nonce,
+                              alive=(lambda: os.getppid() == ppid) if os.environ.get('ECSEG_RDZV_NONCE') else None)
     _native = Comm(uid, rank, world, device)
     return rank, world
 

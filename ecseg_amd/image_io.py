@@ -197,7 +197,7 @@ def read_tiff(path, native=True):
                 out[ty:ty + th, tx:tx + tw] = blk[:min(th, H - ty), :min(tw, W - tx)]
                 k += 1
     else:
-        rps = min(t.get(278, (H,))[0], H)
+        rps = min(t.get(278, (H,))[0] or H, H)      # RowsPerStrip 0: one strip, as libtiff and the native reader read it
         offs, cnts = t[273], t.get(279)
         if cnts is None:
             cnts = [len(buf) - offs[0]] if len(offs) == 1 else None

@@ -129,6 +129,25 @@ def _segment_with_retry(model, imgs, log):
         h.set_images_per_group(before)
 
 
+def _segment_isolating(model, imgs, log):
+    """GPU part of one batch with per-image failure isolation (a per-image status): a batch that fails for any reason
+    other than memory (_segment_with_retry deals with that) is bisected until the failing image(s) stand alone - one bad image
+    costs one status-2 row, not the whole batch.  -> list of (index in batch, gray, post, n_ec) for the images that went
+    through, list of (index, exception) for those that did not."""
+    try:
+        gray, post, nec = _segment_with_retry(model, imgs, log)
+        return [(j, gray[j], post[j], int(nec[j])) for j in range(len(imgs))], []
+    except Exception as e:
+        if len(imgs) == 1:
+            return [], [(0, e)]
+        half = len(imgs) // 2
+        log("A batch of %d image(s) of shape %s failed on the device (%s): retrying it as %d + %d"
+            % (len(imgs), imgs.shape[1:], e, half, len(imgs) - half))
+        ok_a, bad_a = _segment_isolating(model, imgs[:half], log)
+        ok_b, bad_b = _segment_isolating(model, imgs[half:], log)
+        return (ok_a + [(j + half, g, p, n) for j, g, p, n in ok_b], bad_a + [(j + half, e2) for j, e2 in bad_b])
+
+
 def run(inpath, model, image_paths, rank=0, world=1, batch_images=8, io_threads=None, log=print, stats=None, resume=False):
     """Segment this rank's shard; returns records (one row per image of the WHOLE job after the all-gather)."""
     start, stop, per = dist.shard_bounds(len(image_paths), rank, world)
@@ -175,19 +194,17 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
                 for j, k in enumerate(group):
                     n_ec[k] = int(cnt[j])
                 return
-            try:
-                t0 = time.perf_counter()
-                gray, post, nec = _segment_with_retry(model, imgs, log)
-                t_gpu += time.perf_counter() - t0
-            except Exception as e:                         # a failing batch must not take the shard down
-                log("Skipping %d image(s) of shape %s: %s" % (len(group), imgs.shape[1:], e))
-                for k in group:
-                    status[k] = 2
-                return
-            for j, k in enumerate(group):
-                n_ec[k] = int(nec[j])
+            t0 = time.perf_counter()
+            done, bad = _segment_isolating(model, imgs, log)
+            t_gpu += time.perf_counter() - t0
+            for j, e in bad:                               # a failing image must not take its batch or the shard down
+                log("Skipping %s (shape %s): %s" % (mine[group[j]], imgs.shape[1:], e))
+                status[group[j]] = 2
+            for j, gray_j, post_j, nec_j in done:
+                k = group[j]
+                n_ec[k] = nec_j
                 pending_writes.acquire()
-                f = writers.submit(_write_outputs, mine[k], gray[j], post[j], log)
+                f = writers.submit(_write_outputs, mine[k], gray_j, post_j, log)
                 f.add_done_callback(lambda _f: pending_writes.release())
                 write_futs.append((k, f))
 
@@ -276,6 +293,51 @@ def finish(inpath, image_paths, rec, rank, seconds=None, gpu_seconds=0.0, log=pr
     return failed
 
 
+def _supervise_native(n, env, argv=None, poll=0.2, grace=10.0):
+    """Start ``n`` fresh rank processes (ECSEG_DIST=native) and watch ALL of them: on the first non-zero exit the remaining
+    ranks are terminated (then killed) - a rank that died before the record all-gather would otherwise leave its peers
+    blocked for ever in ncclCommInitRank / ncclAllGather (csrc/comm.hip has no timeout) and this parent on the first live
+    child.  The rendezvous directory is removed either way.  Returns the job's exit code (first failure, else 0).  Only
+    fresh children are started, never a re-exec of a process that has touched the GPU."""
+    import shutil
+    import tempfile
+    rdir = tempfile.mkdtemp(prefix='ecseg_rdzv_')
+    rdzv = os.path.join(rdir, 'id')
+    nonce = os.urandom(dist.NONCE_BYTES).hex()
+    cmd = argv or [sys.executable, '-m', 'ecseg_amd.metaseg']
+    procs = []
+    try:
+        for r in range(n):
+            procs.append(subprocess.Popen(cmd, env=dict(env, ECSEG_DIST='native', ECSEG_RDZV=rdzv, ECSEG_RDZV_NONCE=nonce,
+                                                        RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n))))
+        code = 0
+        live = list(procs)
+        while live and code == 0:
+            time.sleep(poll)
+            for p in list(live):
+                c = p.poll()
+                if c is None:
+                    continue
+                live.remove(p)
+                if c != 0 and code == 0:
+                    code = abs(c) or 1
+                    print("Rank %d exited with code %d: stopping the other %d rank(s)" % (procs.index(p), c, len(live)), flush=True)
+        return code
+    finally:
+        for p in procs:                                    # (normal end: nobody is left; failure / KeyboardInterrupt: tear down)
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + grace
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    p.wait(timeout=max(0.1, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+        shutil.rmtree(rdir, ignore_errors=True)
+
+
 def _self_launch(device_ids):
     """``device_ids`` with more than one GPU outside a launcher: one rank per listed GPU (this parent never touches HIP)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))          # the ranks import ecseg_amd from here
@@ -285,15 +347,9 @@ def _self_launch(device_ids):
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'),
                PYTHONPATH=root + (os.pathsep + os.environ['PYTHONPATH'] if os.environ.get('PYTHONPATH') else ''))
     if dist.want_native():
-        # no torch: plain child processes, the library's own RCCL communicator, rendezvous through a file in the job's folder
-        import tempfile
-        rdzv = os.path.join(tempfile.gettempdir(), 'ecseg_rdzv_%d_%d' % (os.getpid(), int(time.time() * 1e3) & 0xffffff))
-        n = len(device_ids)
-        procs = [subprocess.Popen([sys.executable, '-m', 'ecseg_amd.metaseg'],
-                                  env=dict(env, ECSEG_DIST='native', ECSEG_RDZV=rdzv, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n)))
-                 for r in range(n)]
-        codes = [p.wait() for p in procs]
-        sys.exit(max(abs(c) for c in codes))
+        # no torch: plain child processes, the library's own RCCL communicator, rendezvous through a file in a private
+        # directory (mkdtemp: mode 0700, unpredictable name) + a per-job nonce the readers check
+        sys.exit(_supervise_native(len(device_ids), env))
     # --standalone: torch.distributed.run binds its own rendezvous port (no bind-then-close race with other jobs on the node)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1',
            '--nproc-per-node', str(len(device_ids)), '-m', 'ecseg_amd.metaseg']

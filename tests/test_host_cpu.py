@@ -244,3 +244,52 @@ def test_shipped_library_has_no_diagnostic_kernels():
     product = src.split('#ifdef ECSEG_DIAG')[0] + src.split('#endif', 1)[1]          # everything but the hook definitions
     for word in ('ABL', 'STAMP', 'W4_VARIANT', 's_memtime'):
         assert word not in product.replace('W4_KSTAMP', '').replace('W4_ESTAMP', '').replace('WSTAMP', '').replace('ESTAMP', ''), word
+
+
+def test_native_launcher_stops_the_peers_of_a_failed_rank(tmp_path):
+    """a rank that dies before the record all-gather must not leave its peers (blocked in RCCL) and the parent
+    hanging: the supervisor polls ALL children, terminates the others on the first non-zero exit, removes the rendezvous
+    directory and returns that exit code."""
+    import time
+    from ecseg_amd import metaseg
+    marker = tmp_path / 'rdzv_seen'
+    script = ("import os, sys, time\n"
+              "open(%r, 'a').write(os.path.dirname(os.environ['ECSEG_RDZV']) + '\\n')\n"
+              "assert len(bytes.fromhex(os.environ['ECSEG_RDZV_NONCE'])) == 16 and os.environ['ECSEG_DIST'] == 'native'\n"
+              "if os.environ['RANK'] == '1':\n    time.sleep(0.5); sys.exit(3)\n"
+              "time.sleep(120)\n" % str(marker))
+    t0 = time.time()
+    code = metaseg._supervise_native(3, dict(os.environ), argv=[sys.executable, '-c', script])
+    assert code == 3
+    assert time.time() - t0 < 30, 'the surviving ranks were waited for'
+    dirs = set(marker.read_text().split())
+    assert len(dirs) == 1 and not os.path.exists(dirs.pop()), 'rendezvous directory left behind'
+    # all ranks succeed: exit code 0
+    assert metaseg._supervise_native(2, dict(os.environ), argv=[sys.executable, '-c', 'pass']) == 0
+
+
+def test_rendezvous_rejects_a_stale_file_of_another_job(tmp_path, monkeypatch):
+    """a 128-byte id left at a user-supplied ECSEG_RDZV by a crashed job is not this job's: readers check the
+    job nonce in front of the id; the writer replaces the file atomically without following a planted symlink."""
+    import threading
+    path = str(tmp_path / 'id')
+    mine, other = os.urandom(16), os.urandom(16)
+    edist.write_rendezvous(path, b'S' * 128, other)                   # stale file of a crashed job
+    with pytest.raises(TimeoutError):
+        edist.read_rendezvous(path, 128, timeout=0.3, poll=0.05, nonce=mine)
+    t = threading.Timer(0.2, edist.write_rendezvous, (path, b'N' * 128, mine))
+    t.start()
+    assert edist.read_rendezvous(path, 128, timeout=10, poll=0.02, nonce=mine) == b'N' * 128
+    t.join()
+    assert os.stat(path).st_mode & 0o777 == 0o600
+    # a symlink planted at the temporary name is not followed
+    victim = tmp_path / 'victim'
+    victim.write_bytes(b'keep')
+    os.symlink(str(victim), '%s.tmp%d' % (path, os.getpid()))
+    edist.write_rendezvous(path, b'M' * 128, mine)
+    assert victim.read_bytes() == b'keep'
+    monkeypatch.setenv('ECSEG_RDZV_NONCE', mine.hex())
+    assert edist.job_nonce() == mine
+    # the launcher of a polling rank has gone: stop polling
+    with pytest.raises(RuntimeError):
+        edist.read_rendezvous(str(tmp_path / 'never'), 128, timeout=10, poll=0.02, nonce=mine, alive=lambda: False)

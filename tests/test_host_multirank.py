@@ -22,9 +22,10 @@ class StubHandle:
     """What metaseg.run needs of a Handle, computed on the CPU: deterministic functions of the pixels."""
     device = 0
 
-    def __init__(self, fail_above=None):
+    def __init__(self, fail_above=None, poison=None):
         self.images_per_group = 0
         self.fail_above = fail_above           # simulate E_NOMEM for launch groups / batches above this many images
+        self.poison = poison                   # simulate a non-memory device error for any batch holding this pixel value at [0, 0]
         self.calls = []
 
     def set_images_per_group(self, n):
@@ -51,6 +52,10 @@ class StubModel:
         if h.fail_above is not None and min(grp, len(gray)) > h.fail_above:
             e = EcsegError('simulated out of memory')
             e.code = E_NOMEM
+            raise e
+        if h.poison is not None and (np.asarray(gray)[:, 0, 0] == h.poison).any():
+            e = EcsegError('simulated device fault')
+            e.code = -5
             raise e
         post = (np.asarray(gray) >> 6).astype(np.uint8)                    # labels 0..3
         return post, np.array([postproc.count_cc(p == 3)[0] for p in post], np.int32)
@@ -216,3 +221,30 @@ def test_native_rendezvous_file_and_transport_choice(tmp_path, monkeypatch):
     rec = edist.make_records(3, 2, 4, n_ec=[5, 6])
     out = edist.gather_all(rec)
     assert out.shape == (2, edist.RECORD_INT64) and out[:, edist.F_INDEX].tolist() == [3, 4]
+
+
+def test_one_bad_image_costs_one_status_row_not_its_batch(tmp_path):
+    """VERDICT r03 item 8 / SURVEY 5 (per-image status): a device error that is not out-of-memory used to mark the whole batch
+    (8 images) failed; the batch is now bisected like the OOM path, so exactly the bad image gets status 2 and everything
+    else - outputs, counts, CSV - equals a run without it."""
+    from PIL import Image
+    folder = str(tmp_path / 'in')
+    make_inputs(folder, 9)
+    bad = os.path.join(folder, 'img04.tif')
+    img = np.array(Image.open(bad))
+    img[0, 0, 2] = 201                                                       # the stub's poison value
+    Image.fromarray(img).save(bad, compression='tiff_lzw')
+    paths = get_imgs(folder)
+    m = StubModel(poison=201)
+    logs = []
+    rec = metaseg.run(folder, m, paths, 0, 1, batch_images=8, io_threads=2, log=lambda *a: logs.append(' '.join(str(x) for x in a)))
+    failed = metaseg.finish(folder, paths, rec, 0, log=lambda *a: None)
+    assert [int(r[edist.F_STATUS]) for r in rec] == [2 if i == 4 else 0 for i in range(9)]
+    assert len(failed) == 1 and any('img04.tif' in line and 'simulated device fault' in line for line in logs)
+    csv = open(os.path.join(folder, 'ec_quantification.csv')).read()
+    assert csv.count('\n') == 9 and 'img04.tif' not in csv                  # header + 8 rows
+    for i in range(9):
+        assert os.path.exists(os.path.join(folder, 'labels', 'img%02d.npy' % i)) == (i != 4)
+    # the batch of 8 was bisected down to the single image: 8 -> 4 (fine) + 4 -> 2 -> 1 (bad) + 1, then the other 2, then image 8
+    sizes = [c[0] for c in m.handle.calls]
+    assert sizes == [8, 4, 4, 2, 1, 1, 2, 1]

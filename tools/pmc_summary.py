@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, CSV output) into per-kernel HBM traffic.
 
-    python tools/pmc_summary.py <fetch_dir> <write_dir> <out.json>
+    python tools/pmc_summary.py <fetch_dir> <write_dir> <out.json> [base=64,up=transpose,wino=2]
+
+The summary records the configuration of the profiled command and the sha256 of the kernel sources it ran
+(ecseg_amd.build.source_hash): bench.py quotes `roofline.traffic` only from a summary of the same configuration AND the
+same sources, and prints `traffic: null, traffic_stale: true` otherwise.
 
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KiB;
 on gfx950 FETCH_SIZE reports exactly half of the bytes of wide coalesced streaming reads, so it is doubled;
@@ -11,7 +15,10 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def load(d):
@@ -27,7 +34,9 @@ def load(d):
 def main():
     fetch, write, out = sys.argv[1:4]
     f, w = load(fetch), load(write)
-    res = {'units': 'bytes', 'fetch_correction': 'FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count of wide reads)',
+    from ecseg_amd.build import source_hash
+    cfg = dict(kv.split('=') for kv in sys.argv[4].split(',')) if len(sys.argv) > 4 else {'base': '64', 'up': 'transpose', 'wino': '2'}
+    res = {'config': cfg, 'kernel_source_sha256': source_hash(), 'units': 'bytes', 'fetch_correction': 'FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count of wide reads)',
            'write_correction': 'WRITE_SIZE KiB x 1024', 'kernels': {}}
     tot_conv = [0, 0.0, 0.0]
     for k in f:

@@ -24,7 +24,16 @@ echo "pmc mfma rc $?"
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_mix -o bench -- $PMC1 > $OUT/pmc_mix.log 2>&1
 echo "pmc mix rc $?"
 cd $R
-python3 tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_traffic.json
+# configuration key of the summary (bench.py matches it): base / up / wino from the bench arguments
+CFG=$(python3 - $XARGS <<'PY'
+import sys
+a = sys.argv[1:]
+def opt(name, d):
+    return a[a.index(name) + 1] if name in a else d
+print('base=%s,up=%s,wino=%s' % (opt('--base', '64'), opt('--up', 'transpose'), '0' if '--direct' in a else opt('--wino', '2')))
+PY
+)
+python3 tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_traffic.json $CFG
 python3 tools/pmc_mfma_summary.py $OUT $OUT/mfma_busy.json
 find $OUT -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 ls $OUT

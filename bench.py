@@ -185,6 +185,64 @@ def parity_vs_cpu(hnd, refs):
                     'and 0 vs 0.  Clean-up and counting are bit-exact functions of the raw labels'}
 
 
+def aux_device_legs(hnd, local, n=64):
+    """the device cost of BASELINE configs[4] (`make meta_overlay`'s row: ecseg_overlay) and of
+    meta_preprocess (ecseg_preprocess) on n resident synthetic FISH images - HIP events around the kernels alone inside the
+    entry points (ecseg_get_timings()[ECSEG_T_COUNT]; host copies excluded) - with their algorithmic bytes and the fraction of
+    the 8 TB/s HBM roof, plus ONE record all-gather through the C-ABI RCCL communicator with a single rank (the collective of
+    the path has a latency figure even when the driver runs one GPU)."""
+    import torch
+    from ecseg_amd import synth
+    from ecseg_amd._lib import Comm
+    px = H * W
+    base_rgb = [synth.dapi_image(700 + i, H, W, rgb=True) for i in range(8)]
+    base_lab = [synth.label_map(700 + i, H, W) for i in range(8)]
+    rgb = np.stack([np.roll(base_rgb[i % 8], (37 * (i // 8), 53 * (i // 8)), axis=(0, 1)) for i in range(n)])
+    lab = np.stack([np.roll(base_lab[i % 8], (37 * (i // 8), 53 * (i // 8)), axis=(0, 1)) for i in range(n)])
+    out = {}
+    hnd.overlay(lab, rgb, 85)
+    ms = []
+    for _ in range(3):
+        hnd.overlay(lab, rgb, 85)
+        ms.append(hnd.timings()['count'])
+    t = float(np.median(ms)) / n
+    # 5 labellings x 9 B/px (image 1 + parents written 4 + read 4) + aux / mask passes (labels 1 + RGB 3 in, 1 out: 5 passes) +
+    # 2 size filters (parents 4 + flags 2) + 6 flagged-root counts (image 1 + parents 4)
+    ov_bytes = px * (5 * 9 + 5 * 5 + 2 * 6 + 6 * 5)
+    out['overlay_ms_per_image'] = {'value': round(t, 4), 'images': n, 'algorithmic_bytes_per_image': ov_bytes,
+                                   'achieved_GBs': round(ov_bytes / (t * 1e-3) / 1e9, 1), 'frac_of_hbm_peak': round(ov_bytes / (t * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
+                                   'what': 'ecseg_overlay (src/meta_overlay.py:56-95): thresholds + 5 labellings + counts, realistic label maps (synth.label_map) + synthetic FISH RGB, kernels only'}
+    hnd.preprocess(rgb)
+    ms = []
+    for _ in range(3):
+        hnd.preprocess(rgb)
+        ms.append(hnd.timings()['count'])
+    t = float(np.median(ms)) / n
+    pp_bytes = px * (3 + 1 + 1)           # RGB in, gray out, gray re-read by the histogram (+2 for an inverted image: none here)
+    out['preprocess_ms_per_image'] = {'value': round(t, 4), 'images': n, 'algorithmic_bytes_per_image': pp_bytes,
+                                      'achieved_GBs': round(pp_bytes / (t * 1e-3) / 1e9, 1), 'frac_of_hbm_peak': round(pp_bytes / (t * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
+                                      'what': 'ecseg_preprocess (src/image_tools.py:86-96): blue channel + 256-bin histogram + Otsu + invert, uint8 RGB, kernels only'}
+    try:
+        comm = Comm(Comm.unique_id(), 0, 1, local)
+        rec = torch.zeros((n, 16), dtype=torch.int64, device='cuda:%d' % local)
+        got = torch.empty_like(rec)
+        stream = torch.cuda.current_stream().cuda_stream
+        for _ in range(3):
+            comm.allgather_records_dev(rec.data_ptr(), n, got.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            comm.allgather_records_dev(rec.data_ptr(), n, got.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        out['allgather_one_rank_us'] = {'value': round((time.perf_counter() - t0) / reps * 1e6, 1), 'records': n,
+                                        'what': 'ecseg_allgather_records_dev (ncclAllGather of %d x 128-B records) on a 1-rank communicator, enqueue + completion, mean of %d' % (n, reps)}
+        comm.close()
+    except Exception as e:                                         # RCCL not loadable on this box
+        out['allgather_one_rank_us'] = {'value': None, 'error': str(e)}
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def self_launch(args):
     """--gpus N > 1 outside a launcher: start one rank per GPU and relay rank 0's JSON line.  This parent never touches
@@ -585,6 +643,7 @@ def main():
                                              'pipeline, post-processed labels + counts back to host memory (D2H), synchronous'
                                              % B}
         if world == 1 and not args.no_narrow:
+            res.update(aux_device_legs(hnd, local))
             res['single_image_latency_ms'] = run.single_image_latency()
             # "also run base 32 and 16" - the same pipeline on the narrower canonical models with the automatic
             # launch-group size (as many images per U-Net launch as fit ~48 GB of activations: 32 / 64 images), one step =

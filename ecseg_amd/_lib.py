@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('ECSEG_HIP_LIB') or os.path.join(HERE, 'libecseg_hip.s
 EXPORTS = [
     'ecseg_abi_version', 'ecseg_create', 'ecseg_destroy', 'ecseg_last_error', 'ecseg_device_name', 'ecseg_stream',
     'ecseg_model_load', 'ecseg_model_flops_per_patch', 'ecseg_forward_patches', 'ecseg_forward_patches_f32', 'ecseg_read_tensor',
-    'ecseg_segment_images', 'ecseg_segment_images_dev', 'ecseg_set_images_per_group', 'ecseg_set_option', 'ecseg_preprocess', 'ecseg_u16_to_u8',
+    'ecseg_segment_images', 'ecseg_segment_images_ex', 'ecseg_segment_images_dev', 'ecseg_set_images_per_group', 'ecseg_set_option', 'ecseg_preprocess', 'ecseg_u16_to_u8',
     'ecseg_stitch_argmax', 'ecseg_meta_inference', 'ecseg_meta_inference_dev', 'ecseg_count_cc', 'ecseg_ccl_labels',
     'ecseg_count_colocalization', 'ecseg_count_hsr', 'ecseg_overlay', 'ecseg_get_timings',
     'ecseg_set_kernel_profiling', 'ecseg_get_conv_profile', 'ecseg_get_conv_executed_flops', 'ecseg_get_conv_launch_profile', 'ecseg_debug_peek', 'ecseg_lzw_decode', 'ecseg_lzw_encode',
@@ -28,7 +28,7 @@ class EcsegError(RuntimeError):
 
 E_NOMEM = -4
 E_UNSUPPORTED, E_IO = -5, -6
-ABI_VERSION = 2           # ECSEG_ABI_VERSION of include/ecseg_hip.h this binding was written for
+ABI_VERSION = 3           # ECSEG_ABI_VERSION of include/ecseg_hip.h this binding was written for
 
 
 class TensorDesc(C.Structure):
@@ -75,6 +75,7 @@ def load_library():
     lib.ecseg_read_tensor.argtypes = [vp, i32, i32, vp]
     lib.ecseg_segment_images.argtypes = [vp, u8p, i32, i32, i32, vp, vp, vp]
     lib.ecseg_segment_images_dev.argtypes = [vp, u8p, i32, i32, i32, vp, vp, vp]
+    lib.ecseg_segment_images_ex.argtypes = [vp, u8p, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.ecseg_set_images_per_group.argtypes = [vp, i32]
     lib.ecseg_set_option.argtypes = [vp, C.c_char_p, i32]
     lib.ecseg_preprocess.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
@@ -229,8 +230,10 @@ class Handle:
         return out
 
     # ---- image pipeline -----------------------------------------------------------------------------
-    def segment_images(self, gray, want_raw=True):
-        """(n, H, W) uint8 pre-processed images -> (raw labels | None, post-processed labels, n_ec)."""
+    def segment_images(self, gray, want_raw=True, want_tie_risk=False, want_probs=False):
+        """(n, H, W) uint8 pre-processed images -> (raw labels | None, post-processed labels, n_ec)
+        [+ tie_risk int32 (n,) when ``want_tie_risk``: pixels whose two largest uint8-quantised probabilities differ by at most
+        1; + probs float32 (n, H, W, 4) when ``want_probs``: the stitched probabilities of src/utils.py:116]."""
         g = _u8(gray)
         if g.ndim == 2:
             g = g[None]
@@ -238,9 +241,15 @@ class Handle:
         raw = np.empty((n, H, W), np.uint8) if want_raw else None
         post = np.empty((n, H, W), np.uint8)
         nec = np.zeros(n, np.int32)
-        self._check(self.lib.ecseg_segment_images(self.h, _ptr(g), n, H, W, _ptr(raw), _ptr(post), _ptr(nec)),
-                    'ecseg_segment_images')
-        return raw, post, nec
+        if not (want_tie_risk or want_probs):
+            self._check(self.lib.ecseg_segment_images(self.h, _ptr(g), n, H, W, _ptr(raw), _ptr(post), _ptr(nec)),
+                        'ecseg_segment_images')
+            return raw, post, nec
+        tie = np.zeros(n, np.int32) if want_tie_risk else None
+        probs = np.empty((n, H, W, 4), np.float32) if want_probs else None
+        self._check(self.lib.ecseg_segment_images_ex(self.h, _ptr(g), n, H, W, _ptr(raw), _ptr(post), _ptr(nec), _ptr(tie), _ptr(probs)),
+                    'ecseg_segment_images_ex')
+        return (raw, post, nec) + ((tie,) if want_tie_risk else ()) + ((probs,) if want_probs else ())
 
     def segment_images_dev(self, gray_ptr, n, H, W, raw_ptr, post_ptr, nec_ptr):
         self._check(self.lib.ecseg_segment_images_dev(self.h, C.c_void_p(gray_ptr), n, H, W,

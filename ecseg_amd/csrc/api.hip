@@ -80,6 +80,8 @@ struct ecseg_ctx {
     std::map<std::pair<int, int>, StitchPlan> stitch;
     uint8_t* d_gray = nullptr; size_t d_gray_cap = 0;
     uint8_t* d_raw = nullptr; size_t d_raw_cap = 0;
+    int32_t* d_tie = nullptr; size_t d_tie_cap = 0;        // per-image tie-risk counts of the last segment call
+    float* d_sprobs = nullptr; size_t d_sprobs_cap = 0;    // stitched probabilities of one launch group (ecseg_segment_images_ex)
     uint8_t* d_post = nullptr; size_t d_post_cap = 0;
     uint8_t* d_aux8 = nullptr; size_t d_aux8_cap = 0;      // second uint8 input (masks, rgb)
     uint8_t* d_u8in = nullptr; size_t d_u8in_cap = 0;      // uint8 patches of forward_patches
@@ -247,11 +249,7 @@ std::vector<float> winograd4_filter(const float* w, int cin, int cout) {
             for (int a = 0; a < 6; ++a)
                 for (int b = 0; b < 6; ++b) {
                     const double u = t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2];
-#if ECSEG_W4_FREG
-                    const size_t idx = (((size_t)nb * nstages + stage) * 12 + (half * 6 + a)) * 768 + ((((size_t)(b >> 1) * 64 + hh * 32 + m) * 2 + (b & 1)) * 2) + e;
-#else
                     const size_t idx = (((size_t)nb * nstages + stage) * 12 + (half * 6 + a)) * 768 + (((size_t)b * 2 + hh) * 32 + m) * 2 + e;
-#endif
                     o[idx] = (float)u;
                 }
         }
@@ -685,7 +683,7 @@ int ensure_post(ecseg_ctx* h, int n_img, size_t px) {
     drop_post_graphs(h);                                     // the captured launches hold the old workspace pointers
     const int ni = std::max(n_img, w.cap_img);
     const size_t np = std::max(px, w.cap_px);
-    void* ptrs[] = {w.L, w.area, w.sumy, w.sumx, w.flag, w.tmpA, w.tmpB, w.list, w.g, w.tile_any, w.binned, w.binstart};
+    void* ptrs[] = {w.L, w.area, w.sumy, w.sumx, w.flag, w.tmpA, w.tmpB, w.list, w.g, w.tile_any, w.own_bits, w.binned, w.binstart};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     w = PostWorkspace{};
     const size_t tot = (size_t)ni * np;
@@ -706,6 +704,8 @@ int ensure_post(ecseg_ctx* h, int n_img, size_t px) {
     A(reinterpret_cast<void**>(&w.list), list_bytes);
     A(reinterpret_cast<void**>(&w.g), (size_t)ni * G_STRIDE * G_SHARDS * 4);
     A(reinterpret_cast<void**>(&w.tile_any), (size_t)ni * (np / 16 + 2));
+    // owner bits: 256 B per 64 x 32 tile; ceil(W/64) ceil(H/32) <= px/2048 + W/64 + H/32 + 1 <= px/31 + 3 tiles for any H x W = px
+    A(reinterpret_cast<void**>(&w.own_bits), (size_t)ni * (np / 31 + 4) * 256);
     const size_t binned_cap = std::min(list_cap, (size_t)1 << 20);
     A(reinterpret_cast<void**>(&w.binned), (size_t)ni * 2 * binned_cap * sizeof(double));
     A(reinterpret_cast<void**>(&w.binstart), (size_t)ni * 2 * (NUCLEUS_BIN_EXTENT + 2) * sizeof(int32_t));   // (W/64 + 1)(H/32 + 1) <= px/16 + 1 tiles per image
@@ -727,9 +727,13 @@ float stage_elapsed(hipEvent_t a, hipEvent_t b) {
 }
 
 // Device-resident pipeline: gray (n_img, H, W) -> raw labels, post labels, counts.  All pointers are device pointers.
-int segment_dev(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint8_t* raw, uint8_t* post, int32_t* n_ec) {
+// probs_host (optional): the stitched float32 probabilities of every image, copied out group by group.
+int segment_dev(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint8_t* raw, uint8_t* post, int32_t* n_ec,
+                float* probs_host = nullptr) {
     int rc = check_model(h);
     if (rc) return rc;
+    if ((rc = ensure(h, h->d_tie, h->d_tie_cap, (size_t)n_img))) return rc;
+    HIP_TRY(h, hipMemsetAsync(h->d_tie, 0, (size_t)n_img * sizeof(int32_t), h->stream));
     const ecseg_tensor_desc& ti = h->tensors[h->input_tensor];
     const ecseg_tensor_desc& to = h->tensors[h->output_tensor];
     if (ti.h != 256 || ti.w != 256 || ti.c != 1 || ti.c_stride != 1)
@@ -746,6 +750,7 @@ int segment_dev(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint
     const int grp = std::max(1, std::min(wpg / 35, std::max(1, wpg / sp->n_pos)));
     if ((rc = ensure_patches(h, std::min(grp, n_img) * sp->n_pos))) return rc;
     if ((rc = ensure_post(h, std::min(n_img, grp), px))) return rc;
+    if (probs_host && (rc = ensure(h, h->d_sprobs, h->d_sprobs_cap, (size_t)std::min(grp, n_img) * px * 4))) return rc;
     for (float& v : h->stage_ms) v = 0.f;
     prof_begin(h);
     // Per group: tile -> U-Net -> stitch/argmax on the main stream; the group's clean-up + count then runs on the second
@@ -772,8 +777,12 @@ int segment_dev(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint
         if ((rc = run_plan(h, ni * sp->n_pos, sp))) return rc;
         HIP_TRY(h, hipEventRecord(e6[2], s));
         const TView pv = view_of(h, h->output_tensor);
-        HIP_TRY(h, launch_stitch_argmax(pv.p, pv.cs, sp->map_dev, ni, sp->n_pos, H, W, raw + (size_t)i0 * px, s));
+        HIP_TRY(h, launch_stitch_argmax(pv.p, pv.cs, sp->map_dev, ni, sp->n_pos, H, W, raw + (size_t)i0 * px, s, h->d_tie + i0));
         HIP_TRY(h, hipEventRecord(e6[3], s));
+        if (probs_host) {                                  // (diagnostic output: outside the stage timers)
+            HIP_TRY(h, launch_stitch_probs(pv.p, pv.cs, sp->map_dev, ni, sp->n_pos, H, W, h->d_sprobs, s));
+            HIP_TRY(h, hipMemcpyAsync(probs_host + (size_t)i0 * px * 4, h->d_sprobs, (size_t)ni * px * 4 * sizeof(float), hipMemcpyDeviceToHost, s));
+        }
         if (s2 != s) HIP_TRY(h, hipStreamWaitEvent(s2, e6[3], 0));
         HIP_TRY(h, hipEventRecord(e6[4], s2));
         if (post != raw)
@@ -842,8 +851,8 @@ void ecseg_destroy(ecseg_ctx* h) {
         for (auto& lk : kv.second.luts) if (lk.second.dev) (void)hipFree(lk.second.dev);
     }
     if (h->zero_page) (void)hipFree(h->zero_page);
-    void* ptrs[] = {h->d_gray, h->d_raw, h->d_post, h->d_aux8, h->d_u8in, h->d_i32, h->d_i64, h->d_probs_in, h->d_hist,
-                    h->ws.L, h->ws.area, h->ws.sumy, h->ws.sumx, h->ws.flag, h->ws.tmpA, h->ws.tmpB, h->ws.list, h->ws.g, h->ws.tile_any, h->ws.binned, h->ws.binstart};
+    void* ptrs[] = {h->d_tie, h->d_sprobs, h->d_gray, h->d_raw, h->d_post, h->d_aux8, h->d_u8in, h->d_i32, h->d_i64, h->d_probs_in, h->d_hist,
+                    h->ws.L, h->ws.area, h->ws.sumy, h->ws.sumx, h->ws.flag, h->ws.tmpA, h->ws.tmpB, h->ws.list, h->ws.g, h->ws.tile_any, h->ws.own_bits, h->ws.binned, h->ws.binstart};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
@@ -1171,6 +1180,11 @@ int ecseg_segment_images_dev(ecseg_ctx* h, const uint8_t* gray, int n_img, int H
 }
 
 int ecseg_segment_images(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint8_t* raw, uint8_t* post, int32_t* n_ec) {
+    return ecseg_segment_images_ex(h, gray, n_img, H, W, raw, post, n_ec, nullptr, nullptr);
+}
+
+int ecseg_segment_images_ex(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint8_t* raw, uint8_t* post, int32_t* n_ec,
+                            int32_t* tie_risk, float* probs) {
     if (!h) return ECSEG_E_INVALID;
     if (n_img < 0 || (n_img > 0 && (!gray || !post))) return fail(h, ECSEG_E_INVALID, "segment: bad arguments");
     if (n_img == 0) return ECSEG_OK;
@@ -1183,8 +1197,9 @@ int ecseg_segment_images(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, in
     if ((rc = ensure(h, h->d_post, h->d_post_cap, tot))) return rc;
     if ((rc = ensure(h, h->d_i32, h->d_i32_cap, (size_t)n_img))) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->d_gray, gray, tot, hipMemcpyHostToDevice, h->stream));
-    if ((rc = segment_dev(h, h->d_gray, n_img, H, W, h->d_raw, h->d_post, h->d_i32))) return rc;
+    if ((rc = segment_dev(h, h->d_gray, n_img, H, W, h->d_raw, h->d_post, h->d_i32, probs))) return rc;
     if (raw) HIP_TRY(h, hipMemcpyAsync(raw, h->d_raw, tot, hipMemcpyDeviceToHost, h->stream));
+    if (tie_risk) HIP_TRY(h, hipMemcpyAsync(tie_risk, h->d_tie, (size_t)n_img * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(post, h->d_post, tot, hipMemcpyDeviceToHost, h->stream));
     if (n_ec) HIP_TRY(h, hipMemcpyAsync(n_ec, h->d_i32, (size_t)n_img * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1205,10 +1220,14 @@ int ecseg_preprocess(ecseg_ctx* h, const void* img, int n_img, int H, int W, int
     if ((rc = ensure(h, h->d_hist, h->d_hist_cap, (size_t)n_img * 256))) return rc;
     hipStream_t s = h->stream;
     HIP_TRY(h, hipMemcpyAsync(h->d_aux8, img, in_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipEventRecord(h->ev[0], s));                 // the kernels alone (inputs resident): ecseg_get_timings()[ECSEG_T_COUNT]
     HIP_TRY(h, run_preprocess(h->d_aux8, n_img, H, W, C, bps, h->d_gray, h->d_i32, h->d_hist, s));
+    HIP_TRY(h, hipEventRecord(h->ev[1], s));
     HIP_TRY(h, hipMemcpyAsync(gray_out, h->d_gray, tot, hipMemcpyDeviceToHost, s));
     if (inverted_out) HIP_TRY(h, hipMemcpyAsync(inverted_out, h->d_i32, (size_t)n_img * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
+    for (float& v : h->stage_ms) v = 0.f;
+    h->stage_ms[ECSEG_T_COUNT] = stage_elapsed(h->ev[0], h->ev[1]);
     return ECSEG_OK;
 }
 
@@ -1304,20 +1323,24 @@ static int count_driver(ecseg_ctx* h, const uint8_t* a, const uint8_t* b, int n_
     if ((rc = ensure(h, h->d_i32, h->d_i32_cap, labels_out ? px * std::min(n_img, chunk) : (size_t)chunk))) return rc;
     if ((rc = ensure(h, h->d_i64, h->d_i64_cap, (size_t)chunk))) return rc;
     hipStream_t s = h->stream;
+    for (float& v : h->stage_ms) v = 0.f;
     for (int i0 = 0; i0 < n_img; i0 += chunk) {
         const int ni = std::min(chunk, n_img - i0);
         HIP_TRY(h, hipMemcpyAsync(h->d_gray, a + (size_t)i0 * px, px * ni, hipMemcpyHostToDevice, s));
         if (b) HIP_TRY(h, hipMemcpyAsync(h->d_aux8, b + (size_t)i0 * px, px * ni, hipMemcpyHostToDevice, s));
         hipError_t e = hipSuccess;
+        HIP_TRY(h, hipEventRecord(h->ev[0], s));
         if (kind == 0) e = run_count_cc(h->ws, h->d_gray, ni, H, W, h->d_i32, h->d_i64, s);
         else if (kind == 1) e = run_count_coloc(h->ws, h->d_gray, h->d_aux8, ni, H, W, h->d_i32, s);
         else if (kind == 2) e = run_count_hsr(h->ws, h->d_gray, h->d_aux8, ni, H, W, arg, h->d_i32, s);
         else e = run_ccl_labels(h->ws, h->d_gray, ni, H, W, arg, h->d_i32, s);
         if (e != hipSuccess) return fail_hip(h, e, "count kernels");
+        HIP_TRY(h, hipEventRecord(h->ev[1], s));
         if (labels_out) HIP_TRY(h, hipMemcpyAsync(labels_out + (size_t)i0 * px, h->d_i32, px * ni * 4, hipMemcpyDeviceToHost, s));
         else if (n_out) HIP_TRY(h, hipMemcpyAsync(n_out + i0, h->d_i32, (size_t)ni * 4, hipMemcpyDeviceToHost, s));
         if (px_out) HIP_TRY(h, hipMemcpyAsync(px_out + i0, h->d_i64, (size_t)ni * 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipStreamSynchronize(s));
+        h->stage_ms[ECSEG_T_COUNT] += stage_elapsed(h->ev[0], h->ev[1]);
     }
     return ECSEG_OK;
 }
@@ -1355,13 +1378,17 @@ int ecseg_overlay(ecseg_ctx* h, const uint8_t* labels, const uint8_t* rgb, int n
     if ((rc = ensure(h, h->d_aux8, h->d_aux8_cap, px * C * std::min(n_img, chunk)))) return rc;
     if ((rc = ensure(h, h->d_i64, h->d_i64_cap, (size_t)chunk * 12))) return rc;
     hipStream_t s = h->stream;
+    for (float& v : h->stage_ms) v = 0.f;
     for (int i0 = 0; i0 < n_img; i0 += chunk) {
         const int ni = std::min(chunk, n_img - i0);
         HIP_TRY(h, hipMemcpyAsync(h->d_gray, labels + (size_t)i0 * px, px * ni, hipMemcpyHostToDevice, s));
         HIP_TRY(h, hipMemcpyAsync(h->d_aux8, rgb + (size_t)i0 * px * C, px * C * ni, hipMemcpyHostToDevice, s));
+        HIP_TRY(h, hipEventRecord(h->ev[0], s));             // the kernels alone (inputs resident): ecseg_get_timings()[ECSEG_T_COUNT]
         HIP_TRY(h, run_overlay(h->ws, h->d_gray, h->d_aux8, ni, H, W, C, sens, hsr_thr, h->d_i64, s));
+        HIP_TRY(h, hipEventRecord(h->ev[1], s));
         HIP_TRY(h, hipMemcpyAsync(out + (size_t)i0 * 12, h->d_i64, (size_t)ni * 12 * 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipStreamSynchronize(s));
+        h->stage_ms[ECSEG_T_COUNT] += stage_elapsed(h->ev[0], h->ev[1]);
     }
     return ECSEG_OK;
 }

@@ -65,13 +65,6 @@ struct ConvParams {
 #define ECSEG_W4_PB 1.5
 #endif
 constexpr double W4_PA = ECSEG_W4_PA, W4_PB = ECSEG_W4_PB;
-// ECSEG_W4_FREG=1 (round-4 experiment, tools/build_variants.sh freg): the F(4x4) kernel loads its filter fragments from global
-// memory straight into registers (double-buffered, no LDS stage buffers) - the filter image then holds, per (block, stage,
-// wave), three 1-KiB pieces [piece k][lane][point 2k + {0, 1}][channel e] so that one dwordx4 load per lane and piece
-// delivers the B operands of four MFMAs.  0: LDS-DMA into private per-wave stage buffers, image [point][lane][e].
-#ifndef ECSEG_W4_FREG
-#define ECSEG_W4_FREG 0
-#endif
 
 // pitches used by relayout_* (api.hip) and the kernels
 inline long wt_chunk_pitch(int np_total) { return (long)2 * np_total * 4 + 32; }
@@ -117,8 +110,12 @@ hipError_t launch_tile_patches(const uint8_t* gray, int n_img, int H, int W, con
 
 // ---- launchers implemented in post_kernels.hip -----------------------------------------------------------------
 // stitch + img_as_ubyte + argmax; src_map: (H*W) int32 = (patch << 16) | (y << 8) | x, or -1 when never written
+// tie_risk (may be null): per image, += the pixels whose two largest quantised values differ by at most 1 (zeroed by the caller)
 hipError_t launch_stitch_argmax(const float* probs, int prob_cs, const int32_t* src_map, int n_img, int n_pos,
-                                int H, int W, uint8_t* labels, hipStream_t s);
+                                int H, int W, uint8_t* labels, hipStream_t s, int32_t* tie_risk = nullptr);
+// the stitched probabilities themselves: float32 (n_img, H, W, 4); never-written canvas pixels are 0
+hipError_t launch_stitch_probs(const float* probs, int prob_cs, const int32_t* src_map, int n_img, int n_pos,
+                               int H, int W, float* out, hipStream_t s);
 
 struct PostWorkspace {
     // all sized for `cap_img` images of `cap_px` pixels
@@ -132,6 +129,7 @@ struct PostWorkspace {
     int32_t* list;       // per image: compacted root lists for the nucleus-in-metaphase test
     int32_t* g;          // per image: small block of global counters (G_STRIDE ints)
     uint8_t* tile_any;   // per image and 64 x 32 labelling tile: the tile holds a keyed pixel (written by ccl_local)
+    uint32_t* own_bits;  // per image and tile: 2048 bits, bit = the pixel is the root of a tile component ("owner"; ccl_local -> ccl_resolve)
     double* binned;      // per image and axis: the chromosome centroids' coordinates grouped by integer bin (nucleus test)
     int32_t* binstart;   // per image and axis: first entry of every bin in `binned` (NUCLEUS_BIN_EXTENT + 2 ints)
     size_t binned_cap;   // entries per image and axis in `binned`

@@ -145,25 +145,46 @@ __global__ __launch_bounds__(256) void ccl_local_kernel(CclGeom g, const uint8_t
                                                         int32_t* __restrict__ L_all, uint32_t* __restrict__ area_all,
                                                         u64* __restrict__ sumy_all, u64* __restrict__ sumx_all,
                                                         uint32_t* __restrict__ flag_all, int stat, int sparse,
-                                                        uint8_t* __restrict__ tile_any, int allow_full) {
+                                                        uint8_t* __restrict__ tile_any, int allow_full,
+                                                        int aux_mode, int aux_c, const uint8_t* __restrict__ aux_img, int need,
+                                                        int32_t* __restrict__ G_all, uint32_t* __restrict__ own_bits) {
     __shared__ int Ls[CCL_BLOCK_ROWS * 64];
     __shared__ uint8_t Kl[4][64];                          // keys of every wave's last row (the next wave's "row above")
+    // per-tile-component statistics (round 4: accumulated HERE, where a pixel's tile root is known from the LDS labelling, instead
+    // of in a separate flatten pass that re-read every pixel's parent from global memory): bits 0-15 pixels of the slot
+    // (<= 2048), bits 16-20 flag bits
+    __shared__ uint32_t af_s[CCL_BLOCK_ROWS * 64];
+    __shared__ int red[8];                                 // npx[1..3]
+    extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+    // [TP] only when STAT_SUMS: coordinate sums of the slot RELATIVE to the tile origin, packed (sum of rows << 32 | sum of
+    // columns; each < 2^18 inside a 64 x 32 tile): one 64-bit LDS atomic per run
+    u64* sum_s = reinterpret_cast<u64*>(dyn_smem);
     int img, y0, cx;
     if (!decode_block(g, img, y0, cx)) return;            // block-uniform
     const size_t base = (size_t)img * g.H * g.W;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool want_slots = stat != 0 || aux_mode != AUX_NONE;
+    if (want_slots) {
+        for (int i = threadIdx.x; i < CCL_BLOCK_ROWS * 64; i += 256) {
+            af_s[i] = 0u;
+            if (stat & STAT_SUMS) sum_s[i] = 0ull;
+        }
+    }
+    if (threadIdx.x < 8) red[threadIdx.x] = 0;
     const int x = cx * 64 + lane;
     const int yblk = y0 - wave * CCL_ROWS;                 // first row of the tile
     const u64 upto = (2ull << lane) - 1ull;                // lanes <= this one
     // The keys of the wave's 8 rows stay in registers: the neighbours above come from the previous row's register through
     // DPP wave shifts (one VALU instruction each) instead of byte reads from an LDS copy of the tile.
     int keys[CCL_ROWS], hpos[CCL_ROWS];                    // key, lane of the pixel's run head
+    uint8_t vals[CCL_ROWS];
     int hole = 0;                                          // a valid pixel of this thread without a key
 #pragma unroll
     for (int r = 0; r < CCL_ROWS; ++r) {
         const int y = y0 + r, li = (wave * CCL_ROWS + r) * 64 + lane;
         const bool valid = y < g.H && x < g.W;
-        const int key = valid ? key_of(img_all[base + (size_t)y * g.W + x], lut) : 0;
+        vals[r] = valid ? img_all[base + (size_t)y * g.W + x] : (uint8_t)0;
+        const int key = valid ? key_of(vals[r], lut) : 0;
         keys[r] = key;
         hole |= (valid && key == 0) ? 1 : 0;
         const int kprev = wave_from_left(key);
@@ -189,12 +210,15 @@ __global__ __launch_bounds__(256) void ccl_local_kernel(CclGeom g, const uint8_t
     const int holes = allow_full ? __syncthreads_or(hole) : 1;
     const bool full = allow_full && any && !holes;
     if (threadIdx.x == 0) tile_any[tile_index(g, img)] = (uint8_t)(full ? 2 : (any != 0));
-    if (!any && sparse) return;
+    uint32_t* ob = own_bits + tile_index(g, img) * 64;     // owner bits of this tile: bit (li & 31) of word li >> 5
+    if (!any && sparse) return;                            // (later kernels skip the tile on tile_any == 0: its owner bits are never read)
     if (full) {
+        // the whole tile is one component and its first pixel the only owner; its "touches the image border" bit is the tile's
         if (threadIdx.x == 0) {
             const size_t p0 = base + (size_t)yblk * g.W + cx * 64;
             L_all[p0] = yblk * g.W + cx * 64;
-            flag_all[p0] = 0u;
+            const bool edge = yblk == 0 || yblk + CCL_BLOCK_ROWS >= g.H || cx == 0 || cx * 64 + 64 >= g.W;
+            flag_all[p0] = (aux_mode == AUX_BORDER && edge) ? 1u : 0u;
         }
         return;
     }
@@ -217,6 +241,7 @@ __global__ __launch_bounds__(256) void ccl_local_kernel(CclGeom g, const uint8_t
         }
     }
     __syncthreads();
+    int troot[CCL_ROWS];                                   // tile-local index of the pixel's tile root, -1 = unkeyed
 #pragma unroll
     for (int r = 0; r < CCL_ROWS; ++r) {
         const int y = y0 + r, li = (wave * CCL_ROWS + r) * 64 + lane;
@@ -230,17 +255,84 @@ __global__ __launch_bounds__(256) void ccl_local_kernel(CclGeom g, const uint8_t
             Ls[li] = root;
         }
         const int rl = key ? Ls[(li - lane) + hpos[r]] : -1;
+        troot[r] = rl;
         if (y < g.H && x < g.W) {
             const size_t p = base + (size_t)y * g.W + x;
             int lab = -1;
             if (key) lab = (yblk + (rl >> 6)) * g.W + cx * 64 + (rl & 63);
-            if (key || !sparse) L_all[p] = lab;
-            if (key && rl == li) {                                 // only tile roots can become global roots
-                flag_all[p] = 0u;
-                if (stat & STAT_AREA) area_all[p] = 0u;
-                if (stat & STAT_SUMS) { sumy_all[p] = 0ull; sumx_all[p] = 0ull; }
+            if (key || !sparse) L_all[p] = lab;            // a pixel points at its TILE root for good; only tile roots are re-linked later
+        }
+    }
+    // ---- per-run accumulation into the tile root's LDS slot (runs of equal key = runs of equal tile root) ----
+    int npx[4] = {0, 0, 0, 0};
+    if (want_slots || (need & NEED_NPX)) {
+#pragma unroll
+        for (int r = 0; r < CCL_ROWS; ++r) {
+            const int y = y0 + r;
+            const int key = keys[r], tr = troot[r];
+            if (need & NEED_NPX) {
+#pragma unroll
+                for (int k = 1; k < 4; ++k) npx[k] += __popcll(__ballot(key == k));
+            }
+            if (!want_slots) continue;
+            const u64 F = __ballot(key != 0);
+            if (!F) continue;                                  // wave-uniform
+            const bool start = key != 0 && hpos[r] == lane;
+            const u64 S = __ballot(start);
+            uint32_t bits = 0;
+            if (aux_mode == AUX_BORDER) bits = (key && (y == 0 || y == g.H - 1 || x == 0 || x == g.W - 1)) ? 1u : 0u;
+            else if (aux_mode == AUX_VALUE_EQ) bits = (key && vals[r] == aux_c) ? 1u : 0u;
+            else if (aux_mode == AUX_IMAGE) bits = key ? aux_img[base + (size_t)y * g.W + x] : 0u;
+            u64 B[5];
+            const int nb = (aux_mode == AUX_IMAGE) ? 5 : (aux_mode == AUX_NONE ? 0 : 1);
+#pragma unroll
+            for (int b = 0; b < 5; ++b) B[b] = (b < nb) ? __ballot((bits >> b) & 1u) : 0ull;
+            if (start) {
+                const u64 above = ~((2ull << lane) - 1ull);
+                const u64 stop = (S | ~F) & above;
+                const int len = stop ? (__ffsll((long long)stop) - 1 - lane) : (64 - lane);
+                const u64 run = (len == 64) ? ~0ull : (((1ull << len) - 1ull) << lane);
+                if (stat & STAT_SUMS) {
+                    const unsigned ry = (unsigned)(y - yblk), rx = (unsigned)lane, ulen = (unsigned)len;
+                    atomicAdd(&sum_s[tr], ((u64)(ry * ulen) << 32) | (u64)(rx * ulen + ulen * (ulen - 1) / 2u));
+                }
+                uint32_t fb = 0;
+#pragma unroll
+                for (int b = 0; b < 5; ++b) if (B[b] & run) fb |= 1u << b;
+                if (stat & (STAT_AREA | STAT_SUMS)) atomicAdd(&af_s[tr], (uint32_t)len);
+                if (fb) atomicOr(&af_s[tr], fb << 16);
             }
         }
+    }
+    __syncthreads();
+    // ---- owners (tile roots): partial statistics of the tile component into the owner's own global slots, owner bit for
+    //      ccl_resolve (which walks only the owners and forwards their slots to the global roots) ----
+#pragma unroll
+    for (int r = 0; r < CCL_ROWS; ++r) {
+        const int y = y0 + r, li = (wave * CCL_ROWS + r) * 64 + lane;
+        const bool own = keys[r] != 0 && troot[r] == li;
+        const u64 m = __ballot(own);
+        if (lane == 0) { ob[2 * (wave * CCL_ROWS + r)] = (uint32_t)m; ob[2 * (wave * CCL_ROWS + r) + 1] = (uint32_t)(m >> 32); }
+        if (own) {
+            const size_t p = base + (size_t)y * g.W + x;
+            const uint32_t af = want_slots ? af_s[li] : 0u;
+            flag_all[p] = af >> 16;
+            if (stat & STAT_AREA) area_all[p] = af & 0xffffu;
+            if (stat & STAT_SUMS) {
+                const u64 pk = sum_s[li], cnt = af & 0xffffu;
+                sumy_all[p] = (pk >> 32) + (u64)yblk * cnt;
+                sumx_all[p] = (pk & 0xffffffffull) + (u64)(cx * 64) * cnt;
+            }
+        }
+    }
+    if (need & NEED_NPX) {
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 1; k < 4; ++k) if (npx[k]) atomicAdd(&red[k], npx[k]);
+        }
+        __syncthreads();
+        int32_t* G = G_all + (size_t)img * G_IMG + (size_t)((blockIdx.x >> 3) % G_SHARDS) * G_STRIDE;
+        if (threadIdx.x >= 1 && threadIdx.x < 4 && red[threadIdx.x]) atomicAdd(G + G_NPX + threadIdx.x, red[threadIdx.x]);
     }
 }
 
@@ -318,191 +410,86 @@ __global__ __launch_bounds__(128) void ccl_border_kernel(CclGeom g, const uint8_
     }
 }
 
-// ---- phase 3: flatten + statistics ------------------------------------------------------------------------------------
-// aux_mode selects the bits OR-ed into flag[root]:
-//   AUX_BORDER   bit0 = component touches the image border
-//   AUX_VALUE_EQ bit0 = component holds a pixel with value == aux_c
-//   AUX_IMAGE    bits of aux_img[p]
-// After ccl_local every pixel points at its tile root, so all per-component sums are first accumulated per TILE ROOT
-// in LDS (one LDS atomic per run) and only the tile roots touch global memory: one chain walk and at most four global
-// atomics per (tile, component).  A noisy label image with millions of runs inside a few huge components therefore
-// no longer funnels millions of atomics into a handful of addresses.
-__global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8_t* __restrict__ img_all, uint32_t lut,
+// ---- phase 3: resolve the tile roots ----------------------------------------------------------------------------------
+// After ccl_local every pixel points at its tile root (the "owner" of a tile component) and the owner's global slots hold
+// the component's statistics within the tile; ccl_border has linked owners across tiles.  Only the owners are touched
+// here: each walks to its global root once, keeps it as its parent (a consumer reads a pixel's component as L[L[p]]: pixel
+// -> owner -> global root) and forwards its slots to the root's with at most four global atomics.  No per-pixel pass: the
+// int32 parent image is written once (ccl_local) and read once (the consumer).  (Rounds 1-3 re-read every pixel's parent
+// here to rebuild the per-tile sums and rewrote it with the global root: ccl_flatten, 25 % of the post-processing time.)
+// aux bits OR-ed into flag[root] (set per run by ccl_local): AUX_BORDER bit0 = touches the image border, AUX_VALUE_EQ
+// bit0 = holds a pixel with value == aux_c, AUX_IMAGE bits of aux_img[p].
+__global__ __launch_bounds__(256) void ccl_resolve_kernel(CclGeom g, const uint8_t* __restrict__ img_all, uint32_t lut,
                                                           int32_t* __restrict__ L_all, uint32_t* __restrict__ area_all,
                                                           u64* __restrict__ sumy_all, u64* __restrict__ sumx_all,
                                                           uint32_t* __restrict__ flag_all, int32_t* __restrict__ G_all,
-                                                          int stat, int aux_mode, int aux_c,
-                                                          const uint8_t* __restrict__ aux_img, int need,
+                                                          int stat, int need,
                                                           int32_t* __restrict__ list1, int32_t* __restrict__ list2, size_t list_cap,
-                                                          const uint8_t* __restrict__ tile_any) {
+                                                          const uint8_t* __restrict__ tile_any, const uint32_t* __restrict__ own_bits) {
     constexpr int TP = CCL_BLOCK_ROWS * 64;                    // pixels per tile
-    __shared__ int red[16];                                    // ncomp[1..3], npx[1..3], -, -, last root, list counts [9..10], list bases [11..12], owners [13] (64 B keeps the dynamic LDS base 16-B aligned)
-    __shared__ int groot_s[TP];                                // tile root -> global root
-    __shared__ uint32_t af_s[TP];                              // bits 0-15: pixels of the slot (<= 2048), bits 16-20: flag bits
-    __shared__ uint32_t used_s[TP / 32];                       // bit per slot: some run accumulated into it
-    __shared__ uint16_t own_s[TP];                             // compacted list of the slots in use
-    extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
-    // [TP] only when STAT_SUMS: coordinate sums of the slot RELATIVE to the tile origin, packed (sum of rows << 32 | sum of
-    // columns; each < 2^18 inside a 64 x 32 tile): one 64-bit LDS atomic per run instead of two, and half the LDS
-    u64* sum_s = reinterpret_cast<u64*>(dyn_smem);
-    int16_t* lsl_s = reinterpret_cast<int16_t*>(dyn_smem + ((stat & STAT_SUMS) ? (size_t)TP * 8 : 0));   // [TP] only when NEED_LISTS: list position of owner k
+    __shared__ int red[16];                                    // ncomp[1..3] at [0..2], last root [8], list counts [9..10], list bases [11..12], owners [13]
+    __shared__ uint16_t own_s[TP];                             // compacted list of the owners
+    __shared__ int16_t lsl_s[TP];                              // NEED_LISTS: (class << 12 | index inside the block's range) of owner k, -1 = none
     int img, y0, cx;
     if (!decode_block(g, img, y0, cx)) return;                 // block-uniform
     const int tid = threadIdx.x;
-    const int ta_ = tile_any[tile_index(g, img)];
-    if (!ta_) return;                                          // ccl_local's vote: no keyed pixel, nothing to accumulate or rewrite
-    if (ta_ == 2) {
-        // full tile (fill_holes background labelling: no statistics, no counters): one component, only its root pixel holds a
-        // parent.  The root takes the global root and passes the tile's "touches the image border" bit on.
-        if (tid == 0) {
-            const int yt = y0, W_ = g.W;                       // (wave 0: y0 is the tile's first row)
-            const size_t base_ = (size_t)img * g.H * g.W;
-            const int p0 = yt * W_ + cx * 64;
-            const int gr = uf_find(L_all + base_, p0);
-            L_all[base_ + p0] = gr;
-            const bool edge = yt == 0 || yt + CCL_BLOCK_ROWS >= g.H || cx == 0 || cx * 64 + 64 >= W_;
-            if (aux_mode == AUX_BORDER && edge) atomicOr(flag_all + base_ + gr, 1u);
-        }
-        return;
-    }
-    // all sixteen loads of the thread (pixel values and parents of its eight rows) go out together, before the LDS set-up;
-    // stale parents of unkeyed pixels are read and ignored
-    uint8_t vals[CCL_ROWS];
-    int labs[CCL_ROWS];
-    {
-        const uint8_t* im0 = img_all + (size_t)img * g.H * g.W;
-        const int32_t* L0 = L_all + (size_t)img * g.H * g.W;
-        const int x0 = cx * 64 + (tid & 63);
-#pragma unroll
-        for (int r = 0; r < CCL_ROWS; ++r) {
-            const int y = y0 + r;
-            const bool ok = y < g.H && x0 < g.W;
-            vals[r] = ok ? im0[y * g.W + x0] : (uint8_t)0;
-            labs[r] = ok ? L0[y * g.W + x0] : -1;
-        }
-    }
-    if (tid < 16) red[tid] = 0;
-    if (tid < TP / 32) used_s[tid] = 0u;
-    for (int i = tid; i < TP; i += 256) {
-        af_s[i] = 0u;
-        if (stat & STAT_SUMS) sum_s[i] = 0ull;
-    }
-    __syncthreads();
+    const size_t ti = tile_index(g, img);
+    const int ta = tile_any[ti];
+    if (!ta) return;                                           // ccl_local's vote: no keyed pixel, no owner
     const size_t base = (size_t)img * g.H * g.W;
     const uint8_t* im = img_all + base;
     int32_t* L = L_all + base;
-    int32_t* G = G_all + (size_t)img * G_IMG + (size_t)((blockIdx.x >> 3) % G_SHARDS) * G_STRIDE;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int x = cx * 64 + lane;
-    const int W = g.W, H = g.H;
-    const int yblk = y0 - wave * CCL_ROWS;
-    const int strip_org = yblk * W;                           // first pixel of the tile's first image row
-    const float inv_w = 1.0f / (float)W;
-    int npx[4] = {0, 0, 0, 0};
-    int troot[CCL_ROWS];                                       // tile-local index of this pixel's tile root, -1 = background
-    // ---- A: per-run accumulation into the tile root's LDS slot ----
-#pragma unroll
-    for (int r = 0; r < CCL_ROWS; ++r) {
-        const int y = y0 + r;
-        const bool valid = y < H && x < W;
-        const int p = y * W + x;
-        const uint8_t v = vals[r];
-        const int key = valid ? key_of(v, lut) : 0;
-        const int lab = labs[r];
-        // Slot of this pixel's tile component: the tile root it points at.  A tile root that ccl_border has meanwhile
-        // linked to a pixel of another tile no longer points into the tile: it keeps its own slot (the other pixels
-        // of its tile component still point at it).
-        int tr = -1;
-        if (key) {
-            // (row, column) of the root relative to the tile's first image row: an in-strip d < 32 W < 2^24 is exact in
-            // float, so the quotient by the reciprocal is off by at most one (no integer division per pixel).  The COLUMN
-            // must be the root's true image column: a root left of the tile in a later row is not in the tile.
-            const int d = lab - strip_org;
-            int dy, rx;
-            if (W < (1 << 19)) {
-                dy = (int)((float)d * inv_w);
-                rx = d - dy * W;
-                if (rx < 0) { dy -= 1; rx += W; } else if (rx >= W) { dy += 1; rx -= W; }
-            } else {                                           // 32 W >= 2^24: not exact in float
-                dy = d / W;
-                rx = d - dy * W;
+    const int W = g.W;
+    const int yblk = y0 - (tid >> 6) * CCL_ROWS;
+    if (ta == 2) {
+        // full tile (fill_holes background labelling: no statistics, no counters): its first pixel is the only owner
+        if (tid == 0) {
+            const int p0 = yblk * W + cx * 64;
+            const int gr = uf_find(L, p0);
+            if (gr != p0) {
+                L[p0] = gr;
+                const uint32_t f = flag_all[base + p0];
+                if (f) atomicOr(flag_all + base + gr, f);
             }
-            const int dx = rx - cx * 64;
-            tr = ((unsigned)d < (unsigned)(CCL_BLOCK_ROWS * W) && (unsigned)dy < (unsigned)CCL_BLOCK_ROWS && (unsigned)dx < 64u)
-                     ? dy * 64 + dx : (wave * CCL_ROWS + r) * 64 + lane;
         }
-        troot[r] = tr;
-        if (need & NEED_NPX) {
-#pragma unroll
-            for (int k = 1; k < 4; ++k) npx[k] += __popcll(__ballot(key == k));
-        }
-        const u64 F = __ballot(key != 0);
-        if (!F) continue;                                      // wave-uniform
-        const int tprev = __shfl_up(tr, 1, 64);
-        const bool start = key != 0 && (lane == 0 || tprev != tr);
-        const u64 S = __ballot(start);
-        uint32_t bits = 0;
-        if (aux_mode == AUX_BORDER) bits = (key && (y == 0 || y == H - 1 || x == 0 || x == W - 1)) ? 1u : 0u;
-        else if (aux_mode == AUX_VALUE_EQ) bits = (key && v == aux_c) ? 1u : 0u;
-        else if (aux_mode == AUX_IMAGE) bits = key ? aux_img[base + p] : 0u;
-        u64 B[5];
-        const int nb = (aux_mode == AUX_IMAGE) ? 5 : (aux_mode == AUX_NONE ? 0 : 1);
-#pragma unroll
-        for (int b = 0; b < 5; ++b) B[b] = (b < nb) ? __ballot((bits >> b) & 1u) : 0ull;
-        if (start) {
-            const u64 above = ~((2ull << lane) - 1ull);
-            const u64 stop = (S | ~F) & above;
-            const int len = stop ? (__ffsll((long long)stop) - 1 - lane) : (64 - lane);
-            const u64 run = (len == 64) ? ~0ull : (((1ull << len) - 1ull) << lane);
-            // (with pixel counts the slot's count marks it as used: no separate bit)
-            if (!(stat & (STAT_AREA | STAT_SUMS))) atomicOr(&used_s[tr >> 5], 1u << (tr & 31));
-            if (stat & STAT_SUMS) {
-                const unsigned ry = (unsigned)(y - yblk), rx = (unsigned)(x - cx * 64), ulen = (unsigned)len;
-                atomicAdd(&sum_s[tr], ((u64)(ry * ulen) << 32) | (u64)(rx * ulen + ulen * (ulen - 1) / 2u));
-            }
-            uint32_t fb = 0;
-#pragma unroll
-            for (int b = 0; b < 5; ++b) if (B[b] & run) fb |= 1u << b;
-            // pixel count and flag bits share a word (the count never carries into bit 16)
-            if (stat & (STAT_AREA | STAT_SUMS)) atomicAdd(&af_s[tr], (uint32_t)len);
-            if (fb) atomicOr(&af_s[tr], fb << 16);
-        }
+        return;
     }
+    if (tid < 16) red[tid] = 0;
     __syncthreads();
-    // ---- B: slot owners (tile roots) resolve their global root and forward the slot's sums.  The owners are first
-    //      compacted into a list, then thread k takes owner k: the chain walks and global atomics of all owners of a tile
-    //      are in flight together (a loop over each thread's own eight rows queued up to eight walks behind each other) ----
-    int ncomp[4] = {0, 0, 0, 0};
-    int last_root = 0;
-#pragma unroll
-    for (int r = 0; r < CCL_ROWS; ++r) {
-        const int li = (wave * CCL_ROWS + r) * 64 + lane;
-        const bool own = (stat & (STAT_AREA | STAT_SUMS)) ? (af_s[li] & 0xffffu) != 0u : ((used_s[li >> 5] >> (li & 31)) & 1u) != 0u;
-        const u64 m = __ballot(own);
-        if (!m) continue;                                      // wave-uniform
-        int at = 0;
-        const int first = __ffsll((long long)m) - 1;
-        if (lane == first) at = atomicAdd(&red[13], __popcll(m));
-        at = __shfl(at, first, 64);
-        if (own) own_s[at + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)li;
+    // owners -> compact list (thread = 8 consecutive pixels of the tile = one byte of the owner bits)
+    {
+        const uint32_t bits = (own_bits[ti * 64 + (tid >> 2)] >> ((tid & 3) * 8)) & 0xffu;
+        if (bits) {
+            int at = atomicAdd(&red[13], __popc(bits));
+            uint32_t b = bits;
+            while (b) {
+                const int k = __ffs((int)b) - 1;
+                b &= b - 1;
+                own_s[at++] = (uint16_t)(tid * 8 + k);
+            }
+        }
     }
     __syncthreads();
     const int n_own = red[13];
+    int32_t* G = G_all + (size_t)img * G_IMG + (size_t)((blockIdx.x >> 3) % G_SHARDS) * G_STRIDE;
+    int ncomp[4] = {0, 0, 0, 0};
+    int last_root = 0;
+    // thread k takes owner k: the chain walks and global atomics of all owners of a tile are in flight together
     for (int k = tid; k < n_own; k += 256) {
         const int li = own_s[k];
         const int p = (yblk + (li >> 6)) * W + cx * 64 + (li & 63);
         const int gr = uf_find(L, p);
-        groot_s[li] = gr;
-        const uint32_t af = af_s[li];
-        if (stat & STAT_AREA) atomicAdd(area_all + base + gr, af & 0xffffu);
-        if (stat & STAT_SUMS) {
-            const u64 pk = sum_s[li], cnt = af & 0xffffu;
-            atomicAdd(sumy_all + base + gr, (pk >> 32) + (u64)yblk * cnt);
-            atomicAdd(sumx_all + base + gr, (pk & 0xffffffffull) + (u64)(cx * 64) * cnt);
-        }
-        if (af >> 16) atomicOr(flag_all + base + gr, af >> 16);
-        int16_t ls = -1;                                       // (class << 12 | index inside the block's range), -1 = none
-        if (gr == p) {                                         // a global root lives in this tile
+        int16_t ls = -1;
+        if (gr != p) {
+            L[p] = gr;                                         // (a concurrent walk through p sees the old parent or the root: both on the chain)
+            if (stat & STAT_AREA) atomicAdd(area_all + base + gr, area_all[base + p]);
+            if (stat & STAT_SUMS) {
+                atomicAdd(sumy_all + base + gr, sumy_all[base + p]);
+                atomicAdd(sumx_all + base + gr, sumx_all[base + p]);
+            }
+            const uint32_t f = flag_all[base + p];
+            if (f) atomicOr(flag_all + base + gr, f);
+        } else {                                               // a global root lives in this tile
             const uint8_t v = im[p];
             if (need & NEED_NCOMP) ncomp[key_of(v, lut) & 3] += 1;
             last_root = max(last_root, p + 1);
@@ -511,6 +498,7 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8
         }
         if (need & NEED_LISTS) lsl_s[k] = ls;
     }
+    if (!(need & (NEED_NCOMP | NEED_LAST | NEED_LISTS))) return;
     __syncthreads();
     if (need & NEED_LISTS) {
         // one global atomic per workgroup and class reserves the block's range in the image's list
@@ -525,25 +513,14 @@ __global__ __launch_bounds__(256) void ccl_flatten_kernel(CclGeom g, const uint8
             else list2[((size_t)img * list_cap + red[12] + idx) * 4] = p;      // first word of the chromosome's centroid slot
         }
     }
-    // ---- C: every pixel takes its component's global root ----
-#pragma unroll
-    for (int r = 0; r < CCL_ROWS; ++r) {
-        const int y = y0 + r;
-        if (troot[r] >= 0 && y < H && x < W) L[y * W + x] = groot_s[troot[r]];
-    }
-    // ---- per-image counters: registers -> LDS -> one global atomic per workgroup and counter ----
+    // per-image counters: registers -> LDS -> one global atomic per workgroup and counter
     if (need & NEED_NCOMP) {
 #pragma unroll
         for (int k = 1; k < 4; ++k) if (ncomp[k]) atomicAdd(&red[k - 1], ncomp[k]);
     }
     if ((need & NEED_LAST) && last_root) atomicMax(&red[8], last_root);
-    if ((need & NEED_NPX) && lane == 0) {
-#pragma unroll
-        for (int k = 1; k < 4; ++k) if (npx[k]) atomicAdd(&red[3 + k - 1], npx[k]);
-    }
     __syncthreads();
     if (tid < 3) { if (red[tid]) atomicAdd(G + G_NCOMP + 1 + tid, red[tid]); }
-    else if (tid < 6) { if (red[tid]) atomicAdd(G + G_NPX + 1 + (tid - 3), red[tid]); }
     else if (tid == 8) { if (red[8]) atomicMax(G + G_LAST_ROOT, red[8]); }
 }
 
@@ -626,14 +603,20 @@ static hipError_t run_ccl_pass(PostWorkspace& ws, const CclGeom& g, const CclPas
     const int ng = g.n_img * G_IMG;
     hipLaunchKernelGGL(zero_g_kernel, dim3((ng + 255) / 256), dim3(256), 0, s, ws.g, ng);
     const unsigned grid = geom_grid(g);
+    const bool slots = !c.count_only;                          // count_only: counts per key only - no statistics, no owners' slots
+    const int stat = slots ? c.stat : 0, aux_mode = slots ? c.aux_mode : AUX_NONE;
+    const int need_local = slots ? (c.need & NEED_NPX) : 0;    // (count_roots counts the pixels itself)
+    const size_t dyn = (stat & STAT_SUMS) ? (size_t)CCL_BLOCK_ROWS * 64 * 8 : 0;
     if (c.conn == 8) {
-        hipLaunchKernelGGL(ccl_local_kernel<8>, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy,
-                           ws.sumx, ws.flag, c.stat, c.sparse ? 1 : 0, ws.tile_any, 0);
+        hipLaunchKernelGGL(ccl_local_kernel<8>, dim3(grid), dim3(256), dyn, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy,
+                           ws.sumx, ws.flag, stat, c.sparse ? 1 : 0, ws.tile_any, 0, aux_mode, c.aux_c, c.aux_img, need_local,
+                           ws.g, ws.own_bits);
         hipLaunchKernelGGL(ccl_border_kernel<8>, dim3(grid), dim3(128), 0, s, g, c.key_img, c.lut, ws.L, ws.tile_any);
     } else {
-        hipLaunchKernelGGL(ccl_local_kernel<4>, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy,
-                           ws.sumx, ws.flag, c.stat, c.sparse ? 1 : 0, ws.tile_any,
-                           (c.allow_full && c.stat == 0 && c.need == 0 && !c.count_only) ? 1 : 0);
+        hipLaunchKernelGGL(ccl_local_kernel<4>, dim3(grid), dim3(256), dyn, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy,
+                           ws.sumx, ws.flag, stat, c.sparse ? 1 : 0, ws.tile_any,
+                           (c.allow_full && c.stat == 0 && c.need == 0 && !c.count_only) ? 1 : 0, aux_mode, c.aux_c, c.aux_img,
+                           need_local, ws.g, ws.own_bits);
         hipLaunchKernelGGL(ccl_border_kernel<4>, dim3(grid), dim3(128), 0, s, g, c.key_img, c.lut, ws.L, ws.tile_any);
     }
     if (c.count_only) {        // counts per key only: no per-pixel roots, no statistics
@@ -641,9 +624,8 @@ static hipError_t run_ccl_pass(PostWorkspace& ws, const CclGeom& g, const CclPas
         hipLaunchKernelGGL(reduce_g_kernel, dim3(g.n_img), dim3(G_STRIDE), 0, s, ws.g, g.n_img);
         return hipGetLastError();
     }
-    const size_t dyn = ((c.stat & STAT_SUMS) ? (size_t)CCL_BLOCK_ROWS * 64 * 8 : 0) + ((c.need & NEED_LISTS) ? (size_t)CCL_BLOCK_ROWS * 64 * 2 : 0);
-    hipLaunchKernelGGL(ccl_flatten_kernel, dim3(grid), dim3(256), dyn, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy,
-                       ws.sumx, ws.flag, ws.g, c.stat, c.aux_mode, c.aux_c, c.aux_img, c.need, c.list1, c.list2, c.list_cap, ws.tile_any);
+    hipLaunchKernelGGL(ccl_resolve_kernel, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy, ws.sumx,
+                       ws.flag, ws.g, c.stat, c.need, c.list1, c.list2, c.list_cap, ws.tile_any, ws.own_bits);
     if (c.need) hipLaunchKernelGGL(reduce_g_kernel, dim3(g.n_img), dim3(G_STRIDE), 0, s, ws.g, g.n_img);
     return hipGetLastError();
 }
@@ -675,7 +657,7 @@ __global__ __launch_bounds__(256) void apply_fill_kernel(uint8_t* __restrict__ i
                                                          const uint32_t* __restrict__ flag, int n_img, size_t px, int c, uint32_t lut) {
     IMG_PX_LOOP(n_img, px) {
         if (!key_of(img[t], lut)) continue;                    // not part of the labelled background: its parent is stale
-        const int r = L[t];
+        const int r = L[ib + L[t]];                            // pixel -> owner (tile root) -> global root
         if (!(flag[ib + r] & 1u)) img[t] = (uint8_t)c;
     }
 }
@@ -696,7 +678,7 @@ __global__ __launch_bounds__(256) void apply_fill_tile_kernel(CclGeom g, uint8_t
     bool fill_all = false;
     if (ta == 2) {
         const int p0 = (y0 - wave * CCL_ROWS) * g.W + cx * 64;
-        const int r = L_all[base + p0];
+        const int r = L_all[base + L_all[base + p0]];          // (the tile's first pixel is its own owner: -> global root)
         if (flag_all[base + r] & 1u) return;                   // background connected to the image border
         fill_all = true;
     }
@@ -707,7 +689,7 @@ __global__ __launch_bounds__(256) void apply_fill_tile_kernel(CclGeom g, uint8_t
         const size_t t = base + (size_t)y * g.W + x;
         if (fill_all) { img_all[t] = (uint8_t)c; continue; }
         if (!key_of(img_all[t], lut)) continue;
-        const int root = L_all[t];
+        const int root = L_all[base + L_all[t]];
         if (!(flag_all[base + root] & 1u)) img_all[t] = (uint8_t)c;
     }
 }
@@ -722,7 +704,7 @@ __global__ __launch_bounds__(256) void apply_size_thresh_kernel(uint8_t* __restr
     IMG_PX_LOOP(n_img, px) {
         const uint8_t v = img[t];
         if (!key_of(v, LUT_MULTI)) continue;                   // background: not labelled, its parent is stale
-        const int r = L[t];
+        const int r = L[ib + L[t]];
         const int32_t* G = G_all + (size_t)im * G_IMG;
         // area < mean(areas) = S / n, evaluated exactly in integers: area * n < S.  (The reference compares in float64;
         // S / n is either an integer or at least 1 / n away from one, far more than a rounding error, so both orders
@@ -991,7 +973,7 @@ __global__ __launch_bounds__(256) void apply_nucleus_kill_kernel(uint8_t* __rest
                                                                  const uint32_t* __restrict__ flag, int n_img, size_t px) {
     IMG_PX_LOOP(n_img, px) {
         if (img[t] != 1) continue;
-        const int r = L[t];
+        const int r = L[ib + L[t]];
         if (flag[ib + r] & 2u) img[t] = 0;
     }
 }
@@ -1007,7 +989,7 @@ __global__ __launch_bounds__(256) void apply_merge_kernel(const uint8_t* __restr
         uint8_t v = img[t];
         if (v == m) v = 0;
         if (key_of(img[t], lut)) {                             // a labelled pixel (key = value not in {0, m})
-            const int r = L[t];
+            const int r = L[ib + L[t]];
             const int last = G_all[(size_t)im * G_IMG + G_LAST_ROOT] - 1;
             if ((flag[ib + r] & 1u) && r != last) v = (uint8_t)c;
         }
@@ -1170,8 +1152,11 @@ hipError_t run_count_cc(PostWorkspace& ws, const uint8_t* mask, int n_img, int H
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void export_labels_kernel(const int32_t* __restrict__ L, int32_t* __restrict__ out, size_t total) {
-    PX_LOOP(total) out[t] = L[t] + 1;   // background -1 -> 0, component -> 1 + raster index of its first pixel
+__global__ __launch_bounds__(256) void export_labels_kernel(const int32_t* __restrict__ L, int32_t* __restrict__ out, size_t total, size_t px) {
+    PX_LOOP(total) {                    // background -1 -> 0, component -> 1 + raster index of its first pixel (pixel -> owner -> global root)
+        const int o = L[t];
+        out[t] = o < 0 ? 0 : L[(t / px) * px + o] + 1;
+    }
 }
 
 hipError_t run_ccl_labels(PostWorkspace& ws, const uint8_t* mask, int n_img, int H, int W, int conn, int32_t* labels_dev,
@@ -1182,7 +1167,7 @@ hipError_t run_ccl_labels(PostWorkspace& ws, const uint8_t* mask, int n_img, int
     hipError_t e = run_ccl_pass(ws, g, p, s);
     if (e != hipSuccess) return e;
     const size_t total = (size_t)n_img * H * W;
-    hipLaunchKernelGGL(export_labels_kernel, dim3(px_grid(total)), dim3(256), 0, s, ws.L, labels_dev, total);
+    hipLaunchKernelGGL(export_labels_kernel, dim3(px_grid(total)), dim3(256), 0, s, ws.L, labels_dev, total, (size_t)H * W);
     return hipGetLastError();
 }
 
@@ -1249,9 +1234,12 @@ hipError_t run_count_coloc(PostWorkspace& ws, const uint8_t* ob1, const uint8_t*
 __global__ __launch_bounds__(256) void keep_large_kernel(const int32_t* __restrict__ L, const uint32_t* __restrict__ area,
                                                          uint8_t* __restrict__ out, size_t total, size_t px, int thr, int bit) {
     PX_LOOP(total) {
-        const int r = L[t];
+        const int o = L[t];                                    // (non-sparse labelling: unkeyed pixels hold -1)
         uint8_t v = out[t];
-        if (r >= 0 && area[(t / px) * px + r] >= (uint32_t)thr) v |= (uint8_t)(1u << bit);
+        if (o >= 0) {
+            const size_t ib = (t / px) * px;
+            if (area[ib + L[ib + o]] >= (uint32_t)thr) v |= (uint8_t)(1u << bit);
+        }
         out[t] = v;
     }
 }
@@ -1377,34 +1365,72 @@ hipError_t run_overlay(PostWorkspace& ws, const uint8_t* labels, const uint8_t* 
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void stitch_argmax_kernel(const float* __restrict__ probs, int prob_cs,
                                                             const int32_t* __restrict__ src_map, int n_pos, size_t px,
-                                                            uint8_t* __restrict__ labels, size_t total) {
+                                                            uint8_t* __restrict__ labels, size_t total,
+                                                            int32_t* __restrict__ tie_risk) {
     PX_LOOP(total) {
         const size_t im = t / px, q = t - im * px;
         const int src = src_map[q];
         uint8_t lab = 0;                       // never-written canvas pixels stay 0.0 in every channel -> argmax 0
+        bool tie = false;
         if (src >= 0) {
             const size_t patch = im * n_pos + (size_t)(src >> 16);
             const float* pp = probs + ((patch << 16) + (size_t)(src & 0xffff)) * prob_cs;
-            int best = -1;
+            int best = -1, second = -1;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 // float64(p) * 255 is exact; rint = round half to even; clip to [0, 255]
                 double v = rint((double)pp[c] * 255.0);
                 v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
                 const int qv = (int)v;
-                if (qv > best) { best = qv; lab = (uint8_t)c; }   // strict '>' keeps the first maximum
+                if (qv > best) { second = best; best = qv; lab = (uint8_t)c; }   // strict '>' keeps the first maximum
+                else if (qv > second) second = qv;
             }
+            tie = best - second <= 1;           // a last-bit difference in one probability can change this pixel's label
         }
         labels[t] = lab;
+        if (tie_risk) {
+            // one atomic per wave and image: the lanes of a wave are consecutive pixels, i.e. of one image or (at most) two
+            const int im0 = __shfl((int)im, 0, 64);
+            const unsigned long long m0 = __ballot(tie && (int)im == im0);
+            if ((threadIdx.x & 63) == 0 && m0) atomicAdd(tie_risk + im0, __popcll(m0));
+            if (tie && (int)im != im0) atomicAdd(tie_risk + im, 1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void stitch_probs_kernel(const float* __restrict__ probs, int prob_cs,
+                                                           const int32_t* __restrict__ src_map, int n_pos, size_t px,
+                                                           float* __restrict__ out, size_t total) {
+    PX_LOOP(total) {
+        const size_t im = t / px, q = t - im * px;
+        const int src = src_map[q];
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (src >= 0) {
+            const size_t patch = im * n_pos + (size_t)(src >> 16);
+            const float* pp = probs + ((patch << 16) + (size_t)(src & 0xffff)) * prob_cs;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = pp[c];
+        }
+        *reinterpret_cast<f32x4*>(out + t * 4) = v;
     }
 }
 
 hipError_t launch_stitch_argmax(const float* probs, int prob_cs, const int32_t* src_map, int n_img, int n_pos, int H, int W,
-                                uint8_t* labels, hipStream_t s) {
+                                uint8_t* labels, hipStream_t s, int32_t* tie_risk) {
     const size_t px = (size_t)H * W, total = px * n_img;
     if (!total) return hipSuccess;
+    // (whole waves run the loop body together - the ballot above needs that: the grid-stride loop keeps a wave's lanes on
+    // consecutive pixels and `total` is padded by nothing, so the last wave's tail lanes simply fall out of the loop)
     hipLaunchKernelGGL(stitch_argmax_kernel, dim3(px_grid(total)), dim3(256), 0, s, probs, prob_cs, src_map, n_pos, px,
-                       labels, total);
+                       labels, total, tie_risk);
+    return hipGetLastError();
+}
+
+hipError_t launch_stitch_probs(const float* probs, int prob_cs, const int32_t* src_map, int n_img, int n_pos, int H, int W,
+                               float* out, hipStream_t s) {
+    const size_t px = (size_t)H * W, total = px * n_img;
+    if (!total) return hipSuccess;
+    hipLaunchKernelGGL(stitch_probs_kernel, dim3(px_grid(total)), dim3(256), 0, s, probs, prob_cs, src_map, n_pos, px, out, total);
     return hipGetLastError();
 }
 

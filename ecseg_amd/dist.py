@@ -19,8 +19,9 @@ import numpy as np
 
 RECORD_INT64 = 16      # 128 bytes per image
 # record layout (int64): [0] global image index (-1 = padding) [1] status (0 ok) [2] n_ec
-#                        [3..14] the twelve overlay fields of ecseg_overlay [15] reserved
-F_INDEX, F_STATUS, F_NEC, F_OVERLAY = 0, 1, 2, 3
+#                        [3..14] the twelve overlay fields of ecseg_overlay [15] tie-risk pixels (metaseg: pixels whose two
+#                        largest quantised probabilities differ by <= 1; 0 where not measured)
+F_INDEX, F_STATUS, F_NEC, F_OVERLAY, F_TIE = 0, 1, 2, 3, 15
 
 
 def shard_bounds(n_items, rank, world):
@@ -31,7 +32,7 @@ def shard_bounds(n_items, rank, world):
     return start, stop, per
 
 
-def make_records(start, n_local, padded_len, n_ec=None, overlay=None, status=None):
+def make_records(start, n_local, padded_len, n_ec=None, overlay=None, status=None, tie_risk=None):
     rec = np.zeros((padded_len, RECORD_INT64), np.int64)
     rec[:, F_INDEX] = -1
     rec[:n_local, F_INDEX] = np.arange(start, start + n_local)
@@ -41,6 +42,8 @@ def make_records(start, n_local, padded_len, n_ec=None, overlay=None, status=Non
         rec[:n_local, F_OVERLAY:F_OVERLAY + 12] = np.asarray(overlay, np.int64)[:n_local]
     if status is not None:
         rec[:n_local, F_STATUS] = np.asarray(status, np.int64)[:n_local]
+    if tie_risk is not None:
+        rec[:n_local, F_TIE] = np.asarray(tie_risk, np.int64)[:n_local]
     return rec
 
 

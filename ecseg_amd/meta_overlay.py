@@ -8,7 +8,7 @@ import numpy as np
 import yaml
 
 from . import csvio, image_io, image_tools
-from .utils import get_imgs
+from .utils import get_imgs, tune_host_allocator
 
 HSR_SIZE_THRESHOLD = 20
 
@@ -68,6 +68,7 @@ def run(inpath, handle, image_paths, sensitivity, batch_images=8, io_threads=Non
     io_threads = io_threads or max(2, min(32, os.cpu_count() or 4))
     window = max(2 * batch_images, io_threads)
     rows = [None] * len(image_paths)
+    tune_host_allocator()
     with cf.ThreadPoolExecutor(io_threads) as readers, cf.ThreadPoolExecutor(io_threads) as writers:
         reads, next_submit, writes = {}, 0, []
 

@@ -13,6 +13,7 @@ Optional config keys (defaults keep the reference's behaviour): ``batch_images``
 ``resume`` (false; true: images whose ``labels/<stem>.npy``, ``.png`` and ``dapi/<name>`` exist are not segmented again).
 """
 import concurrent.futures as cf
+import json
 import os
 import queue
 import subprocess
@@ -25,7 +26,7 @@ import yaml
 
 from . import csvio, dist, image_io
 from ._lib import E_NOMEM, EcsegError
-from .utils import get_imgs, load_model, save_img
+from .utils import get_imgs, load_model, save_img, tune_host_allocator
 
 MODEL_NAME = 'metaseg.h5'
 
@@ -78,8 +79,9 @@ def _replace_into(path, write):
         raise
 
 
-def _write_outputs(p, gray, post, log):
-    """gray: the pre-processed image; dapi/<name> holds cv2.bitwise_not of it (src/utils.py:112,122-123)."""
+def _write_outputs(p, gray, post, log, probs=None):
+    """gray: the pre-processed image; dapi/<name> holds cv2.bitwise_not of it (src/utils.py:112,122-123).  probs (config key
+    ``emit_probs``): the stitched float32 probabilities -> labels/<stem>_probs.npy, written before the resume marker."""
     path_split = os.path.split(p)
     dapi = os.path.join(path_split[0], 'dapi', path_split[1])
     if dapi.lower().endswith(('.tif', '.tiff')):
@@ -89,17 +91,27 @@ def _write_outputs(p, gray, post, log):
     outpath = os.path.join(path_split[0], 'labels', path_split[1][:-4])
     log("Saving labels: ", p, " to ", outpath)
     _replace_into(outpath + '.png', lambda t: image_io.write_label_png(t, post))
+    if probs is not None:
+        def save_probs(t):
+            with open(t, 'wb') as f:                        # (np.save would append ".npy" to the temporary name)
+                np.save(f, np.ascontiguousarray(probs, np.float32))
+        _replace_into(outpath + '_probs.npy', save_probs)
     # int64 .npy (src/metaseg.py:53), LAST: its presence is the resume marker
     _replace_into(outpath + '.npy', lambda t: image_io.write_npy_int64(t, post))
 
 
-def _segment_group(model, imgs):
+def _segment_group(model, imgs, emit_probs=False):
+    """-> gray, post, n_ec, tie_risk, probs | None (arrays over the batch)."""
     gray, _ = model.handle.preprocess(imgs)
-    post, nec = model.segment(gray)
-    return gray, post, nec
+    ex = getattr(model, 'segment_ex', None)
+    if ex is None:                                         # a model without the extended call: no tie-risk bound, no probabilities
+        post, nec = model.segment(gray)
+        return gray, post, nec, np.zeros(len(gray), np.int32), None
+    out = ex(gray, want_probs=emit_probs)
+    return (gray, out[0], out[1], out[2], out[3] if emit_probs else None)
 
 
-def _segment_with_retry(model, imgs, log):
+def _segment_with_retry(model, imgs, log, emit_probs=False):
     """GPU part of one batch.  On an out-of-memory status the internal launch group is halved, starting below what the failed
     attempt used (down to one image per launch); if that still does not fit, the batch itself is split by images (allocations
     that scale with the batch: post-processing workspace, input staging).  The handle's setting is restored afterwards, so
@@ -110,7 +122,7 @@ def _segment_with_retry(model, imgs, log):
         group = min(before, len(imgs)) if before > 0 else len(imgs)
         while True:
             try:
-                return _segment_group(model, imgs)
+                return _segment_group(model, imgs, emit_probs)
             except EcsegError as e:
                 if e.code != E_NOMEM:
                     raise
@@ -123,37 +135,39 @@ def _segment_with_retry(model, imgs, log):
             raise EcsegError('out of device memory for a single image of shape %s' % (imgs.shape[1:],))
         half = len(imgs) // 2
         log("Out of device memory for a batch of shape %s: splitting it into %d + %d image(s)" % (imgs.shape, half, len(imgs) - half))
-        a, b = _segment_with_retry(model, imgs[:half], log), _segment_with_retry(model, imgs[half:], log)
-        return tuple(np.concatenate([x, y]) for x, y in zip(a, b))
+        a, b = _segment_with_retry(model, imgs[:half], log, emit_probs), _segment_with_retry(model, imgs[half:], log, emit_probs)
+        return tuple(None if x is None else np.concatenate([x, y]) for x, y in zip(a, b))
     finally:
         h.set_images_per_group(before)
 
 
-def _segment_isolating(model, imgs, log):
+def _segment_isolating(model, imgs, log, emit_probs=False):
     """GPU part of one batch with per-image failure isolation (a per-image status): a batch that fails for any reason
     other than memory (_segment_with_retry deals with that) is bisected until the failing image(s) stand alone - one bad image
-    costs one status-2 row, not the whole batch.  -> list of (index in batch, gray, post, n_ec) for the images that went
-    through, list of (index, exception) for those that did not."""
+    costs one status-2 row, not the whole batch.  -> list of (index in batch, gray, post, n_ec, tie_risk, probs | None) for the
+    images that went through, list of (index, exception) for those that did not."""
     try:
-        gray, post, nec = _segment_with_retry(model, imgs, log)
-        return [(j, gray[j], post[j], int(nec[j])) for j in range(len(imgs))], []
+        gray, post, nec, tie, probs = _segment_with_retry(model, imgs, log, emit_probs)
+        return [(j, gray[j], post[j], int(nec[j]), int(tie[j]), None if probs is None else probs[j]) for j in range(len(imgs))], []
     except Exception as e:
         if len(imgs) == 1:
             return [], [(0, e)]
         half = len(imgs) // 2
         log("A batch of %d image(s) of shape %s failed on the device (%s): retrying it as %d + %d"
             % (len(imgs), imgs.shape[1:], e, half, len(imgs) - half))
-        ok_a, bad_a = _segment_isolating(model, imgs[:half], log)
-        ok_b, bad_b = _segment_isolating(model, imgs[half:], log)
-        return (ok_a + [(j + half, g, p, n) for j, g, p, n in ok_b], bad_a + [(j + half, e2) for j, e2 in bad_b])
+        ok_a, bad_a = _segment_isolating(model, imgs[:half], log, emit_probs)
+        ok_b, bad_b = _segment_isolating(model, imgs[half:], log, emit_probs)
+        return (ok_a + [(r[0] + half,) + r[1:] for r in ok_b], bad_a + [(j + half, e2) for j, e2 in bad_b])
 
 
-def run(inpath, model, image_paths, rank=0, world=1, batch_images=8, io_threads=None, log=print, stats=None, resume=False):
+def run(inpath, model, image_paths, rank=0, world=1, batch_images=8, io_threads=None, log=print, stats=None, resume=False,
+        emit_probs=False):
     """Segment this rank's shard; returns records (one row per image of the WHOLE job after the all-gather)."""
     start, stop, per = dist.shard_bounds(len(image_paths), rank, world)
     mine = image_paths[start:stop]
     n_ec = np.zeros(len(mine), np.int64)
     status = np.zeros(len(mine), np.int64)
+    tie = np.zeros(len(mine), np.int64)
     io_threads = io_threads or max(2, min(32, (os.cpu_count() or 4) // max(world, 1)))
     window = max(2 * batch_images, io_threads)                             # images decoded ahead of the GPU
     pending_writes = threading.BoundedSemaphore(4 * batch_images + io_threads)   # bounds the outputs held in memory
@@ -161,15 +175,16 @@ def run(inpath, model, image_paths, rank=0, world=1, batch_images=8, io_threads=
     # microseconds between calls, so a short switch interval keeps the GPU fed
     old_switch = sys.getswitchinterval()
     sys.setswitchinterval(0.0005)
+    tune_host_allocator()                                                   # one malloc arena, no mmap per buffer (utils.py)
     try:
         return _run_threads(model, mine, start, per, rank, world, batch_images, io_threads, window, pending_writes, n_ec,
-                            status, log, stats, resume)
+                            status, log, stats, resume, tie, emit_probs)
     finally:
         sys.setswitchinterval(old_switch)
 
 
 def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads, window, pending_writes, n_ec, status, log, stats,
-                 resume=False):
+                 resume=False, tie=None, emit_probs=False):
     t_gpu = 0.0
     with cf.ThreadPoolExecutor(io_threads) as readers, cf.ThreadPoolExecutor(io_threads) as writers:
         reads = {}
@@ -195,16 +210,18 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
                     n_ec[k] = int(cnt[j])
                 return
             t0 = time.perf_counter()
-            done, bad = _segment_isolating(model, imgs, log)
+            done, bad = _segment_isolating(model, imgs, log, emit_probs)
             t_gpu += time.perf_counter() - t0
             for j, e in bad:                               # a failing image must not take its batch or the shard down
                 log("Skipping %s (shape %s): %s" % (mine[group[j]], imgs.shape[1:], e))
                 status[group[j]] = 2
-            for j, gray_j, post_j, nec_j in done:
+            for j, gray_j, post_j, nec_j, tie_j, probs_j in done:
                 k = group[j]
                 n_ec[k] = nec_j
+                if tie is not None:
+                    tie[k] = tie_j
                 pending_writes.acquire()
-                f = writers.submit(_write_outputs, mine[k], gray_j, post_j, log)
+                f = writers.submit(_write_outputs, mine[k], gray_j, post_j, log, probs_j)
                 f.add_done_callback(lambda _f: pending_writes.release())
                 write_futs.append((k, f))
 
@@ -261,7 +278,7 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
                 status[k] = 3
     if stats is not None:
         stats['gpu_seconds'] = t_gpu
-    rec = dist.make_records(start, len(mine), per, n_ec=n_ec, status=status)
+    rec = dist.make_records(start, len(mine), per, n_ec=n_ec, status=status, tie_risk=tie)
     return dist.gather_all(rec, device=model.handle.device)        # the path's one exchange (identity for one rank)
 
 
@@ -282,6 +299,14 @@ def finish(inpath, image_paths, rec, rank, seconds=None, gpu_seconds=0.0, log=pr
         with open(tmp, 'w') as f:
             f.write(text)
         os.replace(tmp, os.path.join(inpath, name))
+    # per-image report beside the reference's two-column CSV: status, count and the tie-risk bound of every image (pixels whose
+    # label a last-bit difference between float32 evaluations of the network can flip - record slot 15)
+    report = {'images': [{'image_name': os.path.split(image_paths[int(r[dist.F_INDEX])])[1], 'status': int(r[dist.F_STATUS]),
+                          '# of ec': int(r[dist.F_NEC]), 'tie_risk_pixels': int(r[dist.F_TIE])} for r in rec]}
+    tmp = os.path.join(inpath, 'ec_quantification_report.json.tmp%d' % os.getpid())
+    with open(tmp, 'w') as f:
+        json.dump(report, f, indent=1)
+    os.replace(tmp, os.path.join(inpath, 'ec_quantification_report.json'))
     if image_paths and seconds:
         log("%d image(s) in %.2f s (%.1f images/s; device calls %.2f s on rank 0)"
             % (len(image_paths), seconds, len(image_paths) / seconds, gpu_seconds))
@@ -364,6 +389,14 @@ def main(argv=None):
     if not os.path.isdir(os.path.join(inpath)):
         print("Input folder does not exist. Exiting...")
         sys.exit(2)
+    # precision: fast (default) = Winograd F(4x4,3x3) where a layer allows it; exact = F(2x2,3x3) everywhere - half as many
+    # raw-label pixels away from a float64 evaluation of the network, ~1.7x the U-Net time.  emit_probs: also
+    # write the stitched float32 probabilities as labels/<stem>_probs.npy (23 MB per 1040 x 1392 image).
+    precision = str(var.get('precision', 'fast')).lower()
+    if precision not in ('fast', 'exact'):
+        print("metaseg.precision must be 'fast' or 'exact'. Exiting...")
+        sys.exit(2)
+    emit_probs = bool(var.get('emit_probs', False))
     for sub in ('dapi', 'labels'):
         os.makedirs(os.path.join(inpath, sub), exist_ok=True)
 
@@ -384,12 +417,13 @@ def main(argv=None):
         rank, world = dist.init_process_group(device=device) if under_launcher else (0, 1)     # RCCL on the same physical GPU
     model = load_model(MODEL_NAME, device=device)
     print(model.handle.device_name)
+    model.handle.set_option('winograd', 1 if precision == 'exact' else 2)
     image_paths = get_imgs(inpath)
     print("Reading from: ", inpath)
     t0 = time.perf_counter()
     stats = {}
     rec = run(inpath, model, image_paths, rank, world, batch_images=int(var.get('batch_images', 8)),
-              io_threads=var.get('io_threads'), stats=stats, resume=bool(var.get('resume', False)))
+              io_threads=var.get('io_threads'), stats=stats, resume=bool(var.get('resume', False)), emit_probs=emit_probs)
     failed = finish(inpath, image_paths, rec, rank, seconds=time.perf_counter() - t0, gpu_seconds=stats.get('gpu_seconds', 0.0))
     if native:
         dist.native_close(os.environ['ECSEG_RDZV'], rank)          # (the all-gather was the last thing every rank waited for)

@@ -56,6 +56,13 @@ class MetasegModel:
             return out + (raw[0],) if want_raw else out
         return (post, nec, raw) if want_raw else (post, nec)
 
+    def segment_ex(self, gray, want_probs=False):
+        """(n, H, W) uint8 -> (post labels, n_ec, tie_risk[, stitched probabilities float32 (n, H, W, 4)]): ``segment`` plus
+        the per-image count of pixels whose label a last-bit difference between float32 evaluations can flip (and, on
+        request, the probabilities ``np.argmax`` saw - config key ``emit_probs``)."""
+        out = self.handle.segment_images(np.asarray(gray), want_raw=False, want_tie_risk=True, want_probs=want_probs)
+        return out[1:]
+
     def flops_per_patch(self):
         return self.handle.flops_per_patch()
 

@@ -30,7 +30,8 @@ extern "C" {
 /* 2 (round 3): ecseg_get_conv_launch_profile kinds 3 / 4 and fusion bits, images_per_group 0 = automatic, op code 9
  * (GLOBALPOOL), MAXPOOL honours `mode`, CONV accepts stride != 1, ecseg_npy_write_i64 / ecseg_png_write* /
  * ecseg_tiff_* / ecseg_allgather_records added.  ecseg_amd/_lib.py refuses a library whose version differs from the one it was written for. */
-#define ECSEG_ABI_VERSION 2
+/* 3 (round 4): ecseg_segment_images_ex (per-image tie-risk counts, stitched probabilities). */
+#define ECSEG_ABI_VERSION 3
 
 #define ECSEG_OK             0
 #define ECSEG_E_INVALID     -1   /* bad argument / shape / plan */
@@ -118,6 +119,15 @@ int ecseg_segment_images(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, in
                          uint8_t* labels_raw, uint8_t* labels_post, int32_t* n_ec);
 int ecseg_segment_images_dev(ecseg_ctx* h, const uint8_t* gray_dev, int n_img, int H, int W,
                              uint8_t* labels_raw_dev, uint8_t* labels_post_dev, int32_t* n_ec_dev);
+/* ecseg_segment_images with two optional extra outputs (either may be NULL):
+ *   tie_risk  one int32 per image: the number of pixels whose two largest uint8-quantised probabilities (the values
+ *             np.argmax sees, src/utils.py:117-118) differ by at most 1 - the pixels whose label a last-bit difference between
+ *             two float32 evaluations of the network (this library, TensorFlow, a CPU port) can flip; an upper bound on the
+ *             raw-label disagreement of such evaluations for this image;
+ *   probs     float32 (n_img, H, W, 4): the stitched probabilities themselves (patches2im_overlap, src/utils.py:116; never-
+ *             written canvas pixels are 0), for comparison with the reference's own stitched output. */
+int ecseg_segment_images_ex(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W,
+                            uint8_t* labels_raw, uint8_t* labels_post, int32_t* n_ec, int32_t* tie_risk, float* probs);
 /* Upper bound on images (of 35 windows) per internal U-Net launch group.  Default and n == 0: automatic - as many as fit
  * ~48 GB of activations, between 16 and 64 (16 for the canonical base-64 U-Net, 32 for base 32, 64 for base 16). */
 int ecseg_set_images_per_group(ecseg_ctx* h, int n);
@@ -193,6 +203,8 @@ int ecseg_overlay(ecseg_ctx* h, const uint8_t* labels, const uint8_t* rgb, int n
                   int sensitivity, int hsr_size_threshold, int64_t* out);
 
 /* ---- per-stage device timings of the last segment call (milliseconds, HIP events on the handle's stream) -- */
+/* ECSEG_T_COUNT: device time of the kernels of the last ecseg_overlay / ecseg_preprocess / ecseg_count_* call (inputs
+ * already resident, copies excluded). */
 enum { ECSEG_T_TILE = 0, ECSEG_T_UNET = 1, ECSEG_T_TAIL = 2, ECSEG_T_POST = 3, ECSEG_T_COUNT = 4, ECSEG_T_N = 5 };
 int ecseg_get_timings(ecseg_ctx* h, float* ms_out /* [ECSEG_T_N] */);
 /* Average duration (ms) and launch count of the dominant kernel (MFMA conv) over the last segment/forward call,

@@ -151,3 +151,56 @@ def test_u16_and_reference_call_shapes(gpu):
     img, patches, pos = image_tools.im2patches_overlap(np.zeros((300, 462, 1), np.uint8))
     from oracle import tiling
     assert np.array_equal(np.array(pos), tiling.patch_positions(300, 462))
+
+
+def test_precision_and_emit_probs_config_keys(workdir):
+    """`metaseg: {precision: exact | fast, emit_probs: true}`.  exact = Winograd F(2x2) everywhere (the
+    kernel family closest to a float64 evaluation); emit_probs writes the stitched float32 probabilities np.argmax saw
+    (src/utils.py:116-118) next to the labels; every image's record carries its tie-risk pixel count (record slot 15 ->
+    ec_quantification_report.json), which bounds the raw-label disagreement with any other float32 evaluation."""
+    import json
+    from ecseg_amd import metaseg
+    from oracle import quant, tiling
+    tmp, inp = workdir
+    cfg_path = tmp / 'config.yaml'
+    base = yaml.safe_load(open(cfg_path))
+    outs = {}
+    for precision in ('fast', 'exact'):
+        c = dict(base)
+        c['metaseg'] = dict(base['metaseg'], precision=precision, emit_probs=True)
+        yaml.safe_dump(c, open(cfg_path, 'w'))
+        for sub in ('labels', 'dapi'):
+            shutil.rmtree(str(inp / sub), ignore_errors=True)
+        metaseg.main([])
+        rep = json.load(open(str(inp / 'ec_quantification_report.json')))
+        assert [r['image_name'] for r in rep['images']] == ['gray.tif', 'img0.tif', 'img1.tif', 'img2.tif']
+        outs[precision] = {}
+        for r in rep['images']:
+            stem = r['image_name'][:-4]
+            probs = np.load(str(inp / 'labels' / (stem + '_probs.npy')))
+            lab = np.load(str(inp / 'labels' / (stem + '.npy')))
+            gray = 255 - np.array(Image.open(str(inp / 'dapi' / r['image_name'])))
+            assert probs.dtype == np.float32 and probs.shape == lab.shape + (4,)
+            # the stored probabilities are what the labels were made from ...
+            raw = quant.quantised_argmax(probs.astype(np.float64))
+            assert np.array_equal(postproc.meta_inference(raw), lab), r['image_name']
+            assert r['# of ec'] == postproc.count_cc(lab == 3)[0] and r['status'] == 0
+            # ... and the record's tie-risk count is the number of written pixels whose two largest quantised values are <= 1 apart
+            q = np.clip(np.rint(probs.astype(np.float64) * 255.0), 0, 255)
+            top = np.sort(q, axis=-1)
+            written = probs.sum(-1) > 0.5
+            assert r['tie_risk_pixels'] == int(((top[..., 3] - top[..., 2] <= 1) & written).sum()), r['image_name']
+            outs[precision][stem] = (probs, lab, gray)
+    # the two kernel families agree to float32 rounding, and wherever their raw labels differ the pixel is a counted tie risk
+    for stem in outs['fast']:
+        pf, lf, _ = outs['fast'][stem]
+        pe, le, _ = outs['exact'][stem]
+        assert np.abs(pf - pe).max() < 1e-4
+        assert not np.array_equal(pf, pe), 'precision: exact did not select another kernel family'
+    # an unknown value is refused with the CLI's exit code 2
+    c = dict(base)
+    c['metaseg'] = dict(base['metaseg'], precision='double')
+    yaml.safe_dump(c, open(cfg_path, 'w'))
+    with pytest.raises(SystemExit) as e:
+        metaseg.main([])
+    assert e.value.code == 2

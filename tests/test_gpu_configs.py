@@ -116,11 +116,12 @@ def test_bench_model_full_size_labels_vs_cpu_oracle(bench_model):
 
 def test_smooth_output_model_labels_vs_cpu_oracle():
     """The label-mismatch bound on a realistic (smooth-output) model: a base-16 U-Net fitted for 120 steps on synthetic
-    scenes (tools/fit_smooth_model.py, torch CPU), two full-size images, all three 3x3 kernels.  At most a few raw pixels
+    scenes (tools/fit_smooth_model.py), cached as float16 weights under tests/golden (tools/make_smooth_fixture.py - no fit
+    inside the GPU session, no dependence on the torch build), two full-size images, all three 3x3 kernels.  At most a few raw pixels
     per image may differ, only at quantised ties; the clean-up is an exact function of the device's raw labels."""
     from ecseg_amd._lib import Handle
-    from tools import fit_smooth_model
-    cfg, weights = fit_smooth_model.fit(base=16, steps=120, threads=8)
+    from tools import make_smooth_fixture
+    cfg, weights = make_smooth_fixture.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'smooth_b16_f16.npz'))
     imgs = np.stack([synth.dapi_image(950 + i) for i in range(2)])
     refs = [oracle_pipeline.segment_gray(cfg, weights, im, return_intermediate=True) for im in imgs]
     assert all(50 < int((r[1] == 3).sum()) for r in refs)          # the fitted model does find ecDNA-like blobs

@@ -138,3 +138,27 @@ def test_repeated_runs_are_bit_identical():
             assert np.array_equal(pref, hnd.forward_patches(x))
     finally:
         hnd.close()
+
+
+def test_tie_risk_counts_and_stitched_probabilities(model16):
+    """ecseg_segment_images_ex: the stitched probabilities are exactly patches2im_overlap of the device's own patch
+    probabilities (src/utils.py:115-116; never-written canvas pixels 0), the labels are their quantised argmax, and the
+    per-image tie-risk count is the number of written pixels whose two largest uint8-quantised values differ by at most 1 -
+    the only pixels on which two float32 evaluations of the network can disagree (two images of different content in one
+    batch: the per-image counters must not mix)."""
+    H, W = 300, 462           # 36 canvas pixels of this size are never written (tests/golden: stitch maps)
+    imgs = np.stack([synth.dapi_image(7, H, W), synth.dapi_image(8, H, W), np.zeros((H, W), np.uint8)])
+    raw, post, nec, tie, probs = model16.handle.segment_images(imgs, want_raw=True, want_tie_risk=True, want_probs=True)
+    pos = tiling.patch_positions(H, W)
+    for i in range(3):
+        g_probs = model16.predict_on_batch(tiling.extract_patches(imgs[i][..., None], pos))
+        want = tiling.stitch(g_probs, pos)
+        assert probs[i].dtype == np.float32 and np.array_equal(probs[i], want.astype(np.float32))
+        assert np.array_equal(raw[i], quant.quantised_argmax(probs[i].astype(np.float64)))
+        q = np.sort(quant.quantise_u8(probs[i].astype(np.float64)).astype(int), axis=-1)
+        written = probs[i].sum(-1) > 0.5
+        assert int(tie[i]) == int(((q[..., 3] - q[..., 2] <= 1) & written).sum())
+    assert tie[0] != tie[1]
+    # the plain call returns the same labels and counts
+    raw2, post2, nec2 = model16.handle.segment_images(imgs, want_raw=True)
+    assert np.array_equal(raw, raw2) and np.array_equal(post, post2) and np.array_equal(nec, nec2)

@@ -178,8 +178,8 @@ def test_oom_retry_halves_below_the_failed_group_and_restores_the_setting(tmp_pa
     model = StubModel(fail_above=2)
     model.handle.set_images_per_group(8)
     logs = []
-    gray, post, nec = metaseg._segment_with_retry(model, imgs, lambda *a: logs.append(a))
-    assert post.shape == (8, H, W) and len(nec) == 8
+    gray, post, nec, tie, probs = metaseg._segment_with_retry(model, imgs, lambda *a: logs.append(a))
+    assert post.shape == (8, H, W) and len(nec) == 8 and len(tie) == 8 and probs is None
     assert [g for _, g in model.handle.calls] == [8, 4, 2]                     # first retry is BELOW the group that failed
     assert model.handle.images_per_group == 8                                  # restored for the next batch
     # a batch that does not fit even with one image per group is split by images
@@ -191,7 +191,7 @@ def test_oom_retry_halves_below_the_failed_group_and_restores_the_setting(tmp_pa
                 raise e
             return StubModel.segment(self, gray)
     m2 = PerBatch()
-    gray, post, nec = metaseg._segment_with_retry(m2, imgs, lambda *a: None)
+    gray, post, nec, tie, probs = metaseg._segment_with_retry(m2, imgs, lambda *a: None)
     assert post.shape == (8, H, W) and m2.handle.images_per_group == 0
     assert [n for n, _ in m2.handle.calls if n <= 3] == [2, 2, 2, 2]
 

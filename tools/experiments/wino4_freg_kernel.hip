@@ -164,7 +164,11 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
     //      ring: nobody ever waits for a halo piece to land).  The per-lane source pointers are computed once and parked
     //      in LDS (bit 0 = "advance with the channel group"; padding / out-of-image lanes point at the zero page and do
     //      not advance): no registers held during the K loop ----
+#if ECSEG_W4_FREG
+    unsigned long long* Hd = reinterpret_cast<unsigned long long*>(Bs) + tid;                      // [2][768] (no filter stages in LDS)
+#else
     unsigned long long* Hd = reinterpret_cast<unsigned long long*>(Bs + 12 * 2 * W4_BWS) + tid;   // [2][768]
+#endif
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int a = 64 * (wave + 12 * i) + lane;
@@ -191,6 +195,22 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
     };
     // ---- filter DMA: wt4[nb][stage][wave][point nu][h][cout 32][k 2], 768 floats per wave and stage ----
     const float* w_src = p.wt + ((size_t)nb * nstages * 12 + (SPLIT ? xi : wave)) * 768 + lane * 4;
+#if ECSEG_W4_FREG
+    // filter fragments global -> registers: two stage buffers of three dwordx4 pieces; the loads are issued through inline asm
+    // like the LDS-DMAs (the counted vmcnt waits of the K loop are the only ordering); W4_WAITF ties the buffer it releases
+    f32x4 wq[2][3];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wq[b][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto dma_filter_piece = [&](int stage, auto bufc, auto kk) __attribute__((always_inline)) {
+        W4_DIAG_SKIP_FILTER_DMA();
+        constexpr int k = decltype(kk)::value, buf = decltype(bufc)::value;
+        const float* g = w_src + (size_t)stage * (12 * 768);
+        f32x4& dst = wq[buf][k];
+        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(g), "n"(k * 1024) : "memory");
+    };
+#else
     f32x4* Bw = Bs + wave * 2 * W4_BWS;
     auto dma_filter_piece = [&](int stage, int buf, auto kk) __attribute__((always_inline)) {
         W4_DIAG_SKIP_FILTER_DMA();
@@ -199,6 +219,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         // the instruction offset advances the global AND the LDS address: one M0 for the three pieces
         glds16<k * 1024>(g, lds_base + (unsigned)(3 * W4_HS + (wave * 2 + buf) * W4_BWS) * 16u);
     };
+#endif
 
     // ---- A-operand lane -> tile.  ds_read_b128 serves lanes {0-3,12-15,20-27} and {4-11,16-19,28-31} of each half
     //      in separate LDS cycles; give each of those groups the 16 tiles of ONE region ----
@@ -241,6 +262,28 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         W4_DIAG_FAKE_TRANSFORM(grp);
         // scalar fmas on purpose (file is built with -fno-slp-vectorize): packed f32 VALU ops (v_pk_fma_f32) stall the
         // SIMD beside MFMAs, single v_fma_f32 hide in the matrix pipe's shadow
+#if ECSEG_W4_TSLOTS == 0
+        if (inner_row) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const f32x4 d0 = A[ro0 + cp[j]], d1 = A[ro1 + cp[j]], d2 = A[ro2 + cp[j]], d3 = A[ro3 + cp[j]];
+#pragma unroll
+                for (int c = 0; c < CN; ++c)
+                    t[j][c] = __builtin_fmaf(c0, d0[CS + c], __builtin_fmaf(c1, d1[CS + c], __builtin_fmaf(c2, d2[CS + c], d3[CS + c])));
+                asm volatile("" : "+v"(t[j]));               // finish this column here: 16 transient registers, not 96
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const f32x4 d0 = A[ro0 + cp[j]], d1 = A[ro1 + cp[j]], d2 = A[ro2 + cp[j]];
+#pragma unroll
+                for (int c = 0; c < CN; ++c) t[j][c] = __builtin_fmaf(c0, d0[CS + c], __builtin_fmaf(c1, d1[CS + c], d2[CS + c]));
+                asm volatile("" : "+v"(t[j]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#else
         // Software-pipelined (round 4): the phase used to be six LDS round trips behind each other (one per halo column:
         // 3 - 4 reads, wait, 12 fmas) and took 2200 - 3200 cycles per group - the three transforms of a SIMD's waves add up to the
         // group period (in-kernel stamps).  Now the LAST term of every column is read straight into t[j] (it enters the
@@ -283,10 +326,17 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             }
 #undef W4_TRD
         }
+#endif
     };
     // ---- one filter stage (2 of the group's 4 channel pairs; buffer ss): column transform + 12 MFMAs ----
+#if ECSEG_W4_FREG
+    auto mfma_stage = [&](int ss, auto fbufc, int next_stage, int halo_grp) __attribute__((always_inline)) {     // ss: channel pair of the group, fbuf: filter buffer; halo_grp: group to prefetch, < 0: none
+        constexpr int fbuf = decltype(fbufc)::value;
+        constexpr std::integral_constant<int, fbuf ^ 1> nbuf{};
+#else
     auto mfma_stage = [&](int ss, int fbuf, int next_stage, int halo_grp) __attribute__((always_inline)) {     // ss: channel pair of the group, fbuf: filter buffer; halo_grp: group to prefetch, < 0: none
         const int nbuf = fbuf ^ 1;
+#endif
         float V[6][2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {   // V[nu] = sum_j B^T[nu][j] t[j], scalar ops (see transform)
@@ -303,9 +353,14 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             V[5][e] = __builtin_fmaf(KP, u1, __builtin_fmaf(KS, u3, u5));
         }
         f32x2 w2[6];
+#if ECSEG_W4_FREG
+#pragma unroll
+        for (int v = 0; v < 6; ++v) w2[v] = f32x2{wq[fbuf][v >> 1][(v & 1) * 2], wq[fbuf][v >> 1][(v & 1) * 2 + 1]};
+#else
         const f32x2* Bp = reinterpret_cast<const f32x2*>(Bw + fbuf * W4_BWS) + lane;
 #pragma unroll
         for (int v = 0; v < 6; ++v) w2[v] = Bp[v * 64];
+#endif
         // 12 MFMAs, channel-major: consecutive MFMAs hit different accumulators (dependency distance 6), so even a lone
         // wave keeps the matrix pipe full.  The next stage's three filter pieces go out one at a time behind MFMAs 2, 4
         // and 6 (pinned): the wave's issue slot is free while the pipe works, and the load path never sees a burst.
@@ -314,7 +369,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
 #pragma unroll
             for (int v = 0; v < 6; ++v) {
                 W4_MFMA(acc[v], V[v][e], w2[v][e]);
-                if (e == 0 && (v == 1 || v == 3 || v == 5)) {
+                if (e == 0 && (v == 1 || v == 3 || v == 5) && (!ECSEG_W4_FREG || next_stage >= 0)) {   // (registers: no dummy load whose result nobody waits for)
                     __builtin_amdgcn_sched_barrier(0);
                     if (v == 1) dma_filter_piece(next_stage, nbuf, std::integral_constant<int, 0>{});
                     if (v == 3) dma_filter_piece(next_stage, nbuf, std::integral_constant<int, 1>{});
@@ -363,9 +418,21 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
 #define W4_T(g, PR) do { __builtin_amdgcn_s_setprio(W4_PT); transform(g, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}); __builtin_amdgcn_s_setprio(W4_PS(PR)); } while (0)
     // S0(g): filter stage 2g has landed (it is the youngest thing this wave issued) -> vmcnt(0); streams stage 2g+1 and
     // the halo of group g+2.  S1(g): only the two halo pieces issued after stage 2g+1 may still fly -> vmcnt(2).
-#define W4_S0(g) do { W4_SB(); W4_WAIT(0); W4_SB(); mfma_stage(0, 0, 2 * (g) + 1, (g) + 2 < ngroups ? (g) + 2 : -1); } while (0)
-#define W4_S1(g) do { W4_SB(); if ((g) + 2 < ngroups) W4_WAIT(2); else W4_WAIT(0); W4_SB(); \
-                      mfma_stage(1, 1, (g) + 1 < ngroups ? 2 * (g) + 2 : 2 * (g), -1); } while (0)
+#if ECSEG_W4_FREG
+#define W4_TIE(b) asm volatile("" : "+v"(wq[b][0]), "+v"(wq[b][1]), "+v"(wq[b][2]))      /* the loads into buffer b have landed: later reads stay behind the wait */
+#else
+#define W4_TIE(b)
+#endif
+#if ECSEG_W4_FREG
+#define W4_C0 std::integral_constant<int, 0>{}
+#define W4_C1 std::integral_constant<int, 1>{}
+#else
+#define W4_C0 0
+#define W4_C1 1
+#endif
+#define W4_S0(g) do { W4_SB(); W4_WAIT(0); W4_TIE(0); W4_SB(); mfma_stage(0, W4_C0, 2 * (g) + 1, (g) + 2 < ngroups ? (g) + 2 : -1); } while (0)
+#define W4_S1(g) do { W4_SB(); if ((g) + 2 < ngroups) W4_WAIT(2); else W4_WAIT(0); W4_TIE(1); W4_SB(); \
+                      mfma_stage(1, W4_C1, (g) + 1 < ngroups ? 2 * (g) + 2 : (ECSEG_W4_FREG ? -1 : 2 * (g)), -1); } while (0)
 // SPLIT: T(g) as above (all four channels of the slot: a two-channel transform made the register allocator spill ~100
 // registers; the wave uses channels 2 ch, 2 ch + 1); S(g) = its one filter stage of group g (stage 2 g + ch of the image, private
 // buffer g & 1): everything this wave issued has landed (vmcnt(0): the filter of this group and its halo pieces of group
@@ -373,8 +440,14 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
 #define W4_TS(g, PR) do { __builtin_amdgcn_s_setprio(W4_PT); \
                           transform(g, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}); \
                           __builtin_amdgcn_s_setprio(W4_PS(PR)); } while (0)
+#if ECSEG_W4_FREG
+#define W4_SS(g) do { W4_SB(); W4_WAIT(0); W4_TIE(0); W4_TIE(1); W4_SB(); \
+                      if ((g) & 1) mfma_stage(CH, W4_C1, (g) + 1 < ngroups ? 2 * (g) + 2 + CH : -1, (g) + 2 < ngroups ? (g) + 2 : -1); \
+                      else mfma_stage(CH, W4_C0, (g) + 1 < ngroups ? 2 * (g) + 2 + CH : -1, (g) + 2 < ngroups ? (g) + 2 : -1); } while (0)
+#else
 #define W4_SS(g) do { W4_SB(); W4_WAIT(0); W4_SB(); \
                       mfma_stage(CH, (g) & 1, ((g) + 1 < ngroups ? 2 * (g) + 2 : 2 * (g)) + CH, (g) + 2 < ngroups ? (g) + 2 : -1); } while (0)
+#endif
     const int cls = wave >> 2;
     dma_halo_piece(0, std::integral_constant<int, 0>{});
     dma_halo_piece(0, std::integral_constant<int, 1>{});
@@ -382,9 +455,9 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         dma_halo_piece(1, std::integral_constant<int, 0>{});
         dma_halo_piece(1, std::integral_constant<int, 1>{});
     }
-    dma_filter_piece(SPLIT ? ch : 0, 0, std::integral_constant<int, 0>{});
-    dma_filter_piece(SPLIT ? ch : 0, 0, std::integral_constant<int, 1>{});
-    dma_filter_piece(SPLIT ? ch : 0, 0, std::integral_constant<int, 2>{});
+    dma_filter_piece(SPLIT ? ch : 0, W4_C0, std::integral_constant<int, 0>{});
+    dma_filter_piece(SPLIT ? ch : 0, W4_C0, std::integral_constant<int, 1>{});
+    dma_filter_piece(SPLIT ? ch : 0, W4_C0, std::integral_constant<int, 2>{});
     if (ngroups > 1) W4_WAIT(5); else W4_WAIT(3);            // halo group 0 has landed (group 1: before barrier 1, below)
     if (SPLIT) {
         // two phases per group.  Waves 0-3 run T(g) S(g) after barrier g; waves 4-11 run S(g - 1) T(g): while one class
@@ -462,6 +535,9 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
 #undef W4_S1
 #undef W4_TS
 #undef W4_SS
+#undef W4_TIE
+#undef W4_C0
+#undef W4_C1
 #undef W4_SB
     W4_KSTAMP_DUMP();
 #undef W4_BARRIER
@@ -643,7 +719,7 @@ hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s) {
     const size_t grid = npairs * (size_t)((p.out.c + 63) / 64);
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    size_t lds = (size_t)(3 * W4_HS + 12 * 2 * W4_BWS) * 16 + 2 * 768 * 8;
+    size_t lds = (size_t)(3 * W4_HS + (ECSEG_W4_FREG ? 0 : 12 * 2 * W4_BWS)) * 16 + 2 * 768 * 8;
     const size_t lds_epi = (size_t)24 * W4_RPLANE * 4;
     if (lds_epi > lds) lds = lds_epi;
     void (*kern)(ConvParams, int, int, int) = conv_wino4_kernel<false, false>;

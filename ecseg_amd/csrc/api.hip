@@ -81,6 +81,7 @@ struct ecseg_ctx {
     uint8_t* d_gray = nullptr; size_t d_gray_cap = 0;
     uint8_t* d_raw = nullptr; size_t d_raw_cap = 0;
     int32_t* d_tie = nullptr; size_t d_tie_cap = 0;        // per-image tie-risk counts of the last segment call
+    int32_t* d_tie_sh = nullptr; size_t d_tie_sh_cap = 0;  // their replicated counters (one launch group)
     float* d_sprobs = nullptr; size_t d_sprobs_cap = 0;    // stitched probabilities of one launch group (ecseg_segment_images_ex)
     uint8_t* d_post = nullptr; size_t d_post_cap = 0;
     uint8_t* d_aux8 = nullptr; size_t d_aux8_cap = 0;      // second uint8 input (masks, rgb)
@@ -733,7 +734,6 @@ int segment_dev(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint
     int rc = check_model(h);
     if (rc) return rc;
     if ((rc = ensure(h, h->d_tie, h->d_tie_cap, (size_t)n_img))) return rc;
-    HIP_TRY(h, hipMemsetAsync(h->d_tie, 0, (size_t)n_img * sizeof(int32_t), h->stream));
     const ecseg_tensor_desc& ti = h->tensors[h->input_tensor];
     const ecseg_tensor_desc& to = h->tensors[h->output_tensor];
     if (ti.h != 256 || ti.w != 256 || ti.c != 1 || ti.c_stride != 1)
@@ -750,6 +750,7 @@ int segment_dev(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint
     const int grp = std::max(1, std::min(wpg / 35, std::max(1, wpg / sp->n_pos)));
     if ((rc = ensure_patches(h, std::min(grp, n_img) * sp->n_pos))) return rc;
     if ((rc = ensure_post(h, std::min(n_img, grp), px))) return rc;
+    if ((rc = ensure(h, h->d_tie_sh, h->d_tie_sh_cap, (size_t)std::min(grp, n_img) * G_SHARDS * G_STRIDE))) return rc;
     if (probs_host && (rc = ensure(h, h->d_sprobs, h->d_sprobs_cap, (size_t)std::min(grp, n_img) * px * 4))) return rc;
     for (float& v : h->stage_ms) v = 0.f;
     prof_begin(h);
@@ -777,7 +778,7 @@ int segment_dev(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint
         if ((rc = run_plan(h, ni * sp->n_pos, sp))) return rc;
         HIP_TRY(h, hipEventRecord(e6[2], s));
         const TView pv = view_of(h, h->output_tensor);
-        HIP_TRY(h, launch_stitch_argmax(pv.p, pv.cs, sp->map_dev, ni, sp->n_pos, H, W, raw + (size_t)i0 * px, s, h->d_tie + i0));
+        HIP_TRY(h, launch_stitch_argmax(pv.p, pv.cs, sp->map_dev, ni, sp->n_pos, H, W, raw + (size_t)i0 * px, s, h->d_tie + i0, h->d_tie_sh));
         HIP_TRY(h, hipEventRecord(e6[3], s));
         if (probs_host) {                                  // (diagnostic output: outside the stage timers)
             HIP_TRY(h, launch_stitch_probs(pv.p, pv.cs, sp->map_dev, ni, sp->n_pos, H, W, h->d_sprobs, s));
@@ -851,7 +852,7 @@ void ecseg_destroy(ecseg_ctx* h) {
         for (auto& lk : kv.second.luts) if (lk.second.dev) (void)hipFree(lk.second.dev);
     }
     if (h->zero_page) (void)hipFree(h->zero_page);
-    void* ptrs[] = {h->d_tie, h->d_sprobs, h->d_gray, h->d_raw, h->d_post, h->d_aux8, h->d_u8in, h->d_i32, h->d_i64, h->d_probs_in, h->d_hist,
+    void* ptrs[] = {h->d_tie, h->d_tie_sh, h->d_sprobs, h->d_gray, h->d_raw, h->d_post, h->d_aux8, h->d_u8in, h->d_i32, h->d_i64, h->d_probs_in, h->d_hist,
                     h->ws.L, h->ws.area, h->ws.sumy, h->ws.sumx, h->ws.flag, h->ws.tmpA, h->ws.tmpB, h->ws.list, h->ws.g, h->ws.tile_any, h->ws.own_bits, h->ws.binned, h->ws.binstart};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);

@@ -110,9 +110,10 @@ hipError_t launch_tile_patches(const uint8_t* gray, int n_img, int H, int W, con
 
 // ---- launchers implemented in post_kernels.hip -----------------------------------------------------------------
 // stitch + img_as_ubyte + argmax; src_map: (H*W) int32 = (patch << 16) | (y << 8) | x, or -1 when never written
-// tie_risk (may be null): per image, += the pixels whose two largest quantised values differ by at most 1 (zeroed by the caller)
+// tie_risk (may be null): per image, the pixels whose two largest quantised values differ by at most 1; tie_shards: scratch of
+// n_img * G_SHARDS * G_STRIDE ints (replicated counters, one 128-B line each)
 hipError_t launch_stitch_argmax(const float* probs, int prob_cs, const int32_t* src_map, int n_img, int n_pos,
-                                int H, int W, uint8_t* labels, hipStream_t s, int32_t* tie_risk = nullptr);
+                                int H, int W, uint8_t* labels, hipStream_t s, int32_t* tie_risk = nullptr, int32_t* tie_shards = nullptr);
 // the stitched probabilities themselves: float32 (n_img, H, W, 4); never-written canvas pixels are 0
 hipError_t launch_stitch_probs(const float* probs, int prob_cs, const int32_t* src_map, int n_img, int n_pos,
                                int H, int W, float* out, hipStream_t s);

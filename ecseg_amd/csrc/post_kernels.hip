@@ -140,8 +140,11 @@ __device__ __forceinline__ void lds_unite(int* Ls, int a, int b) {
 __device__ __forceinline__ int wave_from_left(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }   // wave_shr:1
 __device__ __forceinline__ int wave_from_right(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }  // wave_shl:1
 
+#ifndef ECSEG_CCL_WPE
+#define ECSEG_CCL_WPE 8
+#endif
 template <int CONN>
-__global__ __launch_bounds__(256) void ccl_local_kernel(CclGeom g, const uint8_t* __restrict__ img_all, uint32_t lut,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ECSEG_CCL_WPE, ECSEG_CCL_WPE))) void ccl_local_kernel(CclGeom g, const uint8_t* __restrict__ img_all, uint32_t lut,
                                                         int32_t* __restrict__ L_all, uint32_t* __restrict__ area_all,
                                                         u64* __restrict__ sumy_all, u64* __restrict__ sumx_all,
                                                         uint32_t* __restrict__ flag_all, int stat, int sparse,
@@ -176,28 +179,32 @@ __global__ __launch_bounds__(256) void ccl_local_kernel(CclGeom g, const uint8_t
     const u64 upto = (2ull << lane) - 1ull;                // lanes <= this one
     // The keys of the wave's 8 rows stay in registers: the neighbours above come from the previous row's register through
     // DPP wave shifts (one VALU instruction each) instead of byte reads from an LDS copy of the tile.
-    int keys[CCL_ROWS], hpos[CCL_ROWS];                    // key, lane of the pixel's run head
-    uint8_t vals[CCL_ROWS];
+    // one packed word per row keeps the kernel at 8 waves per SIMD (four arrays of 8 registers each cost three of them and 40 %
+    // of the kernel's speed): bits 0-1 key, 2-7 lane of the pixel's run head, 8-15 pixel value, 16-27 tile root + 1
+    uint32_t info[CCL_ROWS];
+#define KEY_OF(r) ((int)(info[r] & 3u))
+#define HPOS_OF(r) ((int)((info[r] >> 2) & 63u))
+#define VAL_OF(r) ((int)((info[r] >> 8) & 255u))
+#define TROOT_OF(r) ((int)(info[r] >> 16) - 1)
     int hole = 0;                                          // a valid pixel of this thread without a key
 #pragma unroll
     for (int r = 0; r < CCL_ROWS; ++r) {
         const int y = y0 + r, li = (wave * CCL_ROWS + r) * 64 + lane;
         const bool valid = y < g.H && x < g.W;
-        vals[r] = valid ? img_all[base + (size_t)y * g.W + x] : (uint8_t)0;
-        const int key = valid ? key_of(vals[r], lut) : 0;
-        keys[r] = key;
+        const uint8_t v = valid ? img_all[base + (size_t)y * g.W + x] : (uint8_t)0;
+        const int key = valid ? key_of(v, lut) : 0;
         hole |= (valid && key == 0) ? 1 : 0;
         const int kprev = wave_from_left(key);
         const bool start = key != 0 && kprev != key;       // (lane 0: kprev = 0)
         const u64 S = __ballot(start);
         const int hp = 63 - __clzll(S & upto);             // (meaningless where key == 0)
-        hpos[r] = hp;
+        info[r] = (uint32_t)key | ((uint32_t)(hp & 63) << 2) | ((uint32_t)v << 8);
         Ls[li] = key ? (li - lane) + hp : -1;
     }
-    Kl[wave][lane] = (uint8_t)keys[CCL_ROWS - 1];
+    Kl[wave][lane] = (uint8_t)KEY_OF(CCL_ROWS - 1);
     int mine = 0;
 #pragma unroll
-    for (int r = 0; r < CCL_ROWS; ++r) mine |= keys[r];
+    for (int r = 0; r < CCL_ROWS; ++r) mine |= KEY_OF(r);
     // sparse mode (every consumer of this labelling looks at the key before it reads a parent): a tile without a keyed
     // pixel writes nothing, the others write only their keyed pixels - the parents of background pixels stay stale
     // The vote is also left in tile_any for the later kernels of this labelling: ccl_border, ccl_flatten and count_roots
@@ -225,8 +232,8 @@ __global__ __launch_bounds__(256) void ccl_local_kernel(CclGeom g, const uint8_t
 #pragma unroll
     for (int r = 0; r < CCL_ROWS; ++r) {
         const int ly = wave * CCL_ROWS + r, li = ly * 64 + lane;
-        const int key = keys[r];
-        const int above = r ? keys[r > 0 ? r - 1 : 0] : (wave ? (int)Kl[wave > 0 ? wave - 1 : 0][lane] : 0);
+        const int key = KEY_OF(r);
+        const int above = r ? KEY_OF(r > 0 ? r - 1 : 0) : (wave ? (int)Kl[wave > 0 ? wave - 1 : 0][lane] : 0);
         const int al = wave_from_left(above), ar = wave_from_right(above), kl = wave_from_left(key);   // all lanes active here
         if (!key || ly == 0) continue;
         const bool left = kl == key, u0 = above == key, ul = al == key, ur = ar == key;
@@ -241,21 +248,20 @@ __global__ __launch_bounds__(256) void ccl_local_kernel(CclGeom g, const uint8_t
         }
     }
     __syncthreads();
-    int troot[CCL_ROWS];                                   // tile-local index of the pixel's tile root, -1 = unkeyed
 #pragma unroll
     for (int r = 0; r < CCL_ROWS; ++r) {
         const int y = y0 + r, li = (wave * CCL_ROWS + r) * 64 + lane;
-        const int key = keys[r];
+        const int key = KEY_OF(r);
         // run heads look the tile root up and leave it in their own slot (only finds run in this phase: a reader sees the
         // old parent or the root, both are on the chain); the rest of the run reads the head's slot - LDS operations of one
         // wave complete in order
-        const bool head = key != 0 && hpos[r] == lane;
+        const bool head = key != 0 && HPOS_OF(r) == lane;
         if (head) {
             const int root = lds_find(Ls, li);
             Ls[li] = root;
         }
-        const int rl = key ? Ls[(li - lane) + hpos[r]] : -1;
-        troot[r] = rl;
+        const int rl = key ? Ls[(li - lane) + HPOS_OF(r)] : -1;
+        info[r] |= (uint32_t)(rl + 1) << 16;                   // tile-local index of the pixel's tile root (+ 1; 0 = unkeyed)
         if (y < g.H && x < g.W) {
             const size_t p = base + (size_t)y * g.W + x;
             int lab = -1;
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(256) void ccl_local_kernel(CclGeom g, const uint8_t
 #pragma unroll
         for (int r = 0; r < CCL_ROWS; ++r) {
             const int y = y0 + r;
-            const int key = keys[r], tr = troot[r];
+            const int key = KEY_OF(r), tr = TROOT_OF(r);
             if (need & NEED_NPX) {
 #pragma unroll
                 for (int k = 1; k < 4; ++k) npx[k] += __popcll(__ballot(key == k));
@@ -277,11 +283,11 @@ __global__ __launch_bounds__(256) void ccl_local_kernel(CclGeom g, const uint8_t
             if (!want_slots) continue;
             const u64 F = __ballot(key != 0);
             if (!F) continue;                                  // wave-uniform
-            const bool start = key != 0 && hpos[r] == lane;
+            const bool start = key != 0 && HPOS_OF(r) == lane;
             const u64 S = __ballot(start);
             uint32_t bits = 0;
             if (aux_mode == AUX_BORDER) bits = (key && (y == 0 || y == g.H - 1 || x == 0 || x == g.W - 1)) ? 1u : 0u;
-            else if (aux_mode == AUX_VALUE_EQ) bits = (key && vals[r] == aux_c) ? 1u : 0u;
+            else if (aux_mode == AUX_VALUE_EQ) bits = (key && VAL_OF(r) == aux_c) ? 1u : 0u;
             else if (aux_mode == AUX_IMAGE) bits = key ? aux_img[base + (size_t)y * g.W + x] : 0u;
             u64 B[5];
             const int nb = (aux_mode == AUX_IMAGE) ? 5 : (aux_mode == AUX_NONE ? 0 : 1);
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(256) void ccl_local_kernel(CclGeom g, const uint8_t
 #pragma unroll
     for (int r = 0; r < CCL_ROWS; ++r) {
         const int y = y0 + r, li = (wave * CCL_ROWS + r) * 64 + lane;
-        const bool own = keys[r] != 0 && troot[r] == li;
+        const bool own = KEY_OF(r) != 0 && TROOT_OF(r) == li;
         const u64 m = __ballot(own);
         if (lane == 0) { ob[2 * (wave * CCL_ROWS + r)] = (uint32_t)m; ob[2 * (wave * CCL_ROWS + r) + 1] = (uint32_t)(m >> 32); }
         if (own) {
@@ -335,6 +341,10 @@ __global__ __launch_bounds__(256) void ccl_local_kernel(CclGeom g, const uint8_t
         if (threadIdx.x >= 1 && threadIdx.x < 4 && red[threadIdx.x]) atomicAdd(G + G_NPX + threadIdx.x, red[threadIdx.x]);
     }
 }
+#undef KEY_OF
+#undef HPOS_OF
+#undef VAL_OF
+#undef TROOT_OF
 
 // ---- phase 2: unions across tile borders (global atomicMin union-find) ----------------------------------------------
 // Workgroup = one tile, two waves: wave 0 takes the 64 pixels of the tile's first row (contacts with the tile above and,
@@ -1367,6 +1377,8 @@ __global__ __launch_bounds__(256) void stitch_argmax_kernel(const float* __restr
                                                             const int32_t* __restrict__ src_map, int n_pos, size_t px,
                                                             uint8_t* __restrict__ labels, size_t total,
                                                             int32_t* __restrict__ tie_risk) {
+    __shared__ int s_im, s_cnt;
+    int cnt = 0, cur = -1;                                 // tie-risk pixels of image `cur` seen by this thread
     PX_LOOP(total) {
         const size_t im = t / px, q = t - im * px;
         const int src = src_map[q];
@@ -1389,12 +1401,25 @@ __global__ __launch_bounds__(256) void stitch_argmax_kernel(const float* __restr
         }
         labels[t] = lab;
         if (tie_risk) {
-            // one atomic per wave and image: the lanes of a wave are consecutive pixels, i.e. of one image or (at most) two
-            const int im0 = __shfl((int)im, 0, 64);
-            const unsigned long long m0 = __ballot(tie && (int)im == im0);
-            if ((threadIdx.x & 63) == 0 && m0) atomicAdd(tie_risk + im0, __popcll(m0));
-            if (tie && (int)im != im0) atomicAdd(tie_risk + im, 1);
+            if ((int)im != cur) {                              // (a thread's pixels cross an image boundary a few times per launch at most)
+                if (cnt) atomicAdd(tie_risk + ((size_t)cur * G_SHARDS + blockIdx.x % G_SHARDS) * G_STRIDE, cnt);
+                cur = (int)im; cnt = 0;
+            }
+            cnt += tie ? 1 : 0;
         }
+    }
+    if (tie_risk) {
+        // one global atomic per workgroup, into one of G_SHARDS replicas of the image's counter (each on its own 128-B line):
+        // device-scope atomics on ONE line serialise at ~200 ns each across the XCDs - 16 k workgroups adding to the 16
+        // counters of a launch group, all in one line, took 3.2 ms (the whole stitch: 0.09 ms)
+        if (threadIdx.x == 0) { s_im = cur; s_cnt = 0; }
+        __syncthreads();
+        if (cnt) {
+            if (cur == s_im) atomicAdd(&s_cnt, cnt);
+            else atomicAdd(tie_risk + ((size_t)cur * G_SHARDS + blockIdx.x % G_SHARDS) * G_STRIDE, cnt);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && s_cnt) atomicAdd(tie_risk + ((size_t)s_im * G_SHARDS + blockIdx.x % G_SHARDS) * G_STRIDE, s_cnt);
     }
 }
 
@@ -1415,14 +1440,26 @@ __global__ __launch_bounds__(256) void stitch_probs_kernel(const float* __restri
     }
 }
 
+__global__ void tie_reduce_kernel(const int32_t* __restrict__ shards, int32_t* __restrict__ out, int n_img) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_img) return;
+    int v = 0;
+    for (int k = 0; k < G_SHARDS; ++k) v += shards[((size_t)i * G_SHARDS + k) * G_STRIDE];
+    out[i] = v;
+}
+
 hipError_t launch_stitch_argmax(const float* probs, int prob_cs, const int32_t* src_map, int n_img, int n_pos, int H, int W,
-                                uint8_t* labels, hipStream_t s, int32_t* tie_risk) {
+                                uint8_t* labels, hipStream_t s, int32_t* tie_risk, int32_t* tie_shards) {
     const size_t px = (size_t)H * W, total = px * n_img;
     if (!total) return hipSuccess;
-    // (whole waves run the loop body together - the ballot above needs that: the grid-stride loop keeps a wave's lanes on
-    // consecutive pixels and `total` is padded by nothing, so the last wave's tail lanes simply fall out of the loop)
+    const bool tie = tie_risk != nullptr && tie_shards != nullptr;
+    if (tie) {
+        hipError_t e = hipMemsetAsync(tie_shards, 0, (size_t)n_img * G_SHARDS * G_STRIDE * sizeof(int32_t), s);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(stitch_argmax_kernel, dim3(px_grid(total)), dim3(256), 0, s, probs, prob_cs, src_map, n_pos, px,
-                       labels, total, tie_risk);
+                       labels, total, tie ? tie_shards : nullptr);
+    if (tie) hipLaunchKernelGGL(tie_reduce_kernel, dim3((n_img + 63) / 64), dim3(64), 0, s, tie_shards, tie_risk, n_img);
     return hipGetLastError();
 }
 

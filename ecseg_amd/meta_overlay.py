@@ -8,7 +8,7 @@ import numpy as np
 import yaml
 
 from . import csvio, image_io, image_tools
-from .utils import get_imgs, tune_host_allocator
+from .utils import default_io_threads, get_imgs, tune_host_allocator
 
 HSR_SIZE_THRESHOLD = 20
 
@@ -65,7 +65,7 @@ def run(inpath, handle, image_paths, sensitivity, batch_images=8, io_threads=Non
     encoders on worker threads and the nine counts of consecutive same-shaped images computed in one device call.  Rows
     come back in the order of ``image_paths``."""
     import concurrent.futures as cf
-    io_threads = io_threads or max(2, min(32, os.cpu_count() or 4))
+    io_threads = io_threads or default_io_threads(1)
     window = max(2 * batch_images, io_threads)
     rows = [None] * len(image_paths)
     tune_host_allocator()

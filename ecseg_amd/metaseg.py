@@ -26,7 +26,7 @@ import yaml
 
 from . import csvio, dist, image_io
 from ._lib import E_NOMEM, EcsegError
-from .utils import get_imgs, load_model, save_img, tune_host_allocator
+from .utils import default_io_threads, get_imgs, load_model, save_img, tune_host_allocator
 
 MODEL_NAME = 'metaseg.h5'
 
@@ -168,7 +168,7 @@ def run(inpath, model, image_paths, rank=0, world=1, batch_images=8, io_threads=
     n_ec = np.zeros(len(mine), np.int64)
     status = np.zeros(len(mine), np.int64)
     tie = np.zeros(len(mine), np.int64)
-    io_threads = io_threads or max(2, min(32, (os.cpu_count() or 4) // max(world, 1)))
+    io_threads = io_threads or default_io_threads(world)                    # the cgroup-aware CPU budget shared between the ranks
     window = max(2 * batch_images, io_threads)                             # images decoded ahead of the GPU
     pending_writes = threading.BoundedSemaphore(4 * batch_images + io_threads)   # bounds the outputs held in memory
     # dozens of decoder / encoder threads hold the GIL in 5 ms slices by default; the device thread needs it only for

@@ -79,3 +79,29 @@ def tune_host_allocator():
         return bool(ok)
     except Exception:                                       # not glibc: nothing to tune
         return False
+
+
+def host_cpu_budget():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (a 256-core box inside a 16-CPU quota
+    runs 16 busy threads at full speed and 128 at an eighth of it: tools/host_scaling.py measured 4 ranks x 32 I/O threads at
+    HALF the images/s of one rank on such a box)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        q = open('/sys/fs/cgroup/cpu.max').read().split()                  # cgroup v2: "<quota|max> <period>"
+        if q[0] != 'max':
+            n = min(n, max(1, int(int(q[0]) / int(q[1]))))
+    except (OSError, ValueError, IndexError):
+        try:
+            quota = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def default_io_threads(world=1):
+    """Decoder / encoder threads per rank: twice the host's CPU budget (the threads also wait on files) shared between the
+    ranks of the node, 2 ... 32."""
+    return max(2, min(32, 2 * host_cpu_budget() // max(world, 1)))

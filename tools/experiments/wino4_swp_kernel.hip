@@ -395,6 +395,151 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
                           __builtin_amdgcn_s_setprio(W4_PS(PR)); } while (0)
 #define W4_SS(g) do { W4_SB(); W4_WAIT(0); W4_SB(); \
                       mfma_stage(CH, (g) & 1, ((g) + 1 < ngroups ? 2 * (g) + 2 : 2 * (g)) + CH, (g) + 2 < ngroups ? (g) + 2 : -1); } while (0)
+#ifndef ECSEG_W4_SWP
+#define ECSEG_W4_SWP 1
+#endif
+#ifndef ECSEG_W4_SWP_SLOTS
+#define ECSEG_W4_SWP_SLOTS 2
+#endif
+#if ECSEG_W4_SWP
+    if (!SPLIT) {
+        // ---- software-pipelined K loop (round 4) ----------------------------------------------------------------------------
+        // Rounds 1-3 gave every wave three phases per group (T: halo reads + row transform, S0 / S1: 12 MFMAs each) and rotated
+        // them over the three waves of a SIMD.  In-kernel stamps showed T at 2000 - 2800 cycles per group whatever its
+        // instruction count or LDS pipelining (VALU beside two MFMA-issuing waves: ~20 cycles per instruction), and the group
+        // period = the three T phases of a SIMD behind each other.  Here every wave is ONE stream: a stage = column transform of
+        // channel pair ss + 12 MFMAs, and between the MFMAs the row transform of the NEXT stage's channel pair goes out two or
+        // three instructions at a time (8-byte halo reads through 4 rotating slots, results written into the pair of t[] that
+        // the previous stage has finished with: no second copy of t).  All twelve waves issue MFMAs all the time; one barrier
+        // per group (before the first read of the next halo group) as before.
+        // (24 independent scalars instead of six 4-register tuples: the stream updates single components, and tuple-aligned
+        // allocation next to six 16-register accumulators made the register allocator spill accumulators)
+        float ts[6][4];
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ts[j][c] = 0.f;
+        auto stage = [&](auto ssc, auto innerc, auto buildc, int fbuf, int next_stage, int halo_grp, int tgrp) __attribute__((always_inline)) {
+            constexpr int ss = decltype(ssc)::value;
+            constexpr bool INNER = decltype(innerc)::value, BUILD = decltype(buildc)::value;
+            constexpr int CSn = 2 * (ss ^ 1);                                 // the channel pair built for the next stage
+            constexpr int NS = ECSEG_W4_SWP_SLOTS, NSTEP = INNER ? 18 : 12;
+            const int nbuf = fbuf ^ 1;
+            // column transform of ONE channel of the pair at a time (V for e = 1 is formed behind the first six MFMAs, its filter
+            // fragments are read then too): 12 + 12 live registers instead of 24 + 12 - the stream has no room for more
+            float V0[6], V1[6], wa[6], wb[6];
+            auto coltr = [&](auto ec, float (&V)[6]) __attribute__((always_inline)) {
+                constexpr int c = 2 * ss + decltype(ec)::value;
+                const float u0 = ts[0][c], u1 = ts[1][c], u2 = ts[2][c], u3 = ts[3][c], u4 = ts[4][c], u5 = ts[5][c];
+                const float ea = __builtin_fmaf(-KB2, u2, u4), oa = __builtin_fmaf(-KB2, u1, u3);
+                const float eb = __builtin_fmaf(-KA2, u2, u4), ob = __builtin_fmaf(-KA2, u1, u3);
+                V[0] = __builtin_fmaf(KP, u0, __builtin_fmaf(KS, u2, u4));
+                V[1] = __builtin_fmaf(KA, oa, ea);
+                V[2] = __builtin_fmaf(-KA, oa, ea);
+                V[3] = __builtin_fmaf(KB, ob, eb);
+                V[4] = __builtin_fmaf(-KB, ob, eb);
+                V[5] = __builtin_fmaf(KP, u1, __builtin_fmaf(KS, u3, u5));
+            };
+            const float* Bf = reinterpret_cast<const float*>(Bw + fbuf * W4_BWS) + 2 * lane;       // [point][lane][e]
+            coltr(std::integral_constant<int, 0>{}, V0);
+#pragma unroll
+            for (int v = 0; v < 6; ++v) wa[v] = Bf[v * 128];
+            const f32x4* A = Hs + ((BUILD ? tgrp : 0) % 3) * W4_HS + a_lane;
+            constexpr int cp[6] = {w4_cpos(0), w4_cpos(1), w4_cpos(2), w4_cpos(3), w4_cpos(4), w4_cpos(5)};
+            auto rd = [&](int slot) __attribute__((always_inline)) -> f32x2 { return reinterpret_cast<const f32x2*>(A + slot)[CSn / 2]; };
+#define W4_SLOT(i) (INNER ? (((i) % 3 == 0 ? ro2 : (i) % 3 == 1 ? ro1 : ro0) + cp[(i) / 3]) : (((i) % 2 == 0 ? ro1 : ro0) + cp[(i) / 2]))
+#define W4_COEF(i) (INNER ? ((i) % 3 == 0 ? c2 : (i) % 3 == 1 ? c1 : c0) : ((i) % 2 == 0 ? c1 : c0))
+#define W4_COL(i) (INNER ? (i) / 3 : (i) / 2)
+            f32x2 sl[NS];
+            if (BUILD) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {                                  // the last term of every column enters with coefficient 1
+                    const f32x2 d = rd((INNER ? ro3 : ro2) + cp[j]);
+                    ts[j][CSn] = d[0]; ts[j][CSn + 1] = d[1];
+                }
+#pragma unroll
+                for (int k = 0; k < NS; ++k) sl[k] = rd(W4_SLOT(k));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // (every index below is a template constant: a loop variable the unroller has not folded yet would turn t[] and the
+            // slots into scratch arrays)
+            auto step = [&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (BUILD && i < NSTEP) {
+                    const float cf = W4_COEF(i);
+                    ts[W4_COL(i)][CSn] = __builtin_fmaf(cf, sl[i % NS][0], ts[W4_COL(i)][CSn]);
+                    ts[W4_COL(i)][CSn + 1] = __builtin_fmaf(cf, sl[i % NS][1], ts[W4_COL(i)][CSn + 1]);
+                    if constexpr (i + NS < NSTEP) sl[i % NS] = rd(W4_SLOT(i + NS));
+                }
+            };
+            auto one = [&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value, e = k / 6, v = k % 6;
+                if constexpr (e == 0) W4_MFMA(acc[v], V0[v], wa[v]); else W4_MFMA(acc[v], V1[v], wb[v]);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (k == 2) {
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) wb[q] = Bf[q * 128 + 1];
+                }
+                if constexpr (k == 4) coltr(std::integral_constant<int, 1>{}, V1);
+                if constexpr (e == 0 && v == 1) dma_filter_piece(next_stage, nbuf, std::integral_constant<int, 0>{});
+                if constexpr (e == 0 && v == 3) dma_filter_piece(next_stage, nbuf, std::integral_constant<int, 1>{});
+                if constexpr (e == 0 && v == 5) dma_filter_piece(next_stage, nbuf, std::integral_constant<int, 2>{});
+                if constexpr (e == 1 && v == 1) { if (halo_grp >= 0) dma_halo_piece(halo_grp, std::integral_constant<int, 0>{}); }   // behind MFMAs 8 and 10
+                if constexpr (e == 1 && v == 3) { if (halo_grp >= 0) dma_halo_piece(halo_grp, std::integral_constant<int, 1>{}); }
+                constexpr int first = INNER ? (3 * k + 1) / 2 : k, cnt = INNER ? (k % 2 == 0 ? 2 : 1) : 1;
+                step(std::integral_constant<int, first>{});
+                if constexpr (cnt == 2) step(std::integral_constant<int, first + 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{}); one(std::integral_constant<int, 2>{});
+            one(std::integral_constant<int, 3>{}); one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{});
+            one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{}); one(std::integral_constant<int, 8>{});
+            one(std::integral_constant<int, 9>{}); one(std::integral_constant<int, 10>{}); one(std::integral_constant<int, 11>{});
+#undef W4_SLOT
+#undef W4_COEF
+#undef W4_COL
+        };
+        dma_halo_piece(0, std::integral_constant<int, 0>{});
+        dma_halo_piece(0, std::integral_constant<int, 1>{});
+        if (ngroups > 1) {
+            dma_halo_piece(1, std::integral_constant<int, 0>{});
+            dma_halo_piece(1, std::integral_constant<int, 1>{});
+        }
+        if (ngroups > 2) {
+            dma_halo_piece(2, std::integral_constant<int, 0>{});
+            dma_halo_piece(2, std::integral_constant<int, 1>{});
+        }
+        dma_filter_piece(0, 0, std::integral_constant<int, 0>{});
+        dma_filter_piece(0, 0, std::integral_constant<int, 1>{});
+        dma_filter_piece(0, 0, std::integral_constant<int, 2>{});
+        if (ngroups > 2) W4_WAIT(7); else if (ngroups > 1) W4_WAIT(5); else W4_WAIT(3);      // this wave's pieces of halo group 0 have landed
+        W4_BARRIER();                                                                         // everybody's have
+        transform(0, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});     // channel pair 0 of group 0: the one transform that overlaps nothing
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { ts[j][0] = t[j][0]; ts[j][1] = t[j][1]; }
+        auto kloop = [&](auto innerc) __attribute__((always_inline)) {
+            for (int g = 0; g < ngroups; ++g) {
+                // stage 2 g: its filter (issued in stage 2 g - 1) has landed; the two halo pieces issued behind it may still fly
+                __builtin_amdgcn_sched_barrier(0);
+                if (g > 0 && g + 2 < ngroups) W4_WAIT(2); else W4_WAIT(0);
+                __builtin_amdgcn_sched_barrier(0);
+                stage(std::integral_constant<int, 0>{}, innerc, std::true_type{}, 0, 2 * g + 1, -1, g);
+                // stage 2 g + 1: everything this wave issued has landed; behind the barrier every wave has finished with halo
+                // group g (its last reads were the pair built during stage 2 g) and halo group g + 1 is complete in LDS
+                __builtin_amdgcn_sched_barrier(0);
+                W4_WAIT(0);
+                W4_BARRIER();
+                __builtin_amdgcn_sched_barrier(0);
+                // (ONE inlined copy of the stage per loop position: two copies in the arms of a branch get their accumulators in
+                // different registers and the compiler spills all 96 of them at the join.  The last group "builds" from its own halo
+                // group again and re-reads its own filter stage: nobody uses either.)
+                const bool more = g + 1 < ngroups;
+                stage(std::integral_constant<int, 1>{}, innerc, std::true_type{}, 1, more ? 2 * g + 2 : 2 * g, g + 3 < ngroups ? g + 3 : -1, more ? g + 1 : g);
+            }
+        };
+        if (inner_row) kloop(std::true_type{}); else kloop(std::false_type{});
+    } else {
+#endif
     const int cls = wave >> 2;
     dma_halo_piece(0, std::integral_constant<int, 0>{});
     dma_halo_piece(0, std::integral_constant<int, 1>{});
@@ -477,6 +622,9 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         W4_S0(ngroups - 1);
         W4_S1(ngroups - 1);
     }
+#if ECSEG_W4_SWP
+    }
+#endif
 #undef W4_T
 #undef W4_S0
 #undef W4_S1

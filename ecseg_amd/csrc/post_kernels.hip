@@ -283,8 +283,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ECSEG_CCL_W
             if (!want_slots) continue;
             const u64 F = __ballot(key != 0);
             if (!F) continue;                                  // wave-uniform
-            const bool start = key != 0 && HPOS_OF(r) == lane;
-            const u64 S = __ballot(start);
             uint32_t bits = 0;
             if (aux_mode == AUX_BORDER) bits = (key && (y == 0 || y == g.H - 1 || x == 0 || x == g.W - 1)) ? 1u : 0u;
             else if (aux_mode == AUX_VALUE_EQ) bits = (key && VAL_OF(r) == aux_c) ? 1u : 0u;
@@ -293,6 +291,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ECSEG_CCL_W
             const int nb = (aux_mode == AUX_IMAGE) ? 5 : (aux_mode == AUX_NONE ? 0 : 1);
 #pragma unroll
             for (int b = 0; b < 5; ++b) B[b] = (b < nb) ? __ballot((bits >> b) & 1u) : 0ull;
+            // a row without a flagged pixel has nothing to accumulate when only flags are wanted (fill_holes: rows off the image
+            // border; merge_comp: rows without a class-c pixel) - wave-uniform
+            if (!(stat & (STAT_AREA | STAT_SUMS)) && !(B[0] | B[1] | B[2] | B[3] | B[4])) continue;
+            const bool start = key != 0 && HPOS_OF(r) == lane;
+            const u64 S = __ballot(start);
             if (start) {
                 const u64 above = ~((2ull << lane) - 1ull);
                 const u64 stop = (S | ~F) & above;
@@ -408,6 +411,11 @@ __global__ __launch_bounds__(128) void ccl_border_kernel(CclGeom g, const uint8_
                 if (x > 0 && key_of(im[p - 1], lut) == key) {
                     // two full tiles: one union is enough - the first row this wave handles (row 1, or row 0 in the top strip)
                     if (fullA && fullL) { if (r == (ytile > 0 ? 1 : 0)) uf_unite(L, rootA, rootA - 64); }
+                    // one union per VERTICAL RUN of border contacts (round 4): when the pair above (p - W, p - W - 1) is a contact
+                    // too, it is united by the lane above (or by wave 0 for the tile's first row) and both pixels hang on it
+                    // vertically inside their own tiles - this union would walk two long chains of the background component
+                    // to find them equal (32 such walks per tile edge were most of this kernel's time in the fill_holes labellings)
+                    else if (r > 0 && key_of(im[p - W], lut) == key && key_of(im[p - W - 1], lut) == key) { }
                     else uf_unite(L, fullA ? rootA : p, fullL ? rootA - 64 : p - 1);
                 }
                 return;
@@ -419,7 +427,6 @@ __global__ __launch_bounds__(128) void ccl_border_kernel(CclGeom g, const uint8_
         }
     }
 }
-
 // ---- phase 3: resolve the tile roots ----------------------------------------------------------------------------------
 // After ccl_local every pixel points at its tile root (the "owner" of a tile component) and the owner's global slots hold
 // the component's statistics within the tile; ccl_border has linked owners across tiles.  Only the owners are touched
@@ -534,45 +541,36 @@ __global__ __launch_bounds__(256) void ccl_resolve_kernel(CclGeom g, const uint8
     else if (tid == 8) { if (red[8]) atomicMax(G + G_LAST_ROOT, red[8]); }
 }
 
-// count_cc needs no flatten: after ccl_local + ccl_border a component's root is the one pixel that still points at itself,
-// so components and pixels per key are counted straight from (image, parents).
+// count_cc needs no resolve: after ccl_local + ccl_border a component's root is the one OWNER that still points at itself, so
+// the components per key are counted from the owner bits (256 B per tile) and the owners' parents alone; the pixels per key were
+// counted by ccl_local (NEED_NPX).  (Rounds 2-3 re-read image and parents of every pixel for this: 220 us per 64 speckled images.)
 __global__ __launch_bounds__(256) void count_roots_kernel(CclGeom g, const uint8_t* __restrict__ img_all, uint32_t lut,
                                                           const int32_t* __restrict__ L_all, int32_t* __restrict__ G_all,
-                                                          const uint8_t* __restrict__ tile_any) {
-    __shared__ int red[8];
+                                                          const uint8_t* __restrict__ tile_any, const uint32_t* __restrict__ own_bits) {
+    __shared__ int red[4];
     int img, y0, cx;
     if (!decode_block(g, img, y0, cx)) return;
-    if (!tile_any[tile_index(g, img)]) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    if (tid < 8) red[tid] = 0;
+    const size_t ti = tile_index(g, img);
+    if (!tile_any[ti]) return;
+    const int tid = threadIdx.x;
+    if (tid < 4) red[tid] = 0;
     __syncthreads();
     const size_t base = (size_t)img * g.H * g.W;
-    const int x = cx * 64 + lane;
-    int nc[4] = {0, 0, 0, 0}, np[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int r = 0; r < CCL_ROWS; ++r) {
-        const int y = y0 + r;
-        int key = 0;
-        bool root = false;
-        if (y < g.H && x < g.W) {
-            const int p = y * g.W + x;
-            key = key_of(img_all[base + p], lut);
-            root = key != 0 && L_all[base + p] == p;
-        }
-#pragma unroll
-        for (int k = 1; k < 4; ++k) {
-            np[k] += __popcll(__ballot(key == k));
-            nc[k] += __popcll(__ballot(root && key == k));
-        }
+    const int yblk = y0 - (tid >> 6) * CCL_ROWS;
+    uint32_t bits = (own_bits[ti * 64 + (tid >> 2)] >> ((tid & 3) * 8)) & 0xffu;      // thread = 8 consecutive pixels of the tile
+    int nc[4] = {0, 0, 0, 0};
+    while (bits) {
+        const int k = __ffs((int)bits) - 1;
+        bits &= bits - 1;
+        const int li = tid * 8 + k;
+        const int p = (yblk + (li >> 6)) * g.W + cx * 64 + (li & 63);
+        if (L_all[base + p] == p) nc[key_of(img_all[base + p], lut) & 3] += 1;
     }
-    if (lane == 0) {
 #pragma unroll
-        for (int k = 1; k < 4; ++k) { if (nc[k]) atomicAdd(&red[k - 1], nc[k]); if (np[k]) atomicAdd(&red[3 + k - 1], np[k]); }
-    }
+    for (int k = 1; k < 4; ++k) if (nc[k]) atomicAdd(&red[k], nc[k]);
     __syncthreads();
     int32_t* G = G_all + (size_t)img * G_IMG + (size_t)((blockIdx.x >> 3) % G_SHARDS) * G_STRIDE;
-    if (tid < 3) { if (red[tid]) atomicAdd(G + G_NCOMP + 1 + tid, red[tid]); }
-    else if (tid < 6) { if (red[tid]) atomicAdd(G + G_NPX + 1 + (tid - 3), red[tid]); }
+    if (tid >= 1 && tid < 4 && red[tid]) atomicAdd(G + G_NCOMP + tid, red[tid]);
 }
 
 // fold the G_SHARDS replicas of every image's counter block into replica 0
@@ -615,7 +613,7 @@ static hipError_t run_ccl_pass(PostWorkspace& ws, const CclGeom& g, const CclPas
     const unsigned grid = geom_grid(g);
     const bool slots = !c.count_only;                          // count_only: counts per key only - no statistics, no owners' slots
     const int stat = slots ? c.stat : 0, aux_mode = slots ? c.aux_mode : AUX_NONE;
-    const int need_local = slots ? (c.need & NEED_NPX) : 0;    // (count_roots counts the pixels itself)
+    const int need_local = c.need & NEED_NPX;                  // pixels per key: counted where the keys are in registers
     const size_t dyn = (stat & STAT_SUMS) ? (size_t)CCL_BLOCK_ROWS * 64 * 8 : 0;
     if (c.conn == 8) {
         hipLaunchKernelGGL(ccl_local_kernel<8>, dim3(grid), dim3(256), dyn, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy,
@@ -630,7 +628,7 @@ static hipError_t run_ccl_pass(PostWorkspace& ws, const CclGeom& g, const CclPas
         hipLaunchKernelGGL(ccl_border_kernel<4>, dim3(grid), dim3(128), 0, s, g, c.key_img, c.lut, ws.L, ws.tile_any);
     }
     if (c.count_only) {        // counts per key only: no per-pixel roots, no statistics
-        hipLaunchKernelGGL(count_roots_kernel, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L, ws.g, ws.tile_any);
+        hipLaunchKernelGGL(count_roots_kernel, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L, ws.g, ws.tile_any, ws.own_bits);
         hipLaunchKernelGGL(reduce_g_kernel, dim3(g.n_img), dim3(G_STRIDE), 0, s, ws.g, g.n_img);
         return hipGetLastError();
     }

@@ -205,6 +205,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ECSEG_CCL_W
 #define VAL_OF(r) ((int)((info[r] >> 8) & 255u))
 #define TROOT_OF(r) ((int)(info[r] >> 16) - 1)
     int hole = 0;                                          // a valid pixel of this thread without a key
+    int rowmask = 0;                                       // (wave-uniform) bit r: row r of this wave holds a keyed pixel
 #pragma unroll
     for (int r = 0; r < CCL_ROWS; ++r) {
         const int y = y0 + r, li = (wave * CCL_ROWS + r) * 64 + lane;
@@ -212,6 +213,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ECSEG_CCL_W
         const uint8_t v = valid ? img_all[base + (size_t)y * g.W + x] : (uint8_t)0;
         const int key = valid ? key_of(v, lut) : 0;
         hole |= (valid && key == 0) ? 1 : 0;
+        // rows without a keyed pixel (most rows of a realistic class labelling, even inside a busy tile) are skipped by every
+        // later phase on a wave-uniform test: no DPP shifts, ballots or LDS traffic for them (their Ls slots are never read)
+        if (__ballot(key != 0) == 0ull) { info[r] = (uint32_t)v << 8; continue; }
+        rowmask |= 1 << r;
         const int kprev = wave_from_left(key);
         const bool start = key != 0 && kprev != key;       // (lane 0: kprev = 0)
         const u64 S = __ballot(start);
@@ -250,6 +255,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ECSEG_CCL_W
 #pragma unroll
     for (int r = 0; r < CCL_ROWS; ++r) {
         const int ly = wave * CCL_ROWS + r, li = ly * 64 + lane;
+        if (!((rowmask >> r) & 1)) continue;
         const int key = KEY_OF(r);
         const int above = r ? KEY_OF(r > 0 ? r - 1 : 0) : (wave ? (int)Kl[wave > 0 ? wave - 1 : 0][lane] : 0);
         const int al = wave_from_left(above), ar = wave_from_right(above), kl = wave_from_left(key);   // all lanes active here
@@ -269,6 +275,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ECSEG_CCL_W
 #pragma unroll
     for (int r = 0; r < CCL_ROWS; ++r) {
         const int y = y0 + r, li = (wave * CCL_ROWS + r) * 64 + lane;
+        if (!((rowmask >> r) & 1)) {
+            if (!sparse && y < g.H && x < g.W) L_all[base + (size_t)y * g.W + x] = -1;
+            continue;
+        }
         const int key = KEY_OF(r);
         // run heads look the tile root up and leave it in their own slot (only finds run in this phase: a reader sees the
         // old parent or the root, both are on the chain); the rest of the run reads the head's slot - LDS operations of one
@@ -298,9 +308,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ECSEG_CCL_W
 #pragma unroll
                 for (int k = 1; k < 4; ++k) npx[k] += __popcll(__ballot(key == k));
             }
-            if (!want_slots) continue;
+            if (!want_slots || !((rowmask >> r) & 1)) continue;
             const u64 F = __ballot(key != 0);
-            if (!F) continue;                                  // wave-uniform
             uint32_t bits = 0;
             if (aux_mode == AUX_BORDER) bits = (key && (y == 0 || y == g.H - 1 || x == 0 || x == g.W - 1)) ? 1u : 0u;
             else if (aux_mode == AUX_VALUE_EQ) bits = (key && VAL_OF(r) == aux_c) ? 1u : 0u;
@@ -337,6 +346,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ECSEG_CCL_W
 #pragma unroll
     for (int r = 0; r < CCL_ROWS; ++r) {
         const int y = y0 + r, li = (wave * CCL_ROWS + r) * 64 + lane;
+        if (!((rowmask >> r) & 1)) {
+            if (lane == 0) { ob[2 * (wave * CCL_ROWS + r)] = 0u; ob[2 * (wave * CCL_ROWS + r) + 1] = 0u; }
+            continue;
+        }
         const bool own = KEY_OF(r) != 0 && TROOT_OF(r) == li;
         const u64 m = __ballot(own);
         if (lane == 0) { ob[2 * (wave * CCL_ROWS + r)] = (uint32_t)m; ob[2 * (wave * CCL_ROWS + r) + 1] = (uint32_t)(m >> 32); }
@@ -693,14 +706,31 @@ __global__ __launch_bounds__(256) void apply_fill_kernel(uint8_t* __restrict__ i
 // fill; the others go pixel by pixel.
 __global__ __launch_bounds__(256) void apply_fill_tile_kernel(CclGeom g, uint8_t* __restrict__ img_all, const int32_t* __restrict__ L_all,
                                                               const uint32_t* __restrict__ flag_all, int c, uint32_t lut,
-                                                              const uint8_t* __restrict__ tile_any) {
+                                                              const uint8_t* __restrict__ tile_any, const uint32_t* __restrict__ own_bits) {
     int img, y0, cx;
     if (!decode_block(g, img, y0, cx)) return;
-    const int ta = tile_any[tile_index(g, img)];
+    const size_t ti = tile_index(g, img);
+    const int ta = tile_any[ti];
     if (!ta) return;
     const size_t base = (size_t)img * g.H * g.W;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = cx * 64 + lane;
+    if (ta == 1) {
+        // Holes are rare: when every component of the tile (its owners, from the owner bits; their parents are the global roots
+        // since ccl_resolve) reaches the image border there is nothing to fill here - decided from a handful of look-ups
+        // instead of two gathers per pixel (round 4).
+        const int yblk = y0 - wave * CCL_ROWS;
+        uint32_t bits = (own_bits[ti * 64 + (threadIdx.x >> 2)] >> ((threadIdx.x & 3) * 8)) & 0xffu;
+        int open_all = 1;
+        while (bits) {
+            const int k = __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            const int li = (int)threadIdx.x * 8 + k;
+            const int p = (yblk + (li >> 6)) * g.W + cx * 64 + (li & 63);
+            if (!(flag_all[base + L_all[base + p]] & 1u)) open_all = 0;
+        }
+        if (__syncthreads_and(open_all)) return;
+    }
     bool fill_all = false;
     if (ta == 2) {
         const int p0 = (y0 - wave * CCL_ROWS) * g.W + cx * 64;
@@ -1140,7 +1170,7 @@ hipError_t run_meta_inference(PostWorkspace& ws, uint8_t* img, int n_img, int H,
         p.sparse = true;
         p.allow_full = true;
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
-        hipLaunchKernelGGL(apply_fill_tile_kernel, dim3(geom_grid(g)), dim3(256), 0, s, g, img, ws.L, ws.flag, c, lut_ne(c), ws.tile_any);
+        hipLaunchKernelGGL(apply_fill_tile_kernel, dim3(geom_grid(g)), dim3(256), 0, s, g, img, ws.L, ws.flag, c, lut_ne(c), ws.tile_any, ws.own_bits);
     }
     // 2-4. size_thresh
     {

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p, int tiles_
             }
             if (ok) {
                 float* o = p.out.p + (((size_t)img * Hout + oy) * Wout + ox) * p.out.cs + co;
-                if (vec_ok && co + 3 < Cout) *reinterpret_cast<f32x4*>(o) = v;
+                if (vec_ok && co + 3 < Cout) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(o));   // (streamed once, read by a later launch)
                 else {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) if (co + c < Cout) o[c] = v[c];

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(C
 #pragma unroll
                             for (int x = 0; x < 2; ++x)
                                 if (oy + yy < H && ox + x < W)
-                                    *reinterpret_cast<f32x4*>(p.out.p + (((size_t)img * H + oy + yy) * W + ox + x) * p.out.cs + co) = Y[yy][x];
+                                    __builtin_nontemporal_store(Y[yy][x], reinterpret_cast<f32x4*>(p.out.p + (((size_t)img * H + oy + yy) * W + ox + x) * p.out.cs + co));
                     }
                     if (HEAD) {                                  // this lane's 4 channels x 4 classes, for the tile's 2 x 2 pixels
 #pragma unroll

@@ -201,3 +201,20 @@ def test_real_weights_kit_diffs_labels_counts_and_csv(tmp_path, golden_dir):
         assert c.returncode in (0, 3), c.stdout + c.stderr
         assert 'outside the reference' in c.stdout and 'ec_quantification.csv:' in c.stdout and 'labels after meta_inference' in c.stdout
         assert ' 0 of them outside' in c.stdout, c.stdout
+
+
+def test_device_timers_of_overlay_and_preprocess(gpu):
+    """bench.py's overlay_ms_per_image / preprocess_ms_per_image legs read ECSEG_T_COUNT: the device time of the kernels of the last
+    ecseg_overlay / ecseg_preprocess / ecseg_count_* call (HIP events inside the entry point, copies excluded)."""
+    from ecseg_amd import synth
+    H, W = 256, 320
+    rgb = np.stack([synth.dapi_image(11 + i, H, W, rgb=True) for i in range(3)])
+    lab = np.stack([synth.label_map(11 + i, H, W) for i in range(3)])
+    rows = gpu.overlay(lab, rgb, 85)
+    t = gpu.timings()
+    assert rows.shape == (3, 12) and t['count'] > 0.0 and t['unet'] == 0.0 and t['post'] == 0.0
+    gpu.preprocess(rgb)
+    t2 = gpu.timings()
+    assert 0.0 < t2['count'] < t['count']                       # one gather + histogram against five labellings
+    n, px = gpu.count_cc(lab == 3)
+    assert gpu.timings()['count'] > 0.0 and len(n) == 3

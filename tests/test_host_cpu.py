@@ -293,3 +293,31 @@ def test_rendezvous_rejects_a_stale_file_of_another_job(tmp_path, monkeypatch):
     # the launcher of a polling rank has gone: stop polling
     with pytest.raises(RuntimeError):
         edist.read_rendezvous(str(tmp_path / 'never'), 128, timeout=10, poll=0.02, nonce=mine, alive=lambda: False)
+
+
+def test_host_cpu_budget_and_io_thread_default(monkeypatch):
+    """The I/O thread pools of the file pipelines are sized by the CPUs this process may really use (affinity capped by the cgroup
+    quota), shared between the ranks of the node: 4 ranks x 32 threads inside a 16-CPU quota ran at half the rate of one rank
+    (tools/host_scaling.py)."""
+    from ecseg_amd import utils
+    n = utils.host_cpu_budget()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    monkeypatch.setattr(utils, 'host_cpu_budget', lambda: 16)
+    assert utils.default_io_threads(1) == 32 and utils.default_io_threads(4) == 8 and utils.default_io_threads(8) == 4
+    monkeypatch.setattr(utils, 'host_cpu_budget', lambda: 2)
+    assert utils.default_io_threads(8) == 2                      # never fewer than two
+    monkeypatch.setattr(utils, 'host_cpu_budget', lambda: 256)
+    assert utils.default_io_threads(1) == 32                     # capped
+
+
+def test_host_allocator_tuning_is_optional_and_idempotent(monkeypatch):
+    from ecseg_amd import utils
+    monkeypatch.setattr(utils, '_allocator_tuned', False)
+    monkeypatch.setenv('ECSEG_HOST_MALLOC', 'default')
+    assert utils.tune_host_allocator() is False and utils._allocator_tuned is False      # opt-out: allocator left alone
+    monkeypatch.delenv('ECSEG_HOST_MALLOC')
+    first = utils.tune_host_allocator()
+    assert isinstance(first, bool) and utils._allocator_tuned is True
+    assert utils.tune_host_allocator() is False                                           # once per process
+    a = np.ones((1040, 1392), np.int64)                                                    # the allocator still works
+    assert int(a.sum()) == 1040 * 1392

@@ -185,7 +185,13 @@ def run(inpath, model, image_paths, rank=0, world=1, batch_images=8, io_threads=
 
 def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads, window, pending_writes, n_ec, status, log, stats,
                  resume=False, tie=None, emit_probs=False):
+    # `model`: one model, or a list of models on the same GPU (config key device_workers): one device thread per model takes
+    # batches from the common queue, so the host <-> device copies and the per-call synchronisation of one overlap the kernels of
+    # the other (a narrow model spends a third of a call outside its kernels: DESIGN.md 6)
+    models = list(model) if isinstance(model, (list, tuple)) else [model]
+    model = models[0]
     t_gpu = 0.0
+    t_lock = threading.Lock()
     with cf.ThreadPoolExecutor(io_threads) as readers, cf.ThreadPoolExecutor(io_threads) as writers:
         reads = {}
         next_submit = 0
@@ -199,7 +205,7 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
 
         write_futs = []
 
-        def flush(batch):
+        def flush(batch, model):
             nonlocal t_gpu
             group, imgs = batch
             if not group:
@@ -211,7 +217,8 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
                 return
             t0 = time.perf_counter()
             done, bad = _segment_isolating(model, imgs, log, emit_probs)
-            t_gpu += time.perf_counter() - t0
+            with t_lock:
+                t_gpu += time.perf_counter() - t0
             for j, e in bad:                               # a failing image must not take its batch or the shard down
                 log("Skipping %s (shape %s): %s" % (mine[group[j]], imgs.shape[1:], e))
                 status[group[j]] = 2
@@ -227,15 +234,15 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
 
         # the device calls run on their own thread (one batch in the queue, one on the GPU) so that collecting decoded
         # images and handing results to the writers overlaps the U-Net
-        batches = queue.Queue(maxsize=2)
+        batches = queue.Queue(maxsize=2 * len(models))
 
-        def gpu_loop():
+        def gpu_loop(m):
             while True:
                 g = batches.get()
                 if g is None:
                     return
                 try:
-                    flush(g)
+                    flush(g, m)
                 except BaseException as e:                 # never leave the feeding loop blocked on a dead consumer
                     log("Skipping %d image(s): %r" % (len(g[0]), e))
                     for k in g[0]:
@@ -244,8 +251,9 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
         def pack(group):                                   # the batch array is assembled by the feeder, not by the device thread
             return [k for k, _ in group], np.stack([im for _, im in group])
 
-        gpu_thread = threading.Thread(target=gpu_loop, name='ecseg-gpu')
-        gpu_thread.start()
+        gpu_threads = [threading.Thread(target=gpu_loop, args=(m,), name='ecseg-gpu%d' % i) for i, m in enumerate(models)]
+        for th in gpu_threads:
+            th.start()
         try:
             group, key = [], None
             for k in range(len(mine)):
@@ -268,8 +276,10 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
             if group:
                 batches.put(pack(group))
         finally:
-            batches.put(None)
-            gpu_thread.join()
+            for _ in gpu_threads:
+                batches.put(None)
+            for th in gpu_threads:
+                th.join()
         for k, f in write_futs:
             try:
                 f.result()
@@ -415,14 +425,19 @@ def main(argv=None):
                                        device if device is not None else int(os.environ.get('LOCAL_RANK', '0')), os.environ['ECSEG_RDZV'])
     else:
         rank, world = dist.init_process_group(device=device) if under_launcher else (0, 1)     # RCCL on the same physical GPU
-    model = load_model(MODEL_NAME, device=device)
+    # device_workers (default 1): that many handles - each with its own streams, activation buffers and copy of the weights - on
+    # this rank's GPU, fed from one queue of batches; 2 lifts `make metaseg` with a narrow model, whose calls are a third copies
+    workers = max(1, min(4, int(var.get('device_workers', 1))))
+    models = [load_model(MODEL_NAME, device=device) for _ in range(workers)]
+    model = models[0]
     print(model.handle.device_name)
-    model.handle.set_option('winograd', 1 if precision == 'exact' else 2)
+    for m in models:
+        m.handle.set_option('winograd', 1 if precision == 'exact' else 2)
     image_paths = get_imgs(inpath)
     print("Reading from: ", inpath)
     t0 = time.perf_counter()
     stats = {}
-    rec = run(inpath, model, image_paths, rank, world, batch_images=int(var.get('batch_images', 8)),
+    rec = run(inpath, models if workers > 1 else model, image_paths, rank, world, batch_images=int(var.get('batch_images', 8)),
               io_threads=var.get('io_threads'), stats=stats, resume=bool(var.get('resume', False)), emit_probs=emit_probs)
     failed = finish(inpath, image_paths, rec, rank, seconds=time.perf_counter() - t0, gpu_seconds=stats.get('gpu_seconds', 0.0))
     if native:

@@ -204,3 +204,31 @@ def test_precision_and_emit_probs_config_keys(workdir):
     with pytest.raises(SystemExit) as e:
         metaseg.main([])
     assert e.value.code == 2
+
+
+def test_device_workers_two_handles_same_outputs(workdir):
+    """`metaseg: {device_workers: 2}`: two handles on the same GPU (own streams, activation buffers, weights) fed from one queue of
+    batches; every output file and the CSV equal the one-worker run."""
+    from ecseg_amd import metaseg
+    tmp, inp = workdir
+    cfg_path = tmp / 'config.yaml'
+    base = yaml.safe_load(open(cfg_path))
+    snaps = []
+    for workers in (1, 2):
+        c = dict(base)
+        c['metaseg'] = dict(base['metaseg'], device_workers=workers, batch_images=1)
+        yaml.safe_dump(c, open(cfg_path, 'w'))
+        for sub in ('labels', 'dapi'):
+            shutil.rmtree(str(inp / sub), ignore_errors=True)
+        metaseg.main([])
+        snap = {}
+        for sub in ('labels', 'dapi', ''):
+            d = inp / sub if sub else inp
+            for f in sorted(os.listdir(str(d))):
+                p = d / f
+                if p.is_file() and (sub or f.endswith(('.csv', '.json'))):
+                    snap[os.path.join(sub, f)] = p.read_bytes()
+        snaps.append(snap)
+    assert sorted(snaps[0]) == sorted(snaps[1])
+    for k in snaps[0]:
+        assert snaps[0][k] == snaps[1][k], k

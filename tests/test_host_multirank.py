@@ -248,3 +248,21 @@ def test_one_bad_image_costs_one_status_row_not_its_batch(tmp_path):
     # the batch of 8 was bisected down to the single image: 8 -> 4 (fine) + 4 -> 2 -> 1 (bad) + 1, then the other 2, then image 8
     sizes = [c[0] for c in m.handle.calls]
     assert sizes == [8, 4, 4, 2, 1, 1, 2, 1]
+
+
+def test_two_device_workers_give_the_same_outputs_as_one(tmp_path):
+    """Config key device_workers: several handles on one GPU take batches from one queue (copies of one overlap kernels of the
+    other).  Results - per-image records, files, CSV - must not depend on which worker took which batch."""
+    one, two = str(tmp_path / 'one'), str(tmp_path / 'two')
+    make_inputs(one, 11, corrupt=5)
+    shutil.copytree(one, two)
+    p1, p2 = get_imgs(one), get_imgs(two)
+    rec1 = metaseg.run(one, StubModel(), p1, 0, 1, batch_images=2, io_threads=2, log=lambda *a: None)
+    metaseg.finish(one, p1, rec1, 0, log=lambda *a: None)
+    models = [StubModel(), StubModel()]
+    rec2 = metaseg.run(two, models, p2, 0, 1, batch_images=2, io_threads=2, log=lambda *a: None)
+    metaseg.finish(two, p2, rec2, 0, log=lambda *a: None)
+    assert np.array_equal(rec1, rec2)
+    assert all(len(m.handle.calls) > 0 for m in models), 'a worker never got a batch'
+    a, b = _snapshot(one), _snapshot(two)
+    assert sorted(a) == sorted(b) and all(a[k] == b[k] for k in a)

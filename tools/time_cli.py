@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--io-threads', type=int, default=None)
     ap.add_argument('--keep', default=None)
+    ap.add_argument('--workers', type=int, default=1, help='handles (device threads) on the GPU: config key device_workers')
     a = ap.parse_args()
     from PIL import Image
     import yaml
@@ -44,6 +45,7 @@ def main():
     in_bytes = sum(os.path.getsize(os.path.join(inp, f)) for f in os.listdir(inp))
     cfg = synth.unet_config(base=a.base)
     model = MetasegModel(cfg, synth.unet_weights(cfg, seed=0), device=0)
+    extra = [MetasegModel(cfg, synth.unet_weights(cfg, seed=0), device=0) for _ in range(a.workers - 1)]
     if a.base >= 64:
         model.handle.set_images_per_group(16)          # narrower models: the automatic launch-group size
     with open(os.path.join(work, 'config.yaml'), 'w') as f:
@@ -59,7 +61,7 @@ def main():
         stats = {}
         metaseg.run(warm, model, utils.get_imgs(warm), batch_images=a.batch, log=lambda *x: None, stats=stats)   # first-use allocations
         t0 = time.perf_counter()
-        rec = metaseg.run(inp, model, utils.get_imgs(inp), batch_images=a.batch, io_threads=a.io_threads, log=lambda *x: None, stats=stats)
+        rec = metaseg.run(inp, [model] + extra if extra else model, utils.get_imgs(inp), batch_images=a.batch, io_threads=a.io_threads, log=lambda *x: None, stats=stats)
         dt = time.perf_counter() - t0
     finally:
         metaseg.load_model = real_load
@@ -73,7 +75,7 @@ def main():
     dt_ov = time.perf_counter() - t0
     out_bytes = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(inp) for f in fs) - in_bytes
     print(json.dumps({'what': '`make metaseg` loop: %d RGB LZW TIFF files (1040x1392) -> dapi/*.tif, labels/*.png, labels/*.npy (int64), '
-                              'records' % a.n, 'images': a.n, 'unet_base': a.base, 'batch_images': a.batch,
+                              'records' % a.n, 'images': a.n, 'unet_base': a.base, 'batch_images': a.batch, 'device_workers': a.workers,
                       'io_threads': a.io_threads or 'default', 'cpu_count': os.cpu_count(),
                       'seconds': round(dt, 3), 'images_per_s': round(a.n / dt, 2),
                       'device_call_seconds': round(stats.get('gpu_seconds', 0.0), 3),

@@ -250,7 +250,10 @@ std::vector<float> winograd4_filter(const float* w, int cin, int cout) {
             for (int a = 0; a < 6; ++a)
                 for (int b = 0; b < 6; ++b) {
                     const double u = t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2];
-                    const size_t idx = (((size_t)nb * nstages + stage) * 12 + (half * 6 + a)) * 768 + (((size_t)b * 2 + hh) * 32 + m) * 2 + e;
+                    // per (block, stage, wave): [point pair b / 2][lane = hh * 32 + m][point b % 2][channel e] - ONE ds_read_b128 per lane
+                    // and point pair delivers the B operands of four MFMAs (round 4: three 16-byte reads per stage instead of six
+                    // 8-byte ones; an LDS read beside the MFMA stream costs the matrix pipe ~14 cycles whatever its width)
+                    const size_t idx = (((size_t)nb * nstages + stage) * 12 + (half * 6 + a)) * 768 + ((((size_t)(b >> 1) * 64 + hh * 32 + m) * 2 + (b & 1)) * 2) + e;
                     o[idx] = (float)u;
                 }
         }

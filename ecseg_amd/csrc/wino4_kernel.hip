@@ -193,7 +193,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         const float* src = reinterpret_cast<const float*>((size_t)(d & ~3ull)) + (d & 1ull ? grp * 8 : 0);
         glds16<0>(src, lds_base + (unsigned)((grp % 3) * W4_HS + 64 * (wave + 12 * i)) * 16u);
     };
-    // ---- filter DMA: wt4[nb][stage][wave][point nu][h][cout 32][k 2], 768 floats per wave and stage ----
+    // ---- filter DMA: wt4[nb][stage][wave][point pair nu / 2][lane = h * 32 + cout][nu % 2][k 2], 768 floats per wave and stage ----
     const float* w_src = p.wt + ((size_t)nb * nstages * 12 + (SPLIT ? xi : wave)) * 768 + lane * 4;
     f32x4* Bw = Bs + wave * 2 * W4_BWS;
     auto dma_filter_piece = [&](int stage, int buf, auto kk) __attribute__((always_inline)) {
@@ -323,9 +323,13 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             V[5][e] = __builtin_fmaf(KP, u1, __builtin_fmaf(KS, u3, u5));
         }
         f32x2 w2[6];
-        const f32x2* Bp = reinterpret_cast<const f32x2*>(Bw + fbuf * W4_BWS) + lane;
+        const f32x4* Bp = Bw + fbuf * W4_BWS + lane;        // three 16-byte reads: the fragments of point pairs (0, 1), (2, 3), (4, 5)
 #pragma unroll
-        for (int v = 0; v < 6; ++v) w2[v] = Bp[v * 64];
+        for (int k = 0; k < 3; ++k) {
+            const f32x4 w4 = Bp[k * 64];
+            w2[2 * k] = f32x2{w4[0], w4[1]};
+            w2[2 * k + 1] = f32x2{w4[2], w4[3]};
+        }
         // 12 MFMAs, channel-major: consecutive MFMAs hit different accumulators (dependency distance 6), so even a lone
         // wave keeps the matrix pipe full.  The next stage's three filter pieces go out one at a time behind MFMAs 2, 4
         // and 6 (pinned): the wave's issue slot is free while the pipe works, and the load path never sees a burst.

@@ -168,6 +168,72 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
     //      ring: nobody ever waits for a halo piece to land).  The per-lane source pointers are computed once and parked
     //      in LDS (bit 0 = "advance with the channel group"; padding / out-of-image lanes point at the zero page and do
     //      not advance): no registers held during the K loop ----
+#ifndef ECSEG_W4_BUF
+#define ECSEG_W4_BUF 1
+#endif
+#if ECSEG_W4_BUF
+    // Round 4: the halo goes through a BUFFER descriptor - a workgroup-uniform base (the first of its two windows) in four SGPRs
+    // + one 32-bit byte offset per lane and piece, kept in two registers; lanes that have to read zeros (padding, pixels outside
+    // the image, the missing channel half of a Cin % 8 == 4 tail) hold an out-of-range offset and the hardware returns 0 (no zero
+    // page); the 8-channel group advances through the instruction's scalar offset.  Rounds 1-3 parked 64-bit pointers in LDS
+    // and rebuilt the address of every piece from them: 2 LDS reads + ~20 vector instructions per group - each LDS read beside
+    // the MFMA stream costs the matrix pipe ~14 cycles, each vector instruction ~2.2 (tools/micro/mfma_mix.hip).
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const int img_lo = r_img[0] >= 0 ? (r_img[1] >= 0 && r_img[1] < r_img[0] ? r_img[1] : r_img[0]) : (r_img[1] >= 0 ? r_img[1] : 0);
+    const unsigned long long hb = (unsigned long long)(size_t)(p.in.p + (size_t)img_lo * H * W * p.in.cs);
+    i32x4 hrsrc;                                             // V#: base, stride 0, 2 GB of records, gfx9 raw-buffer word 3
+    hrsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)hb);
+    hrsrc[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(hb >> 32) & 0xffffu));
+    hrsrc[2] = 0x7fff0000;
+    hrsrc[3] = 0x00020000;
+    unsigned hoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int a = 64 * (wave + 12 * i) + lane;
+        unsigned off = 0xffffffffu;
+        if (a < 2 * 18 * 36) {
+            const int g = a >= 648 ? 1 : 0, rem = a - g * 648;
+            const int r = rem / 36, cc = rem - r * 36;
+            const int h = cc >= 18 ? 1 : 0, c = cc - h * 18;
+            const int img = g ? r_img[1] : r_img[0];
+            const int iy = (g ? r_y0[1] : r_y0[0]) - 1 + w4_inv(r), ix = (g ? r_x0[1] : r_x0[0]) - 1 + w4_inv(c);
+            if (img >= 0 && iy >= 0 && iy < H && ix >= 0 && ix < W)      // (two neighbouring windows: far below 2 GB)
+                off = (unsigned)(((((size_t)(img - img_lo) * H + iy) * W + ix) * p.in.cs + 4 * h) * 4);
+        }
+        hoff[i] = off;
+    }
+    auto dma_halo_piece = [&](int grp, auto ii) __attribute__((always_inline)) {            // piece ii (0 | 1) of halo group grp (< ngroups)
+        W4_DIAG_SKIP_HALO_DMA();
+        constexpr int i = decltype(ii)::value;
+        unsigned off = hoff[i];
+        if (tail4 && grp == ngroups - 1) {                   // Cin % 8 == 4: the upper channel half of the last group does not exist
+            const int a = 64 * (wave + 12 * i) + lane;
+            if ((a % 36) >= 18) off = 0xffffffffu;
+        }
+        const unsigned dst = lds_base + (unsigned)((grp % 3) * W4_HS + 64 * (wave + 12 * i)) * 16u;
+        const i32x4 rs = hrsrc;                              // (local copies: asm operands do not capture in a generic lambda)
+        const int soff = grp * 32;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(off), "s"(dst), "s"(rs), "s"(soff) : "memory");
+    };
+    // ---- filter DMA: wt4[nb][stage][wave][point pair nu / 2][lane = h * 32 + cout][nu % 2][k 2], 768 floats per wave and stage; the
+    //      address is a scalar base (advanced per stage by scalar adds) + the lane's constant 16-byte offset ----
+    const unsigned long long w_base = (unsigned long long)(size_t)(p.wt + ((size_t)nb * nstages * 12 + (SPLIT ? xi : wave)) * 768);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    f32x4* Bw = Bs + wave * 2 * W4_BWS;
+    auto dma_filter_piece = [&](int stage, int buf, auto kk) __attribute__((always_inline)) {
+        W4_DIAG_SKIP_FILTER_DMA();
+        constexpr int k = decltype(kk)::value;
+        const unsigned long long g = w_base + (unsigned long long)stage * (12 * 768 * 4);
+        const unsigned dst = lds_base + (unsigned)(3 * W4_HS + (wave * 2 + buf) * W4_BWS) * 16u;
+        const unsigned l16 = lane16;
+        unsigned keep;
+        // the instruction offset advances the global AND the LDS address: one M0 for the three pieces
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 offset:%4\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(l16), "s"(dst), "s"(g), "n"(k * 1024) : "memory");
+    };
+#else
     unsigned long long* Hd = reinterpret_cast<unsigned long long*>(Bs + 12 * 2 * W4_BWS) + tid;   // [2][768]
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -203,6 +269,8 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         // the instruction offset advances the global AND the LDS address: one M0 for the three pieces
         glds16<k * 1024>(g, lds_base + (unsigned)(3 * W4_HS + (wave * 2 + buf) * W4_BWS) * 16u);
     };
+
+#endif
 
     // ---- A-operand lane -> tile.  ds_read_b128 serves lanes {0-3,12-15,20-27} and {4-11,16-19,28-31} of each half
     //      in separate LDS cycles; give each of those groups the 16 tiles of ONE region ----

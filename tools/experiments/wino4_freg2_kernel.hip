@@ -1,0 +1,825 @@
+// Winograd F(4x4, 3x3) convolution on the fp32 matrix cores (gfx950): 36 instead of 144 multiplies per 4x4 output
+// block, i.e. 4x fewer MFMAs than the direct convolution and 1.78x fewer than F(2x2,3x3), still exact-f32 fma chains
+// (v_mfma_f32_32x32x2_f32).
+//
+//   Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A        d: 6x6 input tile, g: 3x3 filter, Y: 4x4 outputs
+//
+// The filter transform U = G g G^T is done once at model load (float64 on the host, api.hip: winograd4_filter).
+//
+// Workgroup = 12 waves = 2 regions of 16x16 output pixels (32 Winograd tiles = the MFMA M dimension) x 64 output
+// channels.  Wave w = (channel half ch = w / 6, transform ROW xi = w % 6): it reads the raw halo rows its row transform
+// needs straight from LDS, forms t[j] = B^T[xi,:] d[:,j] and the six column points V[xi][0..5] in registers and
+// multiplies them with U[xi][nu] on the MFMA (6 points x 16 accumulators = 96 registers); no transformed input ever
+// touches LDS or HBM.  After the K loop every wave folds its own row (R = M[xi][:] A) in registers, the six rows
+// meet through LDS, and Y = A^T R + bias, activation is written as 16-byte stores (128-B segments per pixel).
+//
+// Pipeline: the halo arrives 8 input channels at a time by LDS-DMA into a 3-deep ring, two groups ahead of its use
+// (every wave issues two pieces per group, one at a time behind pinned MFMAs; nobody waits for a piece to land; ONE
+// s_barrier per 8 channels).  The filter fragments are private to a wave (nobody else reads them), so every wave
+// streams its own 3-KB stage (6 points x 4 input channels x 32 output channels) by LDS-DMA into a private double
+// buffer, ordered by its own counted vmcnt only - no barrier on the filter path.  All LDS-DMA goes through inline asm
+// (glds16): the compiler orders every ds_read behind a builtin LDS-DMA with vmcnt(0).  The barrier sits at a different
+// point of the phase sequence (transform, MFMA stage 0, MFMA stage 1) for the three waves of a SIMD (phase rotation).
+//
+// The output stage can also write the 2x2 max-pool of its result, finish a 1x1 head (<= 4 classes) and take its region
+// list from a look-up table (demand-driven cropping) - see ConvParams in common.h.
+//
+// LDS halo image, 16-byte slots (4 channels): slot(g, y, x, h) = (g * 18 + P(y)) * 36 + h * 18 + P(x), where
+// P(v) = {0, 5, 10, 14}[v % 4] + v / 4 regroups the 18 halo rows / columns by their phase modulo the tile stride 4.
+// For a fixed tile offset (i, j) the 16 lanes of a ds_read_b128 group then read slots 36 * ty + tx + const:
+// 36 = 4 (mod 16), so all 16 land on different 16-byte bank groups: conflict-free without padding.  The A-operand
+// lane -> tile map follows the hardware's b128 lane groups (see gty below).
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+#include "device_util.h"
+
+namespace ecseg {
+
+namespace {
+
+constexpr int W4_HS = 1536;          // halo slots per buffer: 2 regions x 18 rows x 36 = 1296 used, padded to 24 x 64
+constexpr int W4_BWS = 192;          // filter slots per wave and stage: 6 points x 2 halves x 32 couts x 2 k / 4
+constexpr int W4_RPLANE = 1056;      // floats per (xi, x) plane of the output exchange image: 32 tiles x 32 couts + 32
+
+__device__ __forceinline__ int w4_pos(int v) {           // 0..17 -> regrouped position
+    const int m = v & 3;
+    return (m == 0 ? 0 : m == 1 ? 5 : m == 2 ? 10 : 14) + (v >> 2);
+}
+__device__ __forceinline__ int w4_inv(int r) {           // regrouped position -> 0..17
+    return r < 5 ? 4 * r : r < 10 ? 4 * (r - 5) + 1 : r < 14 ? 4 * (r - 10) + 2 : 4 * (r - 14) + 3;
+}
+constexpr int w4_cpos(int v) { return ((v & 3) == 0 ? 0 : (v & 3) == 1 ? 5 : (v & 3) == 2 ? 10 : 14) + (v >> 2); }
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// value of an integral_constant argument; 0 for a run-time int (mfma_stage takes either)
+template <class T> struct w4_ic { static constexpr int value = 0; };
+template <int N> struct w4_ic<std::integral_constant<int, N>> { static constexpr int value = N; };
+
+// One LDS-DMA piece: 64 lanes x 16 bytes, global (per-lane address) -> LDS bytes [lds_dst + 16 * lane].  Issued through
+// inline asm on purpose: for the builtin the compiler orders every later ds_read behind the DMA with s_waitcnt vmcnt(0)
+// (it cannot tell the LDS buffers apart), which serialises a stream that is interleaved with LDS reads.  Here the
+// counted vmcnt waits in the kernel are the only ordering (lds_dst is wave-uniform; M0 is restored).
+template <int OFF>
+__device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {      // source = gsrc + OFF bytes
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst), "n"(OFF) : "memory");
+}
+
+// Interpolation points {0, +-a, +-b, inf} (common.h: W4_PA, W4_PB) and the constants of B^T and A^T they give:
+//   B^T rows (monic Lagrange numerators): p = 0: [a2b2, 0, -(a2+b2), 0, 1, 0]      p = inf: [0, a2b2, 0, -(a2+b2), 0, 1]
+//                                         p = +-a: [0, -+a b2, -b2, +-a, 1, 0]     p = +-b: [0, -+a2 b, -a2, +-b, 1, 0]
+//   A^T = [1 1 1 1 1 0; 0 a -a b -b 0; 0 a2 a2 b2 b2 0; 0 a3 -a3 b3 -b3 1]
+// All constants are exact in float32 for the dyadic points chosen.
+constexpr float KA = (float)W4_PA, KB = (float)W4_PB, KA2 = KA * KA, KB2 = KB * KB, KA3 = KA2 * KA, KB3 = KB2 * KB;
+constexpr float KP = KA2 * KB2, KS = -(KA2 + KB2);
+static_assert((double)KA2 == W4_PA * W4_PA && (double)KB3 == W4_PB * W4_PB * W4_PB && (double)KP == W4_PA * W4_PA * W4_PB * W4_PB &&
+              (double)KA3 == W4_PA * W4_PA * W4_PA && (double)(KA * KB2) == W4_PA * W4_PB * W4_PB && (double)(KA2 * KB) == W4_PA * W4_PA * W4_PB,
+              "the Winograd points must keep every transform constant exact in float32");
+
+}  // namespace
+
+// Row-transform pipeline depth (slots of in-flight halo reads beside the six direct ones; 0: rounds 1-3, column by column)
+#ifndef ECSEG_W4_TSLOTS
+#define ECSEG_W4_TSLOTS 3
+#endif
+
+// Diagnostics (timing-only ablations, in-kernel cycle stamps) live in wino4_diag.inc and exist only in the -DECSEG_DIAG
+// build (tools/build_variants.sh diag); the product translation unit has ONE code path: every hook below is empty.
+#ifdef ECSEG_DIAG
+#include "wino4_diag.inc"
+#else
+#define W4_TEMPLATE template <bool HEAD = false, bool SPLIT = false>
+#define W4_DIAG_ENTRY()
+#define W4_DIAG_SKIP_HALO_DMA()
+#define W4_DIAG_SKIP_FILTER_DMA()
+#define W4_DIAG_FAKE_TRANSFORM(grp)
+#define W4_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A, B, ACC, 0, 0, 0)
+#define W4_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define W4_KSTAMP_BEGIN()
+#define WSTAMP(i)
+#define W4_KSTAMP_DUMP()
+#define W4_ESTAMP_BEGIN()
+#define ESTAMP(i)
+#define W4_ESTAMP_DUMP()
+#define W4_DIAG_SELECT(kern, p, lds)
+#endif
+
+// SPLIT (a lone 32-channel output block, Cout == 32): the two channel-half waves of a transform row would otherwise
+// multiply real channels (ch = 0) and zero padding (ch = 1).  Instead both work on the SAME 32 outputs and split the 8
+// input channels of a group: wave (ch, xi) runs only filter stage ch (channels 2 ch, 2 ch + 1 of both halo planes) of every
+// group, from the ch = 0 slot of the unchanged filter image; the partial sums meet in the exchange image of the output
+// stage (ch = 0 writes, ch = 1 adds).  Per group a wave has two phases (T, S) instead of three; waves 4-11 run S one
+// group late (phase rotation).
+W4_TEMPLATE
+__global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_x, int regs_y, int npairs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* Hs = reinterpret_cast<f32x4*>(smem);              // [3][W4_HS]        halo ring (group g -> buffer g % 3)
+    f32x4* Bs = Hs + 3 * W4_HS;                              // [12][2][W4_BWS]   per-wave filter stages
+
+    W4_DIAG_ENTRY();
+    const unsigned lds_base = (unsigned)(size_t)(lptr_t)smem;   // LDS byte address of the dynamic segment
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xi = wave % 6, ch = wave / 6;
+    const int li = lane & 31, lh = lane >> 5;
+
+    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    // Block order: output-channel blocks in groups of G = 4 (2) next to each other, region pairs next, groups slowest.  The
+    // workgroups running together on an XCD then share each input halo in L2 between G of them and keep only G filter
+    // slabs streaming (spatial position fastest alone re-read the input Cout / 64 times from the Infinity Cache: 11-13x
+    // the algorithmic bytes on the Cin = 1024 layers; channel block fastest alone streams Cout / 64 slabs at once): +1.4 %.
+    const unsigned nblk_all = gridDim.x / (unsigned)npairs;
+#ifdef ECSEG_W4_G                                               // (A/B builds only: tools/build_variants.sh ECSEG_W4_G=8)
+    const unsigned G = (nblk_all % ECSEG_W4_G) == 0 ? ECSEG_W4_G : (nblk_all & 3u) == 0 ? 4u : (nblk_all & 1u) == 0 ? 2u : 1u;
+#else
+    const unsigned G = (nblk_all & 3u) == 0 ? 4u : (nblk_all & 1u) == 0 ? 2u : 1u;
+#endif
+    const unsigned lo = bid % G, rest = bid / G;
+    const int pair = (int)(rest % (unsigned)npairs);
+    const int nb = (int)((rest / (unsigned)npairs) * G + lo);
+    const int H = p.in.h, W = p.in.w;                        // output extent == input extent
+    const int ngroups = p.cin_chunks;                        // 8 input channels each
+    const int nstages = 2 * ngroups;
+    const bool tail4 = (p.in.c & 7) != 0;                    // (pointers are 16-byte aligned: bits 0 / 1 carry lane flags)
+
+    // the two 16 x 16 regions of this workgroup: consecutive in (patch, region row, region column) order
+    int r_img[2], r_y0[2], r_x0[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int rid = 2 * pair + g;
+        int rx, ry, img;
+        if (p.lut != nullptr) {                              // cropped launch: the regions some later stage reads
+            const int i = rid / p.lut_len, v = p.lut[rid - i * p.lut_len];
+            img = i * p.per_image + (v >> 16); ry = (v >> 8) & 255; rx = v & 255;      // origins in 4-pixel tiles
+            if (i >= p.n / p.per_image) img = p.n;
+            r_img[g] = img < p.n ? img : -1;
+            r_y0[g] = ry * 4; r_x0[g] = rx * 4;
+            continue;
+        } else {
+            rx = rid % regs_x;
+            const int t = rid / regs_x;
+            ry = t % regs_y; img = t / regs_y;
+        }
+        r_img[g] = img < p.n ? img : -1;
+        r_y0[g] = ry * 16; r_x0[g] = rx * 16;
+    }
+
+    // ---- halo DMA: every wave fills slots 64 k + lane, k = wave and wave + 12, two groups ahead of its use (3-deep
+    //      ring: nobody ever waits for a halo piece to land).  The per-lane source pointers are computed once and parked
+    //      in LDS (bit 0 = "advance with the channel group"; padding / out-of-image lanes point at the zero page and do
+    //      not advance): no registers held during the K loop ----
+#ifndef ECSEG_W4_BUF
+#define ECSEG_W4_BUF 1
+#endif
+#if ECSEG_W4_BUF
+    // Round 4: the halo goes through a BUFFER descriptor - a workgroup-uniform base (the first of its two windows) in four SGPRs
+    // + one 32-bit byte offset per lane and piece, kept in two registers; lanes that have to read zeros (padding, pixels outside
+    // the image, the missing channel half of a Cin % 8 == 4 tail) hold an out-of-range offset and the hardware returns 0 (no zero
+    // page); the 8-channel group advances through the instruction's scalar offset.  Rounds 1-3 parked 64-bit pointers in LDS
+    // and rebuilt the address of every piece from them: 2 LDS reads + ~20 vector instructions per group - each LDS read beside
+    // the MFMA stream costs the matrix pipe ~14 cycles, each vector instruction ~2.2 (tools/micro/mfma_mix.hip).
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const int img_lo = r_img[0] >= 0 ? (r_img[1] >= 0 && r_img[1] < r_img[0] ? r_img[1] : r_img[0]) : (r_img[1] >= 0 ? r_img[1] : 0);
+    const unsigned long long hb = (unsigned long long)(size_t)(p.in.p + (size_t)img_lo * H * W * p.in.cs);
+    i32x4 hrsrc;                                             // V#: base, stride 0, 2 GB of records, gfx9 raw-buffer word 3
+    hrsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)hb);
+    hrsrc[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(hb >> 32) & 0xffffu));
+    hrsrc[2] = 0x7fff0000;
+    hrsrc[3] = 0x00020000;
+    unsigned hoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int a = 64 * (wave + 12 * i) + lane;
+        unsigned off = 0xffffffffu;
+        if (a < 2 * 18 * 36) {
+            const int g = a >= 648 ? 1 : 0, rem = a - g * 648;
+            const int r = rem / 36, cc = rem - r * 36;
+            const int h = cc >= 18 ? 1 : 0, c = cc - h * 18;
+            const int img = g ? r_img[1] : r_img[0];
+            const int iy = (g ? r_y0[1] : r_y0[0]) - 1 + w4_inv(r), ix = (g ? r_x0[1] : r_x0[0]) - 1 + w4_inv(c);
+            if (img >= 0 && iy >= 0 && iy < H && ix >= 0 && ix < W)      // (two neighbouring windows: far below 2 GB)
+                off = (unsigned)(((((size_t)(img - img_lo) * H + iy) * W + ix) * p.in.cs + 4 * h) * 4);
+        }
+        hoff[i] = off;
+    }
+    auto dma_halo_piece = [&](int grp, auto ii) __attribute__((always_inline)) {            // piece ii (0 | 1) of halo group grp (< ngroups)
+        W4_DIAG_SKIP_HALO_DMA();
+        constexpr int i = decltype(ii)::value;
+        unsigned off = hoff[i];
+        if (tail4 && grp == ngroups - 1) {                   // Cin % 8 == 4: the upper channel half of the last group does not exist
+            const int a = 64 * (wave + 12 * i) + lane;
+            if ((a % 36) >= 18) off = 0xffffffffu;
+        }
+        const unsigned dst = lds_base + (unsigned)((grp % 3) * W4_HS + 64 * (wave + 12 * i)) * 16u;
+        const i32x4 rs = hrsrc;                              // (local copies: asm operands do not capture in a generic lambda)
+        const int soff = grp * 32;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(off), "s"(dst), "s"(rs), "s"(soff) : "memory");
+    };
+    // ---- filter DMA: wt4[nb][stage][wave][point pair nu / 2][lane = h * 32 + cout][nu % 2][k 2], 768 floats per wave and stage; the
+    //      address is a scalar base (advanced per stage by scalar adds) + the lane's constant 16-byte offset ----
+    const unsigned long long w_base = (unsigned long long)(size_t)(p.wt + ((size_t)nb * nstages * 12 + (SPLIT ? xi : wave)) * 768);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    f32x4* Bw = Bs + wave * 2 * W4_BWS;
+    auto dma_filter_piece = [&](int stage, int buf, auto kk) __attribute__((always_inline)) {
+        W4_DIAG_SKIP_FILTER_DMA();
+        constexpr int k = decltype(kk)::value;
+        const unsigned long long g = w_base + (unsigned long long)stage * (12 * 768 * 4);
+        const unsigned dst = lds_base + (unsigned)(3 * W4_HS + (wave * 2 + buf) * W4_BWS) * 16u;
+        const unsigned l16 = lane16;
+        unsigned keep;
+        // the instruction offset advances the global AND the LDS address: one M0 for the three pieces
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 offset:%4\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(l16), "s"(dst), "s"(g), "n"(k * 1024) : "memory");
+    };
+    // Round 4, last step: in the plain kernel (no fused head, no SPLIT) the filter fragments skip LDS altogether - three plain 16-byte
+    // global loads per stage into one of two register buffers, issued behind the stage's last MFMAs and used by the next stage
+    // (the compiler's own vmcnt before the first use covers them; every LDS-DMA of the stage is older).  Six LDS reads per group
+    // less (~14 matrix-pipe cycles each); the 12 extra registers come from the buffer addressing above and one transform slot.
+#ifndef ECSEG_W4_FREG2
+#define ECSEG_W4_FREG2 1
+#endif
+    constexpr bool FR = ECSEG_W4_FREG2 && !HEAD && !SPLIT;
+    // ONE buffer of three 4-register pieces (point pairs (0, 1), (2, 3), (4, 5)): the MFMAs of a stage run point-major, so piece k is
+    // free after MFMA 4 k + 4 and the next stage's piece k is loaded into the same registers right there - every piece has exactly
+    // one stage of lookahead and the wave holds 12 filter registers, not 24
+    f32x4 wq[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) wq[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto load_filter_piece = [&](int stage, auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        const f32x4* gw = reinterpret_cast<const f32x4*>((size_t)(w_base + (unsigned long long)stage * (12 * 768 * 4))) + lane;
+        wq[k] = gw[k * 64];
+    };
+#else
+    constexpr bool FR = false;
+    unsigned long long* Hd = reinterpret_cast<unsigned long long*>(Bs + 12 * 2 * W4_BWS) + tid;   // [2][768]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int a = 64 * (wave + 12 * i) + lane;
+        unsigned long long d = (unsigned long long)(size_t)p.zero;
+        if (a < 2 * 18 * 36) {
+            const int g = a >= 648 ? 1 : 0, rem = a - g * 648;
+            const int r = rem / 36, cc = rem - r * 36;
+            const int h = cc >= 18 ? 1 : 0, c = cc - h * 18;
+            const int img = g ? r_img[1] : r_img[0];
+            const int iy = (g ? r_y0[1] : r_y0[0]) - 1 + w4_inv(r), ix = (g ? r_x0[1] : r_x0[0]) - 1 + w4_inv(c);
+            if (img >= 0 && iy >= 0 && iy < H && ix >= 0 && ix < W)
+                d = (unsigned long long)(size_t)(p.in.p + (((size_t)img * H + iy) * W + ix) * p.in.cs + 4 * h) | 1ull | (h ? 2ull : 0ull);
+        }
+        Hd[i * 768] = d;
+    }
+    auto dma_halo_piece = [&](int grp, auto ii) __attribute__((always_inline)) {            // piece ii (0 | 1) of halo group grp (< ngroups)
+        W4_DIAG_SKIP_HALO_DMA();
+        constexpr int i = decltype(ii)::value;
+        unsigned long long d = Hd[i * 768];
+        // Cin % 8 == 4: the upper channel half of the last group does not exist - its lanes (bit 1) read the zero page
+        if (tail4 && grp == ngroups - 1 && (d & 2ull)) d = (unsigned long long)(size_t)p.zero;
+        const float* src = reinterpret_cast<const float*>((size_t)(d & ~3ull)) + (d & 1ull ? grp * 8 : 0);
+        glds16<0>(src, lds_base + (unsigned)((grp % 3) * W4_HS + 64 * (wave + 12 * i)) * 16u);
+    };
+    // ---- filter DMA: wt4[nb][stage][wave][point pair nu / 2][lane = h * 32 + cout][nu % 2][k 2], 768 floats per wave and stage ----
+    const float* w_src = p.wt + ((size_t)nb * nstages * 12 + (SPLIT ? xi : wave)) * 768 + lane * 4;
+    f32x4* Bw = Bs + wave * 2 * W4_BWS;
+    auto dma_filter_piece = [&](int stage, int buf, auto kk) __attribute__((always_inline)) {
+        W4_DIAG_SKIP_FILTER_DMA();
+        constexpr int k = decltype(kk)::value;
+        const float* g = w_src + (size_t)stage * (12 * 768);
+        // the instruction offset advances the global AND the LDS address: one M0 for the three pieces
+        glds16<k * 1024>(g, lds_base + (unsigned)(3 * W4_HS + (wave * 2 + buf) * W4_BWS) * 16u);
+    };
+
+#endif
+
+    // ---- A-operand lane -> tile.  ds_read_b128 serves lanes {0-3,12-15,20-27} and {4-11,16-19,28-31} of each half
+    //      in separate LDS cycles; give each of those groups the 16 tiles of ONE region ----
+    const int q8 = li >> 2, tx = li & 3;
+    const int tg = (0x96 >> q8) & 1;                              // region of lane quad q8: 0,1,1,0,1,0,0,1
+    const int ty = (q8 == 0 || q8 == 1) ? 0 : (q8 == 2 || q8 == 3) ? 1 : (q8 == 4 || q8 == 5) ? 2 : 3;
+    const int a_lane = (tg * 18 + ty) * 36 + lh * 18 + tx;       // slot of halo pixel (4 ty, 4 tx) of the lane's tile
+
+    // row transform of wave xi (row xi of B^T): t = c0 d[r0] + c1 d[r1] + c2 d[r2] + d[r3]  (rows 0 and 5: three terms)
+    int rr0, rr1, rr2, rr3; float c0, c1, c2;
+    switch (xi) {
+        case 0:  rr0 = 0; rr1 = 2; rr2 = 4; rr3 = 4; c0 = KP;        c1 = KS;   c2 = 1.f; break;
+        case 1:  rr0 = 1; rr1 = 2; rr2 = 3; rr3 = 4; c0 = -KA * KB2; c1 = -KB2; c2 = KA;  break;
+        case 2:  rr0 = 1; rr1 = 2; rr2 = 3; rr3 = 4; c0 = KA * KB2;  c1 = -KB2; c2 = -KA; break;
+        case 3:  rr0 = 1; rr1 = 2; rr2 = 3; rr3 = 4; c0 = -KA2 * KB; c1 = -KA2; c2 = KB;  break;
+        case 4:  rr0 = 1; rr1 = 2; rr2 = 3; rr3 = 4; c0 = KA2 * KB;  c1 = -KA2; c2 = -KB; break;
+        default: rr0 = 1; rr1 = 3; rr2 = 5; rr3 = 5; c0 = KP;        c1 = KS;   c2 = 1.f; break;
+    }
+    const int ro0 = 36 * w4_pos(rr0), ro1 = 36 * w4_pos(rr1), ro2 = 36 * w4_pos(rr2), ro3 = 36 * w4_pos(rr3);
+
+    f32x16 acc[6];
+#pragma unroll
+    for (int v = 0; v < 6; ++v)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[v][e] = 0.f;
+
+    f32x4 t[6];
+    if (SPLIT) {                                             // (components 2, 3 are never written in this mode: keep the vectors defined)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) t[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // ---- row transform of group grp: t[j] for the six halo columns of the lane's tile, 4 channels each ----
+    // Rows 1-4 of B^T end in +1 (t = c0 d[r0] + c1 d[r1] + c2 d[r2] + d[r3]: three fmas), rows 0 and 5 have only three
+    // terms, the last with +1 (t = c0 d[r0] + c1 d[r1] + d[r2]: three reads, two fmas) - for any point set of this shape.
+    const bool inner_row = xi >= 1 && xi <= 4;
+    auto transform = [&](int grp, auto c_src, auto c_num) __attribute__((always_inline)) {   // t[j][k] = row transform of channel c_src + k of the lane's slot, k < c_num (SPLIT: the wave's two channels, in components 0 and 1)
+        constexpr int CS = decltype(c_src)::value, CN = decltype(c_num)::value;
+        const f32x4* A = Hs + (grp % 3) * W4_HS + a_lane;
+        constexpr int cp[6] = {w4_cpos(0), w4_cpos(1), w4_cpos(2), w4_cpos(3), w4_cpos(4), w4_cpos(5)};
+        W4_DIAG_FAKE_TRANSFORM(grp);
+        // scalar fmas on purpose (file is built with -fno-slp-vectorize): packed f32 VALU ops (v_pk_fma_f32) stall the
+        // SIMD beside MFMAs, single v_fma_f32 hide in the matrix pipe's shadow
+        // Software-pipelined (round 4): the phase used to be six LDS round trips behind each other (one per halo column:
+        // 3 - 4 reads, wait, 12 fmas) and took 2200 - 3200 cycles per group - the three transforms of a SIMD's waves add up to the
+        // group period (in-kernel stamps).  Now the LAST term of every column is read straight into t[j] (it enters the
+        // chain with coefficient 1), the other reads go through NS rotating slots: each step waits for ONE read, accumulates it
+        // into its column (four fmas) and re-issues the slot, so NS reads are always in flight.  The fma chain of a column runs in
+        // the same order as before (innermost term first): results are bit-identical.
+        constexpr int NS = ECSEG_W4_TSLOTS;
+        // CN == 4: the lane's whole 16-byte slots; CN == 2 (SPLIT, round 4): only the wave's two channels CS, CS + 1 of every slot
+        // (8-byte reads, half the fmas - a SPLIT wave multiplies half as often per group, so the row transform weighed twice as
+        // much per MFMA there: 64 -> 32 channels ran at 0.315 of the peak, half the rate of the unsplit layers)
+        static_assert((CN == 4 && CS == 0) || (CN == 2 && (CS == 0 || CS == 2)), "whole slots or one channel pair");
+        typedef typename std::conditional<CN == 4, f32x4, f32x2>::type vt;
+        auto rd = [&](int slot) __attribute__((always_inline)) -> vt {
+            if constexpr (CN == 4) return A[slot];
+            else return reinterpret_cast<const f32x2*>(A + slot)[CS / 2];
+        };
+        vt sl[NS];
+        if (inner_row) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const vt d = rd(ro3 + cp[j]);
+#pragma unroll
+                for (int c = 0; c < CN; ++c) t[j][CS + c] = d[c];
+            }
+#define W4_TRD(i) rd(((i) % 3 == 0 ? ro2 : (i) % 3 == 1 ? ro1 : ro0) + cp[(i) / 3])
+#pragma unroll
+            for (int k = 0; k < NS; ++k) sl[k] = W4_TRD(k);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 18; ++i) {
+                const float cf = i % 3 == 0 ? c2 : i % 3 == 1 ? c1 : c0;
+#pragma unroll
+                for (int c = 0; c < CN; ++c) t[i / 3][CS + c] = __builtin_fmaf(cf, sl[i % NS][c], t[i / 3][CS + c]);
+                if (i + NS < 18) sl[i % NS] = W4_TRD(i + NS);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef W4_TRD
+        } else {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const vt d = rd(ro2 + cp[j]);
+#pragma unroll
+                for (int c = 0; c < CN; ++c) t[j][CS + c] = d[c];
+            }
+#define W4_TRD(i) rd(((i) % 2 == 0 ? ro1 : ro0) + cp[(i) / 2])
+#pragma unroll
+            for (int k = 0; k < NS; ++k) sl[k] = W4_TRD(k);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const float cf = i % 2 == 0 ? c1 : c0;
+#pragma unroll
+                for (int c = 0; c < CN; ++c) t[i / 2][CS + c] = __builtin_fmaf(cf, sl[i % NS][c], t[i / 2][CS + c]);
+                if (i + NS < 12) sl[i % NS] = W4_TRD(i + NS);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef W4_TRD
+        }
+    };
+    // ---- one filter stage (2 of the group's 4 channel pairs; buffer ss): column transform + 12 MFMAs ----
+    auto mfma_stage = [&](int ss, auto fbufc, int next_stage, int halo_grp) __attribute__((always_inline)) {     // ss: channel pair of the group, fbufc: filter buffer (int, or an integral_constant where the register path needs it); halo_grp: group to prefetch, < 0: none
+        int fbuf;
+        if constexpr (std::is_same<decltype(fbufc), int>::value) fbuf = fbufc; else fbuf = w4_ic<decltype(fbufc)>::value;
+        const int nbuf = fbuf ^ 1;
+        float V[6][2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {   // V[nu] = sum_j B^T[nu][j] t[j], scalar ops (see transform)
+            const int c = 2 * ss + e;
+            const float u0 = t[0][c], u1 = t[1][c], u2 = t[2][c], u3 = t[3][c], u4 = t[4][c], u5 = t[5][c];
+            // points +-a share an even part (u4 - b2 u2) and an odd part (u3 - b2 u1), points +-b likewise with a2
+            const float ea = __builtin_fmaf(-KB2, u2, u4), oa = __builtin_fmaf(-KB2, u1, u3);
+            const float eb = __builtin_fmaf(-KA2, u2, u4), ob = __builtin_fmaf(-KA2, u1, u3);
+            V[0][e] = __builtin_fmaf(KP, u0, __builtin_fmaf(KS, u2, u4));
+            V[1][e] = __builtin_fmaf(KA, oa, ea);
+            V[2][e] = __builtin_fmaf(-KA, oa, ea);
+            V[3][e] = __builtin_fmaf(KB, ob, eb);
+            V[4][e] = __builtin_fmaf(-KB, ob, eb);
+            V[5][e] = __builtin_fmaf(KP, u1, __builtin_fmaf(KS, u3, u5));
+        }
+        f32x2 w2[6];
+        if constexpr (FR) {                                 // fragments of point pairs (0, 1), (2, 3), (4, 5) from the register buffer
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                w2[2 * k] = f32x2{wq[k][0], wq[k][1]};
+                w2[2 * k + 1] = f32x2{wq[k][2], wq[k][3]};
+            }
+        } else {
+            const f32x4* Bp = Bw + fbuf * W4_BWS + lane;    // three 16-byte LDS reads
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const f32x4 w4 = Bp[k * 64];
+                w2[2 * k] = f32x2{w4[0], w4[1]};
+                w2[2 * k + 1] = f32x2{w4[2], w4[3]};
+            }
+        }
+        if constexpr (FR) {
+            // register path: 12 MFMAs POINT-major (the two channels of a point back to back: an accumulation chain of this
+            // instruction issues at the pipe's own rate, and the order per accumulator is unchanged), halo pieces behind MFMAs 2
+            // and 6, the next stage's fragment pieces behind MFMAs 4, 8 and 12 - into the registers the MFMAs before them
+            // have just read
+#pragma unroll
+            for (int v = 0; v < 6; ++v)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    W4_MFMA(acc[v], V[v][e], w2[v][e]);
+                    const int k = 2 * v + e;
+                    if ((k == 1 || k == 5) && halo_grp >= 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (k == 1) dma_halo_piece(halo_grp, std::integral_constant<int, 0>{});
+                        if (k == 5) dma_halo_piece(halo_grp, std::integral_constant<int, 1>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if ((k == 3 || k == 7 || k == 11) && next_stage >= 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (k == 3) load_filter_piece(next_stage, std::integral_constant<int, 0>{});
+                        if (k == 7) load_filter_piece(next_stage, std::integral_constant<int, 1>{});
+                        if (k == 11) load_filter_piece(next_stage, std::integral_constant<int, 2>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+        } else {
+        // 12 MFMAs, channel-major: consecutive MFMAs hit different accumulators (dependency distance 6), so even a lone
+        // wave keeps the matrix pipe full.  The next stage's three filter pieces go out one at a time behind MFMAs 2, 4
+        // and 6 (pinned): the wave's issue slot is free while the pipe works, and the load path never sees a burst.
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int v = 0; v < 6; ++v) {
+                W4_MFMA(acc[v], V[v][e], w2[v][e]);
+                if (e == 0 && (v == 1 || v == 3 || v == 5)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (v == 1) dma_filter_piece(next_stage, nbuf, std::integral_constant<int, 0>{});
+                    if (v == 3) dma_filter_piece(next_stage, nbuf, std::integral_constant<int, 1>{});
+                    if (v == 5) dma_filter_piece(next_stage, nbuf, std::integral_constant<int, 2>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (e == 1 && (v == 1 || v == 3) && halo_grp >= 0) {       // behind MFMAs 8 and 10
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (v == 1) dma_halo_piece(halo_grp, std::integral_constant<int, 0>{});
+                    if (v == 3) dma_halo_piece(halo_grp, std::integral_constant<int, 1>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    };
+#define W4_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+    W4_KSTAMP_BEGIN();
+    // Phase rotation.  Per 8-channel group a wave has three phases: T (halo LDS reads + row transform, latency-bound),
+    // S0 and S1 (12 MFMAs each).  The barrier would keep the three waves of a SIMD (w, w + 4, w + 8) in the same phase,
+    // with the matrix pipe idle while all of them transform.  So the barrier sits at a different point of each wave's
+    // phase sequence: class 0 (waves 0-3, also the halo loaders) runs T(g) S0(g) S1(g) after barrier g, class 1 runs
+    // S1(g-1) T(g) S0(g), class 2 runs S0(g-1) S1(g-1) T(g): at any time one wave of a SIMD transforms while the other
+    // two feed the matrix pipe.  t[] lives in registers across the barrier; every class executes ngroups barriers and
+    // reads halo group g only between barriers g and g+1.
+#define W4_SB() __builtin_amdgcn_sched_barrier(0)
+// T(g): raised priority for the few long-latency instructions of the transform; afterwards the MFMA phases run at a
+// priority that orders the three waves of a SIMD (class 2 first): the wave that is latest in the rotation gets the pipe
+// Priorities (round 4, A/B on one box, per-layer tables in gpurun_out/r04_ab1): the MATRIX phases run above the transform
+// (transform 0, matrix phases 1 / 2 / 3 by rotation class): 1024 -> 512 at 32x32 13.83 -> 13.35 ms, 512 -> 512 6.92-7.11 -> 6.73-6.78,
+// every other layer +-0.5 %; the transform is latency-bound on its LDS reads and loses nothing at priority 0, a ready MFMA
+// no longer waits behind another wave's burst of 12 transform fmas.  (ECSEG_W4_PRIO=0: rounds 1-3, transform at 3, matrix
+// phases 0 / 1 / 2; =2: no priorities at all, -6 %.)
+#ifndef ECSEG_W4_PRIO
+#define ECSEG_W4_PRIO 1
+#endif
+#if ECSEG_W4_PRIO == 0
+#define W4_PT 3
+#define W4_PS(PR) (PR)
+#elif ECSEG_W4_PRIO == 1
+#define W4_PT 0
+#define W4_PS(PR) ((PR) + 1)
+#else
+#define W4_PT 0
+#define W4_PS(PR) 0
+#endif
+#define W4_T(g, PR) do { __builtin_amdgcn_s_setprio(W4_PT); transform(g, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}); __builtin_amdgcn_s_setprio(W4_PS(PR)); } while (0)
+    // S0(g): filter stage 2g has landed (it is the youngest thing this wave issued) -> vmcnt(0); streams stage 2g+1 and
+    // the halo of group g+2.  S1(g): only the two halo pieces issued after stage 2g+1 may still fly -> vmcnt(2).
+#define W4_S0(g) do { W4_SB(); if (!FR) W4_WAIT(0); W4_SB(); mfma_stage(0, std::integral_constant<int, 0>{}, 2 * (g) + 1, (g) + 2 < ngroups ? (g) + 2 : -1); } while (0)
+#define W4_S1(g) do { W4_SB(); if (!FR) { if ((g) + 2 < ngroups) W4_WAIT(2); else W4_WAIT(0); } W4_SB(); \
+                      mfma_stage(1, std::integral_constant<int, 1>{}, (g) + 1 < ngroups ? 2 * (g) + 2 : (FR ? -1 : 2 * (g)), -1); } while (0)
+// SPLIT: T(g) of the wave's two channels 2 ch, 2 ch + 1 only (round 4, in the slot-pipelined form; the column-by-column two-channel
+// transform of round 2 made the register allocator spill ~100 registers); S(g) = its one filter stage of group g (stage 2 g + ch of the image, private
+// buffer g & 1): everything this wave issued has landed (vmcnt(0): the filter of this group and its halo pieces of group
+// g + 1); streams the filter of group g + 1 and the halo of group g + 2
+#define W4_TS(g, PR) do { __builtin_amdgcn_s_setprio(W4_PT); \
+                          transform(g, std::integral_constant<int, 2 * CH>{}, std::integral_constant<int, 2>{}); \
+                          __builtin_amdgcn_s_setprio(W4_PS(PR)); } while (0)
+#define W4_SS(g) do { W4_SB(); W4_WAIT(0); W4_SB(); \
+                      mfma_stage(CH, (g) & 1, ((g) + 1 < ngroups ? 2 * (g) + 2 : 2 * (g)) + CH, (g) + 2 < ngroups ? (g) + 2 : -1); } while (0)
+    const int cls = wave >> 2;
+    dma_halo_piece(0, std::integral_constant<int, 0>{});
+    dma_halo_piece(0, std::integral_constant<int, 1>{});
+    if (ngroups > 1) {
+        dma_halo_piece(1, std::integral_constant<int, 0>{});
+        dma_halo_piece(1, std::integral_constant<int, 1>{});
+    }
+    if constexpr (FR) {
+        load_filter_piece(0, std::integral_constant<int, 0>{});
+        load_filter_piece(0, std::integral_constant<int, 1>{});
+        load_filter_piece(0, std::integral_constant<int, 2>{});
+    } else {
+        dma_filter_piece(SPLIT ? ch : 0, 0, std::integral_constant<int, 0>{});
+        dma_filter_piece(SPLIT ? ch : 0, 0, std::integral_constant<int, 1>{});
+        dma_filter_piece(SPLIT ? ch : 0, 0, std::integral_constant<int, 2>{});
+    }
+    if (ngroups > 1) W4_WAIT(5); else W4_WAIT(3);            // halo group 0 has landed (group 1: before barrier 1, below)
+    if (SPLIT) {
+        // two phases per group.  Waves 0-3 run T(g) S(g) after barrier g; waves 4-11 run S(g - 1) T(g): while one class
+        // transforms, the other feeds the matrix pipe.  The late waves' halo pieces of group g + 1 go out in period g (inside
+        // S(g - 1)) and are waited for before barrier g + 1.
+        auto kloop = [&](auto chc) __attribute__((always_inline)) {      // (one copy of the loop per channel half: no branch inside)
+            constexpr int CH = decltype(chc)::value;
+            if (cls == 0) {
+                for (int grp = 0; grp < ngroups; ++grp) {
+                    W4_BARRIER();
+                    W4_TS(grp, 0);
+                    W4_SS(grp);
+                }
+            } else {
+                W4_BARRIER();
+                W4_TS(0, 1);
+                for (int grp = 1; grp < ngroups; ++grp) {
+                    W4_WAIT(0);
+                    W4_BARRIER();
+                    W4_SS(grp - 1);
+                    W4_TS(grp, 1);
+                }
+                W4_SS(ngroups - 1);
+            }
+        };
+        if (ch == 0) kloop(std::integral_constant<int, 0>{}); else kloop(std::integral_constant<int, 1>{});
+    } else if (cls == 0) {
+        for (int grp = 0; grp < ngroups; ++grp) {
+            WSTAMP(0);
+            W4_BARRIER();
+            WSTAMP(1);
+            W4_T(grp, 0);
+            WSTAMP(2);
+            W4_S0(grp);
+            WSTAMP(3);
+            W4_S1(grp);
+            WSTAMP(4);
+        }
+    } else if (cls == 1) {
+        W4_BARRIER();
+        W4_T(0, 1);
+        W4_S0(0);
+        for (int grp = 1; grp < ngroups; ++grp) {
+            WSTAMP(0);
+            W4_BARRIER();
+            WSTAMP(1);
+            W4_S1(grp - 1);
+            WSTAMP(2);
+            W4_T(grp, 1);
+            WSTAMP(3);
+            W4_S0(grp);
+            WSTAMP(4);
+        }
+        W4_S1(ngroups - 1);
+    } else {
+        W4_BARRIER();
+        W4_T(0, 2);
+        for (int grp = 1; grp < ngroups; ++grp) {
+            W4_WAIT(3);                                      // own halo pieces of group grp + 0/1 landed (3 filter pieces may fly)
+            WSTAMP(0);
+            W4_BARRIER();
+            WSTAMP(1);
+            W4_S0(grp - 1);
+            WSTAMP(2);
+            W4_S1(grp - 1);
+            WSTAMP(3);
+            W4_T(grp, 2);
+            WSTAMP(4);
+        }
+        W4_S0(ngroups - 1);
+        W4_S1(ngroups - 1);
+    }
+#undef W4_T
+#undef W4_S0
+#undef W4_S1
+#undef W4_TS
+#undef W4_SS
+#undef W4_SB
+    W4_KSTAMP_DUMP();
+#undef W4_BARRIER
+
+    // ---- output stage: two passes (channel halves) through a [xi][x][tile][32 couts] exchange image ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the compiler does not see the asm LDS-DMAs
+    float* Rs = reinterpret_cast<float*>(smem);
+    const int Cout = p.out.c;
+    W4_ESTAMP_BEGIN();
+    // Work split of the combine step: per pass 2048 "half items" (channel quad q, column x, tile n, row pair yh) over the
+    // 768 threads in three rounds (the last one 2/3 full) - with whole items (1024 over 768 threads) the first four
+    // waves did two rounds of 4 rows while the others idled behind them.
+    float hl[3][2][4];                                       // fused 1x1 head: partial logits [round][row of the pair][class]
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hl[a][b][c] = 0.f;
+    // the bias quads of both passes are fetched here, under the K loop's drain and the first barrier: a global load inside
+    // the combine step would queue behind the previous pass's output stores (one in-order vmcnt)
+    f32x4 bvp[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (p.bias != nullptr) {
+        bvp[0] = *reinterpret_cast<const f32x4*>(p.bias + nb * 64 + 4 * (tid & 7));
+        if (nb * 64 + 32 < Cout) bvp[1] = *reinterpret_cast<const f32x4*>(p.bias + nb * 64 + 32 + 4 * (tid & 7));
+    }
+    // fold the wave's own row (R = M[xi][:] A) into the exchange image; `add` (SPLIT, ch = 1): onto the partner's partial sums
+    auto write_R = [&](auto add_c) __attribute__((always_inline)) {
+        constexpr bool add = decltype(add_c)::value;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int tl = (e & 3) + 8 * (e >> 2) + 4 * lh;               // accumulator row = tile slot
+            const float m0 = acc[0][e], m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e], m5 = acc[5][e];
+            const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+            float* o = Rs + (xi * 4) * W4_RPLANE + tl * 32 + li;
+            const float r0 = m0 + s12 + s34, r1 = __builtin_fmaf(KA, d12, KB * d34), r2 = __builtin_fmaf(KA2, s12, KB2 * s34),
+                        r3 = __builtin_fmaf(KA3, d12, __builtin_fmaf(KB3, d34, m5));
+            if (add) {                                           // (this lane's four words: nobody else touches them in this phase)
+                o[0 * W4_RPLANE] += r0; o[1 * W4_RPLANE] += r1; o[2 * W4_RPLANE] += r2; o[3 * W4_RPLANE] += r3;
+            } else {
+                o[0 * W4_RPLANE] = r0; o[1 * W4_RPLANE] = r1; o[2 * W4_RPLANE] = r2; o[3 * W4_RPLANE] = r3;
+            }
+        }
+    };
+    for (int pass = 0; pass < (SPLIT ? 1 : 2); ++pass) {
+        __syncthreads();                                     // main-loop LDS reads / previous pass's combine are done
+        ESTAMP(0);                                           // [0] barrier (K-loop skew / previous combine)
+        if (SPLIT) {
+            if (ch == 0) write_R(std::false_type{});
+            __syncthreads();
+            if (ch == 1) write_R(std::true_type{});
+        } else if (ch == pass) {
+            write_R(std::false_type{});
+        }
+        ESTAMP(1);                                           // [1] fold own row + write R to LDS
+        __syncthreads();
+        ESTAMP(2);                                           // [2] barrier
+        const int n0 = nb * 64 + pass * 32;
+        const f32x4 bv = pass ? bvp[1] : bvp[0];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int item = tid + k * 768;
+            if (item >= 2048) break;
+            const int q = item & 7, x = (item >> 3) & 3, n = (item >> 5) & 31, yh = item >> 10;
+            const int nq8 = n >> 2, ntx = n & 3;
+            const int g = (0x96 >> nq8) & 1;
+            const int nty = nq8 < 2 ? 0 : nq8 < 4 ? 1 : nq8 < 6 ? 2 : 3;
+            const int img = g ? r_img[1] : r_img[0];
+            if (img < 0) continue;
+            const float* r = Rs + x * W4_RPLANE + n * 32 + 4 * q;
+            // rows 0 / 1 need transform rows 0..4, rows 2 / 3 need 1..5
+            const f32x4 q1 = *reinterpret_cast<const f32x4*>(r + 1 * 4 * W4_RPLANE);
+            const f32x4 q2 = *reinterpret_cast<const f32x4*>(r + 2 * 4 * W4_RPLANE);
+            const f32x4 q3 = *reinterpret_cast<const f32x4*>(r + 3 * 4 * W4_RPLANE);
+            const f32x4 q4 = *reinterpret_cast<const f32x4*>(r + 4 * 4 * W4_RPLANE);
+            const f32x4 qe = *reinterpret_cast<const f32x4*>(r + (yh ? 5 : 0) * 4 * W4_RPLANE);
+            const int co = n0 + 4 * q;
+            const f32x4 s12 = q1 + q2, d12 = q1 - q2, s34 = q3 + q4, d34 = q3 - q4;
+            f32x4 y[2];
+            if (yh == 0) {
+                y[0] = qe + s12 + s34 + bv;
+                y[1] = KA * d12 + KB * d34 + bv;
+            } else {
+                y[0] = KA2 * s12 + KB2 * s34 + bv;
+                y[1] = KA3 * d12 + KB3 * d34 + qe + bv;
+            }
+            const int oy = (g ? r_y0[1] : r_y0[0]) + 4 * nty + 2 * yh, ox = (g ? r_x0[1] : r_x0[0]) + 4 * ntx + x;
+            float* o = p.out.p + (((size_t)img * H + oy) * W + ox) * p.out.cs + co;
+#pragma unroll
+            for (int yy = 0; yy < 2; ++yy) {
+                y[yy] = apply_act4(y[yy], p.act, p.alpha);
+                // non-temporal: the tensor (0.6 - 9.4 GB per launch) fits no cache and is read by a later launch; +0.7 % end to end
+                // (A/B round 4: 64 -> 64 at 256x256 10.79 - 10.92 -> 10.58 - 10.63 ms, the deep layers +-0)
+                if (co + 3 < Cout && !(HEAD && p.head_only))
+                    __builtin_nontemporal_store(y[yy], reinterpret_cast<f32x4*>(o + (size_t)yy * W * p.out.cs));
+            }
+            if (HEAD) {                                      // this lane's 4 channels x 4 classes of the 1x1 head
+                const f32x4* hw = reinterpret_cast<const f32x4*>(p.head_w) + co;
+                const f32x4 w0 = hw[0], w1 = hw[1], w2 = hw[2], w3 = hw[3];
+#pragma unroll
+                for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        hl[k][yy][c] += y[yy][0] * w0[c] + y[yy][1] * w1[c] + y[yy][2] * w2[c] + y[yy][3] * w3[c];
+            }
+            if (p.pool.p != nullptr) {
+                // fused MaxPooling2D(2x2, stride 2): the row pair is in registers, the column partner (x ^ 1) is lane ^ 8 of
+                // the same tile, hence of the same region: it is active whenever this lane is
+                f32x4 m;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float a = fmaxf(y[0][c], y[1][c]);
+                    m[c] = fmaxf(a, __shfl_xor(a, 8));
+                }
+                if (!(x & 1) && co + 3 < Cout)
+                    *reinterpret_cast<f32x4*>(p.pool.p + (((size_t)img * p.pool.h + (oy >> 1)) * p.pool.w + (ox >> 1)) * p.pool.cs + co) = m;
+            }
+        }
+        ESTAMP(3);                                           // [3] combine + output stores issued
+    }
+    if (HEAD) {
+        // the eight lanes q = 0..7 of a pixel column hold partial logits of 8 output channels each: butterfly over q,
+        // then lane q < 2 finishes row q of the pair (bias, softmax / activation over head_k classes) and stores it
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int item = tid + k * 768;
+            if (item >= 2048) break;
+            const int q = item & 7, x = (item >> 3) & 3, n = (item >> 5) & 31, yh = item >> 10;
+            const int nq8 = n >> 2, ntx = n & 3;
+            const int g = (0x96 >> nq8) & 1;
+            const int nty = nq8 < 2 ? 0 : nq8 < 4 ? 1 : nq8 < 6 ? 2 : 3;
+            const int img = g ? r_img[1] : r_img[0];
+            if (img < 0) continue;
+            f32x4 mine = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float v = hl[k][yy][c];
+                    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+                    if (q == yy) mine[c] = v;
+                }
+            if (q < 2) {
+                const f32x4 hb = *reinterpret_cast<const f32x4*>(p.head_b);
+                float l[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) l[c] = mine[c] + hb[c];
+                if (p.head_act == ECSEG_ACT_SOFTMAX) {
+                    float m = l[0];
+#pragma unroll
+                    for (int c = 1; c < 4; ++c) if (c < p.head_k) m = fmaxf(m, l[c]);
+                    float sum = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { l[c] = c < p.head_k ? expf(l[c] - m) : 0.f; sum += l[c]; }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) l[c] = l[c] / sum;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) l[c] = apply_act(l[c], p.head_act, p.alpha);
+                }
+                const int oy = (g ? r_y0[1] : r_y0[0]) + 4 * nty + 2 * yh + q, ox = (g ? r_x0[1] : r_x0[0]) + 4 * ntx + x;
+                float* ho = p.head_out.p + (((size_t)img * H + oy) * W + ox) * p.head_out.cs;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (c < p.head_k) ho[c] = l[c];
+            }
+        }
+    }
+    W4_ESTAMP_DUMP();
+}
+
+// Eligibility beyond "3x3, stride 1, pad 1, same size" (checked by the caller): extents multiples of 16, input channels
+// a multiple of 4 (>= 8), output channels a multiple of 32 (the filter image is zero padded to 8 / 64), 16-byte aligned views.
+bool conv_wino4_supported(const ConvParams& p) {
+    return p.in.h == p.out.h && p.in.w == p.out.w && p.out.h % 16 == 0 && p.out.w % 16 == 0 && p.in.c % 4 == 0 &&
+           p.in.c >= 8 && p.out.c % 32 == 0 && p.in.cs % 4 == 0 && p.out.cs % 4 == 0 && p.zero != nullptr;
+}
+
+hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s) {
+    const int regs_x = p.out.w / 16, regs_y = p.out.h / 16;
+    const size_t nreg = p.lut != nullptr ? (size_t)(p.n / p.per_image) * p.lut_len : (size_t)p.n * regs_x * regs_y;
+    const size_t npairs = (nreg + 1) / 2;
+    const size_t grid = npairs * (size_t)((p.out.c + 63) / 64);
+    if (grid == 0) return hipSuccess;
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    size_t lds = (size_t)(3 * W4_HS + 12 * 2 * W4_BWS) * 16 + 2 * 768 * 8;
+    const size_t lds_epi = (size_t)24 * W4_RPLANE * 4;
+    if (lds_epi > lds) lds = lds_epi;
+    void (*kern)(ConvParams, int, int, int) = conv_wino4_kernel<false, false>;
+    if (p.head_w != nullptr) kern = conv_wino4_kernel<true, false>;
+    else if (p.out.c == 32 && p.w4_split) kern = conv_wino4_kernel<false, true>;   // a lone 32-channel block: split K
+    W4_DIAG_SELECT(kern, p, lds);
+    static DeviceOnce attr_set[3];                          // the attribute is per device
+    const int which = p.head_w != nullptr ? 1 : (p.out.c == 32 && p.w4_split) ? 2 : 0;
+    if (attr_set[which].first()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { attr_set[which].reset(); return e; }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(768), lds, s, p, regs_x, regs_y, (int)npairs);
+    return hipGetLastError();
+}
+
+}  // namespace ecseg

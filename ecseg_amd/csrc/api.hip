@@ -42,7 +42,9 @@ struct OpRt {                 // run-time form of one plan operator
 };
 enum { PATH_MFMA = 1, PATH_SMALL_CIN = 2, PATH_HEAD = 3, PATH_GENERIC = 4, PATH_OTHER = 5 };
 
-struct CropLut { int32_t* dev = nullptr; int len = 0; int size = 0; };   // size: extent (pixels) of the tensors it applies to
+struct CropLut {                  // size: extent (pixels) of the tensors it applies to; start[w]: first entry of window w (entries are window-major)
+    int32_t* dev = nullptr; int len = 0; int size = 0; std::vector<int> start;
+};
 struct StitchPlan {
     int n_pos = 0;
     int32_t* pos_dev = nullptr;   // (n_pos, 2) window origins (row, col), reference order
@@ -51,6 +53,7 @@ struct StitchPlan {
     // lists built from it on first use, keyed by the op's crop recipe (OpRt::crop_code)
     std::vector<int> box;
     std::map<std::string, CropLut> luts;
+    std::map<std::string, int32_t*> boxes;   // per recipe: device (n_pos, 4) need boxes (get_crop_box)
 };
 
 }  // namespace
@@ -59,6 +62,11 @@ struct ecseg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // post-processing of group g overlaps the U-Net of group g+1
+    std::vector<hipStream_t> lane_streams;   // window lanes of small batches (run_plan)
+    std::vector<hipEvent_t> lane_events;
+    int unet_lanes = 0;              // 0: automatic (2 lanes up to lane_auto_windows windows per group, else 1)
+    int lane_auto_windows = 70;
+    bool lanes_ok = false;           // the input's and the output's buffers hold nothing of another per-window size (run_plan)
     std::string err;
     char devname[256] = {0};
 
@@ -346,6 +354,39 @@ hipEvent_t* prof_pair(ecseg_ctx* h) {
 // Region list of a crop recipe: per window the stitch's bounding box is grown / halved as the recipe says, then covered
 // by 16x16 regions whose origins are multiples of 4 pixels (the Winograd tile) and stay inside the tensor.  Entry =
 // window << 16 | (y origin / 4) << 8 | (x origin / 4).  len 0: nothing to gain (or an extent the kernel cannot take).
+// Need box of window i under a crop recipe: the stitch's bounding box, grown by one pixel per 'd' (a 3x3 convolution
+// behind) and halved per 'h' (a stride-2 up-convolution behind).  False: nothing of this window is ever read.
+bool recipe_box(const StitchPlan* sp, const std::string& code, int i, int b[4]) {
+    for (int k = 0; k < 4; ++k) b[k] = sp->box[4 * i + k];
+    if (b[1] < 0) return false;
+    int sz = 256;
+    for (char c : code) {
+        if (c == 'd') { b[0] = std::max(b[0] - 1, 0); b[1] = std::min(b[1] + 1, sz - 1); b[2] = std::max(b[2] - 1, 0); b[3] = std::min(b[3] + 1, sz - 1); }
+        else { sz /= 2; for (int k = 0; k < 4; ++k) b[k] /= 2; }
+    }
+    return true;
+}
+
+// Device table (n_pos, 4) of the need boxes of a recipe (ConvParams::in_box); null on allocation failure (no masking).
+const int32_t* get_crop_box(StitchPlan* sp, const std::string& code) {
+    auto it = sp->boxes.find(code);
+    if (it != sp->boxes.end()) return it->second;
+    std::vector<int32_t> t((size_t)sp->n_pos * 4);
+    for (int i = 0; i < sp->n_pos; ++i) {
+        int b[4];
+        if (!recipe_box(sp, code, i, b)) { b[0] = 1; b[1] = 0; b[2] = 1; b[3] = 0; }      // empty: everything reads as zero
+        for (int k = 0; k < 4; ++k) t[4 * i + k] = b[k];
+    }
+    int32_t* dev = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&dev), t.size() * sizeof(int32_t)) != hipSuccess ||
+        hipMemcpy(dev, t.data(), t.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
+        if (dev) (void)hipFree(dev);
+        dev = nullptr;
+    }
+    sp->boxes.emplace(code, dev);
+    return dev;
+}
+
 const CropLut* get_crop_lut(StitchPlan* sp, const std::string& code, int rh = 16, int rw = 16) {
     const std::string key = code + ":" + std::to_string(rh) + "x" + std::to_string(rw);
     auto it = sp->luts.find(key);
@@ -358,13 +399,9 @@ const CropLut* get_crop_lut(StitchPlan* sp, const std::string& code, int rh = 16
     const int rdim[2] = {rh, rw};
     if (size >= 16 && size % 16 == 0) {
         for (int i = 0; i < sp->n_pos; ++i) {
-            int b[4] = {sp->box[4 * i], sp->box[4 * i + 1], sp->box[4 * i + 2], sp->box[4 * i + 3]};
-            if (b[1] < 0) continue;                            // nothing of this window is ever read
-            int sz = 256;
-            for (char c : code) {
-                if (c == 'd') { b[0] = std::max(b[0] - 1, 0); b[1] = std::min(b[1] + 1, sz - 1); b[2] = std::max(b[2] - 1, 0); b[3] = std::min(b[3] + 1, sz - 1); }
-                else { sz /= 2; for (int& v : b) v /= 2; }
-            }
+            int b[4];
+            cl.start.push_back((int)lut.size());
+            if (!recipe_box(sp, code, i, b)) continue;         // nothing of this window is ever read
             int o[2], nr[2];
             for (int a = 0; a < 2; ++a) {
                 const int lo = b[2 * a], hi = b[2 * a + 1];
@@ -377,6 +414,7 @@ const CropLut* get_crop_lut(StitchPlan* sp, const std::string& code, int rh = 16
             for (int ry = 0; ry < nr[0]; ++ry)
                 for (int rx = 0; rx < nr[1]; ++rx) lut.push_back((i << 16) | (((o[0] + rh * ry) / 4) << 8) | ((o[1] + rw * rx) / 4));
         }
+        cl.start.push_back((int)lut.size());
         if (lut.size() >= (size_t)sp->n_pos * ((size + rh - 1) / rh) * ((size + rw - 1) / rw)) lut.clear();     // nothing to gain
     }
     if (!lut.empty()) {
@@ -390,12 +428,41 @@ const CropLut* get_crop_lut(StitchPlan* sp, const std::string& code, int rh = 16
 }
 
 // `crop`: the stitch that will read the model output (segment path), or null when every output pixel matters.
-int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
-    hipStream_t s = h->stream;
+// Window lanes (round 4): `cnt` >= 0 runs the plan on windows [w0, w0 + cnt) of the `n_all` windows whose input has been
+// written, on stream `lane_s` - several lanes of one small batch run beside each other on their own streams, so the
+// half-empty last round of workgroups of one lane's deep layers (35 windows: 288 / 560 workgroups on 256 CUs) is filled by
+// another lane's next layer.  Same kernels, same per-window arithmetic: results do not depend on the lanes.  A lane is
+// either whole images or a part of ONE image (cropped launches then take a slice of the window-major region list).
+int run_plan(ecseg_ctx* h, int n_all, StitchPlan* crop = nullptr, int w0 = 0, int cnt = -1, hipStream_t lane_s = nullptr) {
+    hipStream_t s = lane_s ? lane_s : h->stream;
+    const bool lane = cnt >= 0;
+    const int n = lane ? cnt : n_all;
+    if (!lane) w0 = 0;
+    const bool part = lane && crop && (w0 % crop->n_pos != 0 || cnt % crop->n_pos != 0);
+    const int wbase = part ? (w0 / crop->n_pos) * crop->n_pos : w0;     // cropped launches of a partial lane: views at the image's first window
+    if (part && w0 + cnt > wbase + crop->n_pos) return fail(h, ECSEG_E_INVALID, "window lane crosses an image boundary");
+    // A lane's windows of tensor t.  Buffers are shared by tensors of different sizes (liveness re-use), so lanes that run at
+    // different points of the plan must not share ANY byte of a buffer: a lane owns the slice [w0, w0 + cnt) x (the buffer's
+    // floats per window) of every buffer and packs its windows of whatever tensor lives there at the slice's start.  The
+    // model input and output keep the plain window order (the tiling kernel / the stitch address them for all lanes at
+    // once): their buffers hold nothing of another size (checked at load: lanes_ok).  `rebase`: views of a partial
+    // lane's cropped launch - the kernel adds (window index within the image) x (window size) itself.
+    auto at = [&](int t, bool rebase = false) {
+        if (t < 0) return TView{};
+        TView v = view_of(h, t);
+        if (!lane) return v;
+        const ecseg_tensor_desc& td = h->tensors[t];
+        const ptrdiff_t hwc = (ptrdiff_t)v.h * v.w * v.cs;
+        const bool io = t == h->input_tensor || t == h->output_tensor;
+        ptrdiff_t off = io ? (ptrdiff_t)w0 * hwc : (ptrdiff_t)w0 * (ptrdiff_t)std::max<size_t>(h->buf_floats[td.buffer], 4);
+        if (rebase) off -= (ptrdiff_t)(w0 - wbase) * hwc;
+        v.p += off;
+        return v;
+    };
     for (size_t oi = 0; oi < h->ops.size(); ++oi) {
         const OpRt& o = h->ops[oi];
         const ecseg_op_desc& d = o.d;
-        const TView in = view_of(h, d.in0), out = view_of(h, d.out);
+        const TView in = at(d.in0), out = at(d.out);
         hipError_t e = hipSuccess;
         switch (d.op) {
             case ECSEG_OP_CONV:
@@ -425,12 +492,34 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                         p.R = 1; p.S = 1; p.pad_top = 0; p.pad_left = 0; p.convt = 1; p.kT = d.kh;
                         p.crop_top = d.pad_top; p.crop_left = d.pad_left;
                     }
+                    bool rebased = false;                      // views of this launch start at the image's first window
+                    // region list of a cropped launch; a partial lane takes the slice of its windows (entries keep their window
+                    // index within the image, so the views go back to the image's first window)
+                    auto use_lut = [&](const CropLut* cl) {
+                        p.lut = cl->dev; p.lut_len = cl->len; p.per_image = crop->n_pos;
+                        if (part) {
+                            const int a = cl->start[w0 - wbase], b = cl->start[w0 - wbase + cnt];
+                            p.lut = cl->dev + a; p.lut_len = b - a; p.n = crop->n_pos;
+                            rebased = true;
+                            p.box_first = 0;
+                            p.in = at(d.in0, true); p.out = at(d.out, true);
+                        }
+                    };
                     hipEvent_t* ev = h->profile_kernels ? prof_pair(h) : nullptr;
                     if (ev) (void)hipEventRecord(ev[0], s);
                     double computed = 1.0;                     // fraction of the layer a cropped launch really computes
                     const bool wino4 = h->use_winograd >= 2 && o.wt_wino4 && conv_wino4_supported(p);   // (wt_wino* exist only for stride-1 3x3 'same' layers)
                     const bool wino = !wino4 && h->use_winograd && o.wt_wino && out.h >= 4 && out.w >= 8;
                     bool w16 = false;
+                    // a 3x3 convolution of the cropped chain on a Winograd kernel reads its input only inside the receptive field
+                    // of the outputs somebody needs (ConvParams::in_box): results do not depend on what a cropped producer left
+                    // outside it
+                    const bool crop_on = crop && h->crop && o.crop_ok && (part || n % crop->n_pos == 0);
+                    if (crop_on && d.op == ECSEG_OP_CONV && d.kh == 3 && d.kw == 3 && (wino4 || wino)) {
+                        p.in_box = get_crop_box(crop, o.crop_code + "d");
+                        p.per_image = crop->n_pos;
+                        p.box_first = part ? w0 - wbase : 0;
+                    }
                     {
                         const int npt = p.convt ? p.kT * p.kT * o.coutp : o.coutp;
                         p.wt_chunk_stride = wt_chunk_pitch(npt); p.wt_tap_stride = wt_tap_pitch(npt, o.cin_chunks);
@@ -440,7 +529,7 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                     auto fuse_following_pool = [&]() {
                         if (oi + 1 >= h->ops.size()) return;
                         const ecseg_op_desc& nx = h->ops[oi + 1].d;
-                        const TView po = nx.op == ECSEG_OP_MAXPOOL ? view_of(h, nx.out) : TView{};
+                        const TView po = nx.op == ECSEG_OP_MAXPOOL ? at(nx.out, rebased) : TView{};
                         if (nx.op == ECSEG_OP_MAXPOOL && nx.mode == 0 /* max, not average */ && nx.in0 == d.out && nx.kh == 2 && nx.kw == 2 && nx.stride == 2 &&
                             h->fuse_pool && !softmax && po.h * 2 == out.h && po.w * 2 == out.w && po.c == out.c && po.cs % 4 == 0 &&
                             reinterpret_cast<uintptr_t>(po.p) % 16 == 0 &&
@@ -460,17 +549,17 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                             // workgroups write head pixels while others still read the convolution's input halo
                             h->tensors[hx.d.out].buffer != h->tensors[d.in0].buffer &&
                             h->tensors[hx.d.out].buffer != td.buffer) {
-                            p.head_w = hx.head_w4; p.head_b = hx.head_b4; p.head_out = view_of(h, hx.d.out);
+                            p.head_w = hx.head_w4; p.head_b = hx.head_b4; p.head_out = at(hx.d.out, rebased);
                             p.head_k = p.head_out.c; p.head_act = hx.d.act; p.head_only = 1;
                             ++oi;                              // the head op is done
                         }
                     };
                     if (wino4) {
                         p.wt = o.wt_wino4; p.coutp = out.c; p.w4_split = h->wino4_split;
-                        if (crop && h->crop && o.crop_ok && n % crop->n_pos == 0) {
+                        if (crop && h->crop && o.crop_ok && (part || n % crop->n_pos == 0)) {
                             const CropLut* cl = get_crop_lut(crop, o.crop_code);
                             if (cl->len > 0 && out.h == cl->size && out.w == cl->size) {
-                                p.lut = cl->dev; p.lut_len = cl->len; p.per_image = crop->n_pos;
+                                use_lut(cl);
                                 computed = (double)cl->len / ((double)crop->n_pos * (out.h / 16) * (out.w / 16));
                             }
                         }
@@ -481,11 +570,11 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                     } else if (wino && h->wino16 && o.wt_wino16 && conv_wino16_supported(p)) {
                         w16 = true;
                         p.wt = o.wt_wino16;
-                        if (crop && h->crop && o.crop_ok && n % crop->n_pos == 0) {
+                        if (crop && h->crop && o.crop_ok && (part || n % crop->n_pos == 0)) {
                             // cropped launch: only the 16 x 32 blocks some later stage reads
                             const CropLut* cl = get_crop_lut(crop, o.crop_code, 16, 32);
                             if (cl->len > 0 && out.h == cl->size && out.w == cl->size) {
-                                p.lut = cl->dev; p.lut_len = cl->len; p.per_image = crop->n_pos;
+                                use_lut(cl);
                                 computed = (double)cl->len / ((double)crop->n_pos * (out.h / 16) * (out.w / 32));
                             }
                         }
@@ -499,7 +588,7 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                         if (out.c % 4 == 0) fuse_following_pool();
                         e = launch_conv_wino(p, s);
                     } else {
-                        if (crop && h->crop && o.crop_ok && p.convt && n % crop->n_pos == 0 && in.h == in.w) {
+                        if (crop && h->crop && o.crop_ok && p.convt && (part || n % crop->n_pos == 0) && in.h == in.w) {
                             // cropped up-convolution: only the input tiles whose outputs somebody reads; of the two tile
                             // shapes (4 x 32, 8 x 16) the one that needs fewer tiles
                             const CropLut* a = get_crop_lut(crop, o.crop_code, 4, 32);
@@ -508,7 +597,7 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                             if (a->len > 0 && a->size == in.h && in.w >= 32 && (b->len == 0 || b->size != in.h || a->len <= b->len)) { cl = a; tw = 32; }
                             else if (b->len > 0 && b->size == in.h) { cl = b; tw = 16; }
                             if (cl) {
-                                p.lut = cl->dev; p.lut_len = cl->len; p.per_image = crop->n_pos; p.force_tw = tw;
+                                use_lut(cl); p.force_tw = tw;
                                 const int th = 128 / tw;
                                 computed = (double)cl->len / ((double)crop->n_pos * ((in.h + th - 1) / th) * ((in.w + tw - 1) / tw));
                             }
@@ -553,7 +642,7 @@ int run_plan(ecseg_ctx* h, int n, StitchPlan* crop = nullptr) {
                 if (d.act == ECSEG_ACT_SOFTMAX) e = launch_softmax(in, out, n, s);
                 else e = launch_affine(in, out, nullptr, nullptr, n, d.act, d.alpha, s);
                 break;
-            case ECSEG_OP_ADD: e = launch_add(in, view_of(h, d.in1), out, n, d.act, d.alpha, s); break;
+            case ECSEG_OP_ADD: e = launch_add(in, at(d.in1), out, n, d.act, d.alpha, s); break;
             case ECSEG_OP_COPY: e = launch_copy(in, out, n, d.pad_top, d.pad_left, s); break;
             default: return fail(h, ECSEG_E_INVALID, "unknown op in plan");
         }
@@ -778,7 +867,36 @@ int segment_dev(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint
         HIP_TRY(h, launch_tile_patches(gray + (size_t)i0 * px, ni, H, W, sp->pos_dev, sp->n_pos,
                                        view_of(h, h->input_tensor).p, s));
         HIP_TRY(h, hipEventRecord(e6[1], s));
-        if ((rc = run_plan(h, ni * sp->n_pos, sp))) return rc;
+        {
+            // small batches: 2+ window lanes on their own streams (see run_plan); lane 0 stays on the main stream
+            const int nw = ni * sp->n_pos;
+            int lanes = h->unet_lanes > 0 ? h->unet_lanes : (nw <= h->lane_auto_windows ? 2 : 1);
+            if (h->profile_kernels || !h->lanes_ok) lanes = 1;     // (per-launch events are taken on the main stream)
+            if (ni > 1) lanes = std::min(lanes, ni);         // whole images per lane
+            lanes = std::max(1, std::min(lanes, std::min(nw, 8)));
+            while ((int)h->lane_streams.size() < lanes - 1) {
+                hipStream_t ls; hipEvent_t le;
+                HIP_TRY(h, hipStreamCreateWithFlags(&ls, hipStreamNonBlocking));
+                h->lane_streams.push_back(ls);
+                HIP_TRY(h, hipEventCreateWithFlags(&le, hipEventDisableTiming));
+                h->lane_events.push_back(le);
+            }
+            if (lanes == 1) {
+                if ((rc = run_plan(h, nw, sp))) return rc;
+            } else {
+                const int unit = ni > 1 ? sp->n_pos : 1, units = nw / unit;
+                int u0 = 0;
+                for (int l = 0; l < lanes; ++l) {
+                    const int u1 = (int)((long long)units * (l + 1) / lanes);
+                    hipStream_t ls = l == 0 ? s : h->lane_streams[l - 1];
+                    if (l > 0) HIP_TRY(h, hipStreamWaitEvent(ls, e6[1], 0));
+                    if (u1 > u0 && (rc = run_plan(h, nw, sp, u0 * unit, (u1 - u0) * unit, ls))) return rc;
+                    if (l > 0) HIP_TRY(h, hipEventRecord(h->lane_events[l - 1], ls));
+                    u0 = u1;
+                }
+                for (int l = 1; l < lanes; ++l) HIP_TRY(h, hipStreamWaitEvent(s, h->lane_events[l - 1], 0));
+            }
+        }
         HIP_TRY(h, hipEventRecord(e6[2], s));
         const TView pv = view_of(h, h->output_tensor);
         HIP_TRY(h, launch_stitch_argmax(pv.p, pv.cs, sp->map_dev, ni, sp->n_pos, H, W, raw + (size_t)i0 * px, s, h->d_tie + i0, h->d_tie_sh));
@@ -853,6 +971,7 @@ void ecseg_destroy(ecseg_ctx* h) {
     for (auto& kv : h->stitch) {
         (void)hipFree(kv.second.pos_dev); (void)hipFree(kv.second.map_dev);
         for (auto& lk : kv.second.luts) if (lk.second.dev) (void)hipFree(lk.second.dev);
+        for (auto& bk : kv.second.boxes) if (bk.second) (void)hipFree(bk.second);
     }
     if (h->zero_page) (void)hipFree(h->zero_page);
     void* ptrs[] = {h->d_tie, h->d_tie_sh, h->d_sprobs, h->d_gray, h->d_raw, h->d_post, h->d_aux8, h->d_u8in, h->d_i32, h->d_i64, h->d_probs_in, h->d_hist,
@@ -861,6 +980,8 @@ void ecseg_destroy(ecseg_ctx* h) {
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->grp_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->lane_events) (void)hipEventDestroy(e);
+    for (hipStream_t ls : h->lane_streams) { (void)hipStreamSynchronize(ls); (void)hipStreamDestroy(ls); }
     (void)hipStreamDestroy(h->stream2);
     (void)hipStreamDestroy(h->stream);
     delete h;
@@ -896,6 +1017,8 @@ int ecseg_set_option(ecseg_ctx* h, const char* key, int value) {
     else if (k == "post_chunk" && value >= 1) h->post_chunk = value;
     else if (k == "post_graph") { h->post_graph = value != 0; if (!h->post_graph) drop_post_graphs(h); }
     else if (k == "images_per_group" && value >= 0) h->images_per_group = value;     // 0: automatic
+    else if (k == "unet_lanes" && value >= 0 && value <= 8) h->unet_lanes = value;   // 0: automatic
+    else if (k == "lane_auto_windows" && value >= 0) h->lane_auto_windows = value;
     else return fail(h, ECSEG_E_INVALID, "unknown option or bad value: " + k);
     return ECSEG_OK;
 }
@@ -1061,6 +1184,14 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
             d.op != ECSEG_OP_COPY && d.op != ECSEG_OP_GLOBALPOOL && (ti.h != to.h || ti.w != to.w || ti.c != to.c))
             return fail(h, ECSEG_E_INVALID, "shape mismatch in element-wise op " + std::to_string(k));
         h->ops.push_back(o);
+    }
+    // window lanes (run_plan) address the model input and output in plain window order: allowed when their buffers hold
+    // only tensors of exactly the buffer's per-window size (keras_plan gives both a buffer of their own)
+    h->lanes_ok = true;
+    for (int io : {input_tensor, output_tensor}) {
+        const int b = h->tensors[io].buffer;
+        for (const ecseg_tensor_desc& t : h->tensors)
+            if (t.buffer == b && (size_t)t.h * t.w * t.c_stride != std::max<size_t>(h->buf_floats[b], 4)) h->lanes_ok = false;
     }
     h->consumers.assign(n_tensors, 0);
     for (const OpRt& o : h->ops) {

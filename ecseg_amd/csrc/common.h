@@ -39,6 +39,12 @@ struct ConvParams {
     // demand-driven cropping (conv_wino4 only): lut != null: only the 16x16 regions listed are computed, the same list
     // for every image of `per_image` consecutive patches; entry = patch-in-image << 16 | (y origin / 4) << 8 | (x origin / 4)
     const int32_t* lut; int lut_len, per_image;
+    // Winograd kernels of a cropped plan: in_box != null: (y0, y1, x0, x1), inclusive, per window of an image - the receptive
+    // field of the outputs a later stage reads; input pixels outside it are read as ZERO.  A Winograd tile mixes its whole
+    // 6x6 (4x4) input tile into every output: pixels outside an output's 3x3 support cancel only up to rounding, and
+    // outside the box a cropped producer has left whatever the buffer held before - the results would depend (in the last
+    // bits) on the history of the buffer.  Window of patch i: (i + box_first) % per_image.
+    const int32_t* in_box; int box_first;
     // conv_mfma (transposed convolutions): the same list idea over its TH x TW tiles of the INPUT extent; force_tw = 16 | 32
     // selects the tile shape the list was built for (0: the launcher's own choice)
     int force_tw;

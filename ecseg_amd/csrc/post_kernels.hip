@@ -61,6 +61,7 @@ struct CclGeom {
     int H, W, n_img;
     int chunks_x, strips_y, blocks_per_img;
     int img_groups;   // ceil(n_img / 8)
+    int spread;       // fewer than 8 images: the tiles of an image go round-robin over all XCDs (see decode_block)
 };
 
 static CclGeom make_geom(int n_img, int H, int W) {
@@ -70,17 +71,24 @@ static CclGeom make_geom(int n_img, int H, int W) {
     g.strips_y = (H + CCL_BLOCK_ROWS - 1) / CCL_BLOCK_ROWS;
     g.blocks_per_img = g.chunks_x * g.strips_y;
     g.img_groups = (n_img + 7) / 8;
+    g.spread = n_img < 8;
     return g;
 }
-static unsigned geom_grid(const CclGeom& g) { return (unsigned)(8 * g.img_groups * g.blocks_per_img); }
+static unsigned geom_grid(const CclGeom& g) { return (unsigned)((g.spread ? g.n_img : 8 * g.img_groups) * g.blocks_per_img); }
 
-// block id -> (image, strip, chunk); images with equal (img % 8) share an XCD
+// block id -> (image, strip, chunk).  Images with equal (img % 8) share an XCD (consecutive workgroups go to consecutive
+// XCDs): the parents, statistics and owner bits of an image stay in ONE L2.  With fewer than 8 images that would leave
+// XCDs idle - a single image ran all its 726 tiles on 32 of the 256 CUs, 67 - 86 us per ccl_local launch - so the tiles of
+// an image are then dealt round-robin over all XCDs (round 4; every cross-tile access is an agent-scope atomic anyway).
+__device__ __forceinline__ unsigned block_in_image(const CclGeom& g) {
+    return (g.spread ? blockIdx.x : (blockIdx.x >> 3)) % (unsigned)g.blocks_per_img;
+}
 __device__ __forceinline__ bool decode_block(const CclGeom& g, int& img, int& y0, int& cx) {
     const unsigned b = blockIdx.x;
-    const unsigned xcd = b & 7u, j = b >> 3;
-    img = (int)((j / g.blocks_per_img) * 8 + xcd);
+    if (g.spread) img = (int)(b / (unsigned)g.blocks_per_img);
+    else img = (int)(((b >> 3) / g.blocks_per_img) * 8 + (b & 7u));
     if (img >= g.n_img) return false;
-    const unsigned blk = j % g.blocks_per_img;
+    const unsigned blk = block_in_image(g);
     cx = (int)(blk % g.chunks_x);
     y0 = (int)(blk / g.chunks_x) * CCL_BLOCK_ROWS + (int)(threadIdx.x >> 6) * CCL_ROWS;
     return true;
@@ -88,7 +96,7 @@ __device__ __forceinline__ bool decode_block(const CclGeom& g, int& img, int& y0
 
 // index of this block's tile in PostWorkspace::tile_any (valid after decode_block returned true)
 __device__ __forceinline__ size_t tile_index(const CclGeom& g, int img) {
-    return (size_t)img * g.blocks_per_img + (blockIdx.x >> 3) % (unsigned)g.blocks_per_img;
+    return (size_t)img * g.blocks_per_img + block_in_image(g);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -206,11 +214,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ECSEG_CCL_W
 #define TROOT_OF(r) ((int)(info[r] >> 16) - 1)
     int hole = 0;                                          // a valid pixel of this thread without a key
     int rowmask = 0;                                       // (wave-uniform) bit r: row r of this wave holds a keyed pixel
+    // all eight rows' bytes first (one round trip to memory instead of eight: the wave-uniform `continue` below keeps the compiler
+    // from hoisting the later rows' loads itself - the whole kernel is a chain of latencies when a single image leaves each SIMD
+    // with two or three waves)
+#pragma unroll
+    for (int r = 0; r < CCL_ROWS; ++r) {
+        const int y = y0 + r;
+        info[r] = (y < g.H && x < g.W) ? (uint32_t)img_all[base + (size_t)y * g.W + x] << 8 : 0u;
+    }
 #pragma unroll
     for (int r = 0; r < CCL_ROWS; ++r) {
         const int y = y0 + r, li = (wave * CCL_ROWS + r) * 64 + lane;
         const bool valid = y < g.H && x < g.W;
-        const uint8_t v = valid ? img_all[base + (size_t)y * g.W + x] : (uint8_t)0;
+        const uint8_t v = (uint8_t)(info[r] >> 8);
         const int key = valid ? key_of(v, lut) : 0;
         hole |= (valid && key == 0) ? 1 : 0;
         // rows without a keyed pixel (most rows of a realistic class labelling, even inside a busy tile) are skipped by every
@@ -371,7 +387,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ECSEG_CCL_W
             for (int k = 1; k < 4; ++k) if (npx[k]) atomicAdd(&red[k], npx[k]);
         }
         __syncthreads();
-        int32_t* G = G_all + (size_t)img * G_IMG + (size_t)((blockIdx.x >> 3) % G_SHARDS) * G_STRIDE;
+        int32_t* G = G_all + (size_t)img * G_IMG + (size_t)(block_in_image(g) % G_SHARDS) * G_STRIDE;
         if (threadIdx.x >= 1 && threadIdx.x < 4 && red[threadIdx.x]) atomicAdd(G + G_NPX + threadIdx.x, red[threadIdx.x]);
     }
 }
@@ -519,7 +535,7 @@ __global__ __launch_bounds__(256) void ccl_resolve_kernel(CclGeom g, const uint8
     }
     __syncthreads();
     const int n_own = red[13];
-    int32_t* G = G_all + (size_t)img * G_IMG + (size_t)((blockIdx.x >> 3) % G_SHARDS) * G_STRIDE;
+    int32_t* G = G_all + (size_t)img * G_IMG + (size_t)(block_in_image(g) % G_SHARDS) * G_STRIDE;
     int ncomp[4] = {0, 0, 0, 0};
     int last_root = 0;
     // thread k takes owner k: the chain walks and global atomics of all owners of a tile are in flight together
@@ -600,7 +616,7 @@ __global__ __launch_bounds__(256) void count_roots_kernel(CclGeom g, const uint8
 #pragma unroll
     for (int k = 1; k < 4; ++k) if (nc[k]) atomicAdd(&red[k], nc[k]);
     __syncthreads();
-    int32_t* G = G_all + (size_t)img * G_IMG + (size_t)((blockIdx.x >> 3) % G_SHARDS) * G_STRIDE;
+    int32_t* G = G_all + (size_t)img * G_IMG + (size_t)(block_in_image(g) % G_SHARDS) * G_STRIDE;
     if (tid >= 1 && tid < 4 && red[tid]) atomicAdd(G + G_NCOMP + tid, red[tid]);
 }
 

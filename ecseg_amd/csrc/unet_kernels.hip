@@ -317,6 +317,12 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void conv_wino_kernel(ConvP
     const int Hin = p.in.h, Win = p.in.w, Cin = p.in.c;
     const size_t in_img = (size_t)img * Hin * Win * p.in.cs;
 
+    // rows / columns this window may read (ConvParams::in_box; the whole image otherwise): zero outside
+    int lo_y = 0, hi_y = Hin - 1, lo_x = 0, hi_x = Win - 1;
+    if (p.in_box != nullptr) {
+        const int32_t* bx = p.in_box + 4 * ((img + p.box_first) % p.per_image);
+        lo_y = bx[0]; hi_y = bx[1]; lo_x = bx[2]; hi_x = bx[3];
+    }
     long a_off[A_PER_T];
     int a_ch[A_PER_T], a_lds[A_PER_T];
 #pragma unroll
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void conv_wino_kernel(ConvP
             const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
             a_lds[k] = (h * 2 + (hx & 1)) * PLANE + hy * CS + (hx >> 1);
             a_ch[k] = h * 4;
-            if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win)
+            if (iy >= lo_y && iy <= hi_y && ix >= lo_x && ix <= hi_x)
                 a_off[k] = (long)(in_img + ((size_t)iy * Win + ix) * p.in.cs + h * 4);
         }
     }
@@ -505,6 +511,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino_res_kernel(ConvParams p, int
     const int Hin = p.in.h, Win = p.in.w, Cin = p.in.c;
     const size_t in_img = (size_t)img * Hin * Win * p.in.cs;
 
+    // rows / columns this window may read (ConvParams::in_box; the whole image otherwise): zero outside
+    int lo_y = 0, hi_y = Hin - 1, lo_x = 0, hi_x = Win - 1;
+    if (p.in_box != nullptr) {
+        const int32_t* bx = p.in_box + 4 * ((img + p.box_first) % p.per_image);
+        lo_y = bx[0]; hi_y = bx[1]; lo_x = bx[2]; hi_x = bx[3];
+    }
     // halo pieces of this thread: consecutive threads take the 2 * CH channel quads of one pixel (Cin * 4 contiguous bytes)
     long a_off[A_PER_T];                                     // offset of the piece for tile column 0 (may be "negative" at x = -1)
     int a_lds[A_PER_T], a_hx[A_PER_T];                       // LDS slot (-1: no piece), halo column | 0x100 when the row / channels are outside
@@ -518,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_res_kernel(ConvParams p, int
             const int hy = pix / HC, hx = pix - hy * HC;
             const int iy = oy0 - 1 + hy;
             a_lds[k] = c * A_SLOTS + (h * 2 + (hx & 1)) * PLANE + hy * CS + (hx >> 1);
-            const bool ok = iy >= 0 && iy < Hin && c * 8 + h * 4 < Cin;
+            const bool ok = iy >= lo_y && iy <= hi_y && c * 8 + h * 4 < Cin;
             a_hx[k] = hx | (ok ? 0 : 0x100);
             a_off[k] = (long)in_img + ((long)iy * Win + (long)(bx0 * 16 - 1 + hx)) * p.in.cs + c * 8 + h * 4;
         }
@@ -529,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_res_kernel(ConvParams p, int
         for (int k = 0; k < A_PER_T; ++k) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             const int ix = (bx0 + t) * 16 - 1 + (a_hx[k] & 0xff);
-            if (!(a_hx[k] & 0x100) && ix >= 0 && ix < Win)
+            if (!(a_hx[k] & 0x100) && ix >= lo_x && ix <= hi_x)
                 v = *reinterpret_cast<const f32x4*>(p.in.p + a_off[k] + (long)t * 16 * p.in.cs);
             a_reg[k] = v;
         }

@@ -109,9 +109,17 @@ __global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(C
         d_meta[k] = (ok ? x : 0) | (y << 8) | (ok ? 0 : 0x10000);
         d_rel[k] = ok ? (y * W + x) * p.in.cs + cq * 4 : 0;
     }
+    // input rows / columns a block may read (ConvParams::in_box: the receptive field of the needed outputs in a cropped plan,
+    // per window; the whole image otherwise); re-read when the window changes (all wave-uniform)
+    int hb_img = -1, lo_y = 0, hi_y = H - 1, lo_x = 0, hi_x = W - 1;
     auto dma_halo = [&](int blk, int kc, int buf) __attribute__((always_inline)) {
         int img, y0, x0;
         block_origin(blk, img, y0, x0);
+        if (p.in_box != nullptr && img != hb_img) {
+            const int32_t* bx = p.in_box + 4 * ((img + p.box_first) % p.per_image);
+            lo_y = bx[0]; hi_y = bx[1]; lo_x = bx[2]; hi_x = bx[3];
+            hb_img = img;
+        }
         const float* base = p.in.p + (((long)img * H + (y0 - 1)) * W + (x0 - 1)) * p.in.cs + kc * 16;      // halo pixel (0, 0); only dereferenced inside the image
 #pragma unroll
         for (int k = 0; k < W16_NP; ++k) {
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(C
             if (piece < W16_PIECES) {
                 const int ix = x0 - 1 + (d_meta[k] & 0xff), iy = y0 - 1 + ((d_meta[k] >> 8) & 0xff);
                 const float* src = p.zero;
-                if (!(d_meta[k] & 0x10000) && ix >= 0 && ix < W && iy >= 0 && iy < H) src = base + d_rel[k];
+                if (!(d_meta[k] & 0x10000) && ix >= lo_x && ix <= hi_x && iy >= lo_y && iy <= hi_y) src = base + d_rel[k];
                 w16_dma16(src, lds_base + (unsigned)(buf * W16_HS + piece * 64) * 16u);
             }
         }

@@ -164,6 +164,17 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         r_y0[g] = ry * 16; r_x0[g] = rx * 16;
     }
 
+    // input rows / columns the two regions may read (ConvParams::in_box: the receptive field of the needed outputs of a cropped
+    // plan; the whole image otherwise) - everything outside reads as zero
+    int r_by0[2] = {0, 0}, r_by1[2] = {H - 1, H - 1}, r_bx0[2] = {0, 0}, r_bx1[2] = {W - 1, W - 1};
+    if (p.in_box != nullptr) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            if (r_img[g] < 0) continue;
+            const int32_t* bx = p.in_box + 4 * ((r_img[g] + p.box_first) % p.per_image);
+            r_by0[g] = bx[0]; r_by1[g] = bx[1]; r_bx0[g] = bx[2]; r_bx1[g] = bx[3];
+        }
+    }
     // ---- halo DMA: every wave fills slots 64 k + lane, k = wave and wave + 12, two groups ahead of its use (3-deep
     //      ring: nobody ever waits for a halo piece to land).  The per-lane source pointers are computed once and parked
     //      in LDS (bit 0 = "advance with the channel group"; padding / out-of-image lanes point at the zero page and do
@@ -197,7 +208,8 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             const int h = cc >= 18 ? 1 : 0, c = cc - h * 18;
             const int img = g ? r_img[1] : r_img[0];
             const int iy = (g ? r_y0[1] : r_y0[0]) - 1 + w4_inv(r), ix = (g ? r_x0[1] : r_x0[0]) - 1 + w4_inv(c);
-            if (img >= 0 && iy >= 0 && iy < H && ix >= 0 && ix < W)      // (two neighbouring windows: far below 2 GB)
+            if (img >= 0 && iy >= (g ? r_by0[1] : r_by0[0]) && iy <= (g ? r_by1[1] : r_by1[0]) && ix >= (g ? r_bx0[1] : r_bx0[0]) &&
+                ix <= (g ? r_bx1[1] : r_bx1[0]))                         // (two neighbouring windows: far below 2 GB)
                 off = (unsigned)(((((size_t)(img - img_lo) * H + iy) * W + ix) * p.in.cs + 4 * h) * 4);
         }
         hoff[i] = off;
@@ -245,7 +257,8 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             const int h = cc >= 18 ? 1 : 0, c = cc - h * 18;
             const int img = g ? r_img[1] : r_img[0];
             const int iy = (g ? r_y0[1] : r_y0[0]) - 1 + w4_inv(r), ix = (g ? r_x0[1] : r_x0[0]) - 1 + w4_inv(c);
-            if (img >= 0 && iy >= 0 && iy < H && ix >= 0 && ix < W)
+            if (img >= 0 && iy >= (g ? r_by0[1] : r_by0[0]) && iy <= (g ? r_by1[1] : r_by1[0]) && ix >= (g ? r_bx0[1] : r_bx0[0]) &&
+                ix <= (g ? r_bx1[1] : r_bx1[0]))
                 d = (unsigned long long)(size_t)(p.in.p + (((size_t)img * H + iy) * W + ix) * p.in.cs + 4 * h) | 1ull | (h ? 2ull : 0ull);
         }
         Hd[i * 768] = d;

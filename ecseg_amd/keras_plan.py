@@ -402,9 +402,9 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
     node_buf = {}      # node -> buffer id (for nodes that own a buffer)
     tensor_of = {}
 
-    def alloc(floats):
+    def alloc(floats, fresh=False):
         best = None
-        for k, (sz, b) in enumerate(free):
+        for k, (sz, b) in enumerate([] if fresh else free):
             if sz >= floats and (best is None or sz < free[best][0]):
                 best = k
         if best is not None:
@@ -425,7 +425,9 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
             return node_buf[root], off, nodes[root]['shape'][2]
         if j not in node_buf:
             h, w, c = nodes[j]['shape']
-            node_buf[j] = alloc(h * w * c)
+            # the model output gets a buffer of its own (and the input's is never re-used, below): the window lanes of
+            # csrc/api.hip run_plan address both in plain window order, whatever else a lane packs into shared buffers
+            node_buf[j] = alloc(h * w * c, fresh=(j == out_node))
         return node_buf[j], 0, nodes[j]['shape'][2]
 
     def new_tensor(j):
@@ -458,7 +460,7 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
             lu = last_use.get(i, i)
             if nodes[i]['kind'] == 'concat':
                 lu = max([lu] + [last_use.get(x, x) for x in nodes[i]['inputs']])
-            if lu <= step:
+            if lu <= step and nodes[i]['kind'] != 'input':
                 released.add(i)
                 free.append((plan.buffer_floats[node_buf[i]], node_buf[i]))
 

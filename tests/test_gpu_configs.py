@@ -85,13 +85,22 @@ def test_bench_model_crop_equals_no_crop_full_size(bench_model):
     h = bench_model.handle
     try:
         h.set_option('crop', 1)
-        a = h.segment_images(imgs, want_raw=True)
+        a = h.segment_images(imgs, want_raw=True, want_probs=True)
         h.set_option('crop', 0)
-        b = h.segment_images(imgs, want_raw=True)
+        b = h.segment_images(imgs, want_raw=True, want_probs=True)
+        h.set_option('crop', 1)
+        c = h.segment_images(imgs, want_raw=True, want_probs=True)
     finally:
         h.set_option('crop', 1)
-    for x, y in zip(a, b):
+    # the cropped plan does not depend on what the buffers held before (its Winograd tiles read zeros outside the receptive field of
+    # the pixels the stitch reads) and agrees with the uncropped plan to float32 rounding
+    for x, y in zip(a, c):
         assert np.array_equal(x, y)
+    assert np.abs(a[3] - b[3]).max() < 1e-5
+    d = a[0] != b[0]
+    if d.any():
+        q = np.sort(quant.quantise_u8(b[3].astype(np.float64))[d].astype(int), axis=-1)
+        assert (q[:, -1] - q[:, -2] <= 1).all() and d.mean() < 1e-5
 
 
 def test_bench_model_full_size_labels_vs_cpu_oracle(bench_model):

@@ -183,7 +183,7 @@ def test_fuzz_layer_graphs(seed0):
 
 
 def test_fuzz_pipeline_cases(monkeypatch):
-    """Six cases of tools/fuzz_pipeline.py (random small U-Nets x random image sizes: crop on == off, probabilities vs the
+    """Six cases of tools/fuzz_pipeline.py (random small U-Nets x random image sizes: the cropped plan vs itself (history, lanes) and vs the uncropped plan, probabilities vs the
     oracle, clean-up / counts on the device raw labels, meta_preprocess, overlay rows)."""
     import os
     import runpy

@@ -218,3 +218,34 @@ def test_device_timers_of_overlay_and_preprocess(gpu):
     assert 0.0 < t2['count'] < t['count']                       # one gather + histogram against five labellings
     n, px = gpu.count_cc(lab == 3)
     assert gpu.timings()['count'] > 0.0 and len(n) == 3
+
+
+@pytest.mark.parametrize('base,up', [(16, 'transpose'), (32, 'transpose'), (64, 'transpose')])
+def test_window_lanes_do_not_change_results(gpu, base, up):
+    """Small batches run the U-Net as several window lanes on their own streams (api.hip: run_plan - a lane is whole images,
+    or a slice of ONE image's windows with the matching slice of every crop list); same kernels, same per-window arithmetic:
+    raw labels, cleaned labels, counts and the stitched probabilities are bit-identical for every lane count."""
+    cfg = synth.unet_config(base=base, up=up)
+    gpu.load_plan(keras_plan.build_plan(cfg, synth.unet_weights(cfg, seed=9)))
+    try:
+        for n_img, lane_counts in ((1, (1, 2, 3, 5, 8)), (3, (1, 2, 3)), (2, (1, 2, 4))):
+            imgs = np.stack([synth.dapi_image(40 + i) for i in range(n_img)])
+            ref = None
+            for lanes in lane_counts:
+                gpu.set_option('unet_lanes', lanes)
+                got = gpu.segment_images(imgs, want_raw=True, want_tie_risk=True, want_probs=(n_img == 1))
+                if ref is None:
+                    ref = got
+                    continue
+                for a, b in zip(ref, got):
+                    assert np.array_equal(a, b), (n_img, lanes)
+        # another image size: 5 x 5 windows, other crop lists
+        img = synth.dapi_image(77, 1100, 1100)[None]
+        gpu.set_option('unet_lanes', 1)
+        ref = gpu.segment_images(img, want_raw=True)
+        gpu.set_option('unet_lanes', 3)
+        got = gpu.segment_images(img, want_raw=True)
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b)
+    finally:
+        gpu.set_option('unet_lanes', 0)

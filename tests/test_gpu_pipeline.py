@@ -35,8 +35,19 @@ def test_segment_matches_oracle_small(model16):
             q = np.sort(quant.quantise_u8(tiling.stitch(o_probs, pos))[diff].astype(int), axis=-1)
             assert (q[:, -1] - q[:, -2] <= 1).all()
         assert diff.mean() < 1e-3
+        # ... the segment path (cropped plan: only what the stitch reads is computed, Winograd tiles read zeros outside the
+        # receptive field of those pixels - ConvParams::in_box) agrees with the stitched full forward pass to float32 rounding:
+        # same probabilities to 1e-5, labels equal except where the two best quantised classes are within one step
+        g_canvas = tiling.stitch(g_probs, pos)
+        s_canvas = model16.handle.segment_images(imgs[i:i + 1], want_raw=False, want_probs=True)[-1][0]
+        written = np.abs(g_canvas).sum(-1) > 0                                  # (never-written canvas pixels stay 0 in both)
+        assert np.abs(s_canvas - g_canvas)[written].max() < 1e-5
+        d2 = raw[i] != quant.quantised_argmax(g_canvas)
+        if d2.any():
+            q = np.sort(quant.quantise_u8(g_canvas)[d2].astype(int), axis=-1)
+            assert (q[:, -1] - q[:, -2] <= 1).all()
+        assert d2.mean() < 1e-4
         # ... and everything downstream of the raw labels is bit-exact
-        assert np.array_equal(raw[i], quant.quantised_argmax(tiling.stitch(g_probs, pos)))
         want_post = postproc.meta_inference(raw[i])
         assert np.array_equal(post[i], want_post)
         assert nec[i] == postproc.count_cc(want_post == 3)[0]
@@ -96,8 +107,10 @@ def test_overlay_full_size_batch_vs_oracle(gpu):
 @pytest.mark.parametrize('hw,depth', [((300, 462), 1), ((600, 500), 2), ((1040, 1392), 2), ((256, 256), 2)])
 def test_crop_of_unread_regions_changes_nothing(hw, depth):
     """Base-64 model: the last 3x3 convolutions of the two highest decoder levels run the F(4x4) kernel only on the regions
-    that the stitch - or the halo of the layers behind them - reads (option crop=1, default).  Raw labels, post-processed
-    labels and counts must be identical to the uncropped run."""
+    that the stitch - or the halo of the layers behind them - reads (option crop=1, default), and read zeros outside the
+    receptive field of those pixels (a Winograd tile leaks what lies outside an output's 3x3 support into its last bits).
+    The probabilities agree with the uncropped run to float32 rounding; raw labels may differ only where the two best
+    quantised classes are within one step (none on these inputs)."""
     from ecseg_amd import keras_plan
     from ecseg_amd._lib import Handle
     cfg = synth.unet_config(base=64, depth=depth)
@@ -107,13 +120,19 @@ def test_crop_of_unread_regions_changes_nothing(hw, depth):
         hnd.load_plan(keras_plan.build_plan(cfg, weights, fuse=True))
         imgs = np.stack([synth.dapi_image(40 + i, hw[0], hw[1]) for i in range(2)])
         hnd.set_option('crop', 1)
-        a = hnd.segment_images(imgs, want_raw=True)
+        a = hnd.segment_images(imgs, want_raw=True, want_probs=True)
         hnd.set_option('crop', 0)
-        b = hnd.segment_images(imgs, want_raw=True)
+        b = hnd.segment_images(imgs, want_raw=True, want_probs=True)
     finally:
         hnd.close()
-    for x, y in zip(a, b):
-        assert np.array_equal(x, y)
+    assert np.abs(a[3] - b[3]).max() < 1e-5
+    d = a[0] != b[0]
+    if d.any():
+        q = np.sort(quant.quantise_u8(b[3].astype(np.float64))[d].astype(int), axis=-1)
+        assert (q[:, -1] - q[:, -2] <= 1).all() and d.mean() < 1e-5
+    else:
+        for x, y in zip(a[:3], b[:3]):
+            assert np.array_equal(x, y)
 
 
 @pytest.mark.gpu
@@ -141,8 +160,8 @@ def test_repeated_runs_are_bit_identical():
 
 
 def test_tie_risk_counts_and_stitched_probabilities(model16):
-    """ecseg_segment_images_ex: the stitched probabilities are exactly patches2im_overlap of the device's own patch
-    probabilities (src/utils.py:115-116; never-written canvas pixels 0), the labels are their quantised argmax, and the
+    """ecseg_segment_images_ex: the stitched probabilities are patches2im_overlap of the device's patch probabilities
+    (src/utils.py:115-116; never-written canvas pixels 0), the labels are their quantised argmax, and the
     per-image tie-risk count is the number of written pixels whose two largest uint8-quantised values differ by at most 1 -
     the only pixels on which two float32 evaluations of the network can disagree (two images of different content in one
     batch: the per-image counters must not mix)."""
@@ -153,7 +172,10 @@ def test_tie_risk_counts_and_stitched_probabilities(model16):
     for i in range(3):
         g_probs = model16.predict_on_batch(tiling.extract_patches(imgs[i][..., None], pos))
         want = tiling.stitch(g_probs, pos)
-        assert probs[i].dtype == np.float32 and np.array_equal(probs[i], want.astype(np.float32))
+        # (the segment path computes only what the stitch reads and its Winograd tiles read zeros outside the receptive field of those
+        # pixels - ConvParams::in_box: equal to the full forward pass up to float32 rounding; never-written pixels are 0 in both)
+        assert probs[i].dtype == np.float32 and np.abs(probs[i] - want.astype(np.float32)).max() < 1e-5
+        assert np.array_equal(probs[i].sum(-1) == 0, want.sum(-1) == 0)
         assert np.array_equal(raw[i], quant.quantised_argmax(probs[i].astype(np.float64)))
         q = np.sort(quant.quantise_u8(probs[i].astype(np.float64)).astype(int), axis=-1)
         written = probs[i].sum(-1) > 0.5

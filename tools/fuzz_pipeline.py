@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised whole-pipeline parity: random small U-Nets (depth, width, up-sampling kind, BatchNormalization) x random image
 sizes through ecseg_segment_images, checked four ways per case:
-  * crop on == crop off, bit for bit (raw labels, cleaned labels, counts) - the demand-driven cropping must be invisible;
+  * the cropped plan (default) is bit-identical to itself whatever ran before and however many window lanes it uses, and agrees
+    with the uncropped plan to float32 rounding (probabilities within 1e-5; labels differ at most at near-ties of the
+    quantised probabilities: its Winograd tiles read zeros outside the receptive field of the pixels the stitch reads);
   * window probabilities vs the CPU oracle within 1e-3 (`predict_on_batch` on the oracle's own tiles);
   * device raw labels differ from the oracle's only at near-ties of the quantised probabilities;
   * clean-up + count are bit-exact functions of the DEVICE raw labels (oracle meta_inference on them);
@@ -73,11 +75,22 @@ def main():
                 h.set_option(kk, vv)
             tag += ' ' + ','.join('%s=%d' % kv for kv in sorted(opts.items()))
             h.set_option('crop', 1)
-            raw1, post1, nec1 = h.segment_images(imgs, want_raw=True)
+            h.set_option('unet_lanes', int(rng.integers(0, 5)))
+            raw1, post1, nec1, probs1 = h.segment_images(imgs, want_raw=True, want_probs=True)
             h.set_option('crop', 0)
-            raw0, post0, nec0 = h.segment_images(imgs, want_raw=True)
-            if not (np.array_equal(raw1, raw0) and np.array_equal(post1, post0) and np.array_equal(nec1, nec0)):
-                fail('crop on/off differ (%d raw px) - %s' % (int((raw1 != raw0).sum()), tag))
+            raw0, post0, nec0, probs0 = h.segment_images(imgs, want_raw=True, want_probs=True)
+            h.set_option('crop', 1)
+            h.set_option('unet_lanes', int(rng.integers(0, 5)))
+            raw2, post2, nec2, probs2 = h.segment_images(imgs, want_raw=True, want_probs=True)
+            if not (np.array_equal(raw1, raw2) and np.array_equal(post1, post2) and np.array_equal(nec1, nec2) and np.array_equal(probs1, probs2)):
+                fail('cropped plan differs from itself after another run / with other lanes (%d raw px) - %s' % (int((raw1 != raw2).sum()), tag))
+            if float(np.abs(probs1 - probs0).max()) > 1e-5:
+                fail('crop on/off probabilities differ by %.3e - %s' % (float(np.abs(probs1 - probs0).max()), tag))
+            dc = raw1 != raw0
+            if dc.any():
+                top = np.sort(quant.quantise_u8(probs0.astype(np.float64)).astype(np.int32), axis=-1)
+                if ((top[..., 3] - top[..., 2])[dc] > 1).any():
+                    fail('crop on/off labels differ away from ties (%d raw px) - %s' % (int(dc.sum()), tag))
             pos = tiling.patch_positions(H, W)
             k = int(rng.integers(0, n))
             patches = tiling.extract_patches(imgs[k][..., None], pos)

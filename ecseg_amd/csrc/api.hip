@@ -433,11 +433,15 @@ const CropLut* get_crop_lut(StitchPlan* sp, const std::string& code, int rh = 16
 // half-empty last round of workgroups of one lane's deep layers (35 windows: 288 / 560 workgroups on 256 CUs) is filled by
 // another lane's next layer.  Same kernels, same per-window arithmetic: results do not depend on the lanes.  A lane is
 // either whole images or a part of ONE image (cropped launches then take a slice of the window-major region list).
-int run_plan(ecseg_ctx* h, int n_all, StitchPlan* crop = nullptr, int w0 = 0, int cnt = -1, hipStream_t lane_s = nullptr) {
-    hipStream_t s = lane_s ? lane_s : h->stream;
-    const bool lane = cnt >= 0;
-    const int n = lane ? cnt : n_all;
-    if (!lane) w0 = 0;
+struct LaneSpec { int w0, cnt; hipStream_t s; };
+
+// Launch op `oi` of the plan (and the ops its kernel takes over: a following pool / head - `oi` is advanced past them) for one
+// lane (null: all n_all windows on the main stream).
+int run_plan_op(ecseg_ctx* h, size_t& oi, int n_all, StitchPlan* crop, const LaneSpec* ls) {
+    hipStream_t s = ls ? ls->s : h->stream;
+    const bool lane = ls != nullptr;
+    const int n = lane ? ls->cnt : n_all;
+    const int w0 = lane ? ls->w0 : 0, cnt = n;
     const bool part = lane && crop && (w0 % crop->n_pos != 0 || cnt % crop->n_pos != 0);
     const int wbase = part ? (w0 / crop->n_pos) * crop->n_pos : w0;     // cropped launches of a partial lane: views at the image's first window
     if (part && w0 + cnt > wbase + crop->n_pos) return fail(h, ECSEG_E_INVALID, "window lane crosses an image boundary");
@@ -459,7 +463,7 @@ int run_plan(ecseg_ctx* h, int n_all, StitchPlan* crop = nullptr, int w0 = 0, in
         v.p += off;
         return v;
     };
-    for (size_t oi = 0; oi < h->ops.size(); ++oi) {
+    {
         const OpRt& o = h->ops[oi];
         const ecseg_op_desc& d = o.d;
         const TView in = at(d.in0), out = at(d.out);
@@ -647,6 +651,26 @@ int run_plan(ecseg_ctx* h, int n_all, StitchPlan* crop = nullptr, int w0 = 0, in
             default: return fail(h, ECSEG_E_INVALID, "unknown op in plan");
         }
         if (e != hipSuccess) return fail_hip(h, e, "plan kernel launch");
+    }
+    return ECSEG_OK;
+}
+
+// The whole plan on n_all patches whose input tensor has been written; with lanes, op by op for every lane in turn (the lanes'
+// kernels are enqueued interleaved, so the streams start together)
+int run_plan(ecseg_ctx* h, int n_all, StitchPlan* crop = nullptr, const std::vector<LaneSpec>* lanes = nullptr) {
+    for (size_t oi = 0; oi < h->ops.size(); ++oi) {
+        int rc;
+        if (!lanes || lanes->empty()) {
+            if ((rc = run_plan_op(h, oi, n_all, crop, nullptr))) return rc;
+        } else {
+            size_t last = oi;
+            for (const LaneSpec& l : *lanes) {
+                size_t o2 = oi;
+                if (l.cnt > 0 && (rc = run_plan_op(h, o2, n_all, crop, &l))) return rc;
+                if (l.cnt > 0) last = o2;
+            }
+            oi = last;
+        }
     }
     return ECSEG_OK;
 }
@@ -885,16 +909,20 @@ int segment_dev(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint
                 if ((rc = run_plan(h, nw, sp))) return rc;
             } else {
                 const int unit = ni > 1 ? sp->n_pos : 1, units = nw / unit;
+                std::vector<LaneSpec> specs;
                 int u0 = 0;
                 for (int l = 0; l < lanes; ++l) {
                     const int u1 = (int)((long long)units * (l + 1) / lanes);
                     hipStream_t ls = l == 0 ? s : h->lane_streams[l - 1];
                     if (l > 0) HIP_TRY(h, hipStreamWaitEvent(ls, e6[1], 0));
-                    if (u1 > u0 && (rc = run_plan(h, nw, sp, u0 * unit, (u1 - u0) * unit, ls))) return rc;
-                    if (l > 0) HIP_TRY(h, hipEventRecord(h->lane_events[l - 1], ls));
+                    specs.push_back({u0 * unit, (u1 - u0) * unit, ls});
                     u0 = u1;
                 }
-                for (int l = 1; l < lanes; ++l) HIP_TRY(h, hipStreamWaitEvent(s, h->lane_events[l - 1], 0));
+                if ((rc = run_plan(h, nw, sp, &specs))) return rc;
+                for (int l = 1; l < lanes; ++l) {
+                    HIP_TRY(h, hipEventRecord(h->lane_events[l - 1], h->lane_streams[l - 1]));
+                    HIP_TRY(h, hipStreamWaitEvent(s, h->lane_events[l - 1], 0));
+                }
             }
         }
         HIP_TRY(h, hipEventRecord(e6[2], s));

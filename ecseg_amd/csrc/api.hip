@@ -109,6 +109,7 @@ struct ecseg_ctx {
     int overlap_post = 0;
     int fuse_pool = 1;        // 2x2 max-pool written by the producing F(4x4) convolution's output stage
     int crop = 1;             // segment path: skip output regions of the last full-resolution convolutions that the stitch never reads
+    int crop_mask = 1;        // cropped plan: Winograd kernels read zeros outside the receptive field of the needed outputs (0: A/B measurements only - results then depend on stale buffer contents in the last bits)
     int fuse_head = 1;        // 1x1 head (<= 4 classes) computed by the output stage of the last F(4x4) convolution
     int use_winograd = 2;     // 0 direct, 1 Winograd F(2x2,3x3), 2 F(4x4,3x3) where eligible (else F(2x2))
     int wino4_split = 1;      // F(4x4) layers with exactly 32 output channels: split-K over the channel-half waves
@@ -519,7 +520,7 @@ int run_plan_op(ecseg_ctx* h, size_t& oi, int n_all, StitchPlan* crop, const Lan
                     // of the outputs somebody needs (ConvParams::in_box): results do not depend on what a cropped producer left
                     // outside it
                     const bool crop_on = crop && h->crop && o.crop_ok && (part || n % crop->n_pos == 0);
-                    if (crop_on && d.op == ECSEG_OP_CONV && d.kh == 3 && d.kw == 3 && (wino4 || wino)) {
+                    if (crop_on && h->crop_mask && d.op == ECSEG_OP_CONV && d.kh == 3 && d.kw == 3 && (wino4 || wino)) {
                         p.in_box = get_crop_box(crop, o.crop_code + "d");
                         p.per_image = crop->n_pos;
                         p.box_first = part ? w0 - wbase : 0;
@@ -1045,6 +1046,7 @@ int ecseg_set_option(ecseg_ctx* h, const char* key, int value) {
     else if (k == "post_chunk" && value >= 1) h->post_chunk = value;
     else if (k == "post_graph") { h->post_graph = value != 0; if (!h->post_graph) drop_post_graphs(h); }
     else if (k == "images_per_group" && value >= 0) h->images_per_group = value;     // 0: automatic
+    else if (k == "crop_mask") h->crop_mask = value != 0;
     else if (k == "unet_lanes" && value >= 0 && value <= 8) h->unet_lanes = value;   // 0: automatic
     else if (k == "lane_auto_windows" && value >= 0) h->lane_auto_windows = value;
     else return fail(h, ECSEG_E_INVALID, "unknown option or bad value: " + k);

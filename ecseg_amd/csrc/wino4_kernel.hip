@@ -143,7 +143,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
     const bool tail4 = (p.in.c & 7) != 0;                    // (pointers are 16-byte aligned: bits 0 / 1 carry lane flags)
 
     // the two 16 x 16 regions of this workgroup: consecutive in (patch, region row, region column) order
-    int r_img[2], r_y0[2], r_x0[2];
+    int r_img[2], r_y0[2], r_x0[2], r_win[2] = {-1, -1};     // r_win: window within its image (known for free in a cropped launch)
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int rid = 2 * pair + g;
@@ -154,6 +154,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             if (i >= p.n / p.per_image) img = p.n;
             r_img[g] = img < p.n ? img : -1;
             r_y0[g] = ry * 4; r_x0[g] = rx * 4;
+            r_win[g] = v >> 16;
             continue;
         } else {
             rx = rid % regs_x;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             if (r_img[g] < 0) continue;
-            const int32_t* bx = p.in_box + 4 * ((r_img[g] + p.box_first) % p.per_image);
+            const int32_t* bx = p.in_box + 4 * (r_win[g] >= 0 ? r_win[g] : (r_img[g] + p.box_first) % p.per_image);
             r_by0[g] = bx[0]; r_by1[g] = bx[1]; r_bx0[g] = bx[2]; r_bx1[g] = bx[3];
         }
     }

@@ -104,6 +104,11 @@ def test_plan_of_canonical_unet(base, up, bn):
         if fuse:
             assert all(o['op'] not in (keras_plan.OP_AFFINE, keras_plan.OP_ACT) for o in plan.ops)
             assert all(o['op'] != keras_plan.OP_COPY for o in plan.ops)     # concatenation is free
+        # window lanes (csrc/api.hip run_plan) address the model input and output in plain window order while every other
+        # tensor is packed into a lane's private slice of its buffer: the two must have buffers of their own
+        for io in (plan.input_tensor, plan.output_tensor):
+            b = plan.tensors[io]['buffer']
+            assert [k for k, t in enumerate(plan.tensors) if t['buffer'] == b] == [io]
     if base == 64 and up == 'transpose':
         assert abs(plan.flops_per_patch() / 1e9 - 96.2) < 0.1
         assert sum(plan.buffer_floats) * 4 < 90e6                           # liveness re-use: < 90 MB per patch

@@ -656,7 +656,8 @@ struct CclPass {
 
 static hipError_t run_ccl_pass(PostWorkspace& ws, const CclGeom& g, const CclPass& c, hipStream_t s) {
     const int ng = g.n_img * G_IMG;
-    hipLaunchKernelGGL(zero_g_kernel, dim3((ng + 255) / 256), dim3(256), 0, s, ws.g, ng);
+    // (a pass that produces no counters - the fill_holes labellings - touches none: no zeroing launch)
+    if (c.need) hipLaunchKernelGGL(zero_g_kernel, dim3((ng + 255) / 256), dim3(256), 0, s, ws.g, ng);
     const unsigned grid = geom_grid(g);
     const bool slots = !c.count_only;                          // count_only: counts per key only - no statistics, no owners' slots
     const int stat = slots ? c.stat : 0, aux_mode = slots ? c.aux_mode : AUX_NONE;

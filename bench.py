@@ -185,7 +185,7 @@ def parity_vs_cpu(hnd, refs):
                     'and 0 vs 0.  Clean-up and counting are bit-exact functions of the raw labels'}
 
 
-def aux_device_legs(hnd, local, n=64):
+def aux_device_legs(hnd, local, n=64, with_comm=True):
     """the device cost of BASELINE configs[4] (`make meta_overlay`'s row: ecseg_overlay) and of
     meta_preprocess (ecseg_preprocess) on n resident synthetic FISH images - HIP events around the kernels alone inside the
     entry points (ecseg_get_timings()[ECSEG_T_COUNT]; host copies excluded) - with their algorithmic bytes and the fraction of
@@ -222,6 +222,8 @@ def aux_device_legs(hnd, local, n=64):
     out['preprocess_ms_per_image'] = {'value': round(t, 4), 'images': n, 'algorithmic_bytes_per_image': pp_bytes,
                                       'achieved_GBs': round(pp_bytes / (t * 1e-3) / 1e9, 1), 'frac_of_hbm_peak': round(pp_bytes / (t * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
                                       'what': 'ecseg_preprocess (src/image_tools.py:86-96): blue channel + 256-bin histogram + Otsu + invert, uint8 RGB, kernels only'}
+    if not with_comm:                                              # (tools/aux_legs.py under rocprofv3: RCCL's own profiler hooks crash there)
+        return out
     try:
         comm = Comm(Comm.unique_id(), 0, 1, local)
         rec = torch.zeros((n, 16), dtype=torch.int64, device='cuda:%d' % local)

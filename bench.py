@@ -207,8 +207,9 @@ def aux_device_legs(hnd, local, n=64, with_comm=True):
         ms.append(hnd.timings()['count'])
     t = float(np.median(ms)) / n
     # 5 labellings x 9 B/px (image 1 + parents written 4 + read 4) + aux / mask passes (labels 1 + RGB 3 in, 1 out: 5 passes) +
-    # 2 size filters (parents 4 + flags 2) + 6 flagged-root counts (image 1 + parents 4)
-    ov_bytes = px * (5 * 9 + 5 * 5 + 2 * 6 + 6 * 5)
+    # 2 size filters (parents 4 + flags 2).  (Rounds 3 - 4a also counted 6 per-pixel flagged-root passes x 5 B/px = 162 MB in all; the
+    # counts now come from the owner bits - 256 B per tile - and are not per-pixel work any more.)
+    ov_bytes = px * (5 * 9 + 5 * 5 + 2 * 6)
     out['overlay_ms_per_image'] = {'value': round(t, 4), 'images': n, 'algorithmic_bytes_per_image': ov_bytes,
                                    'achieved_GBs': round(ov_bytes / (t * 1e-3) / 1e9, 1), 'frac_of_hbm_peak': round(ov_bytes / (t * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
                                    'what': 'ecseg_overlay (src/meta_overlay.py:56-95): thresholds + 5 labellings + counts, realistic label maps (synth.label_map) + synthetic FISH RGB, kernels only'}

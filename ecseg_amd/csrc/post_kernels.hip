@@ -629,6 +629,7 @@ __global__ void reduce_g_kernel(int32_t* __restrict__ G_all, int n_img) {
     for (int sh = 1; sh < G_SHARDS; ++sh) {
         const int w = G[sh * G_STRIDE + t];
         v = (t == G_LAST_ROOT) ? max(v, w) : v + w;
+        G[sh * G_STRIDE + t] = 0;                         // folded: a second fold (count_flagged_owner_roots adds later) adds nothing twice
     }
     G[t] = v;
 }
@@ -1301,30 +1302,56 @@ hipError_t run_ccl_labels(PostWorkspace& ws, const uint8_t* mask, int n_img, int
     return hipGetLastError();
 }
 
-// number of roots whose key == key_sel (0 = any) and whose flag word has all bits of `need` -> G[G_CNT0 + slot]
-__global__ __launch_bounds__(256) void count_flagged_roots_kernel(const uint8_t* __restrict__ key_img, uint32_t lut,
-                                                                  const int32_t* __restrict__ L,
-                                                                  const uint32_t* __restrict__ flag,
-                                                                  int32_t* __restrict__ G_all, size_t total, size_t px,
-                                                                  int key_sel, uint32_t need, int slot) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const int lane = threadIdx.x & 63;
-    for (size_t t0 = (size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); t0 < total; t0 += stride) {
-        const size_t t = t0 + lane;
-        bool hit = false;
-        size_t im = 0;
-        if (t < total) {
-            im = t / px;
-            const int p = (int)(t - im * px);
-            hit = L[t] == p && (!key_sel || key_of(key_img[t], lut) == key_sel) && (flag[t] & need) == need;
-        }
-        const size_t im0 = t0 / px;
+// Up to 5 counts of roots by (key, flag bits) in ONE pass over the owner bits (round 4): roots are owners that still point at
+// themselves, so only the 256 B of owner bits per tile and the owners' parents / flags are read - the per-pixel scan below
+// (image + parent of every pixel, once per query) took 6 x 181 us of the 3.9 ms overlay row of 64 images.
+// Query i: roots whose key == key[i] (0 = any) and whose flag word has all bits of need[i] -> G[G_CNT0 + slot[i]] (sharded:
+// fold with reduce_g_kernel afterwards).
+struct FlagQueries { int n; int key[5]; uint32_t need[5]; int slot[5]; };
+__global__ __launch_bounds__(256) void count_flagged_owner_roots_kernel(CclGeom g, const uint8_t* __restrict__ img_all, uint32_t lut,
+                                                                        const int32_t* __restrict__ L_all,
+                                                                        const uint32_t* __restrict__ flag_all,
+                                                                        int32_t* __restrict__ G_all,
+                                                                        const uint8_t* __restrict__ tile_any,
+                                                                        const uint32_t* __restrict__ own_bits, FlagQueries Q) {
+    __shared__ int red[8];
+    int img, y0, cx;
+    if (!decode_block(g, img, y0, cx)) return;
+    const size_t ti = tile_index(g, img);
+    const int ta = tile_any[ti];
+    if (!ta) return;
+    const int tid = threadIdx.x;
+    if (tid < 8) red[tid] = 0;
+    __syncthreads();
+    const size_t base = (size_t)img * g.H * g.W;
+    const int yblk = y0 - (tid >> 6) * CCL_ROWS;
+    // thread = 8 consecutive pixels of the tile; a FULL tile (tile_any == 2) has one owner, its first pixel, and no owner bits
+    uint32_t bits = ta == 2 ? (tid == 0 ? 1u : 0u) : (own_bits[ti * 64 + (tid >> 2)] >> ((tid & 3) * 8)) & 0xffu;
+    int c[5] = {0, 0, 0, 0, 0};
+    while (bits) {
+        const int k = __ffs((int)bits) - 1;
+        bits &= bits - 1;
+        const int li = tid * 8 + k;
+        const int p = (yblk + (li >> 6)) * g.W + cx * 64 + (li & 63);
+        if (L_all[base + p] != p) continue;
+        const int key = key_of(img_all[base + p], lut);
+        const uint32_t f = flag_all[base + p];
 #pragma unroll
-        for (int side = 0; side < 2; ++side) {                   // a wave may straddle two images
-            const u64 m = __ballot(hit && ((im == im0) == (side == 0)));
-            if (m && lane == __ffsll((long long)m) - 1) atomicAdd(G_all + im * G_IMG + G_CNT0 + slot, __popcll(m));
-        }
+        for (int i = 0; i < 5; ++i)
+            if (i < Q.n && (!Q.key[i] || key == Q.key[i]) && (f & Q.need[i]) == Q.need[i]) c[i] += 1;
     }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) if (c[i]) atomicAdd(&red[i], c[i]);
+    __syncthreads();
+    int32_t* G = G_all + (size_t)img * G_IMG + (size_t)(block_in_image(g) % G_SHARDS) * G_STRIDE;
+    if (tid < Q.n && red[tid]) atomicAdd(G + G_CNT0 + Q.slot[tid], red[tid]);
+}
+
+static void launch_flagged_counts(PostWorkspace& ws, const CclGeom& g, const uint8_t* key_img, uint32_t lut, const FlagQueries& Q,
+                                  hipStream_t s) {
+    hipLaunchKernelGGL(count_flagged_owner_roots_kernel, dim3(geom_grid(g)), dim3(256), 0, s, g, key_img, lut, ws.L, ws.flag, ws.g,
+                       ws.tile_any, ws.own_bits, Q);
+    hipLaunchKernelGGL(reduce_g_kernel, dim3(g.n_img), dim3(G_STRIDE), 0, s, ws.g, g.n_img);
 }
 
 __global__ void gather_slot_kernel(const int32_t* __restrict__ G_all, int n_img, int slot, int key_for_quirk,
@@ -1353,8 +1380,7 @@ hipError_t run_count_coloc(PostWorkspace& ws, const uint8_t* ob1, const uint8_t*
     CclPass p{ob1, LUT_NONZERO, 8, 0, AUX_IMAGE, 0, ws.tmpA, NEED_NPX};
     hipError_t e = run_ccl_pass(ws, g, p, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(count_flagged_roots_kernel, dim3(px_grid(total)), dim3(256), 0, s, ob1, LUT_NONZERO, ws.L, ws.flag,
-                       ws.g, total, px, 0, 1u, 0);
+    launch_flagged_counts(ws, g, ob1, LUT_NONZERO, FlagQueries{1, {0}, {1u}, {0}}, s);
     hipLaunchKernelGGL(gather_slot_kernel, dim3((n_img + 63) / 64), dim3(64), 0, s, ws.g, n_img, 0, 1, (long long)px, n_dev,
                        (long long*)nullptr, 1, 0);
     return hipGetLastError();
@@ -1390,8 +1416,7 @@ hipError_t run_count_hsr(PostWorkspace& ws, const uint8_t* chrom, const uint8_t*
     hipLaunchKernelGGL(keep_large_kernel, dim3(px_grid(total)), dim3(256), 0, s, ws.L, ws.area, ws.tmpA, total, px, thr, 0);
     CclPass p2{chrom, LUT_NONZERO, 8, 0, AUX_IMAGE, 0, ws.tmpA, NEED_NPX};
     if ((e = run_ccl_pass(ws, g, p2, s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(count_flagged_roots_kernel, dim3(px_grid(total)), dim3(256), 0, s, chrom, LUT_NONZERO, ws.L, ws.flag,
-                       ws.g, total, px, 0, 1u, 0);
+    launch_flagged_counts(ws, g, chrom, LUT_NONZERO, FlagQueries{1, {0}, {1u}, {0}}, s);
     hipLaunchKernelGGL(gather_slot_kernel, dim3((n_img + 63) / 64), dim3(64), 0, s, ws.g, n_img, 0, 1, (long long)px, n_dev,
                        (long long*)nullptr, 1, 0);
     return hipGetLastError();
@@ -1462,9 +1487,10 @@ hipError_t run_overlay(PostWorkspace& ws, const uint8_t* labels, const uint8_t* 
         hipLaunchKernelGGL(overlay_cc_gather_kernel, dim3(ig), dim3(64), 0, s, ws.g, n_img, 3, (long long)px, out, 0);
         const struct { int key; uint32_t need; int slot; int off; } q[5] = {
             {3, 1u, 0, 6}, {3, 2u, 1, 7}, {3, 4u, 2, 9}, {2, 8u, 3, 10}, {2, 16u, 4, 11}};
+        FlagQueries Q{5, {}, {}, {}};
+        for (int k = 0; k < 5; ++k) { Q.key[k] = q[k].key; Q.need[k] = q[k].need; Q.slot[k] = q[k].slot; }
+        launch_flagged_counts(ws, g, labels, lut, Q, s);
         for (int k = 0; k < 5; ++k) {
-            hipLaunchKernelGGL(count_flagged_roots_kernel, dim3(pg), dim3(256), 0, s, labels, lut, ws.L, ws.flag, ws.g, total,
-                               px, q[k].key, q[k].need, q[k].slot);
             hipLaunchKernelGGL(gather_slot_kernel, dim3(ig), dim3(64), 0, s, ws.g, n_img, q[k].slot, q[k].key, (long long)px,
                                (int32_t*)nullptr, out, 12, q[k].off);
         }
@@ -1476,8 +1502,7 @@ hipError_t run_overlay(PostWorkspace& ws, const uint8_t* labels, const uint8_t* 
         CclPass p{msk, LUT_NONZERO, 8, 0, AUX_IMAGE, 0, aux, NEED_NCOMP | NEED_NPX};
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
         hipLaunchKernelGGL(overlay_cc_gather_kernel, dim3(ig), dim3(64), 0, s, ws.g, n_img, 1, (long long)px, out, 2);
-        hipLaunchKernelGGL(count_flagged_roots_kernel, dim3(pg), dim3(256), 0, s, msk, LUT_NONZERO, ws.L, ws.flag, ws.g, total,
-                           px, 0, 1u, 0);
+        launch_flagged_counts(ws, g, msk, LUT_NONZERO, FlagQueries{1, {0}, {1u}, {0}}, s);
         hipLaunchKernelGGL(gather_slot_kernel, dim3(ig), dim3(64), 0, s, ws.g, n_img, 0, 1, (long long)px, (int32_t*)nullptr,
                            out, 12, 8);
     }

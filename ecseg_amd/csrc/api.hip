@@ -900,9 +900,12 @@ int segment_dev(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint
             if (ni > 1) lanes = std::min(lanes, ni);         // whole images per lane
             lanes = std::max(1, std::min(lanes, std::min(nw, 8)));
             while ((int)h->lane_streams.size() < lanes - 1) {
-                hipStream_t ls; hipEvent_t le;
+                hipStream_t ls;
                 HIP_TRY(h, hipStreamCreateWithFlags(&ls, hipStreamNonBlocking));
                 h->lane_streams.push_back(ls);
+            }
+            while ((int)h->lane_events.size() < lanes - 1) {     // (its own loop: a failed creation leaves the two lists consistent)
+                hipEvent_t le;
                 HIP_TRY(h, hipEventCreateWithFlags(&le, hipEventDisableTiming));
                 h->lane_events.push_back(le);
             }

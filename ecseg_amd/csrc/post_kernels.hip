@@ -20,6 +20,8 @@
 // array stays in that XCD's L2.
 #include <algorithm>
 
+#include <cstdlib>
+
 #include "common.h"
 #include "device_util.h"
 
@@ -60,8 +62,8 @@ static constexpr int CCL_BLOCK_ROWS = 4 * CCL_ROWS;     // rows per block
 struct CclGeom {
     int H, W, n_img;
     int chunks_x, strips_y, blocks_per_img;
-    int img_groups;   // ceil(n_img / 8)
-    int spread;       // fewer than 8 images: the tiles of an image go round-robin over all XCDs (see decode_block)
+    int img_groups;   // n_img / 8: complete groups of 8 images, one image per XCD (see decode_block)
+    int affine_blocks;   // 8 * img_groups * blocks_per_img: the workgroups of those groups; the rest deal the remaining images' tiles over all XCDs
 };
 
 static CclGeom make_geom(int n_img, int H, int W) {
@@ -70,23 +72,26 @@ static CclGeom make_geom(int n_img, int H, int W) {
     g.chunks_x = (W + 63) / 64;
     g.strips_y = (H + CCL_BLOCK_ROWS - 1) / CCL_BLOCK_ROWS;
     g.blocks_per_img = g.chunks_x * g.strips_y;
-    g.img_groups = (n_img + 7) / 8;
-    g.spread = n_img < 8;
+    g.img_groups = n_img / 8;
+    g.affine_blocks = 8 * g.img_groups * g.blocks_per_img;
     return g;
 }
-static unsigned geom_grid(const CclGeom& g) { return (unsigned)((g.spread ? g.n_img : 8 * g.img_groups) * g.blocks_per_img); }
+static unsigned geom_grid(const CclGeom& g) { return (unsigned)(g.n_img * g.blocks_per_img); }
 
-// block id -> (image, strip, chunk).  Images with equal (img % 8) share an XCD (consecutive workgroups go to consecutive
-// XCDs): the parents, statistics and owner bits of an image stay in ONE L2.  With fewer than 8 images that would leave
-// XCDs idle - a single image ran all its 726 tiles on 32 of the 256 CUs, 67 - 86 us per ccl_local launch - so the tiles of
-// an image are then dealt round-robin over all XCDs (round 4; every cross-tile access is an agent-scope atomic anyway).
+// block id -> (image, strip, chunk).  Complete groups of 8 images: images with equal (img % 8) share an XCD (consecutive
+// workgroups go to consecutive XCDs), so the parents, statistics and owner bits of an image stay in ONE L2 (64 images: 0.135 against
+// 0.146 ms per speckled image with the tiles dealt round-robin).  The images beyond the last complete group - all of them when there are
+// fewer than 8 - would leave XCDs idle that way (a single image ran its 726 tiles on 32 of the 256 CUs: 67 - 86 us per ccl_local
+// launch; 9 images took 2x the time of 8): their tiles are dealt round-robin over all XCDs (round 4; every cross-tile access is an
+// agent-scope atomic anyway: 9 images 0.223 -> 0.174 ms per speckled image, 12 images 0.179 -> 0.165).
 __device__ __forceinline__ unsigned block_in_image(const CclGeom& g) {
-    return (g.spread ? blockIdx.x : (blockIdx.x >> 3)) % (unsigned)g.blocks_per_img;
+    const unsigned b = blockIdx.x;
+    return (b < (unsigned)g.affine_blocks ? (b >> 3) : b - (unsigned)g.affine_blocks) % (unsigned)g.blocks_per_img;
 }
 __device__ __forceinline__ bool decode_block(const CclGeom& g, int& img, int& y0, int& cx) {
     const unsigned b = blockIdx.x;
-    if (g.spread) img = (int)(b / (unsigned)g.blocks_per_img);
-    else img = (int)(((b >> 3) / g.blocks_per_img) * 8 + (b & 7u));
+    if (b < (unsigned)g.affine_blocks) img = (int)(((b >> 3) / g.blocks_per_img) * 8 + (b & 7u));
+    else img = 8 * g.img_groups + (int)((b - (unsigned)g.affine_blocks) / (unsigned)g.blocks_per_img);
     if (img >= g.n_img) return false;
     const unsigned blk = block_in_image(g);
     cx = (int)(blk % g.chunks_x);

@@ -249,3 +249,23 @@ def test_window_lanes_do_not_change_results(gpu, base, up):
             assert np.array_equal(a, b)
     finally:
         gpu.set_option('unet_lanes', 0)
+
+
+@pytest.mark.parametrize('n_img', [1, 7, 8, 9, 13, 16, 19])
+def test_clean_up_and_counts_for_every_batch_remainder(gpu, n_img):
+    """The CCL kernels map complete groups of 8 images to one XCD per image and deal the tiles of the remaining images (all of them
+    below 8) over all XCDs (post_kernels.hip: decode_block): every image of every batch size gets the same answer as alone, and
+    that answer is the oracle's."""
+    rng = np.random.default_rng(100 + n_img)
+    H, W = 150, 333                                             # 5 x 6 tiles, the last ones partial
+    labs = np.stack([synth.label_map(300 + i, H, W) if i % 3 else rng.integers(0, 4, size=(H, W)).astype(np.uint8) for i in range(n_img)])
+    post, nec = gpu.meta_inference(labs)
+    cnt, px = gpu.count_cc(labs == 3)
+    rows = gpu.overlay(labs, np.stack([synth.dapi_image(500 + i, H, W, rgb=True) for i in range(n_img)]), 85)
+    for i in range(n_img):
+        want = postproc.meta_inference(labs[i])
+        assert np.array_equal(post[i], want), i
+        assert nec[i] == postproc.count_cc(want == 3)[0]
+        assert (cnt[i], px[i]) == tuple(postproc.count_cc(labs[i] == 3)), i
+    one = gpu.overlay(labs[-1], synth.dapi_image(500 + n_img - 1, H, W, rgb=True), 85)
+    assert np.array_equal(np.asarray(one).reshape(-1), np.asarray(rows[-1]).reshape(-1))

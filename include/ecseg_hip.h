@@ -148,7 +148,12 @@ int ecseg_set_images_per_group(ecseg_ctx* h, int n);
  * that convolution's output stage and the feature tensor is never written; 0: separate head kernel), "crop" (1 (default): in ecseg_segment_images the last
  * full-resolution convolutions (F(4x4): 16x16 regions; conv_wino16_kernel: 16x32 blocks; 2x2 up-convolutions: input tiles)
  * compute only the parts of every window that the stitch (or the halo of the convolutions behind them) reads - 72 % of them
- * at 1040x1392; results are unchanged; 0: whole windows), "post_graph" (1: the
+ * at 1040x1392, and their Winograd tiles read zeros outside the receptive field of those parts ("crop_mask", 1 (default)), so the result
+ * is a pure function of the image: independent of batch position, window lanes and of what ran before; it agrees with whole windows
+ * (0) to float32 rounding, i.e. labels can differ at near-ties of the quantised probabilities), "unet_lanes" (0 (default): automatic -
+ * a launch group of <= 70 windows (one or two 1040x1392 images) runs its U-Net as two window lanes on their own streams, which fills
+ * the half-empty last round of workgroups of the deep layers (one image: 11.3 -> 10.4 ms); 1..8: that many lanes; results are
+ * bit-identical for every value), "post_graph" (1: the
  * ~60 short kernels of meta_inference + count are captured once per (buffers, geometry) into a HIP graph and replayed;
  * 0 (default): plain launches - measured equal, the asynchronous launch queue already hides the launch gaps). */
 int ecseg_set_option(ecseg_ctx* h, const char* key, int value);

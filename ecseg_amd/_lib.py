@@ -28,7 +28,7 @@ class EcsegError(RuntimeError):
 
 E_NOMEM = -4
 E_UNSUPPORTED, E_IO = -5, -6
-ABI_VERSION = 3           # ECSEG_ABI_VERSION of include/ecseg_hip.h this binding was written for
+ABI_VERSION = 4           # ECSEG_ABI_VERSION of include/ecseg_hip.h this binding was written for
 
 
 class TensorDesc(C.Structure):
@@ -40,7 +40,7 @@ class OpDesc(C.Structure):
     _fields_ = [('op', C.c_int32), ('in0', C.c_int32), ('in1', C.c_int32), ('out', C.c_int32),
                 ('kh', C.c_int32), ('kw', C.c_int32), ('stride', C.c_int32),
                 ('pad_top', C.c_int32), ('pad_left', C.c_int32), ('act', C.c_int32), ('mode', C.c_int32),
-                ('w0', C.c_int32), ('w1', C.c_int32), ('alpha', C.c_float)]
+                ('w0', C.c_int32), ('w1', C.c_int32), ('alpha', C.c_float), ('dilation', C.c_int32)]
 
 
 _lib = None
@@ -180,7 +180,7 @@ class Handle:
         T = (TensorDesc * nt)(*[TensorDesc(t['buffer'], t['h'], t['w'], t['c'], t['c_stride'], t['c_offset'])
                                 for t in plan.tensors])
         O = (OpDesc * no)(*[OpDesc(o['op'], o['in0'], o['in1'], o['out'], o['kh'], o['kw'], o['stride'], o['pad_top'],
-                                   o['pad_left'], o['act'], o['mode'], o['w0'], o['w1'], float(o['alpha']))
+                                   o['pad_left'], o['act'], o['mode'], o['w0'], o['w1'], float(o['alpha']), int(o.get('dilation', 1)))
                             for o in plan.ops])
         keep = [np.ascontiguousarray(w, np.float32) for w in plan.weights]
         Wp = (C.c_void_p * max(nw, 1))(*[w.ctypes.data for w in keep])

@@ -40,7 +40,7 @@ struct OpRt {                 // run-time form of one plan operator
     int subpixel = 0;         // CONVT kh x kw / stride 2 with k in {3, 4} as a 2x2-tap convolution over the input (relayout_convt_subpixel)
     double flops = 0.0;       // algorithmic 2*MAC per patch
 };
-enum { PATH_MFMA = 1, PATH_SMALL_CIN = 2, PATH_HEAD = 3, PATH_GENERIC = 4, PATH_OTHER = 5 };
+enum { PATH_MFMA = 1, PATH_SMALL_CIN = 2, PATH_HEAD = 3, PATH_GENERIC = 4, PATH_OTHER = 5, PATH_TAP = 6 /* conv_mfma_tap_kernel: any taps / stride / dilation */ };
 
 struct CropLut {                  // size: extent (pixels) of the tensors it applies to; start[w]: first entry of window w (entries are window-major)
     int32_t* dev = nullptr; int len = 0; int size = 0; std::vector<int> start;
@@ -513,7 +513,9 @@ int run_plan_op(ecseg_ctx* h, size_t& oi, int n_all, StitchPlan* crop, const Lan
                     hipEvent_t* ev = h->profile_kernels ? prof_pair(h) : nullptr;
                     if (ev) (void)hipEventRecord(ev[0], s);
                     double computed = 1.0;                     // fraction of the layer a cropped launch really computes
-                    const bool wino4 = h->use_winograd >= 2 && o.wt_wino4 && conv_wino4_supported(p);   // (wt_wino* exist only for stride-1 3x3 'same' layers)
+                    // conv_wino4 / conv_wino16 implement activation codes 0..6 with ELU's alpha = 1 (device_util.h: apply_act_core)
+                    const bool act_core_ok = act <= ECSEG_ACT_ELU && !(act == ECSEG_ACT_ELU && d.alpha != 1.f);
+                    const bool wino4 = h->use_winograd >= 2 && o.wt_wino4 && act_core_ok && conv_wino4_supported(p);   // (wt_wino* exist only for stride-1 3x3 'same' layers)
                     const bool wino = !wino4 && h->use_winograd && o.wt_wino && out.h >= 4 && out.w >= 8;
                     bool w16 = false;
                     // a 3x3 convolution of the cropped chain on a Winograd kernel reads its input only inside the receptive field
@@ -549,7 +551,8 @@ int run_plan_op(ecseg_ctx* h, size_t& oi, int n_all, StitchPlan* crop, const Lan
                         if (p.pool.p != nullptr || oi + 1 >= h->ops.size() || !h->fuse_head || out.c != channels || softmax) return;
                         const OpRt& hx = h->ops[oi + 1];
                         const ecseg_tensor_desc& td = h->tensors[d.out];
-                        if (hx.d.op == ECSEG_OP_CONV && hx.path == PATH_HEAD && hx.head_w4 && hx.d.in0 == d.out &&
+                        if (hx.d.op == ECSEG_OP_CONV && hx.path == PATH_HEAD && hx.head_w4 && hx.d.in0 == d.out && hx.d.act <= ECSEG_ACT_TANH &&
+                            hx.d.act != ECSEG_ACT_LEAKY /* (the fused stage has the convolution's alpha, not the head's) */ &&
                             h->consumers[d.out] == 1 && d.out != h->output_tensor && td.c_stride == td.c && td.c_offset == 0 &&
                             // workgroups write head pixels while others still read the convolution's input halo
                             h->tensors[hx.d.out].buffer != h->tensors[d.in0].buffer &&
@@ -572,7 +575,7 @@ int run_plan_op(ecseg_ctx* h, size_t& oi, int n_all, StitchPlan* crop, const Lan
                         fuse_following_pool();
                         fuse_following_head(64);
                         e = launch_conv_wino4(p, s);
-                    } else if (wino && h->wino16 && o.wt_wino16 && conv_wino16_supported(p)) {
+                    } else if (wino && h->wino16 && o.wt_wino16 && act_core_ok && conv_wino16_supported(p)) {
                         w16 = true;
                         p.wt = o.wt_wino16;
                         if (crop && h->crop && o.crop_ok && (part || n % crop->n_pos == 0)) {
@@ -620,19 +623,47 @@ int run_plan_op(ecseg_ctx* h, size_t& oi, int n_all, StitchPlan* crop, const Lan
                         h->prof_recs.push_back({(int)oi_first, (wino4 ? 2 : w16 ? 4 : res ? 3 : wino ? 1 : 0) | (p.pool.p != nullptr ? 0x100 : 0) |
                                                 (p.head_w != nullptr ? 0x200 : 0), o.flops * n, ex, 0.f});
                     }
+                } else if (o.path == PATH_TAP) {
+                    ConvParams p{};
+                    p.in = in; p.out = out; p.wt = o.wt; p.bias = o.bias; p.n = n; p.act = act; p.alpha = d.alpha;
+                    p.cin_chunks = o.cin_chunks; p.coutp = o.coutp; p.zero = h->zero_page;
+                    p.R = d.kh; p.S = d.kw; p.pad_top = d.pad_top; p.pad_left = d.pad_left; p.stride = d.stride;
+                    p.wt_chunk_stride = wt_chunk_pitch(o.coutp); p.wt_tap_stride = wt_tap_pitch(o.coutp, o.cin_chunks);
+                    hipEvent_t* ev = h->profile_kernels ? prof_pair(h) : nullptr;
+                    if (ev) (void)hipEventRecord(ev[0], s);
+                    e = launch_conv_mfma_tap(p, d.dilation, s);
+                    if (ev) {
+                        (void)hipEventRecord(ev[1], s);
+                        h->prof_flops += o.flops * n; h->prof_exec_flops += o.flops * n;
+                        h->prof_recs.push_back({(int)oi, 0, o.flops * n, o.flops * n, 0.f});
+                    }
                 } else if (o.path == PATH_SMALL_CIN) {
                     e = launch_conv_small_cin(in, out, o.wt, o.bias, n, d.kh, d.kw, d.pad_top, d.pad_left, act, d.alpha, s);
                 } else if (o.path == PATH_HEAD) {
                     e = launch_conv_head(in, out, o.wt, o.bias, n, d.act, d.alpha, s);
                 } else if (d.op == ECSEG_OP_CONV) {
-                    e = launch_conv_generic(in, out, o.wt, o.bias, n, d.kh, d.kw, d.stride, d.pad_top, d.pad_left, act, d.alpha, s);
+                    if (d.dilation > 1) e = launch_conv_generic_dil(in, out, o.wt, o.bias, n, d.kh, d.kw, d.stride, d.dilation, d.pad_top, d.pad_left, act, d.alpha, s);
+                    else e = launch_conv_generic(in, out, o.wt, o.bias, n, d.kh, d.kw, d.stride, d.pad_top, d.pad_left, act, d.alpha, s);
                 } else {
                     e = launch_convt_generic(in, out, o.wt, o.bias, n, d.kh, d.kw, d.stride, d.pad_top, d.pad_left, act, d.alpha, s);
                 }
                 if (e == hipSuccess && softmax && o.path != PATH_HEAD) e = launch_softmax(out, out, n, s);
                 break;
             }
-            case ECSEG_OP_MAXPOOL: e = launch_maxpool(in, out, n, d.kh, d.kw, d.stride, d.mode, s); break;
+            case ECSEG_OP_MAXPOOL:
+                if (d.pad_top || d.pad_left || (out.h - 1) * d.stride + d.kh > in.h || (out.w - 1) * d.stride + d.kw > in.w)
+                    e = launch_pool_pad(in, out, n, d.kh, d.kw, d.stride, d.pad_top, d.pad_left, d.mode, s);     // padding = 'same'
+                else e = launch_maxpool(in, out, n, d.kh, d.kw, d.stride, d.mode, s);
+                break;
+            case ECSEG_OP_DWCONV: {
+                const bool softmax = d.act == ECSEG_ACT_SOFTMAX;
+                e = launch_dwconv(in, out, o.wt, o.bias, n, d.kh, d.kw, d.stride, d.dilation, d.pad_top, d.pad_left, d.mode,
+                                  softmax ? ECSEG_ACT_LINEAR : d.act, d.alpha, s);
+                if (e == hipSuccess && softmax) e = launch_softmax(out, out, n, s);
+                break;
+            }
+            case ECSEG_OP_PRELU: e = launch_prelu(in, out, o.wt, n, d.mode, s); break;
+            case ECSEG_OP_LAYERNORM: e = launch_layernorm(in, out, o.scale, o.shift, n, d.alpha, s); break;
             case ECSEG_OP_GLOBALPOOL: e = launch_global_pool(in, out, n, d.mode, s); break;
             case ECSEG_OP_UPSAMPLE: e = launch_upsample(in, out, n, d.stride, d.mode, s); break;
             case ECSEG_OP_AFFINE:
@@ -647,7 +678,16 @@ int run_plan_op(ecseg_ctx* h, size_t& oi, int n_all, StitchPlan* crop, const Lan
                 if (d.act == ECSEG_ACT_SOFTMAX) e = launch_softmax(in, out, n, s);
                 else e = launch_affine(in, out, nullptr, nullptr, n, d.act, d.alpha, s);
                 break;
-            case ECSEG_OP_ADD: e = launch_add(in, at(d.in1), out, n, d.act, d.alpha, s); break;
+            case ECSEG_OP_ADD: {
+                const TView b = at(d.in1);
+                const bool same = in.h == out.h && in.w == out.w && in.c == out.c && b.h == out.h && b.w == out.w && b.c == out.c;
+                if (d.mode == ECSEG_BIN_ADD && same && d.act != ECSEG_ACT_SOFTMAX) e = launch_add(in, b, out, n, d.act, d.alpha, s);
+                else {
+                    e = launch_binary(in, b, out, n, d.mode, d.act == ECSEG_ACT_SOFTMAX ? ECSEG_ACT_LINEAR : d.act, d.alpha, s);
+                    if (e == hipSuccess && d.act == ECSEG_ACT_SOFTMAX) e = launch_softmax(out, out, n, s);
+                }
+                break;
+            }
             case ECSEG_OP_COPY: e = launch_copy(in, out, n, d.pad_top, d.pad_left, s); break;
             default: return fail(h, ECSEG_E_INVALID, "unknown op in plan");
         }
@@ -1111,11 +1151,30 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
             const bool in_al = (ti.c_stride % 4 == 0) && (ti.c_offset % 4 == 0) && (cin % 4 == 0);
             const bool out_al = (to.c_stride % 4 == 0) && (to.c_offset % 4 == 0);
             if (d.op == ECSEG_OP_CONV) {
-                if ((to.h - 1) * d.stride + 1 > ti.h + d.kh - 1 || (to.w - 1) * d.stride + 1 > ti.w + d.kw - 1)
+                const int dil = d.dilation > 1 ? d.dilation : 1;
+                if ((to.h - 1) * d.stride + 1 > ti.h + (d.kh - 1) * dil || (to.w - 1) * d.stride + 1 > ti.w + (d.kw - 1) * dil)
                     return fail(h, ECSEG_E_INVALID, "conv output larger than its input in op " + std::to_string(k));
                 o.flops = 2.0 * d.kh * d.kw * cin * cout * (double)to.h * to.w;
                 const bool taps_ok = d.kh == d.kw && (d.kh == 1 || d.kh == 2 || d.kh == 3);
-                if (d.stride != 1) {
+                // the tap-by-tap MFMA kernel takes whatever the halo-staged kernels do not: dilated taps, taps other than 1x1 / 2x2 /
+                // 3x3 (5x5, 7x7, 1x3 ...), strides above 2
+                auto tap_path = [&]() -> int {
+                    o.path = PATH_TAP;
+                    const int bn = conv_mfma_ntile(cout);
+                    o.coutp = (cout + bn - 1) / bn * bn;
+                    o.cin_chunks = (cin + 7) / 8;
+                    int rc2 = upload(h, relayout_conv(kw, d.kh, d.kw, cin, cout, o.cin_chunks, o.coutp), &o.wt);
+                    if (!rc2) h->mfma_flops_per_patch += o.flops;
+                    return rc2;
+                };
+                const bool tap_ok = in_al && cin >= 8 && cout >= 8;
+                if (dil > 1 && !(d.kh == 1 && d.kw == 1)) {
+                    if (tap_ok) { if ((rc = tap_path())) return rc; }
+                    else {
+                        o.path = PATH_GENERIC;
+                        if ((rc = upload(h, std::vector<float>(kw, kw + (size_t)d.kh * d.kw * cin * cout), &o.wt))) return rc;
+                    }
+                } else if (d.stride != 1) {
                     // strided convolutions (classifier stems, down-sampling convolutions): the direct MFMA kernel gathers a
                     // strided halo (stride 2, 1x1 / 2x2 / 3x3 taps); anything else takes the generic kernel
                     if (d.stride == 2 && taps_ok && in_al && cin >= 8) {
@@ -1125,6 +1184,8 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
                         o.cin_chunks = (cin + 7) / 8;
                         if ((rc = upload(h, relayout_conv(kw, d.kh, d.kw, cin, cout, o.cin_chunks, o.coutp), &o.wt))) return rc;
                         h->mfma_flops_per_patch += o.flops;
+                    } else if (tap_ok) {
+                        if ((rc = tap_path())) return rc;
                     } else {
                         o.path = PATH_GENERIC;
                         if ((rc = upload(h, std::vector<float>(kw, kw + (size_t)d.kh * d.kw * cin * cout), &o.wt))) return rc;
@@ -1164,6 +1225,8 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
                         if (cin % 4 == 0 && cin >= 8 && cout % 32 == 0 && (cout != 32 || cin >= 64) && to.h % 16 == 0 && to.w % 16 == 0)
                             if ((rc = upload(h, winograd4_filter(kw, cin, cout), &o.wt_wino4))) return rc;
                     }
+                } else if (tap_ok && !taps_ok) {
+                    if ((rc = tap_path())) return rc;
                 } else {
                     o.path = PATH_GENERIC;
                     if ((rc = upload(h, std::vector<float>(kw, kw + (size_t)d.kh * d.kw * cin * cout), &o.wt))) return rc;
@@ -1200,21 +1263,56 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
             if (!sc || !sh) return fail(h, ECSEG_E_INVALID, "affine without scale/shift in op " + std::to_string(k));
             if ((rc = upload(h, std::vector<float>(sc, sc + to.c), &o.scale))) return rc;
             if ((rc = upload(h, std::vector<float>(sh, sh + to.c), &o.shift))) return rc;
+        } else if (d.op == ECSEG_OP_DWCONV) {
+            const int mult = d.mode;
+            if (d.kh <= 0 || d.kw <= 0 || d.stride <= 0 || mult < 1 || to.c != ti.c * mult)
+                return fail(h, ECSEG_E_INVALID, "bad depthwise-conv geometry in op " + std::to_string(k));
+            const int dil = d.dilation > 1 ? d.dilation : 1;
+            if ((to.h - 1) * d.stride + 1 > ti.h + (d.kh - 1) * dil || (to.w - 1) * d.stride + 1 > ti.w + (d.kw - 1) * dil || d.pad_top < 0 || d.pad_left < 0)
+                return fail(h, ECSEG_E_INVALID, "depthwise-conv output larger than its input in op " + std::to_string(k));
+            const float *kw = nullptr, *kb = nullptr;
+            if ((rc = W(d.w0, (int64_t)d.kh * d.kw * to.c, "depthwise kernel", &kw))) return rc;
+            if (!kw) return fail(h, ECSEG_E_INVALID, "depthwise conv without kernel in op " + std::to_string(k));
+            if ((rc = W(d.w1, to.c, "depthwise bias", &kb))) return rc;
+            if ((rc = upload(h, std::vector<float>(kw, kw + (size_t)d.kh * d.kw * to.c), &o.wt))) return rc;
+            if (kb) { if ((rc = upload(h, std::vector<float>(kb, kb + to.c), &o.bias))) return rc; }
+            o.flops = 2.0 * d.kh * d.kw * to.c * (double)to.h * to.w;
+            h->flops_per_patch += o.flops;
+        } else if (d.op == ECSEG_OP_PRELU) {
+            const float* a = nullptr;
+            const int64_t len = d.mode ? (int64_t)to.h * to.w * to.c : (int64_t)to.c;
+            if ((rc = W(d.w0, len, "PReLU slopes", &a))) return rc;
+            if (!a) return fail(h, ECSEG_E_INVALID, "PReLU without slopes in op " + std::to_string(k));
+            if ((rc = upload(h, std::vector<float>(a, a + len), &o.wt))) return rc;
+        } else if (d.op == ECSEG_OP_LAYERNORM) {
+            const float *g = nullptr, *b = nullptr;
+            if ((rc = W(d.w0, to.c, "LayerNormalization gamma", &g))) return rc;
+            if ((rc = W(d.w1, to.c, "LayerNormalization beta", &b))) return rc;
+            if (g) { if ((rc = upload(h, std::vector<float>(g, g + to.c), &o.scale))) return rc; }
+            if (b) { if ((rc = upload(h, std::vector<float>(b, b + to.c), &o.shift))) return rc; }
         } else if (d.op == ECSEG_OP_MAXPOOL || d.op == ECSEG_OP_UPSAMPLE) {
             if (d.stride <= 0) return fail(h, ECSEG_E_INVALID, "bad stride in op " + std::to_string(k));
-            if (d.op == ECSEG_OP_MAXPOOL && (d.kh <= 0 || d.kw <= 0 || (to.h - 1) * d.stride + d.kh > ti.h || (to.w - 1) * d.stride + d.kw > ti.w))
+            // 'valid' pooling stays inside the input; 'same' (pad_top / pad_left given, or the last window overhanging) may not
+            // start a window beyond it
+            if (d.op == ECSEG_OP_MAXPOOL && (d.kh <= 0 || d.kw <= 0 || d.pad_top < 0 || d.pad_left < 0 || d.pad_top >= d.kh || d.pad_left >= d.kw ||
+                                             (to.h - 1) * d.stride - d.pad_top >= ti.h || (to.w - 1) * d.stride - d.pad_left >= ti.w))
                 return fail(h, ECSEG_E_INVALID, "max-pool window leaves the input in op " + std::to_string(k));
             if (d.op == ECSEG_OP_UPSAMPLE && (to.h != ti.h * d.stride || to.w != ti.w * d.stride))
                 return fail(h, ECSEG_E_INVALID, "bad upsample shape in op " + std::to_string(k));
         } else if (d.op == ECSEG_OP_GLOBALPOOL) {
             if (to.h != 1 || to.w != 1 || to.c != ti.c) return fail(h, ECSEG_E_INVALID, "bad global-pool shape in op " + std::to_string(k));
-        } else if (d.op == ECSEG_OP_ACT || d.op == ECSEG_OP_ADD || d.op == ECSEG_OP_COPY) {
+        } else if (d.op == ECSEG_OP_ADD) {
+            if (d.mode < ECSEG_BIN_ADD || d.mode > ECSEG_BIN_MIN) return fail(h, ECSEG_E_INVALID, "bad binary mode in op " + std::to_string(k));
+            for (const ecseg_tensor_desc* tb : {&ti, &tensors[d.in1]})
+                if ((tb->h != to.h && tb->h != 1) || (tb->w != to.w && tb->w != 1) || (tb->c != to.c && tb->c != 1))
+                    return fail(h, ECSEG_E_INVALID, "shapes cannot be broadcast in op " + std::to_string(k));
+        } else if (d.op == ECSEG_OP_ACT || d.op == ECSEG_OP_COPY) {
             // nothing to prepare
         } else {
             return fail(h, ECSEG_E_INVALID, "unknown op code in op " + std::to_string(k));
         }
-        if (d.op != ECSEG_OP_CONV && d.op != ECSEG_OP_CONVT && d.op != ECSEG_OP_MAXPOOL && d.op != ECSEG_OP_UPSAMPLE &&
-            d.op != ECSEG_OP_COPY && d.op != ECSEG_OP_GLOBALPOOL && (ti.h != to.h || ti.w != to.w || ti.c != to.c))
+        if (d.op != ECSEG_OP_CONV && d.op != ECSEG_OP_CONVT && d.op != ECSEG_OP_MAXPOOL && d.op != ECSEG_OP_UPSAMPLE && d.op != ECSEG_OP_DWCONV &&
+            d.op != ECSEG_OP_ADD && d.op != ECSEG_OP_COPY && d.op != ECSEG_OP_GLOBALPOOL && (ti.h != to.h || ti.w != to.w || ti.c != to.c))
             return fail(h, ECSEG_E_INVALID, "shape mismatch in element-wise op " + std::to_string(k));
         h->ops.push_back(o);
     }
@@ -1262,7 +1360,7 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
             if (nprod != 1) break;
             OpRt& o = h->ops[prod];
             const ecseg_tensor_desc& ti = tensors[o.d.in0];
-            if (o.d.op != ECSEG_OP_CONV) break;
+            if (o.d.op != ECSEG_OP_CONV || o.d.dilation > 1 || o.d.stride != 1) break;
             o.crop_ok = true; o.crop_code = code;
             if (o.d.kh == 3 && o.d.kw == 3 && o.d.pad_top == 1 && o.d.pad_left == 1) code += 'd';
             else if (!(o.d.kh == 1 && o.d.kw == 1)) break;

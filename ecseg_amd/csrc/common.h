@@ -110,6 +110,22 @@ hipError_t launch_add(const TView& a, const TView& b, const TView& out, int n, i
 hipError_t launch_copy(const TView& in, const TView& out, int n, int off_y, int off_x, hipStream_t s);
 hipError_t launch_softmax(const TView& in, const TView& out, int n, hipStream_t s);
 hipError_t launch_u8_to_f32(const uint8_t* in, float* out, size_t count, hipStream_t s);
+
+// ---- launchers implemented in layer_kernels.hip (the wider Keras vocabulary) -------------------------------------
+// Conv2D with any taps / stride / dilation on the matrix cores; p.wt = relayout_conv image, p.coutp padded to conv_mfma_ntile()
+hipError_t launch_conv_mfma_tap(const ConvParams& p, int dilation, hipStream_t s);
+bool       conv_mfma_tap_supported(const ConvParams& p);
+hipError_t launch_conv_generic_dil(const TView& in, const TView& out, const float* w_hwio, const float* bias, int n, int R, int S,
+                                   int stride, int dilation, int pad_top, int pad_left, int act, float alpha, hipStream_t s);
+// DepthwiseConv2D: kernel (kh, kw, cin, mult), output channel = input channel * mult + j
+hipError_t launch_dwconv(const TView& in, const TView& out, const float* w, const float* bias, int n, int kh, int kw, int stride,
+                         int dilation, int pad_top, int pad_left, int mult, int act, float alpha, hipStream_t s);
+// y = act(a (+) b), mode = ECSEG_BIN_*, extents of 1 broadcast
+hipError_t launch_binary(const TView& a, const TView& b, const TView& out, int n, int mode, int act, float alpha, hipStream_t s);
+hipError_t launch_prelu(const TView& in, const TView& out, const float* slope, int n, int per_element, hipStream_t s);
+hipError_t launch_layernorm(const TView& in, const TView& out, const float* gamma, const float* beta, int n, float eps, hipStream_t s);
+hipError_t launch_pool_pad(const TView& in, const TView& out, int n, int kh, int kw, int stride, int pad_top, int pad_left, int mode,
+                           hipStream_t s);
 // im2patches_overlap on the device: (n_img, H, W) uint8 -> (n_img * n_pos, 256, 256, 1) float32
 hipError_t launch_tile_patches(const uint8_t* gray, int n_img, int H, int W, const int32_t* pos_yx, int n_pos,
                                float* out, hipStream_t s);

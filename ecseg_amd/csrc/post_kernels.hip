@@ -1226,11 +1226,11 @@ hipError_t run_meta_inference(PostWorkspace& ws, uint8_t* img, int n_img, int H,
         if (H <= NUCLEUS_BIN_EXTENT && W <= NUCLEUS_BIN_EXTENT) {
             const size_t bin_lds = (size_t)(std::max(H, W) + 2) * sizeof(int);
             static DeviceOnce bin_attr;                            // up to 128 KB of dynamic LDS: per-device function attribute
-            if (bin_attr.first()) {
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_centroids_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)((NUCLEUS_BIN_EXTENT + 2) * sizeof(int)));
-                if (e != hipSuccess) { bin_attr.reset(); return e; }
-            }
+            e = bin_attr.run([] {
+                return hipFuncSetAttribute(reinterpret_cast<const void*>(bin_centroids_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)((NUCLEUS_BIN_EXTENT + 2) * sizeof(int)));
+            });
+            if (e != hipSuccess) return e;
             hipLaunchKernelGGL(bin_centroids_kernel, dim3(2, n_img), dim3(1024), bin_lds, s, ws.g, list2, ws.binned, ws.binstart,
                                cap, ws.binned_cap, H, W);
             hipLaunchKernelGGL(nucleus_test_binned_kernel, dim3(32, n_img), dim3(256), 0, s, ws.area, ws.sumy, ws.sumx, ws.g,

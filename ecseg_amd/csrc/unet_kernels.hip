@@ -466,11 +466,11 @@ static hipError_t launch_conv_wino_t(const ConvParams& p, hipStream_t s) {
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     static DeviceOnce attr_set;                             // the attribute is per device
-    if (attr_set.first()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<NT, MT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { attr_set.reset(); return e; }
-    }
+    const hipError_t ea = attr_set.run([&] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<NT, MT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    if (ea != hipSuccess) return ea;
     hipLaunchKernelGGL((conv_wino_kernel<NT, MT>), dim3((unsigned)grid), dim3(256), lds, s, p, tiles_x, tiles_y, nblk_n);
     return hipGetLastError();
 }
@@ -1122,7 +1122,7 @@ __global__ __launch_bounds__(256) void affine_kernel(TView in, TView out, const 
         const size_t pix = t / out.c;
         float v = in.p[pix * in.cs + c];
         if (scale) v = v * scale[c] + shift[c];
-        out.p[pix * out.cs + c] = apply_act(v, act, alpha);
+        out.p[pix * out.cs + c] = apply_act_ext(v, act, alpha);
     }
 }
 
@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(256) void add_kernel(TView a, TView b, TView out, s
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(t % out.c);
         const size_t pix = t / out.c;
-        out.p[pix * out.cs + c] = apply_act(a.p[pix * a.cs + c] + b.p[pix * b.cs + c], act, alpha);
+        out.p[pix * out.cs + c] = apply_act_ext(a.p[pix * a.cs + c] + b.p[pix * b.cs + c], act, alpha);
     }
 }
 

@@ -262,8 +262,8 @@ __global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(C
                     f32x4 Y[2][2];
 #pragma unroll
                     for (int x = 0; x < 2; ++x) {
-                        Y[0][x] = apply_act4(R[0][x] + R[1][x] + R[2][x] + bv[nb], p.act, p.alpha);
-                        Y[1][x] = apply_act4(R[1][x] - R[2][x] - R[3][x] + bv[nb], p.act, p.alpha);
+                        Y[0][x] = apply_act4_core(R[0][x] + R[1][x] + R[2][x] + bv[nb], p.act, p.alpha);
+                        Y[1][x] = apply_act4_core(R[1][x] - R[2][x] - R[3][x] + bv[nb], p.act, p.alpha);
                     }
                     const int co = 16 * nb + 4 * kq;
                     if (!(HEAD && p.head_only)) {
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(C
                         for (int c = 0; c < 4; ++c) l[c] = l[c] / sum;
                     } else {
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) l[c] = apply_act(l[c], p.head_act, p.alpha);
+                        for (int c = 0; c < 4; ++c) l[c] = apply_act_core(l[c], p.head_act, p.alpha);
                     }
                     const int py = oy + (kq >> 1), px = ox + (kq & 1);
                     if (py < H && px < W) {
@@ -383,11 +383,11 @@ static hipError_t launch_conv_wino16_tt(const ConvParams& p, hipStream_t s) {
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     const size_t lds = ((size_t)NBUF * W16_HS + (size_t)16 * KC * NB * 64 + (HEAD ? 16 * NB : 0)) * 16;
     static DeviceOnce attr_set;                              // the attribute is per device (and per template instance)
-    if (attr_set.first()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino16_kernel<KC, NB, NBUF, HEAD>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { attr_set.reset(); return e; }
-    }
+    const hipError_t ea = attr_set.run([&] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino16_kernel<KC, NB, NBUF, HEAD>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    if (ea != hipSuccess) return ea;
     hipLaunchKernelGGL((conv_wino16_kernel<KC, NB, NBUF, HEAD>), dim3((unsigned)grid), dim3(512), lds, s, p, blocks_x, strips_y, segs_x, bpw);
     return hipGetLastError();
 }

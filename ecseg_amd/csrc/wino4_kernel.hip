@@ -658,7 +658,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             float* o = p.out.p + (((size_t)img * H + oy) * W + ox) * p.out.cs + co;
 #pragma unroll
             for (int yy = 0; yy < 2; ++yy) {
-                y[yy] = apply_act4(y[yy], p.act, p.alpha);
+                y[yy] = apply_act4_core(y[yy], p.act, p.alpha);
                 // non-temporal: the tensor (0.6 - 9.4 GB per launch) fits no cache and is read by a later launch; +0.7 % end to end
                 // (A/B round 4: 64 -> 64 at 256x256 10.79 - 10.92 -> 10.58 - 10.63 ms, the deep layers +-0)
                 if (co + 3 < Cout && !(HEAD && p.head_only))
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
                     for (int c = 0; c < 4; ++c) l[c] = l[c] / sum;
                 } else {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) l[c] = apply_act(l[c], p.head_act, p.alpha);
+                    for (int c = 0; c < 4; ++c) l[c] = apply_act_core(l[c], p.head_act, p.alpha);
                 }
                 const int oy = (g ? r_y0[1] : r_y0[0]) + 4 * nty + 2 * yh + q, ox = (g ? r_x0[1] : r_x0[0]) + 4 * ntx + x;
                 float* ho = p.head_out.p + (((size_t)img * H + oy) * W + ox) * p.head_out.cs;
@@ -761,10 +761,10 @@ hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s) {
     W4_DIAG_SELECT(kern, p, lds);
     static DeviceOnce attr_set[3];                          // the attribute is per device
     const int which = p.head_w != nullptr ? 1 : (p.out.c == 32 && p.w4_split) ? 2 : 0;
-    if (attr_set[which].first()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { attr_set[which].reset(); return e; }
-    }
+    const hipError_t ea = attr_set[which].run([&] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    if (ea != hipSuccess) return ea;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(768), lds, s, p, regs_x, regs_y, (int)npairs);
     return hipGetLastError();
 }

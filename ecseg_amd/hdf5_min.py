@@ -445,6 +445,7 @@ def _attr_list(attrs, name):
 
 def load_keras_h5(path):
     """-> (model_config_json_text, {layer_name: [np.ndarray, ...] in Keras weight order})."""
+    from .keras_plan import NamedWeights
     f = File(path)
     attrs = f.attrs
     if 'model_config' not in attrs:
@@ -456,8 +457,8 @@ def load_keras_h5(path):
     weights = {}
     for lname in _attr_list(g.attrs, 'layer_names'):
         lg = g[lname]
-        ws = []
-        for wname in _attr_list(lg.attrs, 'weight_names'):
-            ws.append(lg[wname].read())
-        weights[lname] = ws
+        names = _attr_list(lg.attrs, 'weight_names')
+        # a list of arrays that also carries the weight names: a nested model's list mixes the variables of all its layers
+        # (keras_plan.inline_nested sorts them out by name)
+        weights[lname] = NamedWeights([lg[wname].read() for wname in names], names)
     return cfg, weights

@@ -18,7 +18,14 @@ import numpy as np
 
 # op / activation codes mirror include/ecseg_hip.h
 OP_CONV, OP_CONVT, OP_MAXPOOL, OP_UPSAMPLE, OP_AFFINE, OP_ACT, OP_ADD, OP_COPY, OP_GLOBALPOOL = 1, 2, 3, 4, 5, 6, 7, 8, 9
-ACT = {'linear': 0, None: 0, 'relu': 1, 'softmax': 2, 'sigmoid': 3, 'leaky_relu': 4, 'tanh': 5, 'elu': 6}
+OP_DWCONV, OP_PRELU, OP_LAYERNORM = 10, 11, 12
+ACT = {'linear': 0, None: 0, 'relu': 1, 'softmax': 2, 'sigmoid': 3, 'leaky_relu': 4, 'tanh': 5, 'elu': 6, 'relu_clip': 7, 'relu6': 7,
+       'swish': 8, 'silu': 8, 'hard_sigmoid': 9, 'softplus': 10, 'selu': 11, 'gelu': 12, 'exponential': 13, 'softsign': 14}
+ACT_ALPHA = {'elu': 1.0, 'relu6': 6.0}       # parameter of an activation given by name
+BIN = {'Add': 0, 'Multiply': 1, 'Subtract': 2, 'Maximum': 3, 'Minimum': 4, 'Average': 0}
+MODEL_CLASSES = ('Functional', 'Model', 'Sequential')
+CONV_ACT_MAX = 7      # activation codes the convolution kernels' output stages implement (device_util.h: apply_act); the others run
+                      # as an element-wise pass over the convolution's output
 IDENTITY_LAYERS = ('Dropout', 'SpatialDropout2D', 'GaussianNoise', 'GaussianDropout', 'AlphaDropout',
                    'ActivityRegularization')
 
@@ -47,6 +54,8 @@ class Plan:
                 f += 2.0 * o['kh'] * o['kw'] * ti['c'] * to['c'] * to['h'] * to['w']
             elif o['op'] == OP_CONVT:
                 f += 2.0 * o['kh'] * o['kw'] * ti['c'] * to['c'] * ti['h'] * ti['w']
+            elif o['op'] == OP_DWCONV:
+                f += 2.0 * o['kh'] * o['kw'] * to['c'] * to['h'] * to['w']
         return f
 
     def bytes_per_patch_unfused(self):
@@ -66,9 +75,136 @@ def _same_pad(k, s, n):
 
 
 def _act_code(name):
+    if isinstance(name, dict):             # a serialised activation object: {'class_name': ..., 'config': ...}
+        name = (name.get('config') or {}).get('name', name.get('class_name'))
     if name not in ACT:
         raise PlanError('unsupported activation %r' % (name,))
     return ACT[name]
+
+
+def _act_pair(name):
+    """-> dict(act=code, alpha=parameter) of an activation given by name in a layer config."""
+    if isinstance(name, dict):
+        name = (name.get('config') or {}).get('name', name.get('class_name'))
+    return dict(act=_act_code(name), alpha=ACT_ALPHA.get(name, 0.0))
+
+
+class NamedWeights(list):
+    """Weight arrays of one top-level Keras layer with their HDF5 ``weight_names``: a nested model's list mixes the variables
+    of all its layers (trainable ones first), the names say which inner layer each belongs to."""
+
+    def __init__(self, arrays, names=None):
+        super().__init__(arrays)
+        self.names = list(names) if names is not None else None
+
+
+def _refs(L):
+    """The single inbound node of a functional layer as a list of [layer name, node, tensor, kwargs] references."""
+    inb = L.get('inbound_nodes', [])
+    if not inb:
+        return []
+    if len(inb) != 1:
+        raise PlanError('layer %s is shared (%d inbound nodes)' % (L.get('name', L['config'].get('name')), len(inb)))
+    node = inb[0]
+    if isinstance(node, dict):
+        raise PlanError('Keras 3 model_config is not supported (save with TF 2.x / Keras 2)')
+    if node and isinstance(node[0], str):      # single-input short form [name, node, tensor, kwargs]
+        node = [node]
+    return [list(r) for r in node]
+
+
+def _to_functional(mc):
+    """A Sequential model as the equivalent Functional config (a chain), so that the rest of the lowering sees one form."""
+    layers, seq, cfg = _layers_of(mc)
+    if not seq:
+        return mc
+    out, prev = [], None
+    for L in layers:
+        lc = L['config']
+        name = lc.get('name', L.get('name'))
+        if L['class_name'] == 'InputLayer':
+            out.append(dict(L, inbound_nodes=[]))
+            prev = name
+            continue
+        if prev is None:
+            bis = lc.get('batch_input_shape') or lc.get('batch_shape')
+            if bis is None and L['class_name'] in MODEL_CLASSES:        # a Sequential that starts with a nested model
+                ilayers = _layers_of({'class_name': L['class_name'], 'config': lc})[0]
+                bis = ilayers[0]['config'].get('batch_input_shape') or ilayers[0]['config'].get('batch_shape')
+            if bis is None:
+                raise PlanError('cannot determine the input shape')
+            out.append({'class_name': 'InputLayer', 'name': '__input__', 'inbound_nodes': [],
+                        'config': {'name': '__input__', 'batch_input_shape': bis}})
+            prev = '__input__'
+        out.append(dict(L, inbound_nodes=[[[prev, 0, 0, {}]]]))
+        prev = name
+    first = out[0]['config']['name'] if out else None
+    return {'class_name': 'Functional', 'config': {'name': (cfg or {}).get('name', 'sequential') if isinstance(cfg, dict) else 'sequential',
+                                                   'layers': out, 'input_layers': [[first, 0, 0]], 'output_layers': [[prev, 0, 0]]}}
+
+
+def _group_nested_weights(ws, owner):
+    """Weights of a nested model -> {inner layer name: [arrays in that layer's own order]}."""
+    if ws is None:
+        return {}
+    if isinstance(ws, dict):
+        return ws
+    names = getattr(ws, 'names', None)
+    if names is None or len(names) != len(ws):
+        if not len(ws):
+            return {}
+        raise PlanError('nested model %s: its %d weight arrays carry no names - pass {inner layer name: [arrays]} or a '
+                        'NamedWeights list (hdf5_min.load_keras_h5 returns those)' % (owner, len(ws)))
+    d = {}
+    for nm, a in zip(names, ws):
+        parts = str(nm).split(':')[0].split('/')
+        d.setdefault(parts[-2] if len(parts) >= 2 else parts[0], []).append(a)
+    return d
+
+
+def inline_nested(model_config, weights):
+    """-> (flat Functional model_config, weights): every nested Functional / Sequential sub-model (a transfer-learning
+    backbone used as one layer, ``tf.keras.applications.*`` inside a classifier) is replaced by its own layers, named
+    ``<sub-model>/<layer>``; the sub-model's InputLayers become references to the tensors it is called on."""
+    mc = _to_functional(model_config)
+    cfg = mc['config']
+    new_layers, alias, wout = [], {}, dict(weights)
+
+    def resolve(ref):
+        if ref[0] in alias:
+            t = ref[2] if len(ref) > 2 and isinstance(ref[2], int) else 0
+            outs = alias[ref[0]]
+            if t >= len(outs):
+                raise PlanError('reference to output %d of %s, which has %d' % (t, ref[0], len(outs)))
+            return [outs[t], 0, 0] + list(ref[3:])
+        return ref
+
+    for L in cfg['layers']:
+        cls, lc = L['class_name'], L['config']
+        name = lc.get('name', L.get('name'))
+        refs = [resolve(r) for r in _refs(L)]
+        if cls in MODEL_CLASSES:
+            icfg, iw = inline_nested({'class_name': cls, 'config': lc}, _group_nested_weights(weights.get(name), name))
+            in_names = [r[0] for r in icfg['config']['input_layers']]
+            if len(in_names) != len(refs):
+                raise PlanError('nested model %s has %d inputs but is called on %d tensors' % (name, len(in_names), len(refs)))
+            feed = {n: refs[k][0] for k, n in enumerate(in_names)}
+            prefix = name + '/'
+            for IL in icfg['config']['layers']:
+                iname = IL['config'].get('name', IL.get('name'))
+                if IL['class_name'] == 'InputLayer':
+                    continue
+                nrefs = [[feed.get(r[0], prefix + r[0])] + list(r[1:]) for r in _refs(IL)]
+                new_layers.append(dict(IL, name=prefix + iname, config=dict(IL['config'], name=prefix + iname), inbound_nodes=[nrefs]))
+                if iname in iw:
+                    wout[prefix + iname] = iw[iname]
+            alias[name] = [feed.get(r[0], prefix + r[0]) for r in icfg['config']['output_layers']]
+            wout.pop(name, None)
+            continue
+        new_layers.append(dict(L, inbound_nodes=[refs] if refs else []))
+    outs = [resolve(list(r)) for r in cfg['output_layers']]
+    flat = {'class_name': 'Functional', 'config': dict(cfg, layers=new_layers, output_layers=outs)}
+    return flat, wout
 
 
 def _layers_of(model_config):
@@ -105,13 +241,46 @@ def _tfop_affine(L, lc):
     return None
 
 
-def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_overrides=None):
+def _conv_geometry(cls, name, lc, h, w):
+    """Conv2D / DepthwiseConv2D / SeparableConv2D config -> (kh, kw, stride, dilation, pad_top, pad_left, out_h, out_w).
+    'same' pads max((ceil(n / s) - 1) s + (k - 1) d + 1 - n, 0) in total, the smaller half in front (TensorFlow's rule with the
+    dilated extent of the kernel)."""
+    kh, kw = lc['kernel_size']
+    sh, sw = lc.get('strides', [1, 1])
+    dr = lc.get('dilation_rate', [1, 1])
+    dr = [dr, dr] if isinstance(dr, int) else list(dr)
+    if sh != sw or dr[0] != dr[1]:
+        raise PlanError('%s %s: anisotropic strides / dilation rates are not supported' % (cls, name))
+    if lc.get('data_format', 'channels_last') != 'channels_last':
+        raise PlanError('channels_first is not supported')
+    dil = int(dr[0])
+    if dil > 1 and sh > 1:
+        raise PlanError('%s %s: strides > 1 together with dilation_rate > 1 (Keras rejects it too)' % (cls, name))
+    ekh, ekw = (kh - 1) * dil + 1, (kw - 1) * dil + 1
+    if lc['padding'] == 'same':
+        pt, pl = _same_pad(ekh, sh, h)[0], _same_pad(ekw, sw, w)[0]
+        oh, ow = -(-h // sh), -(-w // sw)
+    elif lc['padding'] == 'valid':
+        pt = pl = 0
+        oh, ow = (h - ekh) // sh + 1, (w - ekw) // sw + 1
+    else:
+        raise PlanError('%s %s: padding %r is not supported' % (cls, name, lc['padding']))
+    if oh <= 0 or ow <= 0:
+        raise PlanError('%s %s: the kernel does not fit the %d x %d input' % (cls, name, h, w))
+    return kh, kw, sh, dil, pt, pl, oh, ow
+
+
+def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_overrides=None, output=0):
     """``model_config``: dict or JSON text; ``weights``: {layer name: [arrays]} -> Plan.
     ``lambda_overrides``: {layer name: (scale, offset)} for ``Lambda`` layers (their Python bytecode cannot be
-    interpreted; the common ``Lambda(lambda x: x / 255)`` input normalisation is ``(1/255, 0)``)."""
+    interpreted; the common ``Lambda(lambda x: x / 255)`` input normalisation is ``(1/255, 0)``).
+    ``output``: which output of a model with several (index into ``output_layers``, or a layer name): the plan computes that
+    one (``predict_on_batch`` of such a Keras model returns a list; the callers of the reference read a single array,
+    src/utils.py:115, src/interseg.py:155,168)."""
     lambda_overrides = lambda_overrides or {}
     if isinstance(model_config, (str, bytes)):
         model_config = json.loads(model_config)
+    model_config, weights = inline_nested(model_config, weights)
     layers, seq, cfg = _layers_of(model_config)
 
     # ---------------------------------------------------------------- pass 1: logical graph
@@ -161,24 +330,58 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
         h, w, c = nodes[ins[0]]['shape']
         ws = weights.get(name, [])
         if cls == 'Conv2D':
-            kh, kw = lc['kernel_size']
-            sh, sw = lc.get('strides', [1, 1])
-            if list(lc.get('dilation_rate', [1, 1])) != [1, 1] or lc.get('groups', 1) != 1 or sh != sw:
-                raise PlanError('Conv2D %s: dilation / groups / anisotropic strides are not supported' % name)
-            if lc.get('data_format', 'channels_last') != 'channels_last':
-                raise PlanError('channels_first is not supported')
-            if lc['padding'] == 'same':
-                pt, pl = _same_pad(kh, sh, h)[0], _same_pad(kw, sw, w)[0]
-                oh, ow = -(-h // sh), -(-w // sw)
-            else:
-                pt = pl = 0
-                oh, ow = (h - kh) // sh + 1, (w - kw) // sw + 1
+            kh, kw, sh, dil, pt, pl, oh, ow = _conv_geometry(cls, name, lc, h, w)
+            groups = int(lc.get('groups', 1) or 1)
+            filters = lc['filters']
+            if groups < 1 or c % groups or filters % groups:
+                raise PlanError('Conv2D %s: %d groups do not divide %d -> %d channels' % (name, groups, c, filters))
             kernel = np.ascontiguousarray(ws[0], np.float32)
-            if kernel.shape != (kh, kw, c, lc['filters']):
+            if kernel.shape != (kh, kw, c // groups, filters):
                 raise PlanError('Conv2D %s: kernel shape %s does not match config' % (name, kernel.shape))
             bias = np.ascontiguousarray(ws[1], np.float32) if lc.get('use_bias', True) else None
-            idx = add(name, 'conv', ins, (oh, ow, lc['filters']), kh=kh, kw=kw, stride=sh, pad_top=pt, pad_left=pl,
-                      kernel=kernel, bias=bias, act=_act_code(lc.get('activation')), alpha=0.0)
+            geo = dict(kh=kh, kw=kw, stride=sh, dilation=dil, pad_top=pt, pad_left=pl)
+            if groups == 1:
+                idx = add(name, 'conv', ins, (oh, ow, filters), kernel=kernel, bias=bias, **geo, **_act_pair(lc.get('activation')))
+            elif groups == c:
+                # one input channel per group: a depthwise convolution with depth multiplier filters / c (output channel
+                # o belongs to group o // (filters / groups): Keras' depthwise channel order)
+                idx = add(name, 'dwconv', ins, (oh, ow, filters), kernel=kernel.reshape(kh, kw, c, filters // c), bias=bias,
+                          mult=filters // c, **geo, **_act_pair(lc.get('activation')))
+            else:
+                # grouped convolution: one convolution per group on a channel slice of the input, written straight into its
+                # slice of the output (the Concatenate machinery below)
+                cg, fg = c // groups, filters // groups
+                parts = []
+                for g in range(groups):
+                    si = add('%s/in%d' % (name, g), 'slice', ins, (h, w, cg), c0=g * cg)
+                    parts.append(add('%s/group%d' % (name, g), 'conv', [si], (oh, ow, fg),
+                                     kernel=np.ascontiguousarray(kernel[..., g * fg:(g + 1) * fg]),
+                                     bias=None if bias is None else np.ascontiguousarray(bias[g * fg:(g + 1) * fg]), **geo,
+                                     **_act_pair(lc.get('activation'))))
+                idx = add(name, 'concat', parts, (oh, ow, filters))
+        elif cls == 'DepthwiseConv2D':
+            kh, kw, sh, dil, pt, pl, oh, ow = _conv_geometry(cls, name, lc, h, w)
+            mult = int(lc.get('depth_multiplier', 1))
+            kernel = np.ascontiguousarray(ws[0], np.float32)
+            if kernel.shape != (kh, kw, c, mult):
+                raise PlanError('DepthwiseConv2D %s: kernel shape %s does not match config' % (name, kernel.shape))
+            bias = np.ascontiguousarray(ws[1], np.float32) if lc.get('use_bias', True) else None
+            idx = add(name, 'dwconv', ins, (oh, ow, c * mult), kernel=kernel, bias=bias, mult=mult, kh=kh, kw=kw, stride=sh,
+                      dilation=dil, pad_top=pt, pad_left=pl, **_act_pair(lc.get('activation')))
+        elif cls == 'SeparableConv2D':
+            # depthwise (no bias, no activation) then pointwise 1x1 (bias, activation): weights [depthwise_kernel,
+            # pointwise_kernel, bias]
+            kh, kw, sh, dil, pt, pl, oh, ow = _conv_geometry(cls, name, lc, h, w)
+            mult = int(lc.get('depth_multiplier', 1))
+            dk = np.ascontiguousarray(ws[0], np.float32)
+            pk = np.ascontiguousarray(ws[1], np.float32)
+            if dk.shape != (kh, kw, c, mult) or pk.shape != (1, 1, c * mult, lc['filters']):
+                raise PlanError('SeparableConv2D %s: kernel shapes %s / %s do not match config' % (name, dk.shape, pk.shape))
+            bias = np.ascontiguousarray(ws[2], np.float32) if lc.get('use_bias', True) else None
+            di = add(name + '/depthwise', 'dwconv', ins, (oh, ow, c * mult), kernel=dk, bias=None, mult=mult, kh=kh, kw=kw, stride=sh,
+                     dilation=dil, pad_top=pt, pad_left=pl, act=0, alpha=0.0)
+            idx = add(name, 'conv', [di], (oh, ow, lc['filters']), kh=1, kw=1, stride=1, dilation=1, pad_top=0, pad_left=0, kernel=pk,
+                      bias=bias, **_act_pair(lc.get('activation')))
         elif cls == 'Conv2DTranspose':
             kh, kw = lc['kernel_size']
             sh, sw = lc['strides']
@@ -195,13 +398,19 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
                 oh, ow = (h - 1) * sh + max(kh, sh), (w - 1) * sw + max(kw, sw)
                 ct = cl = 0
             idx = add(name, 'convt', ins, (oh, ow, lc['filters']), kh=kh, kw=kw, stride=sh, pad_top=ct, pad_left=cl,
-                      kernel=kernel, bias=bias, act=_act_code(lc.get('activation')), alpha=0.0)
+                      kernel=kernel, bias=bias, **_act_pair(lc.get('activation')))
         elif cls in ('MaxPooling2D', 'AveragePooling2D'):
             kh, kw = lc['pool_size']
             st = lc.get('strides') or lc['pool_size']
-            if st[0] != st[1] or lc.get('padding', 'valid') != 'valid':
+            if st[0] != st[1]:
                 raise PlanError('%s %s: unsupported geometry' % (cls, name))
-            idx = add(name, 'maxpool', ins, ((h - kh) // st[0] + 1, (w - kw) // st[0] + 1, c), kh=kh, kw=kw, stride=st[0],
+            if lc.get('padding', 'valid') == 'same':
+                pt, pl = _same_pad(kh, st[0], h)[0], _same_pad(kw, st[0], w)[0]
+                oh, ow = -(-h // st[0]), -(-w // st[0])
+            else:
+                pt = pl = 0
+                oh, ow = (h - kh) // st[0] + 1, (w - kw) // st[0] + 1
+            idx = add(name, 'maxpool', ins, (oh, ow, c), kh=kh, kw=kw, stride=st[0], pad_top=pt, pad_left=pl,
                       mode=int(cls == 'AveragePooling2D'))
         elif cls in ('GlobalAveragePooling2D', 'GlobalMaxPooling2D'):
             idx = add(name, 'globalpool', ins, (1, 1, c), mode=int(cls == 'GlobalAveragePooling2D'),
@@ -228,7 +437,7 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
             bias = np.ascontiguousarray(ws[1], np.float32) if lc.get('use_bias', True) else None
             # a Dense layer acts on the last axis: a 1x1 convolution (on a (1, 1, F) tensor after Flatten / global pooling)
             idx = add(name, 'conv', ins, (h, w, lc['units']), kh=1, kw=1, stride=1, pad_top=0, pad_left=0,
-                      kernel=kernel.reshape(1, 1, c, lc['units']), bias=bias, act=_act_code(lc.get('activation')), alpha=0.0)
+                      kernel=kernel.reshape(1, 1, c, lc['units']), bias=bias, **_act_pair(lc.get('activation')))
         elif cls == 'UpSampling2D':
             sz = lc['size']
             if sz[0] != sz[1]:
@@ -244,8 +453,70 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
                 if nodes[i]['shape'][:2] != (h, w):
                     raise PlanError('Concatenate %s: spatial shapes differ' % name)
             idx = add(name, 'concat', ins, (h, w, sum(nodes[i]['shape'][2] for i in ins)))
-        elif cls == 'Add':
-            idx = add(name, 'add', ins, (h, w, c))
+        elif cls in BIN:
+            if len(ins) < 2:
+                raise PlanError('%s %s needs at least two inputs' % (cls, name))
+            shp = [h, w, c]
+            for i in ins[1:]:
+                for a in range(3):
+                    v = nodes[i]['shape'][a]
+                    if v != shp[a] and v != 1 and shp[a] != 1:
+                        raise PlanError('%s %s: shapes %s and %s cannot be broadcast' % (cls, name, tuple(shp), nodes[i]['shape']))
+                    shp[a] = max(shp[a], v)
+            if cls == 'Subtract' and len(ins) != 2:
+                raise PlanError('Subtract %s takes exactly two inputs' % name)
+            if cls == 'Average':                                # mean of n tensors: the sum, then one per-channel scale
+                si = add(name + '/sum', 'add', ins, tuple(shp), mode=0, rank=max(nodes[i].get('rank', 4) for i in ins))
+                sc = 1.0 / len(ins)
+                idx = add(name, 'affine', [si], tuple(shp), scale=np.full(shp[2], sc, np.float32), shift=np.zeros(shp[2], np.float32),
+                          scale64=np.full(shp[2], sc), shift64=np.zeros(shp[2]), act=0, alpha=0.0)
+            else:
+                idx = add(name, 'add', ins, tuple(shp), mode=BIN[cls], rank=max(nodes[i].get('rank', 4) for i in ins))
+        elif cls == 'PReLU':
+            alpha = np.asarray(ws[0], np.float32)
+            shared = lc.get('shared_axes') or []
+            full = [1 if (a + 1) in shared else v for a, v in enumerate((h, w, c))]
+            if nodes[ins[0]].get('rank', 4) == 2:               # (N, K) input: alpha has shape (K,)
+                alpha = alpha.reshape(1, 1, -1)
+            if tuple(alpha.shape) != tuple(full):
+                raise PlanError('PReLU %s: alpha shape %s does not match input %s with shared_axes %s' % (name, alpha.shape, (h, w, c), shared))
+            per_channel = full[0] == 1 and full[1] == 1
+            if per_channel:
+                slopes = np.ascontiguousarray(np.broadcast_to(alpha, (1, 1, c)).reshape(c))
+            else:
+                slopes = np.ascontiguousarray(np.broadcast_to(alpha, (h, w, c)))
+            idx = add(name, 'prelu', ins, (h, w, c), slopes=slopes, mode=int(not per_channel))
+        elif cls == 'LayerNormalization':
+            ax = lc.get('axis', -1)
+            ax = list(ax) if isinstance(ax, (list, tuple)) else [ax]
+            rank_in = nodes[ins[0]].get('rank', 4)
+            if ax not in ([-1], [rank_in - 1]):
+                raise PlanError('LayerNormalization %s: only the channel (last) axis is supported, got axis %s' % (name, ax))
+            wl = [np.asarray(a, np.float32).reshape(-1) for a in ws]
+            gamma = wl.pop(0) if lc.get('scale', True) else None
+            beta = wl.pop(0) if lc.get('center', True) else None
+            idx = add(name, 'layernorm', ins, (h, w, c), gamma=gamma, beta=beta, eps=float(lc.get('epsilon', 1e-3)))
+        elif cls == 'Normalization':
+            # preprocessing layer: (x - mean) / max(sqrt(variance), epsilon); statistics as weights [mean, variance, count] (adapt())
+            # or in the config
+            ax = lc.get('axis', -1)
+            ax = [] if ax is None else (list(ax) if isinstance(ax, (list, tuple)) else [ax])
+            rank_in = nodes[ins[0]].get('rank', 4)
+            if ax not in ([], [-1], [rank_in - 1]):
+                raise PlanError('Normalization %s: only per-channel (or scalar) statistics are supported, got axis %s' % (name, ax))
+            if lc.get('mean') is not None:
+                mean, var = np.asarray(lc['mean'], np.float64), np.asarray(lc['variance'], np.float64)
+            elif len(ws) >= 2:
+                mean, var = np.asarray(ws[0], np.float64), np.asarray(ws[1], np.float64)
+            else:
+                raise PlanError('Normalization %s carries no statistics' % name)
+            mean = np.broadcast_to(mean.reshape(-1), (c,)) if mean.size in (1, c) else None
+            var = np.broadcast_to(var.reshape(-1), (c,)) if var.size in (1, c) else None
+            if mean is None or var is None:
+                raise PlanError('Normalization %s: statistics do not match %d channels' % (name, c))
+            inv = 1.0 / np.maximum(np.sqrt(var), 1e-7)           # backend.epsilon()
+            idx = add(name, 'affine', ins, (h, w, c), scale=inv.astype(np.float32), shift=(-mean * inv).astype(np.float32),
+                      scale64=inv, shift64=-mean * inv, act=0, alpha=0.0)
         elif cls == 'BatchNormalization':
             ax = lc.get('axis', -1)
             ax = ax[0] if isinstance(ax, (list, tuple)) else ax
@@ -280,14 +551,20 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
             prev = ins[0]
             continue
         elif cls == 'Activation':
-            idx = add(name, 'act', ins, (h, w, c), act=_act_code(lc['activation']), alpha=0.0)
+            idx = add(name, 'act', ins, (h, w, c), **_act_pair(lc['activation']))
         elif cls == 'ReLU':
-            if lc.get('max_value') is not None or lc.get('threshold'):
-                raise PlanError('ReLU %s: max_value / threshold are not supported' % name)
             ns = float(lc.get('negative_slope') or 0.0)
-            idx = add(name, 'act', ins, (h, w, c), act=ACT['leaky_relu'] if ns else ACT['relu'], alpha=ns)
+            mv = lc.get('max_value')
+            if lc.get('threshold') or (mv is not None and ns):
+                raise PlanError('ReLU %s: threshold / max_value together with negative_slope are not supported' % name)
+            if mv is not None:                                   # relu6 of the MobileNets
+                idx = add(name, 'act', ins, (h, w, c), act=ACT['relu_clip'], alpha=float(mv))
+            else:
+                idx = add(name, 'act', ins, (h, w, c), act=ACT['leaky_relu'] if ns else ACT['relu'], alpha=ns)
         elif cls == 'LeakyReLU':
             idx = add(name, 'act', ins, (h, w, c), act=ACT['leaky_relu'], alpha=float(lc.get('alpha', 0.3)))
+        elif cls == 'ELU':
+            idx = add(name, 'act', ins, (h, w, c), act=ACT['elu'], alpha=float(lc.get('alpha', 1.0)))
         elif cls == 'Softmax':
             idx = add(name, 'act', ins, (h, w, c), act=ACT['softmax'], alpha=0.0)
         elif cls == 'ZeroPadding2D':
@@ -304,9 +581,14 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
         out_node = prev
     else:
         outs = cfg['output_layers']
-        if len(outs) != 1:
-            raise PlanError('models with %d outputs are not supported' % len(outs))
-        out_node = by_name[outs[0][0]]
+        if isinstance(output, str):
+            if output not in by_name or output not in [o[0] for o in outs]:
+                raise PlanError('%r is not an output of the model (outputs: %s)' % (output, [o[0] for o in outs]))
+            out_node = by_name[output]
+        else:
+            if not 0 <= int(output) < len(outs):
+                raise PlanError('output %r out of range: the model has %d output(s)' % (output, len(outs)))
+            out_node = by_name[outs[int(output)][0]]
     in_nodes = [i for i, n in enumerate(nodes) if n['kind'] == 'input']
     if len(in_nodes) != 1:
         raise PlanError('models with %d inputs are not supported' % len(in_nodes))
@@ -324,15 +606,18 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
                 continue
             i = n['inputs'][0]
             p = nodes[i]
-            if p['kind'] not in ('conv', 'convt') or len(consumers(i)) != 1 or i == out_node:
+            if p['kind'] not in ('conv', 'convt', 'dwconv') or len(consumers(i)) != 1 or i == out_node:
                 continue
             if n['kind'] == 'affine' and p['act'] == 0 and n['act'] == 0:
                 s, t = n['scale64'], n['shift64']
                 k = p['kernel'].astype(np.float64)
-                p['kernel'] = (k * (s[None, None, None, :] if p['kind'] == 'conv' else s[None, None, :, None])).astype(np.float32)
+                if p['kind'] == 'dwconv':                       # (kh, kw, cin, mult): output channel = cin index * mult + j
+                    p['kernel'] = (k * s.reshape(k.shape[2], k.shape[3])[None, None]).astype(np.float32)
+                else:
+                    p['kernel'] = (k * (s[None, None, None, :] if p['kind'] == 'conv' else s[None, None, :, None])).astype(np.float32)
                 b = p['bias'].astype(np.float64) if p['bias'] is not None else np.zeros(len(s))
                 p['bias'] = (b * s + t).astype(np.float32)
-            elif n['kind'] == 'act' and p['act'] == 0:
+            elif n['kind'] == 'act' and p['act'] == 0 and (n['act'] <= CONV_ACT_MAX or p['kind'] == 'dwconv'):
                 p['act'], p['alpha'] = n['act'], n['alpha']
             else:
                 continue
@@ -355,7 +640,7 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
         off = 0
         for pos, i in enumerate(n['inputs']):
             ci = nodes[i]['shape'][2]
-            ok = (i not in view and nodes[i]['kind'] not in ('input', 'concat') and n['inputs'].count(i) == 1
+            ok = (i not in view and nodes[i]['kind'] not in ('input', 'concat', 'reshape', 'slice') and n['inputs'].count(i) == 1
                   and i != out_node)
             if ok:
                 view[i] = (j, off)
@@ -371,13 +656,10 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
         for i in nodes[j]['inputs']:
             last_use[i] = j
     last_use[out_node] = len(nodes) + 1
-    # Flatten / Reshape are views of their input's buffer: the owner lives as long as the view is read
-    def owner(i):
-        while nodes[i]['kind'] == 'reshape':
-            i = nodes[i]['inputs'][0]
-        return i
+    # Flatten / Reshape / channel slices (grouped convolutions) are views of their input's buffer: the owner lives as long as the
+    # view is read
     for j in reversed(order):
-        if nodes[j]['kind'] == 'reshape':
+        if nodes[j]['kind'] in ('reshape', 'slice'):
             o_ = nodes[j]['inputs'][0]
             last_use[o_] = max(last_use.get(o_, o_), last_use.get(j, j))
     # a concat buffer lives from its first producer to the concat's last use
@@ -447,7 +729,7 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
         return len(plan.weights) - 1
 
     def op(**kw):
-        d = dict(op=0, in0=-1, in1=-1, out=-1, kh=0, kw=0, stride=1, pad_top=0, pad_left=0, act=0, mode=0, w0=-1, w1=-1, alpha=0.0)
+        d = dict(op=0, in0=-1, in1=-1, out=-1, kh=0, kw=0, stride=1, pad_top=0, pad_left=0, act=0, mode=0, w0=-1, w1=-1, alpha=0.0, dilation=1)
         d.update(kw)
         plan.ops.append(d)
 
@@ -478,6 +760,13 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
             plan.tensors.append(dict(buffer=ti_['buffer'], h=h_, w=w_, c=c_, c_stride=c_, c_offset=0))
             tensor_of[j] = len(plan.tensors) - 1
             plan.layer_tensor[n['name']] = tensor_of[j]
+        elif k == 'slice':
+            i = n['inputs'][0]
+            ti_ = plan.tensors[tensor_of[i]]
+            h_, w_, c_ = n['shape']
+            plan.tensors.append(dict(buffer=ti_['buffer'], h=h_, w=w_, c=c_, c_stride=ti_['c_stride'], c_offset=ti_['c_offset'] + n['c0']))
+            tensor_of[j] = len(plan.tensors) - 1
+            plan.layer_tensor[n['name']] = tensor_of[j]
         elif k == 'concat':
             t = new_tensor(j)
             off = 0
@@ -491,14 +780,24 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
         else:
             ins = [tensor_of[i] for i in n['inputs']]
             t = new_tensor(j)
+            late_act = k in ('conv', 'convt') and n['act'] > CONV_ACT_MAX
+            conv_act = 0 if late_act else n.get('act', 0)
             if k == 'conv':
                 op(op=OP_CONV, in0=ins[0], out=t, kh=n['kh'], kw=n['kw'], stride=n.get('stride', 1), pad_top=n['pad_top'], pad_left=n['pad_left'],
-                   act=n['act'], alpha=n['alpha'], w0=add_weight(n['kernel']), w1=add_weight(n['bias']))
+                   act=conv_act, alpha=n['alpha'], w0=add_weight(n['kernel']), w1=add_weight(n['bias']), dilation=n.get('dilation', 1))
+            elif k == 'dwconv':
+                op(op=OP_DWCONV, in0=ins[0], out=t, kh=n['kh'], kw=n['kw'], stride=n['stride'], pad_top=n['pad_top'], pad_left=n['pad_left'],
+                   act=n['act'], alpha=n['alpha'], mode=n['mult'], w0=add_weight(n['kernel']), w1=add_weight(n['bias']), dilation=n['dilation'])
+            elif k == 'prelu':
+                op(op=OP_PRELU, in0=ins[0], out=t, mode=n['mode'], w0=add_weight(n['slopes']))
+            elif k == 'layernorm':
+                op(op=OP_LAYERNORM, in0=ins[0], out=t, alpha=n['eps'], w0=add_weight(n['gamma']), w1=add_weight(n['beta']))
             elif k == 'convt':
                 op(op=OP_CONVT, in0=ins[0], out=t, kh=n['kh'], kw=n['kw'], stride=n['stride'], pad_top=n['pad_top'],
-                   pad_left=n['pad_left'], act=n['act'], alpha=n['alpha'], w0=add_weight(n['kernel']), w1=add_weight(n['bias']))
+                   pad_left=n['pad_left'], act=conv_act, alpha=n['alpha'], w0=add_weight(n['kernel']), w1=add_weight(n['bias']))
             elif k == 'maxpool':
-                op(op=OP_MAXPOOL, in0=ins[0], out=t, kh=n['kh'], kw=n['kw'], stride=n['stride'], mode=n.get('mode', 0))
+                op(op=OP_MAXPOOL, in0=ins[0], out=t, kh=n['kh'], kw=n['kw'], stride=n['stride'], mode=n.get('mode', 0),
+                   pad_top=n.get('pad_top', 0), pad_left=n.get('pad_left', 0))
             elif k == 'globalpool':
                 op(op=OP_GLOBALPOOL, in0=ins[0], out=t, mode=n['mode'])
             elif k == 'upsample':
@@ -510,13 +809,15 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
             elif k == 'add':
                 if len(ins) < 2:
                     raise PlanError('Add %s needs two inputs' % n['name'])
-                op(op=OP_ADD, in0=ins[0], in1=ins[1], out=t)
+                op(op=OP_ADD, in0=ins[0], in1=ins[1], out=t, mode=n.get('mode', 0))
                 for extra in ins[2:]:
-                    op(op=OP_ADD, in0=t, in1=extra, out=t)
+                    op(op=OP_ADD, in0=t, in1=extra, out=t, mode=n.get('mode', 0))
             elif k == 'copy':
                 op(op=OP_COPY, in0=ins[0], out=t, pad_top=n['off_y'], pad_left=n['off_x'])
             else:
                 raise PlanError('internal: unknown node kind %s' % k)
+            if late_act:
+                op(op=OP_ACT, in0=t, out=t, act=n['act'], alpha=n['alpha'])
         release_after(j)
     plan.output_tensor = tensor_of[out_node]
     plan.output_rank = 2 if nodes[out_node].get('rank', 4) == 2 else 4

@@ -15,24 +15,25 @@ class MetasegModel:
     ``predict_on_batch(uint8[N,256,256,1]) -> float32[N,256,256,4]`` is the call shape of the Keras model
     (src/utils.py:115); ``segment`` runs the whole device pipeline of ``meta_segment`` (src/utils.py:113-119)."""
 
-    def __init__(self, model_config, weights, device=0, fuse=True, handle=None, lambda_overrides=None):
+    def __init__(self, model_config, weights, device=0, fuse=True, handle=None, lambda_overrides=None, output=0):
+        """``output``: index or layer name of the output to compute when the Keras model has several (default: the first)."""
         if isinstance(model_config, (str, bytes)):
             model_config = json.loads(model_config)
         self.model_config = model_config
         self.weights = weights
-        self.plan = keras_plan.build_plan(model_config, weights, fuse=fuse, lambda_overrides=lambda_overrides)
+        self.plan = keras_plan.build_plan(model_config, weights, fuse=fuse, lambda_overrides=lambda_overrides, output=output)
         self.handle = handle if handle is not None else Handle(device)
         self.handle.load_plan(self.plan)
 
     @classmethod
-    def from_h5(cls, path, device=0, fuse=True, lambda_overrides=None):
+    def from_h5(cls, path, device=0, fuse=True, lambda_overrides=None, handle=None, output=0):
         if not os.path.exists(path):
             raise FileNotFoundError(path)
         if os.path.isdir(path):
             raise ValueError('%s is a TensorFlow SavedModel directory; only the Keras HDF5 format is read here - '
                              're-save it with model.save("<name>.h5") where TensorFlow is available' % path)
         cfg, weights = hdf5_min.load_keras_h5(path)
-        return cls(cfg, weights, device=device, fuse=fuse, lambda_overrides=lambda_overrides)
+        return cls(cfg, weights, device=device, fuse=fuse, lambda_overrides=lambda_overrides, handle=handle, output=output)
 
     # Keras call shapes -----------------------------------------------------------------------------
     def predict_on_batch(self, x):

@@ -359,3 +359,83 @@ def label_map(idx, H=1040, W=1392, salt=0.002):
         m = rng.random((H, W)) < salt
         lab[m] = rng.integers(0, 4, size=int(m.sum()))
     return lab
+
+
+def mobilenet_classifier(seed=0, hw=96, n_classes=3, width=16):
+    """-> (model_config, weights): a MobileNet-style transfer-learning classifier as Keras 2 saves one - the vocabulary an
+    ``interseg_models/*`` file may hold beyond plain convolutions (src/interseg.py:96-98 loads whatever the file contains):
+    a NESTED Functional backbone used as one layer (strided stem, depthwise-separable blocks with BatchNormalization and
+    ReLU(max_value=6), a squeeze-and-excite gate - GlobalAveragePooling2D(keepdims) -> 1x1 convolutions -> Multiply -, a
+    residual Add, a dilated 3x3 convolution, a grouped convolution, a SeparableConv2D, PReLU), then a head of global pooling,
+    LayerNormalization and Dense.  ``weights``: {outer layer: [arrays]} with the backbone's as {inner layer: [arrays]}."""
+    rng = np.random.default_rng(seed)
+    inner, wi = [], {}
+
+    def L(dst, cls, name, inb, **c):
+        dst.append({'class_name': cls, 'name': name, 'config': dict(c, name=name),
+                    'inbound_nodes': [[[i, 0, 0, {}] for i in inb]] if inb else []})
+        return name
+
+    def he(*s):
+        fan = int(np.prod(s[:-1])) if len(s) > 1 else s[0]
+        return (rng.normal(size=s) * np.sqrt(2.0 / fan)).astype(np.float32)
+
+    def bn(name, x, c):
+        wi[name] = [rng.uniform(0.8, 1.2, c).astype(np.float32), (rng.normal(size=c) * 0.05).astype(np.float32),
+                    (rng.normal(size=c) * 0.05).astype(np.float32), rng.uniform(0.8, 1.2, c).astype(np.float32)]
+        return L(inner, 'BatchNormalization', name, [x], axis=[3], momentum=0.99, epsilon=1e-3, center=True, scale=True)
+
+    def relu6(name, x):
+        return L(inner, 'ReLU', name, [x], max_value=6.0, negative_slope=0.0, threshold=0.0)
+
+    def conv(name, x, cin, f, k=1, s=1, act='linear', bias=False, dil=1, groups=1, pad='same'):
+        wi[name] = [he(k, k, cin // groups, f)] + ([(rng.normal(size=f) * 0.05).astype(np.float32)] if bias else [])
+        return L(inner, 'Conv2D', name, [x], filters=f, kernel_size=[k, k], strides=[s, s], padding=pad, data_format='channels_last',
+                 dilation_rate=[dil, dil], groups=groups, activation=act, use_bias=bias)
+
+    def dw(name, x, c, k=3, s=1, dil=1):
+        wi[name] = [(rng.normal(size=(k, k, c, 1)) * np.sqrt(2.0 / (k * k))).astype(np.float32)]
+        return L(inner, 'DepthwiseConv2D', name, [x], kernel_size=[k, k], strides=[s, s], padding='same', data_format='channels_last',
+                 dilation_rate=[dil, dil], depth_multiplier=1, activation='linear', use_bias=False)
+
+    w1, w2 = width, 2 * width
+    x = L(inner, 'InputLayer', 'backbone_in', [], batch_input_shape=[None, hw, hw, 3], dtype='float32')
+    x = relu6('stem_relu', bn('stem_bn', conv('stem', x, 3, w1, k=3, s=2), w1))
+    # depthwise-separable block 1 (stride 1, residual)
+    y = relu6('b1_dw_relu', bn('b1_dw_bn', dw('b1_dw', x, w1), w1))
+    y = bn('b1_pw_bn', conv('b1_pw', y, w1, w1), w1)
+    x = L(inner, 'Add', 'b1_add', [x, y])
+    # block 2: expand, depthwise stride 2, squeeze-and-excite, project
+    y = relu6('b2_exp_relu', bn('b2_exp_bn', conv('b2_exp', x, w1, w2), w2))
+    y = relu6('b2_dw_relu', bn('b2_dw_bn', dw('b2_dw', y, w2, k=3, s=2), w2))
+    se = L(inner, 'GlobalAveragePooling2D', 'b2_se_gap', [y], data_format='channels_last', keepdims=True)
+    se = conv('b2_se_reduce', se, w2, w2 // 4, act='relu', bias=True)
+    se = conv('b2_se_expand', se, w2 // 4, w2, act='hard_sigmoid', bias=True)
+    y = L(inner, 'Multiply', 'b2_se_mul', [y, se])
+    x = bn('b2_pw_bn', conv('b2_pw', y, w2, w2), w2)
+    # dilated context, grouped convolution, separable convolution, PReLU
+    y = conv('ctx_dil', x, w2, w2, k=3, dil=2, act='relu', bias=True)
+    y = conv('ctx_grp', y, w2, w2, k=3, groups=4, act='linear', bias=True)
+    wi['ctx_prelu'] = [rng.uniform(0.05, 0.3, (1, 1, w2)).astype(np.float32)]
+    y = L(inner, 'PReLU', 'ctx_prelu', [y], shared_axes=[1, 2])
+    wi['ctx_sep'] = [(rng.normal(size=(3, 3, w2, 1)) * np.sqrt(2.0 / 9)).astype(np.float32), he(1, 1, w2, w2),
+                     (rng.normal(size=w2) * 0.05).astype(np.float32)]
+    y = L(inner, 'SeparableConv2D', 'ctx_sep', [y], filters=w2, kernel_size=[3, 3], strides=[1, 1], padding='same',
+          data_format='channels_last', dilation_rate=[1, 1], depth_multiplier=1, activation='swish', use_bias=True)
+    x = L(inner, 'Add', 'ctx_add', [x, y])
+    x = L(inner, 'MaxPooling2D', 'ctx_pool', [x], pool_size=[3, 3], strides=[2, 2], padding='same', data_format='channels_last')
+    backbone = {'class_name': 'Functional', 'name': 'backbone',
+                'config': {'name': 'backbone', 'layers': inner, 'input_layers': [['backbone_in', 0, 0]], 'output_layers': [[x, 0, 0]]}}
+    outer, wo = [], {}
+    i = L(outer, 'InputLayer', 'input_1', [], batch_input_shape=[None, hw, hw, 3], dtype='float32')
+    r = L(outer, 'Rescaling', 'rescaling', [i], scale=1.0 / 127.5, offset=-1.0)
+    outer.append(dict(backbone, inbound_nodes=[[[r, 0, 0, {}]]]))
+    g = L(outer, 'GlobalAveragePooling2D', 'gap', ['backbone'], data_format='channels_last', keepdims=False)
+    wo['head_ln'] = [rng.uniform(0.8, 1.2, w2).astype(np.float32), (rng.normal(size=w2) * 0.05).astype(np.float32)]
+    g = L(outer, 'LayerNormalization', 'head_ln', [g], axis=[1], epsilon=1e-3, center=True, scale=True)
+    wo['dense_out'] = [(rng.normal(size=(w2, n_classes)) * np.sqrt(2.0 / w2) * 3).astype(np.float32), (rng.normal(size=n_classes) * 0.05).astype(np.float32)]
+    out = L(outer, 'Dense', 'dense_out', [g], units=n_classes, activation='softmax', use_bias=True)
+    wo['backbone'] = wi
+    cfg = {'class_name': 'Functional', 'config': {'name': 'mobilenet_synth', 'layers': outer, 'input_layers': [['input_1', 0, 0]],
+                                                  'output_layers': [[out, 0, 0]]}}
+    return cfg, wo

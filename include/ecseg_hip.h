@@ -31,7 +31,10 @@ extern "C" {
  * (GLOBALPOOL), MAXPOOL honours `mode`, CONV accepts stride != 1, ecseg_npy_write_i64 / ecseg_png_write* /
  * ecseg_tiff_* / ecseg_allgather_records added.  ecseg_amd/_lib.py refuses a library whose version differs from the one it was written for. */
 /* 3 (round 4): ecseg_segment_images_ex (per-image tie-risk counts, stitched probabilities). */
-#define ECSEG_ABI_VERSION 3
+/* 4 (round 5): ecseg_op_desc gains `dilation`; op codes 10-12 (DWCONV, PRELU, LAYERNORM); ADD takes `mode` (add / multiply / subtract /
+ * maximum / minimum) and broadcasts extents of 1; MAXPOOL honours pad_top / pad_left ('same' pooling); activation codes 7-14;
+ * ECSEG_COMM_TIMEOUT_S bounds ecseg_comm_create / ecseg_allgather_records*. */
+#define ECSEG_ABI_VERSION 4
 
 #define ECSEG_OK             0
 #define ECSEG_E_INVALID     -1   /* bad argument / shape / plan */
@@ -57,19 +60,35 @@ void*       ecseg_stream(ecseg_ctx* h);
  * found in metaseg.h5 to this list; tensors are NHWC float32 "views" into device buffers so that Concatenate
  * costs nothing (producers write straight into the concatenated buffer). */
 enum {
-    ECSEG_OP_CONV      = 1,  /* Conv2D kh x kw, stride s, zero padding (pad_top, pad_left), bias, activation; a Dense
-                                layer is the 1x1 case on a (1, 1, features) tensor */
+    ECSEG_OP_CONV      = 1,  /* Conv2D kh x kw, stride s, dilation d, zero padding (pad_top, pad_left), bias, activation; a Dense
+                                layer is the 1x1 case on a (1, 1, features) tensor; a grouped convolution is one CONV per group
+                                on channel views */
     ECSEG_OP_CONVT     = 2,  /* Conv2DTranspose kh x kw, stride s, crop (pad_top, pad_left), bias, activation */
-    ECSEG_OP_MAXPOOL   = 3,  /* MaxPooling2D (mode 0) / AveragePooling2D (mode 1) kh x kw stride s (valid) */
+    ECSEG_OP_MAXPOOL   = 3,  /* MaxPooling2D (mode 0) / AveragePooling2D (mode 1) kh x kw stride s; 'same': (pad_top, pad_left) window
+                                positions before the input (the maximum / the average runs over the pixels inside the input) */
     ECSEG_OP_UPSAMPLE  = 4,  /* UpSampling2D x s, mode: 0 nearest, 1 bilinear (half-pixel centres) */
     ECSEG_OP_AFFINE    = 5,  /* y = act(x * scale[c] + shift[c]): BatchNormalization (inference), Rescaling */
     ECSEG_OP_ACT       = 6,  /* y = act(x) */
-    ECSEG_OP_ADD       = 7,  /* y = act(a + b) */
+    ECSEG_OP_ADD       = 7,  /* y = act(a (+) b), (+) = `mode` (ECSEG_BIN_*: Add / Multiply / Subtract / Maximum / Minimum); an extent of
+                                1 in either input (h, w or c) is broadcast - the squeeze-and-excite x * s(1, 1, c) */
     ECSEG_OP_COPY      = 8,  /* y = x (materialise a view, ZeroPadding2D / Cropping2D via offsets) */
-    ECSEG_OP_GLOBALPOOL = 9  /* GlobalMaxPooling2D (mode 0) / GlobalAveragePooling2D (mode 1): (h, w, c) -> (1, 1, c) */
+    ECSEG_OP_GLOBALPOOL = 9, /* GlobalMaxPooling2D (mode 0) / GlobalAveragePooling2D (mode 1): (h, w, c) -> (1, 1, c) */
+    ECSEG_OP_DWCONV    = 10, /* DepthwiseConv2D kh x kw, stride s, dilation, zero padding (pad_top, pad_left), depth multiplier
+                                `mode` (>= 1; output channel = input channel * mode + j), kernel (kh, kw, cin, mode), bias,
+                                activation; SeparableConv2D = DWCONV followed by a 1x1 CONV */
+    ECSEG_OP_PRELU     = 11, /* y = x > 0 ? x : a * x; w0 = a: mode 0 one slope per channel (shared_axes [1, 2]), mode 1 one per
+                                (y, x, channel) of the patch */
+    ECSEG_OP_LAYERNORM = 12  /* LayerNormalization over the channel axis of every pixel: (x - mean) / sqrt(var + alpha) * w0[c] +
+                                w1[c] (alpha = epsilon; w0 / w1 = -1: no scale / no centre) */
 };
+/* RELU_CLIP: min(max(x, 0), alpha) (ReLU(max_value) - relu6); ELU: x > 0 ? x : alpha (exp(x) - 1); HARD_SIGMOID: Keras' clip(0.2 x +
+ * 0.5, 0, 1); GELU: the exact erf form (Keras' default approximate=False) */
 enum { ECSEG_ACT_LINEAR = 0, ECSEG_ACT_RELU = 1, ECSEG_ACT_SOFTMAX = 2, ECSEG_ACT_SIGMOID = 3,
-       ECSEG_ACT_LEAKY = 4, ECSEG_ACT_TANH = 5, ECSEG_ACT_ELU = 6 };
+       ECSEG_ACT_LEAKY = 4, ECSEG_ACT_TANH = 5, ECSEG_ACT_ELU = 6, ECSEG_ACT_RELU_CLIP = 7, ECSEG_ACT_SWISH = 8,
+       ECSEG_ACT_HARD_SIGMOID = 9, ECSEG_ACT_SOFTPLUS = 10, ECSEG_ACT_SELU = 11, ECSEG_ACT_GELU = 12, ECSEG_ACT_EXP = 13,
+       ECSEG_ACT_SOFTSIGN = 14 };
+/* ECSEG_OP_ADD `mode` */
+enum { ECSEG_BIN_ADD = 0, ECSEG_BIN_MUL = 1, ECSEG_BIN_SUB = 2, ECSEG_BIN_MAX = 3, ECSEG_BIN_MIN = 4 };
 
 typedef struct ecseg_tensor_desc {
     int32_t buffer;     /* index of the device buffer this view lives in */
@@ -86,9 +105,11 @@ typedef struct ecseg_op_desc {
     int32_t pad_top, pad_left;  /* CONV: zero padding before; CONVT: rows/cols cropped from the full output;
                                    COPY: offset of the input inside the output (>0) or crop (<0) */
     int32_t act;
-    int32_t mode;               /* UPSAMPLE interpolation; MAXPOOL / GLOBALPOOL: 0 max, 1 average */
+    int32_t mode;               /* UPSAMPLE interpolation; MAXPOOL / GLOBALPOOL: 0 max, 1 average; ADD: ECSEG_BIN_*; DWCONV: depth
+                                   multiplier; PRELU: 0 per channel, 1 per element */
     int32_t w0, w1;             /* weight array indices: CONV/CONVT kernel + bias (-1 none); AFFINE scale + shift */
-    float   alpha;              /* LEAKY slope */
+    float   alpha;              /* LEAKY slope / RELU_CLIP maximum / ELU alpha; LAYERNORM epsilon */
+    int32_t dilation;           /* CONV / DWCONV: dilation_rate (0 or 1: none) */
 } ecseg_op_desc;
 
 /* weights[i] is a host float32 array of weight_len[i] elements, Keras layout

@@ -15,6 +15,16 @@ definitions and evaluated with torch CPU float32 ops (``conv_numpy`` is an indep
   Dropout-like layers = identity, Activation / ReLU / LeakyReLU / Softmax, Add, ZeroPadding2D, Cropping2D,
   Rescaling; for the interSeg classifiers (src/interseg.py:96-98,155,168): strided Conv2D, AveragePooling2D,
   GlobalAveragePooling2D / GlobalMaxPooling2D, Flatten (NHWC order), Reshape, Dense (last axis).
+* Round 5 - whatever else a Keras file given to ``load_model`` (src/utils.py:27-33, src/interseg.py:96-98) may hold:
+  Conv2D ``dilation_rate`` (taps ``d`` pixels apart; 'same' pads for the dilated extent ``(k - 1) d + 1``) and ``groups``
+  (output channel ``o`` reads the input channels of group ``o // (filters / groups)``), DepthwiseConv2D (kernel
+  (kh, kw, cin, m); output channel ``ci * m + j``), SeparableConv2D (depthwise, then 1x1 pointwise + bias + activation),
+  Multiply / Subtract / Maximum / Minimum / Average (numpy broadcasting), PReLU (``shared_axes``), LayerNormalization (last
+  axis; moments then ``(x - mean) / sqrt(var + eps) * gamma + beta``), Normalization (``(x - mean) / max(sqrt(var), 1e-7)``),
+  ReLU(max_value), ELU(alpha), the activation names selu / softplus / softsign / swish / gelu / hard_sigmoid / exponential /
+  relu6, 'same' pooling (the average runs over the pixels inside the input), nested Functional / Sequential sub-models
+  (evaluated recursively; their weights arrive as ``{inner layer: [arrays]}`` or as a list with ``.names``) and models with
+  several outputs (``output=`` selects one).
 The uint8 patch batch is cast to float32 without scaling (Keras casts inputs to the InputLayer dtype).
 """
 import json
@@ -43,7 +53,28 @@ def _act(name, x, cfg=None):
         return torch.tanh(x)
     if name == 'elu':
         return F.elu(x)
+    if name == 'relu6':
+        return torch.clamp(x, 0.0, 6.0)
+    if name == 'selu':
+        return F.selu(x)
+    if name == 'softplus':
+        return F.softplus(x)
+    if name == 'softsign':
+        return F.softsign(x)
+    if name in ('swish', 'silu'):
+        return x * torch.sigmoid(x)
+    if name == 'gelu':
+        return F.gelu(x)                                     # exact erf form = Keras' default (approximate=False)
+    if name == 'hard_sigmoid':
+        return torch.clamp(0.2 * x + 0.5, 0.0, 1.0)         # Keras 2.x definition
+    if name == 'exponential':
+        return torch.exp(x)
     raise NotImplementedError('activation %r' % name)
+
+
+def _dil(cfg):
+    d = cfg.get('dilation_rate', [1, 1])
+    return (d, d) if isinstance(d, int) else tuple(d)
 
 
 def _conv2d(x, cfg, w):
@@ -51,13 +82,55 @@ def _conv2d(x, cfg, w):
     bias = torch.from_numpy(np.ascontiguousarray(w[1])) if cfg.get('use_bias', True) else None
     kh, kw = kernel.shape[2:]
     sh, sw = cfg.get('strides', [1, 1])
-    assert list(cfg.get('dilation_rate', [1, 1])) == [1, 1] and cfg.get('groups', 1) == 1
+    dh, dw = _dil(cfg)
     if cfg['padding'] == 'same':
-        pt, pb = _same_pad(kh, sh, x.shape[2])
-        pl, pr = _same_pad(kw, sw, x.shape[3])
+        pt, pb = _same_pad((kh - 1) * dh + 1, sh, x.shape[2])
+        pl, pr = _same_pad((kw - 1) * dw + 1, sw, x.shape[3])
         x = F.pad(x, (pl, pr, pt, pb))
-    y = F.conv2d(x, kernel, bias, stride=(sh, sw))
+    # Keras' grouped kernel (kh, kw, cin / groups, filters) permuted to (filters, cin / groups, kh, kw) is torch's layout as it is
+    y = F.conv2d(x, kernel, bias, stride=(sh, sw), dilation=(dh, dw), groups=int(cfg.get('groups', 1) or 1))
     return _act(cfg.get('activation'), y)
+
+
+def _depthwise(x, cfg, kernel_hwcm, bias, act):
+    """kernel (kh, kw, cin, m): output channel ci * m + j = sum over taps of in[ci] * kernel[:, :, ci, j]."""
+    kh, kw, ci, m = kernel_hwcm.shape
+    wt = torch.from_numpy(np.ascontiguousarray(kernel_hwcm)).permute(2, 3, 0, 1).reshape(ci * m, 1, kh, kw).contiguous()
+    sh, sw = cfg.get('strides', [1, 1])
+    dh, dw = _dil(cfg)
+    if cfg['padding'] == 'same':
+        pt, pb = _same_pad((kh - 1) * dh + 1, sh, x.shape[2])
+        pl, pr = _same_pad((kw - 1) * dw + 1, sw, x.shape[3])
+        x = F.pad(x, (pl, pr, pt, pb))
+    y = F.conv2d(x, wt, None if bias is None else torch.from_numpy(np.ascontiguousarray(bias)), stride=(sh, sw), dilation=(dh, dw), groups=ci)
+    return _act(act, y)
+
+
+def _pool_same(a, lc, avg):
+    """Pooling with padding='same': TensorFlow pads (smaller half in front) with -inf for the maximum and leaves the padding
+    out of the average's divisor."""
+    kh, kw = lc['pool_size']
+    sh, sw = lc.get('strides') or lc['pool_size']
+    pt, pb = _same_pad(kh, sh, a.shape[2])
+    pl, pr = _same_pad(kw, sw, a.shape[3])
+    if not avg:
+        return F.max_pool2d(F.pad(a, (pl, pr, pt, pb), value=float('-inf')), (kh, kw), (sh, sw))
+    ones = F.pad(torch.ones_like(a[:1, :1]), (pl, pr, pt, pb))
+    s = F.avg_pool2d(F.pad(a, (pl, pr, pt, pb)), (kh, kw), (sh, sw)) * (kh * kw)
+    cnt = F.avg_pool2d(ones, (kh, kw), (sh, sw)) * (kh * kw)
+    return s / cnt
+
+
+def _nested_weights(ws):
+    if ws is None or isinstance(ws, dict):
+        return ws or {}
+    names = getattr(ws, 'names', None)
+    assert names is not None and len(names) == len(ws), 'weights of a nested model need names'
+    d = {}
+    for nm, a in zip(names, ws):
+        parts = str(nm).split(':')[0].split('/')
+        d.setdefault(parts[-2] if len(parts) >= 2 else parts[0], []).append(a)
+    return d
 
 
 def _conv2d_transpose(x, cfg, w):
@@ -104,7 +177,7 @@ def _tfop(L, lc, a):
     raise NotImplementedError('TFOpLambda %s' % fn)
 
 
-def forward(model_config, weights, x_nhwc, lambda_fns=None, dtype=np.float32):
+def forward(model_config, weights, x_nhwc, lambda_fns=None, dtype=np.float32, output=0):
     """``model_config``: dict (or JSON text) of a Keras Functional/Sequential model; ``weights``: {layer name:
     [arrays in Keras order]}; ``x_nhwc``: (N, H, W, C) any dtype.  Returns float32 NHWC output of the model.
 
@@ -118,17 +191,24 @@ def forward(model_config, weights, x_nhwc, lambda_fns=None, dtype=np.float32):
     layers = cfg['layers'] if isinstance(cfg, dict) else cfg
     seq = model_config['class_name'] == 'Sequential'
     vals = {}
-    x_nhwc = np.ascontiguousarray(x_nhwc)
-    if x_nhwc.ndim == 3:                      # (N, H, W): a model whose InputLayer has no channel axis
-        x_nhwc = x_nhwc[..., None]
-    x = torch.from_numpy(x_nhwc.astype(dtype)).permute(0, 3, 1, 2).contiguous()
+    if isinstance(x_nhwc, (list, tuple)) and x_nhwc and torch.is_tensor(x_nhwc[0]):
+        xs = list(x_nhwc)                     # a nested model called on the (NCHW / (N, K)) tensors of its parent
+    else:
+        x_nhwc = np.ascontiguousarray(x_nhwc)
+        if x_nhwc.ndim == 3:                  # (N, H, W): a model whose InputLayer has no channel axis
+            x_nhwc = x_nhwc[..., None]
+        xs = [torch.from_numpy(x_nhwc.astype(dtype)).permute(0, 3, 1, 2).contiguous()]
+    x = xs[0]
+    n_in = 0
     prev = None
     with torch.no_grad():
         for L in layers:
             cls, lc = L['class_name'], L['config']
             name = lc['name']
             if cls == 'InputLayer':
-                vals[name] = x
+                order = [r[0] for r in cfg['input_layers']] if isinstance(cfg, dict) and cfg.get('input_layers') else None
+                vals[name] = xs[order.index(name) if order and name in order else n_in]
+                n_in += 1
                 prev = name
                 continue
             if seq:
@@ -142,19 +222,36 @@ def forward(model_config, weights, x_nhwc, lambda_fns=None, dtype=np.float32):
                 node = nodes[0]
                 if node and isinstance(node[0], str):
                     node = [node]
-                ins = [vals[n[0]] for n in node]
-            w = [np.asarray(v, dtype) for v in weights.get(name, [])]
+                ins = [vals[n[0]][n[2]] if isinstance(vals[n[0]], list) else vals[n[0]] for n in node]
             a = ins[0]
+            if cls in ('Functional', 'Model', 'Sequential'):    # a nested model: evaluate it on this layer's inputs
+                outs = forward({'class_name': cls, 'config': lc}, _nested_weights(weights.get(name)), ins, lambda_fns=lambda_fns,
+                               dtype=dtype, output=None)
+                vals[name] = outs if len(outs) > 1 else outs[0]
+                prev = name
+                continue
+            w = [np.asarray(v, dtype) for v in weights.get(name, [])]
             if cls == 'Conv2D':
                 y = _conv2d(a, lc, w)
+            elif cls == 'DepthwiseConv2D':
+                y = _depthwise(a, lc, w[0], w[1] if lc.get('use_bias', True) else None, lc.get('activation'))
+            elif cls == 'SeparableConv2D':
+                y = _depthwise(a, lc, w[0], None, None)
+                pk = torch.from_numpy(np.ascontiguousarray(w[1])).permute(3, 2, 0, 1).contiguous()
+                y = F.conv2d(y, pk, torch.from_numpy(np.ascontiguousarray(w[2])) if lc.get('use_bias', True) else None)
+                y = _act(lc.get('activation'), y)
             elif cls == 'Conv2DTranspose':
                 y = _conv2d_transpose(a, lc, w)
             elif cls == 'MaxPooling2D':
-                assert lc.get('padding', 'valid') == 'valid'
-                y = F.max_pool2d(a, tuple(lc['pool_size']), tuple(lc.get('strides') or lc['pool_size']))
+                if lc.get('padding', 'valid') == 'same':
+                    y = _pool_same(a, lc, False)
+                else:
+                    y = F.max_pool2d(a, tuple(lc['pool_size']), tuple(lc.get('strides') or lc['pool_size']))
             elif cls == 'AveragePooling2D':
-                assert lc.get('padding', 'valid') == 'valid'
-                y = F.avg_pool2d(a, tuple(lc['pool_size']), tuple(lc.get('strides') or lc['pool_size']))
+                if lc.get('padding', 'valid') == 'same':
+                    y = _pool_same(a, lc, True)
+                else:
+                    y = F.avg_pool2d(a, tuple(lc['pool_size']), tuple(lc.get('strides') or lc['pool_size']))
             elif cls == 'GlobalAveragePooling2D':
                 y = a.mean(dim=(2, 3))
                 if lc.get('keepdims'):
@@ -196,10 +293,42 @@ def forward(model_config, weights, x_nhwc, lambda_fns=None, dtype=np.float32):
             elif cls == 'Concatenate':
                 assert lc.get('axis', -1) in (-1, 3)
                 y = torch.cat(ins, dim=1)
-            elif cls == 'Add':
+            elif cls in ('Add', 'Multiply', 'Subtract', 'Maximum', 'Minimum', 'Average'):
+                # NCHW tensors broadcast exactly as their NHWC originals do (extents of 1 stretch)
                 y = ins[0]
                 for t in ins[1:]:
-                    y = y + t
+                    y = (y + t if cls in ('Add', 'Average') else y * t if cls == 'Multiply' else y - t if cls == 'Subtract'
+                         else torch.maximum(y, t) if cls == 'Maximum' else torch.minimum(y, t))
+                if cls == 'Average':
+                    y = y / float(len(ins))
+            elif cls == 'PReLU':
+                al = torch.from_numpy(np.ascontiguousarray(w[0]))
+                al = al.permute(2, 0, 1) if a.dim() == 4 else al          # (h, w, c) with 1s on the shared axes -> (c, h, w)
+                y = torch.where(a > 0, a, al * a)
+            elif cls == 'LayerNormalization':
+                ax = lc.get('axis', -1)
+                ax = list(ax) if isinstance(ax, (list, tuple)) else [ax]
+                assert ax in ([-1], [a.dim() - 1]), 'LayerNormalization over the last axis only'
+                wl = list(w)
+                gamma = torch.from_numpy(wl.pop(0)) if lc.get('scale', True) else None
+                beta = torch.from_numpy(wl.pop(0)) if lc.get('center', True) else None
+                mean = a.mean(dim=1, keepdim=True)
+                var = ((a - mean) ** 2).mean(dim=1, keepdim=True)
+                y = (a - mean) / torch.sqrt(var + lc.get('epsilon', 1e-3))
+                shp = (1, -1, 1, 1) if a.dim() == 4 else (1, -1)
+                if gamma is not None:
+                    y = y * gamma.view(shp)
+                if beta is not None:
+                    y = y + beta.view(shp)
+            elif cls == 'Normalization':
+                if lc.get('mean') is not None:
+                    mean, var = np.asarray(lc['mean'], dtype), np.asarray(lc['variance'], dtype)
+                else:
+                    mean, var = w[0], w[1]
+                shp = (1, -1, 1, 1) if a.dim() == 4 else (1, -1)
+                mean = torch.from_numpy(np.ascontiguousarray(mean).reshape(-1)).view(shp)
+                std = torch.clamp(torch.sqrt(torch.from_numpy(np.ascontiguousarray(var).reshape(-1))), min=1e-7).view(shp)
+                y = (a - mean) / std
             elif cls == 'BatchNormalization':
                 y = _batchnorm(a, lc, w)
             elif cls in ('Dropout', 'SpatialDropout2D', 'GaussianNoise', 'GaussianDropout', 'AlphaDropout'):
@@ -207,8 +336,16 @@ def forward(model_config, weights, x_nhwc, lambda_fns=None, dtype=np.float32):
             elif cls == 'Activation':
                 y = _act(lc['activation'], a)
             elif cls == 'ReLU':
-                assert lc.get('max_value') is None and not lc.get('threshold') and not lc.get('negative_slope')
-                y = F.relu(a)
+                assert not lc.get('threshold')
+                if lc.get('max_value') is not None:
+                    assert not lc.get('negative_slope')
+                    y = torch.clamp(a, 0.0, float(lc['max_value']))
+                elif lc.get('negative_slope'):
+                    y = F.leaky_relu(a, float(lc['negative_slope']))
+                else:
+                    y = F.relu(a)
+            elif cls == 'ELU':
+                y = F.elu(a, float(lc.get('alpha', 1.0)))
             elif cls == 'LeakyReLU':
                 y = F.leaky_relu(a, float(lc.get('alpha', 0.3)))
             elif cls == 'Softmax':
@@ -230,9 +367,12 @@ def forward(model_config, weights, x_nhwc, lambda_fns=None, dtype=np.float32):
             vals[name] = y
             prev = name
         if seq:
-            out = vals[prev]
+            outs = [vals[prev]]
         else:
-            out = vals[cfg['output_layers'][0][0]]
+            outs = [vals[r[0]][r[2]] if isinstance(vals[r[0]], list) else vals[r[0]] for r in cfg['output_layers']]
+        if output is None:                    # (nested call: torch tensors of every output)
+            return outs
+        out = outs[[r[0] for r in cfg['output_layers']].index(output)] if isinstance(output, str) else outs[int(output)]
     if out.dim() == 2:
         return out.contiguous().numpy()
     return out.permute(0, 2, 3, 1).contiguous().numpy()
@@ -348,3 +488,112 @@ def softmax_numpy(x_nhwc):
     x = np.asarray(x_nhwc, np.float64)
     e = np.exp(x - x.max(-1, keepdims=True))
     return (e / e.sum(-1, keepdims=True)).astype(np.float32)
+
+
+# ---- round 5: numpy restatements of the wider layer vocabulary (no torch) ----------------------------------------
+def conv_general_numpy(x_nhwc, kernel, bias, padding='same', stride=1, dilation=1, groups=1):
+    """Conv2D with ``dilation_rate`` and ``groups``: tap (i, j) reads the input ``i * d`` rows / ``j * d`` columns from the
+    window's origin; 'same' pads for the dilated kernel extent (k - 1) d + 1; kernel (kh, kw, cin / groups, filters) and
+    output channel o reads the input channels of group o // (filters / groups)."""
+    x = np.asarray(x_nhwc, np.float32)
+    kh, kw, cg, co = kernel.shape
+    s, d, g = int(stride), int(dilation), int(groups)
+    ekh, ekw = (kh - 1) * d + 1, (kw - 1) * d + 1
+    if padding == 'same':
+        pt, pb = _same_pad(ekh, s, x.shape[1])
+        pl, pr = _same_pad(ekw, s, x.shape[2])
+        x = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+    N, H, W, C = x.shape
+    assert C == cg * g and co % g == 0
+    Ho, Wo = (H - ekh) // s + 1, (W - ekw) // s + 1
+    fg = co // g
+    y = np.zeros((N, Ho, Wo, co), np.float64)
+    for i in range(kh):
+        for j in range(kw):
+            win = x[:, i * d:i * d + (Ho - 1) * s + 1:s, j * d:j * d + (Wo - 1) * s + 1:s, :].astype(np.float64)
+            for q in range(g):
+                y[..., q * fg:(q + 1) * fg] += np.einsum('nhwc,co->nhwo', win[..., q * cg:(q + 1) * cg], kernel[i, j, :, q * fg:(q + 1) * fg].astype(np.float64))
+    return (y + (0 if bias is None else np.asarray(bias, np.float64))).astype(np.float32)
+
+
+def depthwise_numpy(x_nhwc, kernel_hwcm, bias, padding='same', stride=1, dilation=1):
+    """DepthwiseConv2D: output channel ``ci * m + j`` is the 2-D correlation of input channel ``ci`` with
+    ``kernel[:, :, ci, j]`` - no sum over channels."""
+    x = np.asarray(x_nhwc, np.float32)
+    kh, kw, ci, m = kernel_hwcm.shape
+    s, d = int(stride), int(dilation)
+    ekh, ekw = (kh - 1) * d + 1, (kw - 1) * d + 1
+    if padding == 'same':
+        pt, pb = _same_pad(ekh, s, x.shape[1])
+        pl, pr = _same_pad(ekw, s, x.shape[2])
+        x = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+    N, H, W, C = x.shape
+    Ho, Wo = (H - ekh) // s + 1, (W - ekw) // s + 1
+    y = np.zeros((N, Ho, Wo, ci, m), np.float64)
+    for i in range(kh):
+        for j in range(kw):
+            win = x[:, i * d:i * d + (Ho - 1) * s + 1:s, j * d:j * d + (Wo - 1) * s + 1:s, :].astype(np.float64)
+            y += win[..., None] * kernel_hwcm[i, j].astype(np.float64)
+    y = y.reshape(N, Ho, Wo, ci * m)
+    return (y + (0 if bias is None else np.asarray(bias, np.float64))).astype(np.float32)
+
+
+def pool_same_numpy(x_nhwc, k, s, avg):
+    """Pooling with padding='same': windows start ``pad_front`` before the image; only pixels inside it take part."""
+    x = np.asarray(x_nhwc, np.float32)
+    N, H, W, C = x.shape
+    Ho, Wo = -(-H // s), -(-W // s)
+    pt, pl = _same_pad(k, s, H)[0], _same_pad(k, s, W)[0]
+    out = np.zeros((N, Ho, Wo, C), np.float32)
+    for oy in range(Ho):
+        for ox in range(Wo):
+            y0, x0 = oy * s - pt, ox * s - pl
+            win = x[:, max(y0, 0):min(y0 + k, H), max(x0, 0):min(x0 + k, W), :]
+            out[:, oy, ox] = win.mean(axis=(1, 2)) if avg else win.max(axis=(1, 2))
+    return out
+
+
+def layernorm_numpy(x, gamma, beta, eps=1e-3):
+    """LayerNormalization over the last axis."""
+    x = np.asarray(x, np.float64)
+    mean = x.mean(-1, keepdims=True)
+    var = ((x - mean) ** 2).mean(-1, keepdims=True)
+    y = (x - mean) / np.sqrt(var + eps)
+    if gamma is not None:
+        y = y * np.asarray(gamma, np.float64)
+    if beta is not None:
+        y = y + np.asarray(beta, np.float64)
+    return y.astype(np.float32)
+
+
+def prelu_numpy(x_nhwc, alpha):
+    """PReLU: ``alpha`` has the input's (h, w, c) shape with 1 on the shared axes."""
+    x = np.asarray(x_nhwc, np.float32)
+    return np.where(x > 0, x, np.asarray(alpha, np.float32) * x).astype(np.float32)
+
+
+def activation_numpy(name, x, alpha=None):
+    """The activation functions by their published formulas (float64 inside)."""
+    from math import erf
+    x = np.asarray(x, np.float64)
+    if name == 'relu6':
+        y = np.clip(x, 0, 6)
+    elif name == 'selu':
+        y = 1.0507009873554805 * np.where(x > 0, x, 1.6732632423543772 * (np.exp(x) - 1))
+    elif name == 'softplus':
+        y = np.log1p(np.exp(x))
+    elif name == 'softsign':
+        y = x / (1 + np.abs(x))
+    elif name == 'swish':
+        y = x / (1 + np.exp(-x))
+    elif name == 'gelu':
+        y = 0.5 * x * (1 + np.vectorize(erf)(x / np.sqrt(2.0)))
+    elif name == 'hard_sigmoid':
+        y = np.clip(0.2 * x + 0.5, 0, 1)
+    elif name == 'exponential':
+        y = np.exp(x)
+    elif name == 'elu':
+        y = np.where(x > 0, x, (1.0 if alpha is None else alpha) * (np.exp(x) - 1))
+    else:
+        raise NotImplementedError(name)
+    return y.astype(np.float32)

@@ -269,3 +269,156 @@ def test_clean_up_and_counts_for_every_batch_remainder(gpu, n_img):
         assert (cnt[i], px[i]) == tuple(postproc.count_cc(labs[i] == 3)), i
     one = gpu.overlay(labs[-1], synth.dapi_image(500 + n_img - 1, H, W, rgb=True), 85)
     assert np.array_equal(np.asarray(one).reshape(-1), np.asarray(rows[-1]).reshape(-1))
+
+
+# ---- round 5: the wider Keras vocabulary ---------------------------------------------------------
+def _F(layers, ins, outs, name='m'):
+    return {'class_name': 'Functional', 'config': {'name': name, 'layers': layers, 'input_layers': [[i, 0, 0] for i in ins],
+                                                   'output_layers': [[o, 0, 0] for o in outs]}}
+
+
+def _check(gpu, cfg, weights, x, tol=1e-3, output=0, **okw):
+    want = oracle_unet.forward(cfg, weights, x, output=output, **okw)
+    scale = max(1.0, float(np.abs(want).max()))
+    for fuse in (True, False):
+        gpu.load_plan(keras_plan.build_plan(cfg, weights, fuse=fuse, output=output))
+        got = gpu.forward_patches(x)
+        assert got.shape == want.shape, (got.shape, want.shape)
+        err = float(np.abs(got - want).max()) / scale
+        assert np.isfinite(got).all() and err < tol, (fuse, err)
+    return want
+
+
+def _he(rng, *s):
+    return (rng.normal(size=s) / np.sqrt(np.prod(s[:-1]))).astype(np.float32)
+
+
+@pytest.mark.parametrize('case', [
+    # (H, W, cin, cout, k, stride, dilation, padding): the tap-by-tap MFMA kernel (dilated taps, 5x5 / 7x7 / 1x3 taps, stride 3)
+    (32, 48, 16, 32, 3, 1, 2, 'same'), (24, 24, 8, 16, 3, 1, 3, 'same'), (40, 40, 64, 64, 3, 1, 6, 'same'), (33, 20, 32, 128, 3, 1, 2, 'valid'),
+    (32, 32, 12, 24, 3, 1, 4, 'same'), (32, 32, 36, 40, 5, 1, 1, 'same'), (64, 64, 16, 32, 7, 2, 1, 'same'), (32, 32, 16, 16, 3, 3, 1, 'valid'),
+    (16, 16, 256, 96, 3, 1, 12, 'same'), (32, 32, 6, 10, 3, 1, 2, 'same'), (32, 32, 16, 4, 3, 1, 2, 'same'), (32, 32, 1, 8, 3, 1, 2, 'same')])
+def test_dilated_and_odd_tap_convolutions(gpu, case):
+    H, W, cin, cout, k, st, dil, pad = case
+    rng = np.random.default_rng(hash(case) % 2 ** 31)
+    layers = [_L('InputLayer', 'in', [], batch_input_shape=[None, H, W, cin]),
+              _L('Conv2D', 'c', ['in'], filters=cout, kernel_size=[k, k], strides=[st, st], dilation_rate=[dil, dil], padding=pad,
+                 activation='relu', use_bias=True),
+              _L('Conv2D', 'c13', ['c'], filters=16, kernel_size=[1, 3], strides=[1, 1], padding='same', activation='linear', use_bias=True)]
+    w = {'c': [_he(rng, k, k, cin, cout), _he(rng, cout)], 'c13': [_he(rng, 1, 3, cout, 16), _he(rng, 16)]}
+    x = rng.normal(size=(3, H, W, cin)).astype(np.float32)
+    _check(gpu, _F(layers, ['in'], ['c13']), w, x)
+
+
+@pytest.mark.parametrize('case', [
+    # (H, W, c, k, stride, dilation, multiplier, padding)
+    (32, 32, 32, 3, 1, 1, 1, 'same'), (33, 47, 64, 3, 2, 1, 1, 'same'), (24, 24, 24, 5, 1, 1, 1, 'same'), (20, 28, 96, 3, 1, 2, 1, 'same'),
+    (16, 16, 6, 3, 1, 1, 1, 'same'), (16, 16, 8, 3, 1, 1, 2, 'valid'), (40, 40, 128, 7, 2, 1, 1, 'same'), (32, 32, 16, 3, 1, 6, 1, 'same'),
+    (9, 9, 4, 3, 1, 1, 3, 'same')])
+def test_depthwise_separable_and_grouped_convolutions(gpu, case):
+    H, W, c, k, st, dil, m, pad = case
+    rng = np.random.default_rng(hash(case) % 2 ** 31)
+    if dil > 1:
+        st = 1
+    layers = [_L('InputLayer', 'in', [], batch_input_shape=[None, H, W, c]),
+              _L('DepthwiseConv2D', 'dw', ['in'], kernel_size=[k, k], strides=[st, st], dilation_rate=[dil, dil], depth_multiplier=m, padding=pad,
+                 activation='linear', use_bias=False),
+              _L('BatchNormalization', 'bn', ['dw'], axis=[3], epsilon=1e-3, center=True, scale=True),
+              _L('ReLU', 'r6', ['bn'], max_value=6.0, negative_slope=0.0, threshold=0.0),
+              _L('SeparableConv2D', 'sep', ['r6'], filters=16, kernel_size=[3, 3], strides=[1, 1], dilation_rate=[1, 1], depth_multiplier=1,
+                 padding='same', activation='relu', use_bias=True),
+              _L('Conv2D', 'grp', ['sep'], filters=24, kernel_size=[3, 3], strides=[1, 1], padding='same', groups=4, activation='tanh', use_bias=True),
+              _L('Conv2D', 'dwg', ['grp'], filters=48, kernel_size=[3, 3], strides=[1, 1], padding='same', groups=24, activation='linear', use_bias=True)]
+    cm = c * m
+    w = {'dw': [_he(rng, k, k, c, m) * np.float32(np.sqrt(c))],
+         'bn': [rng.uniform(.5, 1.5, cm).astype(np.float32), _he(rng, cm), _he(rng, cm), rng.uniform(.5, 1.5, cm).astype(np.float32)],
+         'sep': [_he(rng, 3, 3, cm, 1) * np.float32(np.sqrt(cm)), _he(rng, 1, 1, cm, 16), _he(rng, 16)],
+         'grp': [_he(rng, 3, 3, 4, 24), _he(rng, 24)], 'dwg': [_he(rng, 3, 3, 1, 48), _he(rng, 48)]}
+    x = rng.normal(size=(2, H, W, c)).astype(np.float32)
+    _check(gpu, _F(layers, ['in'], ['dwg']), w, x)
+
+
+def test_keras_layer_vocabulary_round5(gpu):
+    """Multiply / Subtract / Maximum / Minimum / Average with broadcasting (the squeeze-and-excite gate), PReLU (per channel and per
+    element), Normalization, LayerNormalization, 'same' pooling, every activation name, ELU(alpha), ReLU(max_value), a nested
+    Functional and a nested Sequential sub-model, a model with two outputs - each against the oracle."""
+    rng = np.random.default_rng(55)
+    H, W, C = 24, 40, 16
+    conv = lambda name, src, f, k=3, act='relu', **kw: _L('Conv2D', name, [src], filters=f, kernel_size=[k, k], strides=[1, 1], padding='same',
+                                                          activation=act, use_bias=True, **kw)
+    x = rng.normal(size=(3, H, W, C)).astype(np.float32)
+    # --- squeeze-and-excite + the merge layers
+    layers = [_L('InputLayer', 'in', [], batch_input_shape=[None, H, W, C]),
+              conv('c1', 'in', 32),
+              _L('GlobalAveragePooling2D', 'gap', ['c1'], keepdims=True),
+              conv('se1', 'gap', 8, k=1), conv('se2', 'se1', 32, k=1, act='hard_sigmoid'),
+              _L('Multiply', 'mul', ['c1', 'se2']),
+              conv('att', 'c1', 1, k=1, act='sigmoid'),                     # (h, w, 1) spatial attention map
+              _L('Multiply', 'mul2', ['att', 'mul']),                       # the broadcast operand FIRST
+              _L('Subtract', 'sub', ['mul2', 'c1']),
+              _L('Maximum', 'mx', ['sub', 'mul', 'c1']),
+              _L('Minimum', 'mn', ['mx', 'se2']),
+              _L('Average', 'avg', ['mn', 'mul2', 'c1']),
+              _L('Add', 'addb', ['avg', 'se2'])]
+    w = {'c1': [_he(rng, 3, 3, C, 32), _he(rng, 32)], 'se1': [_he(rng, 1, 1, 32, 8), _he(rng, 8)], 'se2': [_he(rng, 1, 1, 8, 32), _he(rng, 32)],
+         'att': [_he(rng, 1, 1, 32, 1), _he(rng, 1)]}
+    _check(gpu, _F(layers, ['in'], ['addb']), w, x)
+    # --- PReLU x2, Normalization, LayerNormalization (8 / 32 / 96 channels: 4, 16 and 64 lanes per pixel), 'same' pooling
+    for cc in (8, 32, 96):
+        layers = [_L('InputLayer', 'in', [], batch_input_shape=[None, H, W, C]),
+                  _L('Normalization', 'norm', ['in'], axis=[-1], mean=None, variance=None),
+                  conv('c1', 'norm', cc, act='linear'),
+                  _L('PReLU', 'p1', ['c1'], shared_axes=[1, 2]),
+                  _L('LayerNormalization', 'ln', ['p1'], axis=[3], epsilon=1e-3, center=True, scale=True),
+                  _L('MaxPooling2D', 'mp', ['ln'], pool_size=[3, 3], strides=[2, 2], padding='same'),
+                  _L('PReLU', 'p2', ['mp'], shared_axes=None),
+                  _L('AveragePooling2D', 'ap', ['p2'], pool_size=[2, 2], strides=[1, 1], padding='same'),
+                  _L('LayerNormalization', 'ln2', ['ap'], axis=-1, epsilon=1e-5, center=False, scale=False)]
+        w = {'norm': [rng.normal(size=C).astype(np.float32), rng.uniform(.5, 2, C).astype(np.float32), np.array(5, np.int64)],
+             'c1': [_he(rng, 3, 3, C, cc), _he(rng, cc)], 'p1': [rng.uniform(-.3, .3, (1, 1, cc)).astype(np.float32)],
+             'ln': [rng.uniform(.5, 1.5, cc).astype(np.float32), _he(rng, cc)], 'p2': [rng.uniform(-.3, .3, (12, 20, cc)).astype(np.float32)]}
+        _check(gpu, _F(layers, ['in'], ['ln2']), w, x)
+    # --- activations: as a convolution's own activation (fused or split off by the plan) and as layers
+    for name in ('relu6', 'selu', 'softplus', 'softsign', 'swish', 'gelu', 'hard_sigmoid', 'exponential', 'elu', 'tanh', 'sigmoid'):
+        layers = [_L('InputLayer', 'in', [], batch_input_shape=[None, H, W, C]),
+                  conv('c1', 'in', 32, act=name), conv('c2', 'c1', 16, act='linear'), _L('Activation', 'a', ['c2'], activation=name),
+                  _L('DepthwiseConv2D', 'dw', ['a'], kernel_size=[3, 3], strides=[1, 1], depth_multiplier=1, padding='same', activation=name, use_bias=True),
+                  _L('ELU', 'elu', ['dw'], alpha=0.6), _L('ReLU', 'clip', ['elu'], max_value=2.5, negative_slope=0.0, threshold=0.0)]
+        w = {'c1': [_he(rng, 3, 3, C, 32), _he(rng, 32)], 'c2': [_he(rng, 3, 3, 32, 16), _he(rng, 16)], 'dw': [_he(rng, 3, 3, 16, 1) * 4, _he(rng, 16)]}
+        _check(gpu, _F(layers, ['in'], ['clip']), w, x)
+    # --- nested Functional (with a skip connection) + nested Sequential + two outputs
+    bn = lambda name, src: _L('BatchNormalization', name, [src], axis=[3], epsilon=1e-3, center=True, scale=True)
+    inner = _F([_L('InputLayer', 'bin', [], batch_input_shape=[None, H, W, C]), conv('b1', 'bin', 32), bn('bbn', 'b1'), conv('b2', 'bbn', C),
+                _L('Add', 'badd', ['b2', 'bin'])], ['bin'], ['badd'], name='backbone')
+    seq = {'class_name': 'Sequential', 'name': 'headseq',
+           'config': {'name': 'headseq', 'layers': [_L('Conv2D', 's1', [], filters=8, kernel_size=[1, 1], strides=[1, 1], padding='same',
+                                                       activation='linear', use_bias=True, batch_input_shape=[None, H, W, C]),
+                                                    _L('Softmax', 's2', [], axis=-1)]}}
+    outer = _F([_L('InputLayer', 'in', [], batch_input_shape=[None, H, W, C]), dict(inner, name='backbone', inbound_nodes=[[['in', 0, 0, {}]]]),
+                dict(seq, inbound_nodes=[[['backbone', 0, 0, {}]]]), _L('GlobalMaxPooling2D', 'gmp', ['backbone'])], ['in'], ['headseq', 'gmp'])
+    wi = {'b1': [_he(rng, 3, 3, C, 32), _he(rng, 32)],
+          'bbn': [rng.uniform(.5, 1.5, 32).astype(np.float32), _he(rng, 32), _he(rng, 32), rng.uniform(.5, 1.5, 32).astype(np.float32)],
+          'b2': [_he(rng, 3, 3, 32, C), _he(rng, C)]}
+    w = {'backbone': wi, 'headseq': {'s1': [_he(rng, 1, 1, C, 8), _he(rng, 8)]}}
+    a = _check(gpu, outer, w, x, output=0)
+    b = _check(gpu, outer, w, x, output='gmp')
+    assert a.shape == (3, H, W, 8) and b.shape == (3, C)
+
+
+def test_mobilenet_style_fixture_matches_oracle(gpu, golden_dir):
+    """The h5py-written MobileNet-style classifier (tests/golden/mobilenet_synth.h5: nested backbone, depthwise + squeeze-and-excite
+    Multiply + dilated + grouped + separable convolutions, PReLU, LayerNormalization) loads through hdf5_min - no h5py here - and
+    its class probabilities match the oracle; the interSeg decision logic (src/interseg.py:153-190) runs on it."""
+    import json
+    from ecseg_amd import hdf5_min, interseg
+    from ecseg_amd.model import MetasegModel
+    path = os.path.join(golden_dir, 'mobilenet_synth.h5')
+    cfg_txt, weights = hdf5_min.load_keras_h5(path)
+    rng = np.random.default_rng(8)
+    x = rng.integers(0, 256, size=(5, 96, 96, 3), dtype=np.uint8)
+    want = oracle_unet.forward(json.loads(cfg_txt), weights, x)
+    m = MetasegModel.from_h5(path, handle=gpu)
+    got = m.predict(x)
+    assert got.shape == want.shape == (5, 3)
+    assert np.abs(got - want).max() < 1e-3 and np.abs(got.sum(1) - 1).max() < 1e-5
+    assert [int(np.argmax(r)) for r in got] == [int(np.argmax(r)) for r in want]

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), 'libecseg_hip.so does not export %s' % name
     assert declared == set(EXPORTS)
-    assert lib.ecseg_abi_version() == 3
+    assert lib.ecseg_abi_version() == 4
 
 
 def test_missing_gpu_fails_loudly():
@@ -118,7 +118,7 @@ def test_plan_rejects_what_it_cannot_lower():
     cfg = synth.unet_config(base=16, depth=1)
     w = synth.unet_weights(cfg)
     bad = json.loads(json.dumps(cfg))
-    bad['config']['layers'][1]['class_name'] = 'SeparableConv2D'
+    bad['config']['layers'][1]['class_name'] = 'ConvLSTM2D'
     with pytest.raises(keras_plan.PlanError):
         keras_plan.build_plan(bad, w)
     bad = json.loads(json.dumps(cfg))
@@ -126,9 +126,68 @@ def test_plan_rejects_what_it_cannot_lower():
     with pytest.raises(keras_plan.PlanError):
         keras_plan.build_plan(bad, w)
     bad = json.loads(json.dumps(cfg))
-    bad['config']['layers'][1]['config']['dilation_rate'] = [2, 2]
+    bad['config']['layers'][1]['config']['dilation_rate'] = [2, 3]        # (isotropic dilation rates are lowered since r05)
     with pytest.raises(keras_plan.PlanError):
         keras_plan.build_plan(bad, w)
+    bad = json.loads(json.dumps(cfg))
+    bad['config']['layers'][1]['config']['groups'] = 3                    # 3 groups do not divide 1 -> 16 channels
+    with pytest.raises(keras_plan.PlanError):
+        keras_plan.build_plan(bad, w)
+    with pytest.raises(keras_plan.PlanError):
+        keras_plan.build_plan(cfg, w, output=1)                           # the model has one output
+
+
+def test_plan_lowers_round5_vocabulary(golden_dir):
+    """dilation_rate, groups, DepthwiseConv2D / SeparableConv2D, Multiply, PReLU, Normalization,
+    LayerNormalization, nested sub-models and several outputs lower to a plan (they ended in PlanError before); the h5py-written
+    MobileNet-style fixture (nested backbone whose group mixes the variables of all its layers, trainable ones first) loads
+    through hdf5_min into the same plan as its in-memory definition."""
+    from ecseg_amd import keras_plan as kp
+    cfg_txt, w = hdf5_min.load_keras_h5(os.path.join(golden_dir, 'mobilenet_synth.h5'))
+    assert isinstance(w['backbone'], kp.NamedWeights) and w['backbone'].names[0] == 'stem/kernel:0'
+    assert w['backbone'].names[-1].endswith('moving_variance:0')            # the frozen statistics come last
+    plan = kp.build_plan(cfg_txt, w)
+    cfg0, w0 = synth.mobilenet_classifier(31)
+    plan0 = kp.build_plan(cfg0, w0)
+    assert plan.ops == plan0.ops and all(np.array_equal(a, b) for a, b in zip(plan.weights, plan0.weights))
+    ops = [o['op'] for o in plan.ops]
+    assert kp.OP_DWCONV in ops and kp.OP_PRELU in ops and kp.OP_LAYERNORM in ops and plan.output_rank == 2
+    assert any(o['op'] == kp.OP_ADD and o['mode'] == 1 for o in plan.ops)                     # the squeeze-and-excite Multiply
+    assert any(o['op'] == kp.OP_CONV and o['dilation'] == 2 for o in plan.ops)                # the dilated 3x3
+    assert any(o['op'] == kp.OP_MAXPOOL and o['pad_top'] == 0 and o['kh'] == 3 for o in plan.ops)   # 'same' 3x3 / 2 pooling of 24 rows: pad (0, 1)
+    assert 'backbone/b2_se_mul' in plan.layer_tensor and 'backbone' not in plan.layer_tensor  # inlined, prefixed names
+    # BatchNormalization folded into the depthwise kernels, ReLU6 fused: DWCONV carries bias + RELU_CLIP(6)
+    dws = [o for o in plan.ops if o['op'] == kp.OP_DWCONV]
+    assert dws[0]['act'] == kp.ACT['relu_clip'] and dws[0]['alpha'] == 6.0 and dws[0]['w1'] >= 0
+    # the grouped convolution: four CONV ops on 8-channel slices of one buffer, writing 8-channel slices of the output
+    grp = [o for o in plan.ops if o['op'] == kp.OP_CONV and plan.tensors[o['in0']]['c'] == 8 and o['kh'] == 3]
+    assert len(grp) == 4
+    assert sorted(plan.tensors[o['in0']]['c_offset'] for o in grp) == [0, 8, 16, 24]
+    assert sorted(plan.tensors[o['out']]['c_offset'] for o in grp) == [0, 8, 16, 24]
+    assert len({plan.tensors[o['out']]['buffer'] for o in grp}) == 1 and all(plan.tensors[o['out']]['c_stride'] == 32 for o in grp)
+    # the separable convolution's swish is not one of the convolution kernels' activations: linear conv + ACT pass
+    k = [i for i, o in enumerate(plan.ops) if o['op'] == kp.OP_ACT and o['act'] == kp.ACT['swish']]
+    assert len(k) == 1 and plan.ops[k[0] - 1]['op'] == kp.OP_CONV and plan.ops[k[0] - 1]['act'] == 0 and plan.ops[k[0]]['in0'] == plan.ops[k[0]]['out']
+    # several outputs: either can be the plan's
+    two = json.loads(json.dumps(cfg0))
+    two['config']['output_layers'].append(['gap', 0, 0])
+    assert kp.build_plan(two, w0).output_tensor == plan0.output_tensor
+    p1 = kp.build_plan(two, w0, output=1)
+    p1n = kp.build_plan(two, w0, output='gap')
+    assert p1.output_tensor == p1n.output_tensor == p1.layer_tensor['gap'] and p1.tensors[p1.output_tensor]['c'] == 32
+    # a top-level Sequential whose first layer is a nested model
+    seq = {'class_name': 'Sequential', 'config': {'name': 's', 'layers': [
+        dict(cfg0['config']['layers'][2], inbound_nodes=[]),
+        {'class_name': 'GlobalMaxPooling2D', 'config': {'name': 'gmp'}}]}}
+    ps = kp.build_plan(seq, {'backbone': w0['backbone']})
+    assert ps.output_rank == 2 and ps.tensors[ps.output_tensor]['c'] == 32
+    # Normalization from config statistics and from adapted weights give the same affine op
+    norm = lambda **c: {'class_name': 'Sequential', 'config': {'name': 'n', 'layers': [
+        {'class_name': 'Normalization', 'config': dict(c, name='norm', batch_input_shape=[None, 8, 8, 3])}]}}
+    pa = kp.build_plan(norm(axis=[-1], mean=[1.0, 2.0, 3.0], variance=[4.0, 9.0, 16.0]), {})
+    pb = kp.build_plan(norm(axis=[-1], mean=None, variance=None), {'norm': [np.array([1., 2., 3.], np.float32), np.array([4., 9., 16.], np.float32), np.array(7)]})
+    assert np.allclose(pa.weights[0], [0.5, 1 / 3, 0.25]) and np.allclose(pa.weights[1], [-0.5, -2 / 3, -0.75])
+    assert all(np.array_equal(a, b) for a, b in zip(pa.weights, pb.weights))
 
 
 def test_shard_bounds_and_records():

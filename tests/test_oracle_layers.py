@@ -244,3 +244,168 @@ def test_preprocess_ecseg_c_known_answer():
     assert np.allclose(y[..., 1], 1.0)
     assert np.allclose(y[..., 2], np.rint(np.array([[1, 2], [3, 4]]) / 4 * 255) / 255)
     assert y[0, 1, 0] == np.float32(64 / 255)                               # 63.75 -> 64
+
+
+# ---- round 5: the wider vocabulary (dilation, groups, depthwise / separable, broadcasting binary layers, PReLU,
+# ---- LayerNormalization, Normalization, 'same' pooling, activations, nested sub-models, several outputs) --------------
+def _L(cls, name, inbound, **cfg):
+    return {'class_name': cls, 'name': name, 'config': dict(cfg, name=name),
+            'inbound_nodes': [[[i, 0, 0, {}] for i in inbound]] if inbound else []}
+
+
+def _F(layers, ins, outs, name='m'):
+    return {'class_name': 'Functional', 'config': {'name': name, 'layers': layers, 'input_layers': [[i, 0, 0] for i in ins],
+                                                   'output_layers': [[o, 0, 0] for o in outs]}}
+
+
+def test_dilated_conv_known_answer():
+    """dilation_rate 2, 3x3, 'same' on a 5x5 ramp: the output centre sums the 9 taps two pixels apart; 'same' pads 2 per side."""
+    x = np.arange(25, dtype=np.float32).reshape(1, 5, 5, 1)
+    k = np.ones((3, 3, 1, 1), np.float32)
+    cfg = _model('Conv2D', (5, 5, 1), filters=1, kernel_size=[3, 3], strides=[1, 1], dilation_rate=[2, 2], padding='same',
+                 activation='linear', use_bias=False)
+    got = unet.forward(cfg, {'L': [k]}, x)[0, :, :, 0]
+    assert got.shape == (5, 5)
+    assert got[2, 2] == x[0, ::2, ::2, 0].sum()                 # taps at rows / columns 0, 2, 4
+    assert got[0, 0] == x[0, 0:3:2, 0:3:2, 0].sum()             # taps at -2 fall into the padding
+    assert np.array_equal(unet.conv_general_numpy(x, k, None, 'same', 1, 2)[0, :, :, 0], got)
+    cfgv = _model('Conv2D', (5, 5, 1), filters=1, kernel_size=[3, 3], strides=[1, 1], dilation_rate=[2, 2], padding='valid',
+                  activation='linear', use_bias=False)
+    assert unet.forward(cfgv, {'L': [k]}, x).shape == (1, 1, 1, 1)
+
+
+def test_grouped_and_depthwise_conv_known_answers():
+    """groups = 2 on 4 -> 2 channels, 1x1: output 0 sees input channels {0, 1}, output 1 sees {2, 3}.  DepthwiseConv2D with
+    depth multiplier 2: output channel ci * 2 + j = input channel ci times kernel[0, 0, ci, j]."""
+    x = np.array([1, 2, 3, 4], np.float32).reshape(1, 1, 1, 4)
+    k = np.array([[10, 1000], [100, 10000]], np.float32).reshape(1, 1, 2, 2)          # (kh, kw, cin / groups, filters)
+    cfg = _model('Conv2D', (1, 1, 4), filters=2, kernel_size=[1, 1], strides=[1, 1], groups=2, padding='valid', activation='linear',
+                 use_bias=False)
+    got = unet.forward(cfg, {'L': [k]}, x).reshape(-1)
+    assert got.tolist() == [1 * 10 + 2 * 100, 3 * 1000 + 4 * 10000]
+    assert np.array_equal(unet.conv_general_numpy(x, k, None, 'valid', 1, 1, 2).reshape(-1), got)
+    xd = np.array([1, 2], np.float32).reshape(1, 1, 1, 2)
+    kd = np.array([[3, 5], [7, 11]], np.float32).reshape(1, 1, 2, 2)                  # (kh, kw, cin, multiplier)
+    cfgd = _model('DepthwiseConv2D', (1, 1, 2), kernel_size=[1, 1], strides=[1, 1], depth_multiplier=2, padding='same',
+                  activation='linear', use_bias=True)
+    gotd = unet.forward(cfgd, {'L': [kd, np.array([.5, .5, .5, .5], np.float32)]}, xd).reshape(-1)
+    assert gotd.tolist() == [3.5, 5.5, 14.5, 22.5]
+    assert np.array_equal(unet.depthwise_numpy(xd, kd, [.5] * 4).reshape(-1), gotd)
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_round5_numpy_restatements_match_torch_path(seed):
+    rng = np.random.default_rng(seed)
+    x = rng.normal(size=(2, 9, 11, 8)).astype(np.float32)
+    # dilated / grouped / strided Conv2D
+    for (k, s, d, g, pad) in [(3, 1, 2, 1, 'same'), (3, 1, 3, 2, 'valid'), (5, 2, 1, 4, 'same'), (1, 1, 1, 8, 'same'), (2, 1, 2, 1, 'same')]:
+        ker = rng.normal(size=(k, k, 8 // g, 16)).astype(np.float32)
+        b = rng.normal(size=16).astype(np.float32)
+        cfg = _model('Conv2D', (9, 11, 8), filters=16, kernel_size=[k, k], strides=[s, s], dilation_rate=[d, d], groups=g, padding=pad,
+                     activation='linear', use_bias=True)
+        got = unet.forward(cfg, {'L': [ker, b]}, x)
+        want = unet.conv_general_numpy(x, ker, b, pad, s, d, g)
+        assert got.shape == want.shape and np.abs(got - want).max() < 1e-4, (k, s, d, g, pad)
+    # DepthwiseConv2D / SeparableConv2D
+    for (k, s, d, m, pad) in [(3, 1, 1, 1, 'same'), (3, 2, 1, 1, 'same'), (5, 1, 1, 2, 'valid'), (3, 1, 2, 1, 'same')]:
+        dk = rng.normal(size=(k, k, 8, m)).astype(np.float32)
+        b = rng.normal(size=8 * m).astype(np.float32)
+        cfg = _model('DepthwiseConv2D', (9, 11, 8), kernel_size=[k, k], strides=[s, s], dilation_rate=[d, d], depth_multiplier=m,
+                     padding=pad, activation='linear', use_bias=True)
+        got = unet.forward(cfg, {'L': [dk, b]}, x)
+        want = unet.depthwise_numpy(x, dk, b, pad, s, d)
+        assert got.shape == want.shape and np.abs(got - want).max() < 1e-4
+        pk = rng.normal(size=(1, 1, 8 * m, 5)).astype(np.float32)
+        pb = rng.normal(size=5).astype(np.float32)
+        cfgs = _model('SeparableConv2D', (9, 11, 8), filters=5, kernel_size=[k, k], strides=[s, s], dilation_rate=[d, d],
+                      depth_multiplier=m, padding=pad, activation='relu', use_bias=True)
+        gots = unet.forward(cfgs, {'L': [dk, pk, pb]}, x)
+        wants = np.maximum(unet.conv_numpy(unet.depthwise_numpy(x, dk, None, pad, s, d), pk, pb, 'valid'), 0)
+        assert np.abs(gots - wants).max() < 1e-4
+    # 'same' pooling
+    for (k, s) in [(2, 2), (3, 2), (3, 1)]:
+        for cls, avg in (('MaxPooling2D', False), ('AveragePooling2D', True)):
+            cfg = _model(cls, (9, 11, 8), pool_size=[k, k], strides=[s, s], padding='same')
+            got = unet.forward(cfg, {}, x)
+            assert np.abs(got - unet.pool_same_numpy(x, k, s, avg)).max() < 1e-6, (cls, k, s)
+    # LayerNormalization / PReLU / Normalization
+    g, b = rng.uniform(.5, 1.5, 8).astype(np.float32), rng.normal(size=8).astype(np.float32)
+    cfg = _model('LayerNormalization', (9, 11, 8), axis=[3], epsilon=1e-3, center=True, scale=True)
+    assert np.abs(unet.forward(cfg, {'L': [g, b]}, x) - unet.layernorm_numpy(x, g, b)).max() < 1e-5
+    cfg = _model('LayerNormalization', (9, 11, 8), axis=-1, epsilon=1e-5, center=False, scale=True)
+    assert np.abs(unet.forward(cfg, {'L': [g]}, x) - unet.layernorm_numpy(x, g, None, 1e-5)).max() < 1e-5
+    for shared, shp in (([1, 2], (1, 1, 8)), (None, (9, 11, 8)), ([1], (1, 11, 8))):
+        al = rng.uniform(-.5, .5, shp).astype(np.float32)
+        cfg = _model('PReLU', (9, 11, 8), shared_axes=shared)
+        assert np.array_equal(unet.forward(cfg, {'L': [al]}, x), unet.prelu_numpy(x, al))
+    mean, var = rng.normal(size=8).astype(np.float32), rng.uniform(.5, 2, 8).astype(np.float32)
+    cfg = _model('Normalization', (9, 11, 8), axis=[-1], mean=None, variance=None)
+    got = unet.forward(cfg, {'L': [mean, var, np.array(0, np.int64)]}, x)
+    assert np.abs(got - (x - mean) / np.sqrt(var)).max() < 1e-5
+    # activations
+    for name in ('relu6', 'selu', 'softplus', 'softsign', 'swish', 'gelu', 'hard_sigmoid', 'exponential', 'elu'):
+        cfg = _model('Activation', (9, 11, 8), activation=name)
+        assert np.abs(unet.forward(cfg, {}, 3 * x) - unet.activation_numpy(name, 3 * x)).max() < 2e-5, name
+    cfg = _model('ReLU', (9, 11, 8), max_value=6.0, negative_slope=0.0, threshold=0.0)
+    assert np.array_equal(unet.forward(cfg, {}, 4 * x), np.clip(4 * x, 0, 6))
+    cfg = _model('ELU', (9, 11, 8), alpha=0.7)
+    assert np.abs(unet.forward(cfg, {}, x) - unet.activation_numpy('elu', x, 0.7)).max() < 1e-6
+
+
+def test_binary_layers_broadcast_like_numpy():
+    """Multiply of (h, w, c) by (1, 1, c) - the squeeze-and-excite gate - and by (h, w, 1) - a spatial attention map - and the
+    other merge layers, against numpy broadcasting on the NHWC arrays."""
+    rng = np.random.default_rng(5)
+    a = rng.normal(size=(2, 6, 7, 8)).astype(np.float32)
+    for shape_b in ((1, 1, 8), (6, 7, 1), (6, 7, 8)):
+        b = rng.normal(size=(2,) + shape_b).astype(np.float32)
+        for cls, fn in (('Multiply', np.multiply), ('Add', np.add), ('Subtract', np.subtract), ('Maximum', np.maximum),
+                        ('Minimum', np.minimum), ('Average', lambda p, q: (p + q) / 2)):
+            layers = [_L('InputLayer', 'a', [], batch_input_shape=[None, 6, 7, 8]),
+                      _L('InputLayer', 'b', [], batch_input_shape=[None] + list(shape_b)), _L(cls, 'm', ['a', 'b'])]
+            cfg = _F(layers, ['a', 'b'], ['m'])
+            ta = [__import__('torch').from_numpy(np.ascontiguousarray(v.transpose(0, 3, 1, 2))) for v in (a, b)]
+            got = unet.forward(cfg, {}, ta)
+            assert np.abs(got - fn(a, b)).max() < 1e-6, (cls, shape_b)
+
+
+def test_nested_submodel_and_second_output():
+    """A Functional model that calls a nested Functional sub-model (with its own skip connection) and a nested Sequential one,
+    with two outputs: the recursive evaluation equals the same layers written flat, for both weight forms (a dict per inner
+    layer, and the flat HDF5 list with weight names - trainable variables first, as Keras saves a nested model)."""
+    rng = np.random.default_rng(9)
+    k = lambda *s: (rng.normal(size=s) / np.sqrt(np.prod(s[:-1]))).astype(np.float32)
+    conv = lambda name, src, f, **kw: _L('Conv2D', name, [src], filters=f, kernel_size=[3, 3], strides=[1, 1], padding='same',
+                                         activation='relu', use_bias=True, **kw)
+    bn = lambda name, src: _L('BatchNormalization', name, [src], axis=[3], epsilon=1e-3, center=True, scale=True)
+    inner = _F([_L('InputLayer', 'bin', [], batch_input_shape=[None, 8, 8, 4]), conv('b1', 'bin', 8), bn('bbn', 'b1'),
+                conv('b2', 'bbn', 4), _L('Add', 'badd', ['b2', 'bin'])], ['bin'], ['badd'], name='backbone')
+    seq = {'class_name': 'Sequential', 'name': 'headseq',
+           'config': {'name': 'headseq', 'layers': [_L('Conv2D', 's1', [], filters=6, kernel_size=[1, 1], strides=[1, 1], padding='same',
+                                                       activation='linear', use_bias=True, batch_input_shape=[None, 8, 8, 4]),
+                                                    _L('Activation', 's2', [], activation='tanh')]}}
+    outer = _F([_L('InputLayer', 'in', [], batch_input_shape=[None, 8, 8, 4]),
+                dict(inner, name='backbone', inbound_nodes=[[['in', 0, 0, {}]]]),
+                dict(seq, inbound_nodes=[[['backbone', 0, 0, {}]]]),
+                _L('GlobalAveragePooling2D', 'gap', ['backbone'])], ['in'], ['headseq', 'gap'])
+    wi = {'b1': [k(3, 3, 4, 8), k(8)], 'bbn': [rng.uniform(.5, 1.5, 8).astype(np.float32), k(8), k(8), rng.uniform(.5, 1.5, 8).astype(np.float32)],
+          'b2': [k(3, 3, 8, 4), k(4)]}
+    ws = {'s1': [k(1, 1, 4, 6), k(6)]}
+    x = rng.normal(size=(2, 8, 8, 4)).astype(np.float32)
+    flat = _F([_L('InputLayer', 'in', [], batch_input_shape=[None, 8, 8, 4]), conv('b1', 'in', 8), bn('bbn', 'b1'), conv('b2', 'bbn', 4),
+               _L('Add', 'badd', ['b2', 'in']),
+               _L('Conv2D', 's1', ['badd'], filters=6, kernel_size=[1, 1], strides=[1, 1], padding='same', activation='tanh', use_bias=True),
+               _L('GlobalAveragePooling2D', 'gap', ['badd'])], ['in'], ['s1', 'gap'])
+    want0 = unet.forward(flat, dict(wi, **ws), x, output=0)
+    want1 = unet.forward(flat, dict(wi, **ws), x, output='gap')
+    got0 = unet.forward(outer, {'backbone': wi, 'headseq': ws}, x)
+    got1 = unet.forward(outer, {'backbone': wi, 'headseq': ws}, x, output=1)
+    assert got0.shape == (2, 8, 8, 6) and got1.shape == (2, 4)
+    assert np.array_equal(got0, want0) and np.array_equal(got1, want1)
+    # the HDF5 form: trainable variables of all inner layers first, then the moving statistics
+    class Named(list):
+        pass
+    nw = Named([wi['b1'][0], wi['b1'][1], wi['bbn'][0], wi['bbn'][1], wi['b2'][0], wi['b2'][1], wi['bbn'][2], wi['bbn'][3]])
+    nw.names = ['b1/kernel:0', 'b1/bias:0', 'bbn/gamma:0', 'bbn/beta:0', 'b2/kernel:0', 'b2/bias:0', 'bbn/moving_mean:0', 'bbn/moving_variance:0']
+    sw = Named(ws['s1']); sw.names = ['headseq/s1/kernel:0', 'headseq/s1/bias:0']
+    assert np.array_equal(unet.forward(outer, {'backbone': nw, 'headseq': sw}, x), want0)

@@ -504,6 +504,51 @@ def gen_metaseg_h5():
         write_keras_h5(os.path.join(OUT, '%s_synth.h5' % kind), cfg, synth.classifier_weights(cfg, seed=seed))
 
 
+def gen_mobilenet_h5():
+    """``mobilenet_synth.h5``: the MobileNet-style classifier of ecseg_amd/synth.py:mobilenet_classifier written the way
+    Keras 2.8 saves a model that uses a NESTED sub-model as one layer: the sub-model's group holds the variables of all its
+    layers under ``<inner layer>/<variable>:0`` and its ``weight_names`` lists the trainable ones first, then the moving
+    statistics of the BatchNormalization layers (``layer.trainable_weights + layer.non_trainable_weights``)."""
+    import h5py
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    from ecseg_amd import synth
+    cfg, weights = synth.mobilenet_classifier(seed=31)
+    var_names = {'BatchNormalization': ['gamma:0', 'beta:0', 'moving_mean:0', 'moving_variance:0'], 'PReLU': ['alpha:0'],
+                 'DepthwiseConv2D': ['depthwise_kernel:0', 'bias:0'], 'SeparableConv2D': ['depthwise_kernel:0', 'pointwise_kernel:0', 'bias:0'],
+                 'LayerNormalization': ['gamma:0', 'beta:0']}
+    path = os.path.join(OUT, 'mobilenet_synth.h5')
+    with h5py.File(path, 'w') as f:
+        f.attrs['keras_version'] = '2.8.0'
+        f.attrs['backend'] = 'tensorflow'
+        f.attrs['model_config'] = json.dumps(cfg)
+        g = f.create_group('model_weights')
+        layers = cfg['config']['layers']
+        g.attrs['layer_names'] = np.array([l['config']['name'].encode() for l in layers])
+        g.attrs['backend'] = 'tensorflow'; g.attrs['keras_version'] = '2.8.0'
+        for l in layers:
+            n = l['config']['name']
+            lg = g.create_group(n)
+            if l['class_name'] == 'Functional':
+                train, frozen = [], []
+                for il in l['config']['layers']:
+                    iname = il['config']['name']
+                    ws = weights[n].get(iname, [])
+                    vn = var_names.get(il['class_name'], ['kernel:0', 'bias:0'])[:len(ws)]
+                    for k, (v, arr) in enumerate(zip(vn, ws)):
+                        (frozen if v.startswith('moving_') else train).append(('%s/%s' % (iname, v), arr))
+                allw = train + frozen
+                lg.attrs['weight_names'] = np.array([w[0].encode() for w in allw])
+                for wn, arr in allw:
+                    lg.create_dataset(wn, data=arr)
+                continue
+            ws = weights.get(n, [])
+            vn = var_names.get(l['class_name'], ['kernel:0', 'bias:0'])[:len(ws)]
+            lg.attrs['weight_names'] = np.array([('%s/%s' % (n, v)).encode() for v in vn]) if ws else np.zeros((0,), 'S1')
+            for v, arr in zip(vn, ws):
+                lg.create_dataset('%s/%s' % (n, v), data=arr)
+    print('mobilenet_synth.h5', os.path.getsize(path), 'bytes')
+
+
 def gen_io():
     """I/O-layer fixtures written / decoded by the libraries the reference itself uses: TIFF files written by tifffile
     (the decoder behind ``skimage.io.imread``, src/utils.py:110) in the variants microscopes and OpenCV produce, with the
@@ -619,10 +664,11 @@ def gen_otsu():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['tiling', 'quant', 'meta', 'counting', 'overlay', 'h5', 'metaseg_h5', 'io', 'otsu']
+    which = sys.argv[1:] or ['tiling', 'quant', 'meta', 'counting', 'overlay', 'h5', 'metaseg_h5', 'mobilenet_h5', 'io', 'otsu']
     if 'io' in which: gen_io()
     if 'otsu' in which: gen_otsu()
     if 'metaseg_h5' in which: gen_metaseg_h5()
+    if 'mobilenet_h5' in which: gen_mobilenet_h5()
     if 'tiling' in which: gen_tiling()
     if 'quant' in which: gen_quant()
     if 'meta' in which: gen_meta_inference()

@@ -281,6 +281,9 @@ int ecseg_tiff_read(const char* path, void* dst, long long dst_bytes);
  * (src/metaseg.py:44-57).  Record = ECSEG_RECORD_INT64 int64: [0] global image index (-1 = padding of the last shard)
  * [1] status (0 ok) [2] n_ec [3..14] the twelve fields of ecseg_overlay [15] reserved.  Shards are padded to equal length.
  * librccl.so is loaded on first use (no link-time dependency); ECSEG_E_UNSUPPORTED when it is not installed.
+ * Every wait is bounded: ecseg_comm_create and the synchronous all-gathers return ECSEG_E_HIP with a message when the peers do
+ * not answer within ECSEG_COMM_TIMEOUT_S seconds (environment variable, default 300) - the communicator is aborted and unusable
+ * afterwards (ecseg_comm_destroy it).
  * Rendezvous: rank 0 obtains ECSEG_COMM_ID_BYTES from ecseg_comm_unique_id and hands them to the other ranks by any channel
  * of the host's (file, environment, socket); then every rank calls ecseg_comm_create (collective).  One process per GPU. */
 #define ECSEG_RECORD_INT64  16

@@ -110,3 +110,31 @@ def test_native_transport_one_rank(tmp_path):
     finally:
         edist.native_close(path, 0)
     assert not os.path.exists(path) and edist._native is None
+
+
+def test_collective_is_bounded_when_a_peer_never_arrives(tmp_path):
+    """a library user binding ecseg_comm_create directly must not hang for ever when a peer is missing.  A
+    fresh child process creates rank 0 of a world-2 communicator on the one GPU with nobody playing rank 1 and
+    ECSEG_COMM_TIMEOUT_S=4: the call returns ECSEG_E_HIP with a message naming the timeout, well inside the test's own limit."""
+    import time
+    code = (
+        "import sys, time\n"
+        "sys.path.insert(0, %r)\n"
+        "from ecseg_amd._lib import Comm, EcsegError\n"
+        "uid = Comm.unique_id()\n"
+        "t0 = time.time()\n"
+        "try:\n"
+        "    Comm(uid, 0, 2, 0)\n"
+        "    print('CREATED')\n"
+        "except EcsegError as e:\n"
+        "    print('ERROR %%d %%.1f %%s' %% (e.code, time.time() - t0, e))\n"
+    ) % ROOT
+    t0 = time.time()
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, ECSEG_COMM_TIMEOUT_S='4'))
+    took = time.time() - t0
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith(('ERROR', 'CREATED'))][-1]
+    assert line.startswith('ERROR -2 '), line
+    assert 'ECSEG_COMM_TIMEOUT_S' in line and 'aborted' in line
+    assert 3.0 < float(line.split()[2]) < 30.0 and took < 90.0, (line, took)

@@ -119,12 +119,126 @@ def random_graph(rng, seed_kind=0, wide=False):
     return cfg, weights, shape['in']
 
 
+ACTS_R5 = ('relu', 'relu6', 'selu', 'softplus', 'softsign', 'swish', 'gelu', 'hard_sigmoid', 'elu', 'tanh', 'sigmoid', 'linear')
+
+
+def random_graph_r5(rng):
+    """-> (model_config, weights, input shape): a chain of random blocks from the round-5 vocabulary - dilated / grouped / odd-tap
+    convolutions, DepthwiseConv2D / SeparableConv2D, squeeze-and-excite Multiply, merge layers with broadcasting, PReLU,
+    LayerNormalization, Normalization, 'same' pooling, the new activation names - optionally wrapped into a nested sub-model and
+    given a second output."""
+    h = int(rng.choice((16, 24, 32, 40, 33))); w = int(rng.choice((16, 32, 48, 20, 37)))
+    c = int(rng.choice((4, 8, 16, 24, 32, 64)))
+    layers, weights, shape = [_L('InputLayer', 'in', [], batch_input_shape=[None, h, w, c])], {}, {'in': (h, w, c)}
+    he = lambda *s: (rng.normal(size=s) / np.sqrt(np.prod(s[:-1]))).astype(np.float32)
+
+    def add(cls, name, inb, out_shape, ws=None, **cfg):
+        layers.append(_L(cls, name, inb, **cfg))
+        shape[name] = out_shape
+        if ws is not None:
+            weights[name] = ws
+        return name
+
+    def out_hw(n, k, s, d, pad):
+        e = (k - 1) * d + 1
+        return -(-n // s) if pad == 'same' else (n - e) // s + 1
+
+    prev = 'in'
+    for b in range(int(rng.integers(3, 7))):
+        hh, ww, cc = shape[prev]
+        kind = str(rng.choice(('conv', 'conv', 'dw', 'sep', 'se', 'merge', 'prelu', 'ln', 'norm', 'pool', 'act')))
+        n = 'b%d' % b
+        if kind == 'conv':
+            k = int(rng.choice((1, 3, 3, 5, 2))); d = int(rng.choice((1, 1, 2, 3, 6))) if k > 1 else 1
+            s = 1 if d > 1 else int(rng.choice((1, 1, 2, 3)))
+            pad = str(rng.choice(('same', 'same', 'valid')))
+            if out_hw(hh, k, s, d, pad) < 4 or out_hw(ww, k, s, d, pad) < 4:
+                pad = 'same'
+            g = int(rng.choice([q for q in (1, 1, 1, 2, 4, cc) if cc % q == 0]))
+            f = int(rng.choice((8, 16, 24, 32, 64, 96)))
+            f = -(-f // g) * g
+            prev = add('Conv2D', n, [prev], (out_hw(hh, k, s, d, pad), out_hw(ww, k, s, d, pad), f), [he(k, k, cc // g, f), he(f)], filters=f,
+                       kernel_size=[k, k], strides=[s, s], dilation_rate=[d, d], groups=g, padding=pad, activation=str(rng.choice(ACTS_R5)), use_bias=True)
+        elif kind in ('dw', 'sep'):
+            k = int(rng.choice((3, 3, 5))); d = int(rng.choice((1, 1, 2))); s = 1 if d > 1 else int(rng.choice((1, 1, 2)))
+            m = int(rng.choice((1, 1, 1, 2)))
+            dk = he(k, k, cc, m) * np.float32(np.sqrt(cc))
+            if kind == 'dw':
+                prev = add('DepthwiseConv2D', n, [prev], (out_hw(hh, k, s, d, 'same'), out_hw(ww, k, s, d, 'same'), cc * m), [dk, he(cc * m)],
+                           kernel_size=[k, k], strides=[s, s], dilation_rate=[d, d], depth_multiplier=m, padding='same',
+                           activation=str(rng.choice(ACTS_R5)), use_bias=True)
+            else:
+                f = int(rng.choice((8, 16, 32, 40)))
+                prev = add('SeparableConv2D', n, [prev], (out_hw(hh, k, s, d, 'same'), out_hw(ww, k, s, d, 'same'), f),
+                           [dk, he(1, 1, cc * m, f), he(f)], filters=f, kernel_size=[k, k], strides=[s, s], dilation_rate=[d, d],
+                           depth_multiplier=m, padding='same', activation=str(rng.choice(ACTS_R5)), use_bias=True)
+        elif kind == 'se':
+            r = max(cc // 4, 1)
+            g = add('GlobalAveragePooling2D', n + '_gap', [prev], (1, 1, cc), keepdims=True)
+            a = add('Conv2D', n + '_r', [g], (1, 1, r), [he(1, 1, cc, r), he(r)], filters=r, kernel_size=[1, 1], strides=[1, 1], padding='same',
+                    activation='relu', use_bias=True)
+            e = add('Conv2D', n + '_e', [a], (1, 1, cc), [he(1, 1, r, cc), he(cc)], filters=cc, kernel_size=[1, 1], strides=[1, 1], padding='same',
+                    activation=str(rng.choice(('sigmoid', 'hard_sigmoid'))), use_bias=True)
+            prev = add('Multiply', n, [prev, e] if rng.random() < 0.5 else [e, prev], (hh, ww, cc))
+        elif kind == 'merge':
+            other = add('Conv2D', n + '_o', [prev], (hh, ww, 1 if rng.random() < 0.3 else cc), None, filters=1, kernel_size=[1, 1], strides=[1, 1],
+                        padding='same', activation='tanh', use_bias=True)
+            co = shape[other][2]
+            layers[-1]['config']['filters'] = co
+            weights[other] = [he(1, 1, cc, co), he(co)]
+            prev = add(str(rng.choice(('Add', 'Multiply', 'Subtract', 'Maximum', 'Minimum', 'Average'))), n, [prev, other], (hh, ww, cc))
+        elif kind == 'prelu':
+            shared = [None, [1, 2], [1, 2], [1], [2]][int(rng.integers(0, 5))]
+            shp = [1 if shared and (a + 1) in shared else v for a, v in enumerate((hh, ww, cc))]
+            prev = add('PReLU', n, [prev], (hh, ww, cc), [rng.uniform(-.4, .4, shp).astype(np.float32)], shared_axes=shared)
+        elif kind == 'ln':
+            ws, center, scale = [], bool(rng.random() < 0.8), bool(rng.random() < 0.8)
+            if scale:
+                ws.append(rng.uniform(.5, 1.5, cc).astype(np.float32))
+            if center:
+                ws.append(he(cc))
+            prev = add('LayerNormalization', n, [prev], (hh, ww, cc), ws, axis=[3], epsilon=float(rng.choice((1e-3, 1e-5))), center=center, scale=scale)
+        elif kind == 'norm':
+            prev = add('Normalization', n, [prev], (hh, ww, cc), [he(cc), rng.uniform(.5, 2, cc).astype(np.float32), np.array(3, np.int64)], axis=[-1],
+                       mean=None, variance=None)
+        elif kind == 'pool':
+            k = int(rng.choice((2, 3))); s = int(rng.choice((1, 2)))
+            if -(-hh // s) < 4 or -(-ww // s) < 4:
+                s = 1
+            prev = add(str(rng.choice(('MaxPooling2D', 'AveragePooling2D'))), n, [prev], (-(-hh // s), -(-ww // s), cc), pool_size=[k, k],
+                       strides=[s, s], padding='same')
+        else:
+            prev = add('Activation', n, [prev], (hh, ww, cc), activation=str(rng.choice(ACTS_R5)))
+    hh, ww, cc = shape[prev]
+    ncls = int(rng.choice((2, 3, 4)))
+    head = add('Conv2D', 'head', [prev], (hh, ww, ncls), [he(1, 1, cc, ncls) * 3, he(ncls)], filters=ncls, kernel_size=[1, 1], strides=[1, 1],
+               padding='same', activation=str(rng.choice(('softmax', 'sigmoid'))), use_bias=True)
+    outs = [[head, 0, 0]]
+    if rng.random() < 0.3:
+        add('GlobalMaxPooling2D', 'aux', [prev], (1, 1, cc))
+        outs.append(['aux', 0, 0])
+    cfg = {'class_name': 'Functional', 'config': {'name': 'fuzz5', 'layers': layers, 'input_layers': [['in', 0, 0]], 'output_layers': outs}}
+    if rng.random() < 0.35 and len(outs) == 1:
+        # the whole graph as a nested sub-model of an outer model that rescales its input and post-processes the output
+        inner = dict(cfg, name='sub')
+        inner['config'] = dict(cfg['config'], name='sub')
+        outer_layers = [_L('InputLayer', 'oin', [], batch_input_shape=[None, h, w, c]),
+                        _L('Rescaling', 'resc', ['oin'], scale=0.5, offset=0.1),
+                        dict(inner, inbound_nodes=[[['resc', 0, 0, {}]]]),
+                        _L('Activation', 'oact', ['sub'], activation='linear')]
+        cfg = {'class_name': 'Functional', 'config': {'name': 'outer', 'layers': outer_layers, 'input_layers': [['oin', 0, 0]],
+                                                     'output_layers': [['oact', 0, 0]]}}
+        weights = {'sub': weights}
+    return cfg, weights, (h, w, c)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--seconds', type=float, default=300)
     ap.add_argument('--seed0', type=int, default=0)
     ap.add_argument('--seeds', default=None)
     ap.add_argument('--wide', action='store_true', help='wider layers / larger extents')
+    ap.add_argument('--vocab', action='store_true', help='graphs from the round-5 vocabulary (random_graph_r5)')
     a = ap.parse_args()
     import torch  # noqa: F401
     from ecseg_amd.model import MetasegModel
@@ -140,13 +254,19 @@ def main():
                 break
             seed = todo.pop(0)
         rng = np.random.default_rng(5 * 10 ** 6 + seed)
-        cfg, weights, (h, w, cin) = random_graph(rng, seed_kind=1 if seed >= 10 ** 5 else 0, wide=a.wide)
+        if a.vocab:
+            cfg, weights, (h, w, cin) = random_graph_r5(rng)
+        else:
+            cfg, weights, (h, w, cin) = random_graph(rng, seed_kind=1 if seed >= 10 ** 5 else 0, wide=a.wide)
         n = int(rng.integers(1, 5))
         x = rng.integers(0, 256, size=(n, h, w, cin), dtype=np.uint8)
-        want = oracle_unet.forward(cfg, weights, x.astype(np.float32))
+        if a.vocab:
+            x = (x.astype(np.float32) - 128) / 64            # (these graphs carry no input scaling of their own)
+        out_sel = int(rng.integers(0, len(cfg['config']['output_layers'])))
+        want = oracle_unet.forward(cfg, weights, x.astype(np.float32), output=out_sel)
         scale = max(1.0, float(np.abs(want).max()))
         try:
-            m = MetasegModel(cfg, weights, device=0)
+            m = MetasegModel(cfg, weights, device=0, output=out_sel)
             for mode in (2, 1, 0):
                 m.handle.set_option('winograd', mode)
                 for fuse in (1, 0):
@@ -156,7 +276,9 @@ def main():
                     err = float(np.abs(got - want).max()) / scale
                     worst = max(worst, err)
                     if not np.isfinite(got).all() or err > 1e-3:
-                        desc = ' '.join('%s:%s' % (L['class_name'][:6], L['config'].get('filters', '')) for L in cfg['config']['layers'])
+                        ll = cfg['config']['layers']
+                        ll = next((L['config']['layers'] for L in ll if L['class_name'] == 'Functional'), ll)
+                        desc = ' '.join('%s:%s' % (L['class_name'][:6], L['config'].get('filters', '')) for L in ll)
                         print('FAIL seed %d mode %d fuse %d err %.3e  in %s x%d  %s' % (seed, mode, fuse, err, (h, w, cin), n, desc), flush=True)
                         fails += 1
             del m

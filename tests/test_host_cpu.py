@@ -245,6 +245,71 @@ def test_allgather_records_gloo_world2(n_images):
         assert nec == [1000 + i for i in range(n_images)]
 
 
+def _expected_fields(i):
+    """What image i's device results are in the configs[3] rehearsal: a deterministic function of the global index."""
+    return (i * 7919) % 20011, [(i * (k + 3) + k) % 9973 for k in range(12)], (3 if i % 997 == 5 else 0), (i * 31) % 1009
+
+
+def _worker_configs3(rank, world, port, sizes, folder, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), LOCAL_RANK=str(rank))
+    import torch
+    from ecseg_amd import metaseg
+    r, w = edist.init_process_group('gloo')
+    digest = []
+    for n_images in sizes:
+        a, b, per = edist.shard_bounds(n_images, r, w)
+        f = [_expected_fields(i) for i in range(a, b)]
+        rec = edist.make_records(a, b - a, per, n_ec=[x[0] for x in f], overlay=[x[1] for x in f], status=[x[2] for x in f],
+                                 tie_risk=[x[3] for x in f])
+        assert rec.shape == (per, edist.RECORD_INT64) and (rec[b - a:, edist.F_INDEX] == -1).all()
+        out = edist.compact_records(edist.allgather_records(torch.from_numpy(rec)))
+        paths = [os.path.join(folder, 'img%05d.tif' % i) for i in range(n_images)]
+        sub = os.path.join(folder, 'n%d' % n_images)
+        if r == 0:
+            os.makedirs(sub, exist_ok=True)
+        failed = metaseg.finish(sub, paths, out, r, log=lambda *a_: None)
+        digest.append((n_images, per, out.shape, bool((out[:, edist.F_INDEX] == np.arange(n_images)).all()),
+                       int(out[:, edist.F_NEC].sum()), int(out[:, edist.F_OVERLAY:edist.F_OVERLAY + 12].sum()), int(out[:, edist.F_TIE].sum()), len(failed)))
+        torch.distributed.barrier()
+    q.put((rank, digest))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_configs3_4096_records_over_8_gloo_ranks(tmp_path):
+    """BASELINE.json configs[3] on paper (no 8-GPU node has ever run it: VERDICT r04 item 8): 4096 images sharded over 8 ranks
+    as contiguous blocks of 512, one all-gather of the 128-byte records, every rank ends up with all 4096 rows in
+    sorted-path order and rank 0 writes ec_quantification.csv (src/metaseg.py:44-46,56-57) - through shard_bounds /
+    make_records / allgather_records / compact_records / metaseg.finish with the job's real sizes; and 4090 images, where the
+    last shard is padded (6 rows of index -1)."""
+    import torch.multiprocessing as mp
+    world, sizes = 8, (4096, 4090)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_configs3, args=(r, world, port, sizes, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [r for r, _ in res] == list(range(world))
+    for n_images in sizes:
+        exp = [_expected_fields(i) for i in range(n_images)]
+        want = (n_images, 512, (n_images, edist.RECORD_INT64), True, sum(x[0] for x in exp), sum(sum(x[1]) for x in exp),
+                sum(x[3] for x in exp), sum(1 for x in exp if x[2]))
+        for rank, digest in res:
+            got = [d for d in digest if d[0] == n_images][0]
+            assert tuple(got) == want, (rank, got, want)
+        text = open(os.path.join(str(tmp_path), 'n%d' % n_images, 'ec_quantification.csv')).read()
+        rows = text.strip().split('\n')
+        ok = [i for i in range(n_images) if not exp[i][2]]
+        assert rows[0] == 'image name,# of ec' and len(rows) == 1 + len(ok)      # (the reference's column name: src/metaseg.py:40)
+        assert rows[1:] == ['img%05d.tif,%d' % (i, exp[i][0]) for i in ok]
+    assert edist.shard_bounds(4096, 7, 8) == (3584, 4096, 512) and edist.shard_bounds(4090, 7, 8) == (3584, 4090, 512)
+
+
 @pytest.mark.parametrize('n_convs', [2, 3, 4, 5])
 def test_fusable_head_never_shares_a_buffer_with_the_fused_convs_input(n_convs):
     """the 1x1 head may be finished by the output stage of the 3x3 convolution in front of it; workgroups

@@ -860,7 +860,7 @@ int ensure_post(ecseg_ctx* h, int n_img, size_t px) {
     A(reinterpret_cast<void**>(&w.tmpA), tot);
     A(reinterpret_cast<void**>(&w.tmpB), tot);
     A(reinterpret_cast<void**>(&w.list), list_bytes);
-    A(reinterpret_cast<void**>(&w.g), (size_t)ni * G_STRIDE * G_SHARDS * 4);
+    A(reinterpret_cast<void**>(&w.g), (size_t)G_SLOTS * ni * G_STRIDE * G_SHARDS * 4);
     A(reinterpret_cast<void**>(&w.tile_any), (size_t)ni * (np / 16 + 2));
     // owner bits: 256 B per 64 x 32 tile; ceil(W/64) ceil(H/32) <= px/2048 + W/64 + H/32 + 1 <= px/31 + 3 tiles for any H x W = px
     A(reinterpret_cast<void**>(&w.own_bits), (size_t)ni * (np / 31 + 4) * 256);

@@ -150,7 +150,7 @@ struct PostWorkspace {
     uint8_t* tmpA;       // scratch label images
     uint8_t* tmpB;
     int32_t* list;       // per image: compacted root lists for the nucleus-in-metaphase test
-    int32_t* g;          // per image: small block of global counters (G_STRIDE ints)
+    int32_t* g;          // G_SLOTS x cap_img blocks of per-image counters (G_STRIDE ints x G_SHARDS replicas each)
     uint8_t* tile_any;   // per image and 64 x 32 labelling tile: the tile holds a keyed pixel (written by ccl_local)
     uint32_t* own_bits;  // per image and tile: 2048 bits, bit = the pixel is the root of a tile component ("owner"; ccl_local -> ccl_resolve)
     double* binned;      // per image and axis: the chromosome centroids' coordinates grouped by integer bin (nucleus test)
@@ -160,6 +160,7 @@ struct PostWorkspace {
     size_t cap_px;
 };
 enum { G_STRIDE = 32, G_SHARDS = 16 };
+enum { G_SLOTS = 6 };                  // counter blocks in PostWorkspace::g: one per labelling of run_meta_inference that produces counters (zeroed by ONE memset)
 enum { NUCLEUS_BIN_EXTENT = 32768 };   // largest image extent for which the nucleus test runs on binned coordinates (LDS histogram)
 
 // meta_inference on n_img uint8 label images, in place; n_ec receives count_cc(img==3)[0] per image

@@ -207,6 +207,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ECSEG_CCL_W
             return;
         }
     }
+    // Full-tile pre-pass (round 5), the mirror image for the background labellings of fill_holes (allow_full: binary keys,
+    // 4-connectivity, no statistics): most tiles of a realistic image hold no pixel of the class being filled at all - every
+    // pixel is keyed and the tile is ONE node.  Decided from one 8-byte load per thread; such a tile used to run the whole
+    // first pass (8 byte loads, DPP shifts, ballots and LDS writes per thread) before it found out.
+    if (allow_full && (g.W & 7) == 0 && cx * 64 + 64 <= g.W && yblk + CCL_BLOCK_ROWS <= g.H &&
+        (reinterpret_cast<uintptr_t>(img_all) & 7) == 0) {
+        const u64 w8 = *reinterpret_cast<const u64*>(img_all + base + (size_t)(y0 + (lane >> 3)) * g.W + cx * 64 + (lane & 7) * 8);
+        int unkeyed = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) unkeyed |= key_of((uint8_t)(w8 >> (8 * b)), lut) == 0;
+        if (!__syncthreads_or(unkeyed)) {
+            if (threadIdx.x == 0) {
+                tile_any[tile_index(g, img)] = 2;
+                const size_t p0 = base + (size_t)yblk * g.W + cx * 64;
+                L_all[p0] = yblk * g.W + cx * 64;
+                const bool edge = yblk == 0 || yblk + CCL_BLOCK_ROWS >= g.H || cx == 0 || cx * 64 + 64 >= g.W;
+                flag_all[p0] = (aux_mode == AUX_BORDER && edge) ? 1u : 0u;
+            }
+            return;
+        }
+    }
     const u64 upto = (2ull << lane) - 1ull;                // lanes <= this one
     // The keys of the wave's 8 rows stay in registers: the neighbours above come from the previous row's register through
     // DPP wave shifts (one VALU instruction each) instead of byte reads from an LDS copy of the tile.
@@ -603,26 +624,27 @@ __global__ __launch_bounds__(256) void count_roots_kernel(CclGeom g, const uint8
     int img, y0, cx;
     if (!decode_block(g, img, y0, cx)) return;
     const size_t ti = tile_index(g, img);
-    if (!tile_any[ti]) return;
     const int tid = threadIdx.x;
-    if (tid < 4) red[tid] = 0;
-    __syncthreads();
-    const size_t base = (size_t)img * g.H * g.W;
-    const int yblk = y0 - (tid >> 6) * CCL_ROWS;
-    uint32_t bits = (own_bits[ti * 64 + (tid >> 2)] >> ((tid & 3) * 8)) & 0xffu;      // thread = 8 consecutive pixels of the tile
-    int nc[4] = {0, 0, 0, 0};
-    while (bits) {
-        const int k = __ffs((int)bits) - 1;
-        bits &= bits - 1;
-        const int li = tid * 8 + k;
-        const int p = (yblk + (li >> 6)) * g.W + cx * 64 + (li & 63);
-        if (L_all[base + p] == p) nc[key_of(img_all[base + p], lut) & 3] += 1;
-    }
+    if (tile_any[ti]) {                                        // block-uniform
+        if (tid < 4) red[tid] = 0;
+        __syncthreads();
+        const size_t base = (size_t)img * g.H * g.W;
+        const int yblk = y0 - (tid >> 6) * CCL_ROWS;
+        uint32_t bits = (own_bits[ti * 64 + (tid >> 2)] >> ((tid & 3) * 8)) & 0xffu;      // thread = 8 consecutive pixels of the tile
+        int nc[4] = {0, 0, 0, 0};
+        while (bits) {
+            const int k = __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            const int li = tid * 8 + k;
+            const int p = (yblk + (li >> 6)) * g.W + cx * 64 + (li & 63);
+            if (L_all[base + p] == p) nc[key_of(img_all[base + p], lut) & 3] += 1;
+        }
 #pragma unroll
-    for (int k = 1; k < 4; ++k) if (nc[k]) atomicAdd(&red[k], nc[k]);
-    __syncthreads();
-    int32_t* G = G_all + (size_t)img * G_IMG + (size_t)(block_in_image(g) % G_SHARDS) * G_STRIDE;
-    if (tid >= 1 && tid < 4 && red[tid]) atomicAdd(G + G_NCOMP + tid, red[tid]);
+        for (int k = 1; k < 4; ++k) if (nc[k]) atomicAdd(&red[k], nc[k]);
+        __syncthreads();
+        int32_t* G = G_all + (size_t)img * G_IMG + (size_t)(block_in_image(g) % G_SHARDS) * G_STRIDE;
+        if (tid >= 1 && tid < 4 && red[tid]) atomicAdd(G + G_NCOMP + tid, red[tid]);
+    }
 }
 
 // fold the G_SHARDS replicas of every image's counter block into replica 0
@@ -637,6 +659,18 @@ __global__ void reduce_g_kernel(int32_t* __restrict__ G_all, int n_img) {
         G[sh * G_STRIDE + t] = 0;                         // folded: a second fold (count_flagged_owner_roots adds later) adds nothing twice
     }
     G[t] = v;
+}
+
+// consumers of a pass with its own counter block fold the replicas themselves (one thread, once per workgroup)
+__device__ __forceinline__ int g_fold_sum(const int32_t* G_img, int idx) {
+    int v = 0;
+    for (int sh = 0; sh < G_SHARDS; ++sh) v += G_img[sh * G_STRIDE + idx];
+    return v;
+}
+__device__ __forceinline__ int g_fold_max(const int32_t* G_img, int idx) {
+    int v = 0;
+    for (int sh = 0; sh < G_SHARDS; ++sh) v = max(v, G_img[sh * G_STRIDE + idx]);
+    return v;
 }
 
 __global__ void zero_g_kernel(int32_t* G, int n) {
@@ -658,12 +692,20 @@ struct CclPass {
     int32_t* list1 = nullptr;  // NEED_LISTS: per-image lists of class-1 roots / class-2 roots (first word of 16-byte slots)
     int32_t* list2 = nullptr;
     size_t list_cap = 0;
+    // counter block of this pass (null: ws.g, zeroed by a launch of its own and folded by reduce_g_kernel).  run_meta_inference
+    // gives every labelling its own block, zeroes them all with ONE memset and lets the consumers fold the replicas themselves
+    // (g_fold_*): two launches less per labelling
+    int32_t* g = nullptr;
+    // (round 5 tried to publish a count_only pass's result from the last workgroup of every image to finish - a ticket counter per
+    // image: 726 workgroups x 64 images adding to ONE line per image made count_roots_kernel 25x slower (20 -> 546 us); the
+    // per-image gather launch stays)
 };
 
 static hipError_t run_ccl_pass(PostWorkspace& ws, const CclGeom& g, const CclPass& c, hipStream_t s) {
     const int ng = g.n_img * G_IMG;
+    int32_t* const G = c.g ? c.g : ws.g;
     // (a pass that produces no counters - the fill_holes labellings - touches none: no zeroing launch)
-    if (c.need) hipLaunchKernelGGL(zero_g_kernel, dim3((ng + 255) / 256), dim3(256), 0, s, ws.g, ng);
+    if (c.need && !c.g) hipLaunchKernelGGL(zero_g_kernel, dim3((ng + 255) / 256), dim3(256), 0, s, G, ng);
     const unsigned grid = geom_grid(g);
     const bool slots = !c.count_only;                          // count_only: counts per key only - no statistics, no owners' slots
     const int stat = slots ? c.stat : 0, aux_mode = slots ? c.aux_mode : AUX_NONE;
@@ -672,23 +714,23 @@ static hipError_t run_ccl_pass(PostWorkspace& ws, const CclGeom& g, const CclPas
     if (c.conn == 8) {
         hipLaunchKernelGGL(ccl_local_kernel<8>, dim3(grid), dim3(256), dyn, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy,
                            ws.sumx, ws.flag, stat, c.sparse ? 1 : 0, ws.tile_any, 0, aux_mode, c.aux_c, c.aux_img, need_local,
-                           ws.g, ws.own_bits);
+                           G, ws.own_bits);
         hipLaunchKernelGGL(ccl_border_kernel<8>, dim3(grid), dim3(128), 0, s, g, c.key_img, c.lut, ws.L, ws.tile_any);
     } else {
         hipLaunchKernelGGL(ccl_local_kernel<4>, dim3(grid), dim3(256), dyn, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy,
                            ws.sumx, ws.flag, stat, c.sparse ? 1 : 0, ws.tile_any,
                            (c.allow_full && c.stat == 0 && c.need == 0 && !c.count_only) ? 1 : 0, aux_mode, c.aux_c, c.aux_img,
-                           need_local, ws.g, ws.own_bits);
+                           need_local, G, ws.own_bits);
         hipLaunchKernelGGL(ccl_border_kernel<4>, dim3(grid), dim3(128), 0, s, g, c.key_img, c.lut, ws.L, ws.tile_any);
     }
     if (c.count_only) {        // counts per key only: no per-pixel roots, no statistics
-        hipLaunchKernelGGL(count_roots_kernel, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L, ws.g, ws.tile_any, ws.own_bits);
-        hipLaunchKernelGGL(reduce_g_kernel, dim3(g.n_img), dim3(G_STRIDE), 0, s, ws.g, g.n_img);
+        hipLaunchKernelGGL(count_roots_kernel, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L, G, ws.tile_any, ws.own_bits);
+        if (!c.g) hipLaunchKernelGGL(reduce_g_kernel, dim3(g.n_img), dim3(G_STRIDE), 0, s, G, g.n_img);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(ccl_resolve_kernel, dim3(grid), dim3(256), 0, s, g, c.key_img, c.lut, ws.L, ws.area, ws.sumy, ws.sumx,
-                       ws.flag, ws.g, c.stat, c.need, c.list1, c.list2, c.list_cap, ws.tile_any, ws.own_bits);
-    if (c.need) hipLaunchKernelGGL(reduce_g_kernel, dim3(g.n_img), dim3(G_STRIDE), 0, s, ws.g, g.n_img);
+                       ws.flag, G, c.stat, c.need, c.list1, c.list2, c.list_cap, ws.tile_any, ws.own_bits);
+    if (c.need && !c.g) hipLaunchKernelGGL(reduce_g_kernel, dim3(g.n_img), dim3(G_STRIDE), 0, s, G, g.n_img);
     return hipGetLastError();
 }
 
@@ -773,122 +815,6 @@ __global__ __launch_bounds__(256) void apply_fill_tile_kernel(CclGeom g, uint8_t
     }
 }
 
-// size_thresh (src/image_tools.py:41-59) from ONE multi-class labelling: nuclei smaller than the mean chromosome
-// area -> 0; chromosomes smaller than the mean ecDNA area -> 3; ecDNA components (as labelled before that
-// reassignment) smaller than 15 px -> 0.  Means are exact integer sums divided in float64; NaN compares false.
-__global__ __launch_bounds__(256) void apply_size_thresh_kernel(uint8_t* __restrict__ img, const int32_t* __restrict__ L,
-                                                                const uint32_t* __restrict__ area,
-                                                                const int32_t* __restrict__ G_all, int n_img, size_t px,
-                                                                int ec_thresh) {
-    IMG_PX_LOOP(n_img, px) {
-        const uint8_t v = img[t];
-        if (!key_of(v, LUT_MULTI)) continue;                   // background: not labelled, its parent is stale
-        const int r = L[ib + L[t]];
-        const int32_t* G = G_all + (size_t)im * G_IMG;
-        // area < mean(areas) = S / n, evaluated exactly in integers: area * n < S.  (The reference compares in float64;
-        // S / n is either an integer or at least 1 / n away from one, far more than a rounding error, so both orders
-        // agree.  n == 0: the reference's mean is NaN and every comparison false; here S == 0 gives the same.)
-        const long long a = (long long)area[ib + r];
-        if (v == 1) { if (a * (long long)G[G_NCOMP + 2] < (long long)G[G_NPX + 2]) img[t] = 0; }
-        else if (v == 2) { if (a * (long long)G[G_NCOMP + 3] < (long long)G[G_NPX + 3]) img[t] = 3; }
-        else if (v == 3) { if (a < (long long)ec_thresh) img[t] = 0; }
-    }
-}
-
-// img[dilate(img==3) ^ erode(img==3)] = 0 (src/image_tools.py:64): dilation pads with 0, erosion with 1
-__global__ __launch_bounds__(256) void band_removal_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                           size_t total, int H, int W) {
-    const size_t px = (size_t)H * W;
-    PX_LOOP(total) {
-        const size_t q = t % px;
-        const int y = (int)(q / W), x = (int)(q % W);
-        const uint8_t v = in[t];
-        const bool c = v == 3;
-        const bool n = y > 0 ? in[t - W] == 3 : false, s = y < H - 1 ? in[t + W] == 3 : false;
-        const bool w = x > 0 ? in[t - 1] == 3 : false, e = x < W - 1 ? in[t + 1] == 3 : false;
-        const bool dil = c | n | s | w | e;
-        const bool ero = c & (y > 0 ? n : true) & (y < H - 1 ? s : true) & (x > 0 ? w : true) & (x < W - 1 ? e : true);
-        out[t] = (dil != ero) ? 0 : v;
-    }
-}
-
-// img[dilate(img==3)] = 3 (src/image_tools.py:83)
-__global__ __launch_bounds__(256) void ec_dilate_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                        size_t total, int H, int W) {
-    const size_t px = (size_t)H * W;
-    PX_LOOP(total) {
-        const size_t q = t % px;
-        const int y = (int)(q / W), x = (int)(q % W);
-        const uint8_t v = in[t];
-        bool d = v == 3;
-        if (y > 0) d |= in[t - W] == 3;
-        if (y < H - 1) d |= in[t + W] == 3;
-        if (x > 0) d |= in[t - 1] == 3;
-        if (x < W - 1) d |= in[t + 1] == 3;
-        out[t] = d ? 3 : v;
-    }
-}
-
-// The four 3x3-cross stencils above, four pixels per thread (W % 4 == 0: one aligned 32-bit load per row instead of four
-// byte loads; the scalar kernels remain for other widths).  OP: 0 band removal, 1 ecDNA dilation, 2 grey erosion,
-// 3 opening + combine (A = eroded image; B = label image, updated in place; C = merge_comp's working image).
-template <int OP>
-__global__ __launch_bounds__(256) void stencil4_kernel(const uint8_t* __restrict__ A, const uint8_t* B,
-                                                       const uint8_t* __restrict__ C, uint8_t* out, int n_img,
-                                                       int H, int W, int c, int m, uint32_t w4_magic) {
-    const int W4 = W >> 2;
-    const size_t px4 = (size_t)H * W4;                         // (< 2^30: H * W < 2^31 everywhere in this file)
-    IMG_PX_LOOP(n_img, px4) {
-        // row / column of the 4-pixel group inside its image: quotient by the host's floor(2^32 / W4), short by at most 2
-        const uint32_t q = (uint32_t)(t - ib);
-        uint32_t yq = __umulhi(q, w4_magic), xq = q - yq * (uint32_t)W4;
-        while (xq >= (uint32_t)W4) { xq -= (uint32_t)W4; ++yq; }
-        const int y = (int)yq, x4 = (int)xq;
-        const size_t p = t * 4;
-        const uint32_t cw = *reinterpret_cast<const uint32_t*>(A + p);
-        const bool hn = y > 0, hs = y < H - 1, hw = x4 > 0, he = x4 < W4 - 1;
-        const uint32_t nw = hn ? *reinterpret_cast<const uint32_t*>(A + p - W) : 0u;
-        const uint32_t sw = hs ? *reinterpret_cast<const uint32_t*>(A + p + W) : 0u;
-        const uint32_t wb = hw ? A[p - 1] : 0u, eb = he ? A[p + 4] : 0u;
-        uint32_t bw = 0, tw = 0;
-        if (OP == 3) { bw = *reinterpret_cast<const uint32_t*>(B + p); tw = *reinterpret_cast<const uint32_t*>(C + p); }
-        uint32_t res = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t v = (cw >> (8 * k)) & 0xffu;
-            const uint32_t n = (nw >> (8 * k)) & 0xffu, sv = (sw >> (8 * k)) & 0xffu;
-            const uint32_t wv = k ? (cw >> (8 * (k - 1))) & 0xffu : wb, ev = k < 3 ? (cw >> (8 * (k + 1))) & 0xffu : eb;
-            const bool bwst = k ? true : hw, best = k < 3 ? true : he;     // west / east neighbour exists
-            uint32_t o;
-            if (OP == 0) {
-                const bool cc = v == 3, nn = hn && n == 3, ss = hs && sv == 3, ww = bwst && wv == 3, ee = best && ev == 3;
-                const bool dil = cc | nn | ss | ww | ee;
-                const bool ero = cc & (hn ? nn : true) & (hs ? ss : true) & (bwst ? ww : true) & (best ? ee : true);
-                o = (dil != ero) ? 0u : v;
-            } else if (OP == 1) {
-                const bool d = v == 3 || (hn && n == 3) || (hs && sv == 3) || (bwst && wv == 3) || (best && ev == 3);
-                o = d ? 3u : v;
-            } else if (OP == 2) {
-                o = v;
-                if (hn) o = min(o, n);
-                if (hs) o = min(o, sv);
-                if (bwst) o = min(o, wv);
-                if (best) o = min(o, ev);
-            } else {
-                uint32_t mx = v;
-                if (hn) mx = max(mx, n);
-                if (hs) mx = max(mx, sv);
-                if (bwst) mx = max(mx, wv);
-                if (best) mx = max(mx, ev);
-                const uint32_t orig = (bw >> (8 * k)) & 0xffu;
-                o = (orig == (uint32_t)m) ? (uint32_t)m : (mx == (uint32_t)c ? (uint32_t)c : (tw >> (8 * k)) & 0xffu);
-            }
-            res |= o << (8 * k);
-        }
-        *reinterpret_cast<uint32_t*>(out + p) = res;
-    }
-}
-
 // The class-2 root indices that ccl_flatten appended (first word of every 16-byte slot) become regionprops centroids
 // (mean of the pixel coordinates, float64) in place.
 __global__ __launch_bounds__(256) void centroids_kernel(const uint32_t* __restrict__ area, const u64* __restrict__ sumy,
@@ -956,9 +882,21 @@ __global__ __launch_bounds__(256) void nucleus_test_kernel(const uint32_t* __res
 // the n1 * n2 pair tests of nucleus_test_kernel (the speckled output of a random-weight base-16 model - 10^4..10^5 nuclei and
 // chromosomes per image - spent 0.37 ms per image there).  The comparisons are the reference's own (strict, on the same
 // doubles).  Images wider / taller than NUCLEUS_BIN_EXTENT or with more chromosomes than `binned` holds go to the pair test.
+// `converted` == 0: the list still holds the roots (first word of every slot, as ccl_resolve left them) and the centroid is
+// computed here from the root's area / coordinate sums - the same float64 quotients centroids_kernel would have stored.
+__device__ __forceinline__ double list_centroid(const double2* __restrict__ src, int i, int axis, int converted,
+                                                const uint32_t* __restrict__ area, const u64* __restrict__ sumy,
+                                                const u64* __restrict__ sumx, size_t ib) {
+    if (converted) return axis ? src[i].y : src[i].x;
+    const size_t t = ib + (size_t)*reinterpret_cast<const int32_t*>(src + i);
+    return (double)(axis ? sumx[t] : sumy[t]) / (double)area[t];
+}
+
 __global__ __launch_bounds__(1024) void bin_centroids_kernel(const int32_t* __restrict__ G_all, const double2* __restrict__ list2,
                                                              double* __restrict__ binned, int32_t* __restrict__ binstart,
-                                                             size_t cap, size_t binned_cap, int H, int W) {
+                                                             size_t cap, size_t binned_cap, int H, int W,
+                                                             const uint32_t* __restrict__ area, const u64* __restrict__ sumy,
+                                                             const u64* __restrict__ sumx, size_t px, int converted) {
     extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
     int* hist = reinterpret_cast<int*>(dyn_smem);                        // [E + 1]: counts, then bin starts, then cursors
     __shared__ int part[1024];
@@ -970,8 +908,9 @@ __global__ __launch_bounds__(1024) void bin_centroids_kernel(const int32_t* __re
     for (int i = tid; i <= E; i += 1024) hist[i] = 0;
     __syncthreads();
     const double2* src = list2 + (size_t)im * cap;
+    const size_t ib = (size_t)im * px;
     for (int i = tid; i < n2; i += 1024) {
-        const double c = axis ? src[i].y : src[i].x;
+        const double c = list_centroid(src, i, axis, converted, area, sumy, sumx, ib);
         int b = (int)c;                                                  // centroids are means of pixel coordinates: 0 <= c <= E - 1
         b = b < 0 ? 0 : (b > E - 1 ? E - 1 : b);
         atomicAdd(&hist[b], 1);
@@ -996,7 +935,7 @@ __global__ __launch_bounds__(1024) void bin_centroids_kernel(const int32_t* __re
     __syncthreads();
     double* out = binned + ((size_t)im * 2 + axis) * binned_cap;
     for (int i = tid; i < n2; i += 1024) {
-        const double c = axis ? src[i].y : src[i].x;
+        const double c = list_centroid(src, i, axis, converted, area, sumy, sumx, ib);
         int b = (int)c;
         b = b < 0 ? 0 : (b > E - 1 ? E - 1 : b);
         out[atomicAdd(&hist[b], 1)] = c;
@@ -1057,161 +996,251 @@ __global__ __launch_bounds__(256) void apply_nucleus_kill_kernel(uint8_t* __rest
     }
 }
 
-// merge_comp, first half (src/image_tools.py:19-30): lift class m out (-> 0), turn every component of the remaining
-// non-zero pixels that holds a class-c pixel into c, except the component with the highest scipy label (= the one
-// whose first pixel comes last in raster order).  Output: the working image `t`.
-__global__ __launch_bounds__(256) void apply_merge_kernel(const uint8_t* __restrict__ img, uint8_t* __restrict__ tmp,
-                                                          const int32_t* __restrict__ L, const uint32_t* __restrict__ flag,
-                                                          const int32_t* __restrict__ G_all, int n_img, size_t px,
-                                                          int c, int m, uint32_t lut) {
-    IMG_PX_LOOP(n_img, px) {
-        uint8_t v = img[t];
-        if (v == m) v = 0;
-        if (key_of(img[t], lut)) {                             // a labelled pixel (key = value not in {0, m})
-            const int r = L[ib + L[t]];
-            const int last = G_all[(size_t)im * G_IMG + G_LAST_ROOT] - 1;
-            if ((flag[ib + r] & 1u) && r != last) v = (uint8_t)c;
-        }
-        tmp[t] = v;
-    }
-}
-
-// The three per-pixel appliers above, four pixels per thread (px % 4 == 0, 4-byte-aligned images; round 4): one 32-bit load decides
-// for four pixels whether anything is labelled at all - on a realistic label map 94 % of the pixels are background and the byte-wise
-// kernels spent their time on 64-byte wave loads.  MODE 0 size_thresh, 1 nucleus kill, 2 merge (img -> tmp).
-template <int MODE>
-__global__ __launch_bounds__(256) void apply4_kernel(uint8_t* __restrict__ img, uint8_t* __restrict__ tmp, const int32_t* __restrict__ L,
-                                                      const uint32_t* __restrict__ area, const uint32_t* __restrict__ flag,
-                                                      const int32_t* __restrict__ G_all, int n_img, size_t px4, int ec_thresh,
-                                                      int c, int m, uint32_t lut) {
+// The nucleus kill, four pixels per thread (px % 4 == 0, 4-byte-aligned images): one 32-bit load decides for four pixels whether
+// anything is a nucleus at all - on a realistic label map 94 % of the pixels are background.
+__global__ __launch_bounds__(256) void nucleus_kill4_kernel(uint8_t* __restrict__ img, const int32_t* __restrict__ L,
+                                                            const uint32_t* __restrict__ flag, int n_img, size_t px4) {
     IMG_PX_LOOP(n_img, px4) {                                  // t, ib: in 4-pixel groups
         const size_t p0 = t * 4, ibp = ib * 4;
         const uint32_t w = *reinterpret_cast<const uint32_t*>(img + p0);
         uint32_t o = w;
-        const int32_t* G = G_all + (size_t)im * G_IMG;
-        if (MODE == 2) {                                       // lift class m out
-#pragma unroll
-            for (int k = 0; k < 4; ++k) if (((w >> (8 * k)) & 0xffu) == (uint32_t)m) o &= ~(0xffu << (8 * k));
-        }
-        bool any = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint8_t v = (uint8_t)(w >> (8 * k));
-            any |= MODE == 0 ? key_of(v, LUT_MULTI) != 0 : MODE == 1 ? v == 1 : key_of(v, lut) != 0;
+            if (((w >> (8 * k)) & 0xffu) != 1u) continue;
+            const int r = L[ibp + L[p0 + k]];
+            if (flag[ibp + r] & 2u) o &= ~(0xffu << (8 * k));
         }
-        if (any) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint8_t v = (uint8_t)(w >> (8 * k));
-                if (MODE == 0) {
-                    if (!key_of(v, LUT_MULTI)) continue;
-                    const int r = L[ibp + L[p0 + k]];
-                    const long long a = (long long)area[ibp + r];
-                    uint32_t nv = v;
-                    if (v == 1) { if (a * (long long)G[G_NCOMP + 2] < (long long)G[G_NPX + 2]) nv = 0; }
-                    else if (v == 2) { if (a * (long long)G[G_NCOMP + 3] < (long long)G[G_NPX + 3]) nv = 3; }
-                    else if (v == 3) { if (a < (long long)ec_thresh) nv = 0; }
-                    o = (o & ~(0xffu << (8 * k))) | (nv << (8 * k));
-                } else if (MODE == 1) {
-                    if (v != 1) continue;
-                    const int r = L[ibp + L[p0 + k]];
-                    if (flag[ibp + r] & 2u) o &= ~(0xffu << (8 * k));
-                } else {
-                    if (!key_of(v, lut)) continue;
-                    const int r = L[ibp + L[p0 + k]];
-                    const int last = G[G_LAST_ROOT] - 1;
-                    if ((flag[ibp + r] & 1u) && r != last) o = (o & ~(0xffu << (8 * k))) | ((uint32_t)c << (8 * k));
-                }
-            }
-        }
-        if (MODE == 2) *reinterpret_cast<uint32_t*>(tmp + p0) = o;
-        else if (o != w) *reinterpret_cast<uint32_t*>(img + p0) = o;
+        if (o != w) *reinterpret_cast<uint32_t*>(img + p0) = o;
     }
 }
 
-// grey erosion with the 3x3 cross, borders reflected (= out-of-image neighbours ignored)
-__global__ __launch_bounds__(256) void grey_erode_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                         size_t total, int H, int W) {
-    const size_t px = (size_t)H * W;
-    PX_LOOP(total) {
-        const size_t q = t % px;
-        const int y = (int)(q / W), x = (int)(q % W);
-        uint8_t v = in[t];
-        if (y > 0) v = min(v, in[t - W]);
-        if (y < H - 1) v = min(v, in[t + W]);
-        if (x > 0) v = min(v, in[t - 1]);
-        if (x < W - 1) v = min(v, in[t + 1]);
-        out[t] = v;
-    }
-}
-
-// merge_comp, second half (src/image_tools.py:31-32): grey dilation of the eroded image (= opening), pixels whose
-// opened value equals c become c, lifted class m is restored.
-__global__ __launch_bounds__(256) void open_combine_kernel(uint8_t* __restrict__ img, const uint8_t* __restrict__ tmp,
-                                                           const uint8_t* __restrict__ ero, size_t total, int H, int W,
-                                                           int c, int m) {
-    const size_t px = (size_t)H * W;
-    PX_LOOP(total) {
-        const size_t q = t % px;
-        const int y = (int)(q / W), x = (int)(q % W);
-        uint8_t o = ero[t];
-        if (y > 0) o = max(o, ero[t - W]);
-        if (y < H - 1) o = max(o, ero[t + W]);
-        if (x > 0) o = max(o, ero[t - 1]);
-        if (x < W - 1) o = max(o, ero[t + 1]);
-        const uint8_t orig = img[t];
-        img[t] = (orig == m) ? (uint8_t)m : (o == c ? (uint8_t)c : tmp[t]);
-    }
-}
-
+// fold != 0: the pass had a counter block of its own whose replicas nobody has folded yet
 __global__ void gather_counts_kernel(const int32_t* __restrict__ G_all, int n_img, int key, int32_t* __restrict__ n_out,
-                                     long long* __restrict__ px_out, long long full_px) {
+                                     long long* __restrict__ px_out, long long full_px, int fold) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_img) return;
-    const int n = G_all[(size_t)i * G_IMG + G_NCOMP + key];
-    const long long px = G_all[(size_t)i * G_IMG + G_NPX + key];
+    const int32_t* G = G_all + (size_t)i * G_IMG;
+    const int n = fold ? g_fold_sum(G, G_NCOMP + key) : G[G_NCOMP + key];
+    const long long px = fold ? g_fold_sum(G, G_NPX + key) : G[G_NPX + key];
     if (n_out) n_out[i] = n;
     // count_cc's pixel total (src/image_tools.py:116-119) is float 0.0 when nothing is counted: no component, or no
     // background label for np.unique(...)[1:] to drop (mask without a single zero pixel)
     if (px_out) px_out[i] = (n == 0 || px == full_px) ? -1 : px;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused tile kernels of the clean-up schedule (round 5).  Rounds 1-4 ran every step of the schedule as a pass of its own over
+// the whole batch - applier (gathers through the parent image), then each 3x3 stencil: 14 launches and as many round trips
+// of the label images through HBM.  Here a workgroup owns one 64 x 32 labelling tile (same blockIdx -> tile map as the CCL
+// kernels, so the parents / flags it gathers are in its XCD's L2), evaluates the applier on the tile plus the halo the
+// stencils behind it need, keeps the intermediate images in LDS and writes only the final one:
+//   thresh_band_kernel    size_thresh applier (src/image_tools.py:41-59) + ecDNA band removal (:64)                halo 1
+//   merge_open_kernel     merge_comp applier (:19-30) + grey erosion + grey dilation / combine (:31-32)            halo 2
+//                         FINAL: + the last ecDNA dilation (:83)                                                    halo 3
+// Halo columns are staged in whole 4-pixel words (4 columns either side); W % 4 == 0 reads the images with 32-bit loads and
+// skips the gathers of a word without a labelled pixel at once (94 % of a realistic label map is background).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int FT_HX = 4;                     // halo columns staged either side (a whole word)
+constexpr int FT_HW = 64 + 2 * FT_HX;        // LDS row pitch in pixels (72 = 18 words)
+
+template <bool W4>
+__device__ __forceinline__ uint32_t ft_load_word(const uint8_t* __restrict__ im, size_t p, int x, int W) {
+    if (W4) return *reinterpret_cast<const uint32_t*>(im + p);
+    uint32_t w = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (x + k >= 0 && x + k < W) w |= (uint32_t)im[p + k] << (8 * k);
+    return w;
+}
+
+template <bool W4>
+__global__ __launch_bounds__(256) void thresh_band_kernel(CclGeom g, const uint8_t* __restrict__ img_all, uint8_t* __restrict__ out_all,
+                                                          const int32_t* __restrict__ L_all, const uint32_t* __restrict__ area_all,
+                                                          const int32_t* __restrict__ G_all, int ec_thresh) {
+    constexpr int R = 1, HH = CCL_BLOCK_ROWS + 2 * R;
+    __shared__ __attribute__((aligned(16))) uint8_t T[HH * FT_HW];
+    __shared__ long long gs[4];
+    int img, y0, cx;
+    if (!decode_block(g, img, y0, cx)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int yblk = y0 - wave * CCL_ROWS, x0 = cx * 64;
+    const int H = g.H, W = g.W;
+    const size_t base = (size_t)img * H * W;
+    if (tid < 4) gs[tid] = g_fold_sum(G_all + (size_t)img * G_IMG, tid == 0 ? G_NCOMP + 2 : tid == 1 ? G_NPX + 2 : tid == 2 ? G_NCOMP + 3 : G_NPX + 3);
+    __syncthreads();
+    // stage 1: thresholded labels of the tile + halo
+    for (int i = tid; i < HH * (FT_HW / 4); i += 256) {
+        const int hy = i / (FT_HW / 4), wx = i - hy * (FT_HW / 4);
+        const int y = yblk - R + hy, x = x0 - FT_HX + wx * 4;
+        uint32_t o = 0;
+        if (y >= 0 && y < H && x + 3 >= 0 && x < W) {
+            const size_t p0 = (size_t)y * W + x;             // (W4: x is a multiple of 4 inside [0, W))
+            const uint32_t w = ft_load_word<W4>(img_all + base, p0, x, W);
+            o = w;
+            if (w) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t v = (w >> (8 * k)) & 0xffu;
+                    if (!v) continue;                          // LUT_MULTI: key = value
+                    const int r = L_all[base + L_all[base + p0 + k]];
+                    // area < mean(areas) = S / n, evaluated exactly in integers: area * n < S.  (The reference compares in float64;
+                    // S / n is an integer or at least 1 / n away from one, far more than a rounding error, so both orders agree.
+                    // n == 0: the reference's mean is NaN and every comparison false; here S == 0 gives the same.)
+                    const long long a = (long long)area_all[base + r];
+                    uint32_t nv = v;
+                    if (v == 1) { if (a * gs[0] < gs[1]) nv = 0; }
+                    else if (v == 2) { if (a * gs[2] < gs[3]) nv = 3; }
+                    else if (v == 3) { if (a < (long long)ec_thresh) nv = 0; }
+                    o = (o & ~(0xffu << (8 * k))) | (nv << (8 * k));
+                }
+            }
+        }
+        *reinterpret_cast<uint32_t*>(T + hy * FT_HW + wx * 4) = o;
+    }
+    __syncthreads();
+    // stage 2: img[dilate(img == 3) ^ erode(img == 3)] = 0 (dilation pads with 0, erosion with 1)
+#pragma unroll
+    for (int r = 0; r < CCL_ROWS; ++r) {
+        const int y = y0 + r, x = x0 + lane;
+        if (y >= H || x >= W) continue;
+        const uint8_t* c = T + (wave * CCL_ROWS + r + R) * FT_HW + lane + FT_HX;
+        const uint8_t v = c[0];
+        const bool cc = v == 3;
+        const bool hn = y > 0, hs = y < H - 1, hw = x > 0, he = x < W - 1;
+        const bool nn = hn && c[-FT_HW] == 3, ss = hs && c[FT_HW] == 3, ww = hw && c[-1] == 3, ee = he && c[1] == 3;
+        const bool dil = cc | nn | ss | ww | ee;
+        const bool ero = cc & (hn ? nn : true) & (hs ? ss : true) & (hw ? ww : true) & (he ? ee : true);
+        out_all[base + (size_t)y * W + x] = (dil != ero) ? (uint8_t)0 : v;
+    }
+}
+
+template <bool FINAL, bool W4>
+__global__ __launch_bounds__(256) void merge_open_kernel(CclGeom g, const uint8_t* __restrict__ cur_all, uint8_t* __restrict__ out_all,
+                                                         const int32_t* __restrict__ L_all, const uint32_t* __restrict__ flag_all,
+                                                         const int32_t* __restrict__ G_all, int c, int m, uint32_t lut) {
+    constexpr int R = FINAL ? 3 : 2, HH = CCL_BLOCK_ROWS + 2 * R;
+    __shared__ __attribute__((aligned(16))) uint8_t Tm[HH * FT_HW];      // merge_comp's working image t (0xff outside the image)
+    __shared__ __attribute__((aligned(16))) uint8_t Or[HH * FT_HW];      // the label image itself
+    __shared__ __attribute__((aligned(16))) uint8_t Er[HH * FT_HW];      // grey erosion of t (0 outside the image)
+    __shared__ __attribute__((aligned(16))) uint8_t Cm[FINAL ? HH * FT_HW : 16];   // FINAL: merged result before the last dilation
+    __shared__ int s_last;
+    int img, y0, cx;
+    if (!decode_block(g, img, y0, cx)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int yblk = y0 - wave * CCL_ROWS, x0 = cx * 64;
+    const int H = g.H, W = g.W;
+    const size_t base = (size_t)img * H * W;
+    if (tid == 0) s_last = g_fold_max(G_all + (size_t)img * G_IMG, G_LAST_ROOT) - 1;
+    __syncthreads();
+    const int last = s_last;
+    // stage 1: t = the image with class m lifted out and every component (of the remaining non-zero pixels) that holds a class-c
+    // pixel turned into c - except the component with the highest scipy label (src/image_tools.py:27: range(1, num))
+    for (int i = tid; i < HH * (FT_HW / 4); i += 256) {
+        const int hy = i / (FT_HW / 4), wx = i - hy * (FT_HW / 4);
+        const int y = yblk - R + hy, x = x0 - FT_HX + wx * 4;
+        uint32_t t = 0xffffffffu, orig = 0;
+        if (y >= 0 && y < H && x + 3 >= 0 && x < W) {
+            const size_t p0 = (size_t)y * W + x;
+            const uint32_t w = ft_load_word<W4>(cur_all + base, p0, x, W);
+            orig = w;
+            t = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t v = (w >> (8 * k)) & 0xffu;
+                uint32_t tv = (v == (uint32_t)m) ? 0u : v;
+                if (!W4 && (x + k < 0 || x + k >= W)) tv = 0xffu;
+                else if (v && key_of((uint8_t)v, lut)) {
+                    const int r = L_all[base + L_all[base + p0 + k]];
+                    if ((flag_all[base + r] & 1u) && r != last) tv = (uint32_t)c;
+                }
+                t |= tv << (8 * k);
+            }
+        }
+        *reinterpret_cast<uint32_t*>(Tm + hy * FT_HW + wx * 4) = t;
+        *reinterpret_cast<uint32_t*>(Or + hy * FT_HW + wx * 4) = orig;
+    }
+    __syncthreads();
+    // stage 2: grey erosion with the 3x3 cross, out-of-image neighbours ignored (0xff never wins a minimum of labels)
+    for (int i = tid; i < (HH - 2) * (FT_HW - 2); i += 256) {
+        const int hy = 1 + i / (FT_HW - 2), hx = 1 + i % (FT_HW - 2);
+        const uint8_t* p = Tm + hy * FT_HW + hx;
+        uint8_t v = p[0];
+        if (v != 0xff) v = min(min(min(v, p[-1]), min(p[1], p[-FT_HW])), p[FT_HW]);
+        Er[hy * FT_HW + hx] = v == 0xff ? (uint8_t)0 : v;
+    }
+    __syncthreads();
+    // stage 3: grey dilation of the eroded image (= opening; the 0 of out-of-image pixels never wins a maximum), pixels whose
+    // opened value equals c become c, lifted class m is restored
+    auto combine = [&](int hy, int hx) -> uint8_t {
+        const uint8_t* e = Er + hy * FT_HW + hx;
+        const uint8_t mx = max(max(max(e[0], e[-1]), max(e[1], e[-FT_HW])), e[FT_HW]);
+        const uint8_t orig = Or[hy * FT_HW + hx];
+        return (orig == m) ? (uint8_t)m : (mx == c ? (uint8_t)c : Tm[hy * FT_HW + hx]);
+    };
+    if (!FINAL) {
+#pragma unroll
+        for (int r = 0; r < CCL_ROWS; ++r) {
+            const int y = y0 + r, x = x0 + lane;
+            if (y >= H || x >= W) continue;
+            out_all[base + (size_t)y * W + x] = combine(wave * CCL_ROWS + r + R, lane + FT_HX);
+        }
+        return;
+    }
+    // FINAL: the merged image on the tile + 1 pixel, then img[dilate(img == 3)] = 3 (out-of-image neighbours ignored)
+    for (int i = tid; i < (CCL_BLOCK_ROWS + 2) * 66; i += 256) {
+        const int hy = R - 1 + i / 66, hx = FT_HX - 1 + i % 66;
+        const int y = yblk - R + hy, x = x0 - FT_HX + hx;
+        Cm[hy * FT_HW + hx] = (y >= 0 && y < H && x >= 0 && x < W) ? combine(hy, hx) : (uint8_t)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < CCL_ROWS; ++r) {
+        const int y = y0 + r, x = x0 + lane;
+        if (y >= H || x >= W) continue;
+        const uint8_t* q = Cm + (wave * CCL_ROWS + r + R) * FT_HW + lane + FT_HX;
+        const bool d = q[0] == 3 || q[-1] == 3 || q[1] == 3 || q[-FT_HW] == 3 || q[FT_HW] == 3;
+        out_all[base + (size_t)y * W + x] = d ? (uint8_t)3 : q[0];
+    }
+}
+
 hipError_t run_meta_inference(PostWorkspace& ws, uint8_t* img, int n_img, int H, int W, int32_t* n_ec_dev, hipStream_t s) {
     if (n_img <= 0) return hipSuccess;
     const CclGeom g = make_geom(n_img, H, W);
-    const size_t px = (size_t)H * W, total = px * n_img;
-    const unsigned pg = px_grid(total);
+    const size_t px = (size_t)H * W;
     const dim3 ig = img_grid(px, n_img);
-    // W % 4 == 0 and 4-byte-aligned images: four pixels per thread in the appliers and stencils
+    const unsigned tg = geom_grid(g);
+    // W % 4 == 0 and 4-byte-aligned images: 32-bit loads in the fused tile kernels, four pixels per thread in the nucleus kill
     const bool v4 = (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(img) | reinterpret_cast<uintptr_t>(ws.tmpA) |
                                       reinterpret_cast<uintptr_t>(ws.tmpB)) & 3) == 0;
     const dim3 ig4 = img_grid(px / 4, n_img);
     hipError_t e;
+    // one counter block per labelling that produces counters, all zeroed here: no zeroing / folding launches in between
+    // (a kernel, not hipMemsetAsync: replayed from a HIP graph - option post_graph - the memset node of ROCm 7.2 was not ordered
+    // before the kernels behind it and zeroed list counters in mid-use: a memory fault on speckled images, round 5)
+    const size_t gslot = (size_t)ws.cap_img * G_IMG;
+    {
+        const int nz = (int)((n_ec_dev ? 5 : 4) * gslot);
+        hipLaunchKernelGGL(zero_g_kernel, dim3((nz + 255) / 256), dim3(256), 0, s, ws.g, nz);
+    }
     // 1. fill_holes(1), fill_holes(2)
     for (int c = 1; c <= 2; ++c) {
         CclPass p{img, lut_ne(c), 4, 0, AUX_BORDER, 0, nullptr, 0};
         p.sparse = true;
         p.allow_full = true;
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
-        hipLaunchKernelGGL(apply_fill_tile_kernel, dim3(geom_grid(g)), dim3(256), 0, s, g, img, ws.L, ws.flag, c, lut_ne(c), ws.tile_any, ws.own_bits);
+        hipLaunchKernelGGL(apply_fill_tile_kernel, dim3(tg), dim3(256), 0, s, g, img, ws.L, ws.flag, c, lut_ne(c), ws.tile_any, ws.own_bits);
     }
-    // 2-4. size_thresh
+    // 2-5. size_thresh + ecDNA band removal -> ws.tmpA (the caller's buffer is free from here until the last step writes the
+    // result into it)
+    uint8_t* cur = ws.tmpA;
+    uint8_t* nxt = ws.tmpB;
     {
         CclPass p{img, LUT_MULTI, 8, STAT_AREA, AUX_NONE, 0, nullptr, NEED_NCOMP | NEED_NPX};
         p.sparse = true;
+        p.g = ws.g + 0 * gslot;
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
-        if (v4) hipLaunchKernelGGL(apply4_kernel<0>, ig4, dim3(256), 0, s, img, (uint8_t*)nullptr, ws.L, ws.area, ws.flag, ws.g, n_img, px / 4, 15, 0, 0, 0u);
-        else hipLaunchKernelGGL(apply_size_thresh_kernel, ig, dim3(256), 0, s, img, ws.L, ws.area, ws.g, n_img, px, 15);
+        if (v4) hipLaunchKernelGGL(thresh_band_kernel<true>, dim3(tg), dim3(256), 0, s, g, img, cur, ws.L, ws.area, p.g, 15);
+        else hipLaunchKernelGGL(thresh_band_kernel<false>, dim3(tg), dim3(256), 0, s, g, img, cur, ws.L, ws.area, p.g, 15);
     }
-    // From here on the working image is ws.tmpA and the caller's buffer is a scratch image (no copies back and forth);
-    // the last stencil writes the result into the caller's buffer.  W % 4 == 0: four pixels per thread.
-    const uint32_t w4_magic = W >= 8 ? (uint32_t)((1ull << 32) / (uint64_t)(W >> 2)) : 0xffffffffu / (uint32_t)(W >= 4 ? (W >> 2) : 1);
-    uint8_t* cur = ws.tmpA;
-    uint8_t* t1 = img;
-    uint8_t* t2 = ws.tmpB;
-    // 5. ecDNA band removal
-    if (v4) hipLaunchKernelGGL(stencil4_kernel<0>, ig4, dim3(256), 0, s, img, nullptr, nullptr, cur, n_img, H, W, 0, 0, w4_magic);
-    else hipLaunchKernelGGL(band_removal_kernel, dim3(pg), dim3(256), 0, s, img, cur, total, H, W);
     // 6. nucleus-in-metaphase test
     {
         const size_t cap = px / 4 + (size_t)(H + W) / 2 + 4;
@@ -1219,11 +1248,15 @@ hipError_t run_meta_inference(PostWorkspace& ws, uint8_t* img, int n_img, int H,
         double2* list2 = reinterpret_cast<double2*>(ws.list + (((size_t)n_img * cap + 3) & ~(size_t)3));
         CclPass p{cur, LUT_MULTI, 8, STAT_AREA | STAT_SUMS, AUX_NONE, 0, nullptr, NEED_LISTS};
         p.sparse = true;
+        p.g = ws.g + 1 * gslot;
         p.list1 = list1; p.list2 = reinterpret_cast<int32_t*>(list2); p.list_cap = cap;
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
-        hipLaunchKernelGGL(centroids_kernel, dim3(8, n_img), dim3(256), 0, s, ws.area, ws.sumy, ws.sumx, ws.g, list2, px, cap);
-        const int bpi = 32;
-        if (H <= NUCLEUS_BIN_EXTENT && W <= NUCLEUS_BIN_EXTENT) {
+        const bool binned = H <= NUCLEUS_BIN_EXTENT && W <= NUCLEUS_BIN_EXTENT;
+        // the pair test is only ever needed for images the binned test cannot take: extents beyond the LDS histogram, or more
+        // chromosomes than `binned` holds (n2 <= cap); it reads the centroids that centroids_kernel leaves in the list
+        const bool pairs = !binned || cap > ws.binned_cap;
+        if (pairs) hipLaunchKernelGGL(centroids_kernel, dim3(8, n_img), dim3(256), 0, s, ws.area, ws.sumy, ws.sumx, p.g, list2, px, cap);
+        if (binned) {
             const size_t bin_lds = (size_t)(std::max(H, W) + 2) * sizeof(int);
             static DeviceOnce bin_attr;                            // up to 128 KB of dynamic LDS: per-device function attribute
             e = bin_attr.run([] {
@@ -1231,43 +1264,44 @@ hipError_t run_meta_inference(PostWorkspace& ws, uint8_t* img, int n_img, int H,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)((NUCLEUS_BIN_EXTENT + 2) * sizeof(int)));
             });
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(bin_centroids_kernel, dim3(2, n_img), dim3(1024), bin_lds, s, ws.g, list2, ws.binned, ws.binstart,
-                               cap, ws.binned_cap, H, W);
-            hipLaunchKernelGGL(nucleus_test_binned_kernel, dim3(32, n_img), dim3(256), 0, s, ws.area, ws.sumy, ws.sumx, ws.g,
+            hipLaunchKernelGGL(bin_centroids_kernel, dim3(2, n_img), dim3(1024), bin_lds, s, p.g, list2, ws.binned, ws.binstart,
+                               cap, ws.binned_cap, H, W, ws.area, ws.sumy, ws.sumx, px, pairs ? 1 : 0);
+            hipLaunchKernelGGL(nucleus_test_binned_kernel, dim3(32, n_img), dim3(256), 0, s, ws.area, ws.sumy, ws.sumx, p.g,
                                list1, ws.binned, ws.binstart, ws.flag, px, cap, ws.binned_cap, H, W, 70.0, 5);
         }
-        // images the binned path does not take (the others return at once)
-        hipLaunchKernelGGL(nucleus_test_kernel, dim3(n_img * bpi), dim3(256), 0, s, ws.area, ws.sumy, ws.sumx, ws.g, list1,
-                           list2, ws.flag, px, cap, bpi, 70.0, 5, H, W, ws.binned_cap);
-        if (v4) hipLaunchKernelGGL(apply4_kernel<1>, ig4, dim3(256), 0, s, cur, (uint8_t*)nullptr, ws.L, ws.area, ws.flag, ws.g, n_img, px / 4, 0, 0, 0, 0u);
+        if (pairs) {
+            const int bpi = 32;
+            hipLaunchKernelGGL(nucleus_test_kernel, dim3(n_img * bpi), dim3(256), 0, s, ws.area, ws.sumy, ws.sumx, p.g, list1,
+                               list2, ws.flag, px, cap, bpi, 70.0, 5, H, W, ws.binned_cap);
+        }
+        if (v4) hipLaunchKernelGGL(nucleus_kill4_kernel, ig4, dim3(256), 0, s, cur, ws.L, ws.flag, n_img, px / 4);
         else hipLaunchKernelGGL(apply_nucleus_kill_kernel, ig, dim3(256), 0, s, cur, ws.L, ws.flag, n_img, px);
     }
-    // 7-8. merge_comp(1), merge_comp(2)
+    // 7-8. merge_comp(1), merge_comp(2); 9. the final ecDNA dilation rides on the second one, which writes the caller's buffer
     for (int c = 1; c <= 2; ++c) {
         const int m = (c == 1) ? 2 : 1;
-        CclPass p{cur, lut_nonzero_except(m), 8, 0, AUX_VALUE_EQ, c, nullptr, NEED_LAST};
+        const uint32_t lut = lut_nonzero_except(m);
+        CclPass p{cur, lut, 8, 0, AUX_VALUE_EQ, c, nullptr, NEED_LAST};
         p.sparse = true;
+        p.g = ws.g + (size_t)(1 + c) * gslot;
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
-        if (v4) hipLaunchKernelGGL(apply4_kernel<2>, ig4, dim3(256), 0, s, cur, t1, ws.L, ws.area, ws.flag, ws.g, n_img, px / 4, 0, c, m, lut_nonzero_except(m));
-        else hipLaunchKernelGGL(apply_merge_kernel, ig, dim3(256), 0, s, cur, t1, ws.L, ws.flag, ws.g, n_img, px, c, m, lut_nonzero_except(m));
-        if (v4) {
-            hipLaunchKernelGGL(stencil4_kernel<2>, ig4, dim3(256), 0, s, t1, nullptr, nullptr, t2, n_img, H, W, 0, 0, w4_magic);
-            hipLaunchKernelGGL(stencil4_kernel<3>, ig4, dim3(256), 0, s, t2, cur, t1, cur, n_img, H, W, c, m, w4_magic);
+        if (c == 1) {
+            if (v4) hipLaunchKernelGGL((merge_open_kernel<false, true>), dim3(tg), dim3(256), 0, s, g, cur, nxt, ws.L, ws.flag, p.g, c, m, lut);
+            else hipLaunchKernelGGL((merge_open_kernel<false, false>), dim3(tg), dim3(256), 0, s, g, cur, nxt, ws.L, ws.flag, p.g, c, m, lut);
+            std::swap(cur, nxt);
         } else {
-            hipLaunchKernelGGL(grey_erode_kernel, dim3(pg), dim3(256), 0, s, t1, t2, total, H, W);
-            hipLaunchKernelGGL(open_combine_kernel, dim3(pg), dim3(256), 0, s, cur, t1, t2, total, H, W, c, m);
+            if (v4) hipLaunchKernelGGL((merge_open_kernel<true, true>), dim3(tg), dim3(256), 0, s, g, cur, img, ws.L, ws.flag, p.g, c, m, lut);
+            else hipLaunchKernelGGL((merge_open_kernel<true, false>), dim3(tg), dim3(256), 0, s, g, cur, img, ws.L, ws.flag, p.g, c, m, lut);
         }
     }
-    // 9. final ecDNA dilation, back into the caller's buffer
-    if (v4) hipLaunchKernelGGL(stencil4_kernel<1>, ig4, dim3(256), 0, s, cur, nullptr, nullptr, img, n_img, H, W, 0, 0, w4_magic);
-    else hipLaunchKernelGGL(ec_dilate_kernel, dim3(pg), dim3(256), 0, s, cur, img, total, H, W);
     // 10. count_cc(img == 3)[0]
     if (n_ec_dev) {
         CclPass p{img, lut_eq(3), 8, 0, AUX_NONE, 0, nullptr, NEED_NCOMP | NEED_NPX, true};
         p.sparse = true;
+        p.g = ws.g + 4 * gslot;
         if ((e = run_ccl_pass(ws, g, p, s)) != hipSuccess) return e;
-        hipLaunchKernelGGL(gather_counts_kernel, dim3((n_img + 63) / 64), dim3(64), 0, s, ws.g, n_img, 1, n_ec_dev,
-                           (long long*)nullptr, (long long)px);
+        hipLaunchKernelGGL(gather_counts_kernel, dim3((n_img + 63) / 64), dim3(64), 0, s, p.g, n_img, 1, n_ec_dev,
+                           (long long*)nullptr, (long long)px, 1);
     }
     return hipGetLastError();
 }
@@ -1284,7 +1318,7 @@ hipError_t run_count_cc(PostWorkspace& ws, const uint8_t* mask, int n_img, int H
     hipError_t e = run_ccl_pass(ws, g, p, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(gather_counts_kernel, dim3((n_img + 63) / 64), dim3(64), 0, s, ws.g, n_img, 1, n_dev, px_dev,
-                       (long long)H * W);
+                       (long long)H * W, 0);
     return hipGetLastError();
 }
 

@@ -17,7 +17,7 @@ EXPORTS = [
     'ecseg_count_colocalization', 'ecseg_count_hsr', 'ecseg_overlay', 'ecseg_get_timings',
     'ecseg_set_kernel_profiling', 'ecseg_get_conv_profile', 'ecseg_get_conv_executed_flops', 'ecseg_get_conv_launch_profile', 'ecseg_debug_peek', 'ecseg_lzw_decode', 'ecseg_lzw_encode',
     'ecseg_comm_unique_id', 'ecseg_comm_create', 'ecseg_comm_destroy', 'ecseg_comm_last_error', 'ecseg_allgather_records', 'ecseg_allgather_records_dev',
-    'ecseg_npy_write_i64', 'ecseg_png_write_labels', 'ecseg_png_write', 'ecseg_tiff_write_gray8', 'ecseg_tiff_info', 'ecseg_tiff_read',
+    'ecseg_npy_write_i64', 'ecseg_png_write_labels', 'ecseg_png_write', 'ecseg_png_write_channel', 'ecseg_npy_label_info', 'ecseg_npy_read_labels_u8', 'ecseg_tiff_write_gray8', 'ecseg_tiff_info', 'ecseg_tiff_read',
 ]
 
 
@@ -106,6 +106,9 @@ def load_library():
     lib.ecseg_npy_write_i64.argtypes = [C.c_char_p, vp, i32, i32]
     lib.ecseg_png_write_labels.argtypes = [C.c_char_p, vp, i32, i32]
     lib.ecseg_png_write.argtypes = [C.c_char_p, vp, i32, i32, i32, i32]
+    lib.ecseg_png_write_channel.argtypes = [C.c_char_p, vp, i32, i32, i32, i32, i32]
+    lib.ecseg_npy_label_info.argtypes = [C.c_char_p, C.POINTER(i32), C.POINTER(i32)]
+    lib.ecseg_npy_read_labels_u8.argtypes = [C.c_char_p, vp, i32, i32]
     lib.ecseg_tiff_write_gray8.argtypes = [C.c_char_p, vp, i32, i32, i32]
     lib.ecseg_tiff_info.argtypes = [C.c_char_p, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     lib.ecseg_tiff_read.argtypes = [C.c_char_p, vp, C.c_longlong]

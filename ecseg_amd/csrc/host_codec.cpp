@@ -67,7 +67,18 @@ long long ecseg_lzw_decode(const uint8_t* src, long long n, uint8_t* dst, long l
         const long long start = out;
         const long long room = dst_cap - out;
         const int ncopy = (long long)clen <= room ? clen : (int)room;
-        if (code < 256) { if (ncopy > 0) dst[out] = (uint8_t)code; }
+        // Round 5: on noisy images most strings are 1 - 3 bytes long and start a few bytes before the write position, where
+        // the 8-byte-step copy above did not apply and every code paid a byte loop plus the mispredicted literal / string
+        // branch.  A string of a code < next never reaches into the bytes being written (cpos + clen <= out; only KwKwK
+        // does), so ONE 8-byte load followed by ONE 8-byte store is exact for clen <= 8 whatever the distance; literals take
+        // the same path from a table of their own bytes.
+        if (room >= 16 && clen <= 8 && code != next) {
+            uint64_t v;
+            if (code < 256) v = (uint64_t)code;
+            else std::memcpy(&v, dst + cpos, 8);               // (cpos + 8 <= out + 8 <= dst_cap)
+            std::memcpy(dst + out, &v, 8);
+        }
+        else if (code < 256) { if (ncopy > 0) dst[out] = (uint8_t)code; }
         else if (out - cpos >= 8 && room >= (long long)ncopy + 8) {
             const uint8_t* sp = dst + cpos; uint8_t* dp = dst + out;
             for (int k = 0; k < ncopy; k += 8) std::memcpy(dp + k, sp + k, 8);

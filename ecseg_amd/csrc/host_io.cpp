@@ -54,10 +54,25 @@ bool png_chunk(File& out, const char tag[4], const uint8_t* data, size_t n) {
 }
 
 // rows: H scan lines of `stride` bytes, each starting with its filter byte
+// level < 0: OpenCV's default encoder settings (cv2.imwrite without parameters, modules/imgcodecs/src/grfmt_png.cpp: "tune
+// parameters for speed" - Z_BEST_SPEED with the Z_RLE strategy; the caller has applied the SUB filter): run-length matching only,
+// 5x faster than level-1 deflate on the noisy FISH channels
 int png_write_rows(const char* path, const std::vector<uint8_t>& rows, int H, int W, int color_type, int level) {
-    uLongf cap = compressBound((uLong)rows.size());
+    uLongf cap = compressBound((uLong)rows.size()) + 64;
     std::vector<uint8_t> z(cap);
-    if (compress2(z.data(), &cap, rows.data(), (uLong)rows.size(), level) != Z_OK) return ECSEG_E_INVALID;
+    if (level >= 0) {
+        if (compress2(z.data(), &cap, rows.data(), (uLong)rows.size(), level) != Z_OK) return ECSEG_E_INVALID;
+    } else {
+        z_stream zs;
+        std::memset(&zs, 0, sizeof zs);
+        if (deflateInit2(&zs, Z_BEST_SPEED, Z_DEFLATED, 15, 8, Z_RLE) != Z_OK) return ECSEG_E_INVALID;
+        zs.next_in = const_cast<Bytef*>(rows.data()); zs.avail_in = (uInt)rows.size();
+        zs.next_out = z.data(); zs.avail_out = (uInt)cap;
+        const int r = deflate(&zs, Z_FINISH);
+        cap = zs.total_out;
+        deflateEnd(&zs);
+        if (r != Z_STREAM_END) return ECSEG_E_INVALID;
+    }
     File out(path, "wb");
     if (!out.f) return ECSEG_E_IO;
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
@@ -288,6 +303,90 @@ void deflate_labels(const uint8_t* labels, int H, int W, const uint8_t pal[4][4]
     z->assign(buf.get(), end);
 }
 
+// ---- deflate for 8-bit gray channel images (red/ green/ of split_FISH_channels) -------------------------------------------
+// cv2.imwrite without parameters encodes a PNG with the SUB filter, Z_BEST_SPEED and the Z_RLE strategy (OpenCV
+// modules/imgcodecs/src/grfmt_png.cpp): literals plus matches of distance 1 only.  This is that coder without zlib's
+// generality: every scan line is SUB-filtered (optionally of the inverted samples: cv2.bitwise_not, src/image_tools.py:143-144),
+// a byte repeated four times or more becomes one literal + distance-1 matches, everything goes out as ONE dynamic-Huffman block
+// built from the image's own symbol counts (two scans of the filtered bytes: count, then emit).  zlib's deflate_rle takes 16 ms
+// for a 1040 x 1392 noisy FISH channel, its level-1 deflate 43 ms; any inflate reproduces the rows exactly.
+template <typename Emit>
+inline void rle_scan(const uint8_t* f, size_t n, Emit&& emit) {      // emit(literal) / emit(-length) for a distance-1 match
+    size_t i = 0;
+    while (i < n) {
+        const uint8_t b = f[i];
+        emit((int)b);
+        ++i;
+        if (i + 2 < n && f[i] == b && f[i + 1] == b && f[i + 2] == b) {      // a run worth a match (>= 3 more of the same byte)
+            size_t j = i + 3;
+            while (j < n && f[j] == b) ++j;
+            size_t r = j - i;
+            while (r >= 3) {
+                size_t L = r > 258 ? 258 : r;
+                if (r - L > 0 && r - L < 3) L = r - 3;                       // never leave a tail shorter than a match
+                emit(-(int)L);
+                r -= L;
+            }
+            i = j - r;                                                      // (r == 0 here by construction)
+        }
+    }
+}
+
+void deflate_gray_sub(const uint8_t* px, int H, int W, size_t pixel_stride, size_t row_stride, bool invert, std::vector<uint8_t>* z) {
+    const size_t line = (size_t)W + 1, n = (size_t)H * line;
+    std::unique_ptr<uint8_t[]> f(new uint8_t[n + 8]);
+    const uint8_t x = invert ? 0xff : 0x00;
+    for (int y = 0; y < H; ++y) {
+        uint8_t* d = f.get() + (size_t)y * line;
+        const uint8_t* s = px + (size_t)y * row_stride;
+        d[0] = 1;                                                           // filter type SUB
+        uint8_t prev = 0;
+        for (int i = 0; i < W; ++i) { const uint8_t v = (uint8_t)(s[(size_t)i * pixel_stride] ^ x); d[1 + i] = (uint8_t)(v - prev); prev = v; }
+    }
+    uint32_t freq[286] = {0};
+    bool any_match = false;
+    rle_scan(f.get(), n, [&](int t) {
+        if (t >= 0) ++freq[t];
+        else { ++freq[length_code(-t).sym]; any_match = true; }
+    });
+    freq[256] = 1;
+    uint8_t llen[286];
+    uint16_t lcode[286];
+    huffman_lengths(freq, 286, llen);
+    canonical_codes(llen, 286, lcode);
+    uint8_t cl_len[19];
+    uint16_t cl_code[19];
+    for (int i = 0; i < 19; ++i) cl_len[i] = i < 13 ? 4 : 5;                 // a fixed complete code for the code lengths, sent one by one
+    canonical_codes(cl_len, 19, cl_code);
+    std::unique_ptr<uint8_t[]> buf(new uint8_t[n * 2 + 4096]);             // <= 15 bits per literal
+    buf[0] = 0x78; buf[1] = 0x01;
+    BitWriter bw(buf.get() + 2);
+    bw.put(1, 1); bw.put(2, 2);                                             // BFINAL, BTYPE = dynamic
+    bw.put(286 - 257, 5); bw.put(1 - 1, 5); bw.put(19 - 4, 4);              // 286 literal / length codes, ONE distance code
+    static const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    for (int i = 0; i < 19; ++i) bw.put(cl_len[order[i]], 3);
+    for (int i = 0; i < 286; ++i) bw.put(cl_code[llen[i]], cl_len[llen[i]]);
+    const int d0 = any_match ? 1 : 0;                                       // distance code 0 (distance 1): a 1-bit code, bit 0
+    bw.put(cl_code[d0], cl_len[d0]);
+    // match bit strings by length: length code + extra bits + the distance code "0"
+    uint32_t mbits[259]; uint8_t mn[259];
+    for (int L = 3; L <= 258; ++L) {
+        const LenCode lc = length_code(L);
+        mbits[L] = (uint32_t)lcode[lc.sym] | ((uint32_t)lc.extra << llen[lc.sym]);
+        mn[L] = (uint8_t)(llen[lc.sym] + lc.extra_bits + 1);
+    }
+    rle_scan(f.get(), n, [&](int t) {
+        if (t >= 0) bw.put(lcode[t], llen[t]);
+        else bw.put(mbits[-t], mn[-t]);
+    });
+    bw.put(lcode[256], llen[256]);
+    uint8_t* end = bw.finish();
+    uLong ad = adler32(0L, Z_NULL, 0);
+    for (size_t off = 0; off < n; off += (1u << 30)) ad = adler32(ad, f.get() + off, (uInt)std::min<size_t>(n - off, 1u << 30));
+    *end++ = (uint8_t)(ad >> 24); *end++ = (uint8_t)(ad >> 16); *end++ = (uint8_t)(ad >> 8); *end++ = (uint8_t)ad;
+    z->assign(buf.get(), end);
+}
+
 int png_write_stream(const char* path, const std::vector<uint8_t>& z, int H, int W, int color_type) {
     File out(path, "wb");
     if (!out.f) return ECSEG_E_IO;
@@ -298,6 +397,58 @@ int png_write_stream(const char* path, const std::vector<uint8_t>& z, int H, int
     const bool ok = out.put(sig, 8) && png_chunk(out, "IHDR", ihdr, 13) && png_chunk(out, "IDAT", z.data(), z.size()) &&
                     png_chunk(out, "IEND", nullptr, 0);
     return ok && out.close() ? ECSEG_OK : ECSEG_E_IO;
+}
+
+// ---- .npy header (format 1.0 / 2.0 / 3.0) of a little-endian C-order 2-D integer array ---------------------------------------
+struct NpyHeader { long long H = 0, W = 0; int itemsize = 0; };
+int npy_parse_header(FILE* f, NpyHeader* out) {
+    uint8_t pre[12];
+    if (std::fread(pre, 1, 10, f) != 10 || std::memcmp(pre, "\x93NUMPY", 6) != 0) return ECSEG_E_INVALID;
+    size_t hlen = 0;
+    if (pre[6] == 1) hlen = (size_t)pre[8] | ((size_t)pre[9] << 8);
+    else if (pre[6] == 2 || pre[6] == 3) {
+        if (std::fread(pre + 10, 1, 2, f) != 2) return ECSEG_E_INVALID;
+        hlen = (size_t)pre[8] | ((size_t)pre[9] << 8) | ((size_t)pre[10] << 16) | ((size_t)pre[11] << 24);
+    } else return ECSEG_E_UNSUPPORTED;
+    if (hlen < 16 || hlen > (1u << 20)) return ECSEG_E_INVALID;
+    std::string h(hlen, '\0');
+    if (std::fread(&h[0], 1, hlen, f) != hlen) return ECSEG_E_INVALID;
+    auto value_after = [&](const char* key) -> size_t {                      // index just behind "'key':"
+        const size_t k = h.find(key);
+        if (k == std::string::npos) return std::string::npos;
+        const size_t c = h.find(':', k);
+        return c == std::string::npos ? c : c + 1;
+    };
+    size_t p = value_after("'descr'");
+    if (p == std::string::npos) return ECSEG_E_INVALID;
+    const size_t q0 = h.find('\'', p);
+    const size_t q1 = q0 == std::string::npos ? q0 : h.find('\'', q0 + 1);
+    if (q1 == std::string::npos) return ECSEG_E_INVALID;
+    const std::string descr = h.substr(q0 + 1, q1 - q0 - 1);
+    if (descr == "<i8" || descr == "<u8") out->itemsize = 8;
+    else if (descr == "<i4" || descr == "<u4") out->itemsize = 4;
+    else if (descr == "<i2" || descr == "<u2") out->itemsize = 2;
+    else if (descr == "|u1" || descr == "|i1" || descr == "|b1") out->itemsize = 1;
+    else return ECSEG_E_UNSUPPORTED;
+    p = value_after("'fortran_order'");
+    if (p == std::string::npos || h.find("False", p) == std::string::npos || h.find("False", p) > h.find(',', p)) return ECSEG_E_UNSUPPORTED;
+    p = value_after("'shape'");
+    if (p == std::string::npos) return ECSEG_E_INVALID;
+    const size_t a = h.find('(', p), b = a == std::string::npos ? a : h.find(')', a);
+    if (b == std::string::npos) return ECSEG_E_INVALID;
+    long long dims[3] = {0, 0, 0};
+    int nd = 0;
+    for (size_t i = a + 1; i < b;) {
+        while (i < b && (h[i] == ' ' || h[i] == ',')) ++i;
+        if (i >= b) break;
+        if (h[i] < '0' || h[i] > '9' || nd >= 3) return ECSEG_E_UNSUPPORTED;
+        long long v = 0;
+        while (i < b && h[i] >= '0' && h[i] <= '9') { v = v * 10 + (h[i] - '0'); if (v > (1ll << 31)) return ECSEG_E_INVALID; ++i; }
+        dims[nd++] = v;
+    }
+    if (nd != 2 || dims[0] <= 0 || dims[1] <= 0 || dims[0] * dims[1] >= (1ll << 31)) return ECSEG_E_UNSUPPORTED;
+    out->H = dims[0]; out->W = dims[1];
+    return ECSEG_OK;
 }
 
 // ---- TIFF reading -----------------------------------------------------------------------------------------------
@@ -411,17 +562,25 @@ int ecseg_npy_write_i64(const char* path, const uint8_t* labels, int H, int W) {
     hdr.append(pad, ' ');
     hdr.push_back('\n');
     const size_t npx = (size_t)H * W;
-    std::vector<uint8_t> buf(10 + hdr.size() + npx * 8);
     static const uint8_t magic[8] = {0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0};
-    std::memcpy(buf.data(), magic, 8);
-    buf[8] = (uint8_t)(hdr.size() & 255); buf[9] = (uint8_t)(hdr.size() >> 8);
-    std::memcpy(buf.data() + 10, hdr.data(), hdr.size());
-    uint8_t* d = buf.data() + 10 + hdr.size();                            // (not 8-byte aligned in general: byte stores)
-    std::memset(d, 0, npx * 8);
-    for (size_t i = 0; i < npx; ++i) d[8 * i] = labels[i];                // little-endian int64 of a value 0..255
+    uint8_t pre[10];
+    std::memcpy(pre, magic, 8);
+    pre[8] = (uint8_t)(hdr.size() & 255); pre[9] = (uint8_t)(hdr.size() >> 8);
     File out(path, "wb");
     if (!out.f) return ECSEG_E_IO;
-    return out.put(buf.data(), buf.size()) && out.close() ? ECSEG_OK : ECSEG_E_IO;
+    std::setvbuf(out.f, nullptr, _IONBF, 0);                              // whole chunks go straight to write(2)
+    if (!out.put(pre, 10) || !out.put(hdr.data(), hdr.size())) return ECSEG_E_IO;
+    // widened 64 Ki pixels at a time into a 512-KB buffer that stays in the L2 cache (round 5: one 11.6-MB buffer per 1040 x 1392
+    // image was allocated, zeroed twice and filled byte by byte before it went to the page cache - 8 of the 18 ms a
+    // `make metaseg` writer thread spent per image)
+    constexpr size_t CH = 1 << 16;
+    std::unique_ptr<uint64_t[]> buf(new uint64_t[CH]);
+    for (size_t off = 0; off < npx; off += CH) {
+        const size_t k = std::min(CH, npx - off);
+        for (size_t i = 0; i < k; ++i) buf[i] = labels[off + i];          // little-endian host: int64 of a value 0..255
+        if (!out.put(buf.get(), k * 8)) return ECSEG_E_IO;
+    }
+    return out.close() ? ECSEG_OK : ECSEG_E_IO;
 }
 
 // labels/<stem>.png: plt.imsave(path, I.astype('uint8'), cmap=ListedColormap(['#386cb0', '#ffff99', '#7fc97f', '#f0027f']),
@@ -439,14 +598,69 @@ int ecseg_png_write_labels(const char* path, const uint8_t* labels, int H, int W
 // 8-bit PNG of a (H, W, channels) image, channels 1 (gray), 3 (RGB) or 4 (RGBA): the red/ green/ channel images of
 // split_FISH_channels (src/image_tools.py:136-146).
 int ecseg_png_write(const char* path, const uint8_t* px, int H, int W, int channels, int level) {
-    if (!path || !px || H <= 0 || W <= 0 || (channels != 1 && channels != 3 && channels != 4) || level < 0 || level > 9) return ECSEG_E_INVALID;
+    if (!path || !px || H <= 0 || W <= 0 || (channels != 1 && channels != 3 && channels != 4) || level < -1 || level > 9) return ECSEG_E_INVALID;
     const size_t line = (size_t)W * channels, stride = 1 + line;
+    if ((size_t)H * stride >= 0xffffffffull) return ECSEG_E_INVALID;
     std::vector<uint8_t> rows((size_t)H * stride);
     for (int y = 0; y < H; ++y) {
-        rows[(size_t)y * stride] = 0;
-        std::memcpy(rows.data() + (size_t)y * stride + 1, px + (size_t)y * line, line);
+        uint8_t* dst = rows.data() + (size_t)y * stride;
+        const uint8_t* src = px + (size_t)y * line;
+        if (level >= 0) {
+            dst[0] = 0;
+            std::memcpy(dst + 1, src, line);
+        } else {                                              // filter type 1 (SUB): byte - the byte one pixel to the left
+            dst[0] = 1;
+            for (size_t i = 0; i < (size_t)channels && i < line; ++i) dst[1 + i] = src[i];
+            for (size_t i = channels; i < line; ++i) dst[1 + i] = (uint8_t)(src[i] - src[i - channels]);
+        }
     }
     return png_write_rows(path, rows, H, W, channels == 1 ? 0 : channels == 3 ? 2 : 6, level);
+}
+
+// One channel of an interleaved 8-bit image as a gray PNG, optionally inverted, encoded as cv2.imwrite does by default (SUB
+// filter + run-length deflate, deflate_gray_sub above): cv2.imwrite(red/<name>.png, cv2.bitwise_not(np.uint8(I[..., 0])))
+// (src/image_tools.py:143-144) without the channel gather / inversion passes on the Python side.
+int ecseg_png_write_channel(const char* path, const uint8_t* px, int H, int W, int channels, int channel, int invert) {
+    if (!path || !px || H <= 0 || W <= 0 || channels <= 0 || channel < 0 || channel >= channels) return ECSEG_E_INVALID;
+    if (((size_t)W + 1) * (size_t)H >= 0x7fffffffull) return ECSEG_E_INVALID;
+    std::vector<uint8_t> z;
+    deflate_gray_sub(px + channel, H, W, (size_t)channels, (size_t)W * channels, invert != 0, &z);
+    return png_write_stream(path, z, H, W, 0);
+}
+
+// np.load(labels/<stem>.npy) + astype(uint8) (read_seg, src/utils.py:125-132; src/meta_overlay.py:59): the int64 (H, W) array that
+// `make metaseg` wrote, narrowed to uint8 while it is read - 11.6 MB per 1040 x 1392 image never exist as a numpy array and the
+// interpreter lock is not held.  Accepts C-order 2-D arrays of dtype <i8 / <i4 / <i2 / |u1 / |i1 / |b1 (format 1.0 - 3.0).
+int ecseg_npy_label_info(const char* path, int* H, int* W) {
+    if (!path || !H || !W) return ECSEG_E_INVALID;
+    File in(path, "rb");
+    if (!in.f) return ECSEG_E_IO;
+    NpyHeader hd;
+    const int rc = npy_parse_header(in.f, &hd);
+    if (rc != ECSEG_OK) return rc;
+    *H = (int)hd.H; *W = (int)hd.W;
+    return ECSEG_OK;
+}
+
+int ecseg_npy_read_labels_u8(const char* path, uint8_t* dst, int H, int W) {
+    if (!path || !dst || H <= 0 || W <= 0) return ECSEG_E_INVALID;
+    File in(path, "rb");
+    if (!in.f) return ECSEG_E_IO;
+    NpyHeader hd;
+    const int rc = npy_parse_header(in.f, &hd);
+    if (rc != ECSEG_OK) return rc;
+    if (hd.H != (long long)H || hd.W != (long long)W) return ECSEG_E_INVALID;
+    const size_t n = (size_t)H * W;
+    if (hd.itemsize == 1) return std::fread(dst, 1, n, in.f) == n ? ECSEG_OK : ECSEG_E_INVALID;
+    constexpr size_t CH = 1 << 16;                                          // elements per chunk
+    std::unique_ptr<uint8_t[]> buf(new uint8_t[CH * 8]);
+    for (size_t off = 0; off < n; off += CH) {
+        const size_t k = std::min(CH, n - off);
+        if (std::fread(buf.get(), (size_t)hd.itemsize, k, in.f) != k) return ECSEG_E_INVALID;   // truncated file
+        const uint8_t* s = buf.get();
+        for (size_t i = 0; i < k; ++i) dst[off + i] = s[i * (size_t)hd.itemsize];              // little-endian: the low byte
+    }
+    return ECSEG_OK;
 }
 
 // dapi/<name>.tif: cv2.imwrite of an 8-bit gray image (src/utils.py:122-123): LZW + horizontal predictor, strips of

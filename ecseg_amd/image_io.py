@@ -359,3 +359,32 @@ def write_npy_int64(path, labels):
         return
     with open(path, 'wb') as f:
         np.save(f, lab.astype(np.int64))
+
+
+def write_png_channel(path, img, channel, invert=False):
+    """``cv2.imwrite(path, cv2.bitwise_not(np.uint8(I[..., channel])))`` (src/image_tools.py:143-144) for an interleaved uint8
+    (H, W, C) image: the channel gather, the inversion and cv2's default PNG coder (SUB filter + run-length deflate) run in
+    csrc/host_io.cpp without the interpreter lock."""
+    a = np.asarray(img)
+    if a.dtype != np.uint8 or a.ndim != 3 or not a.flags.c_contiguous or not a.size:
+        g = np.ascontiguousarray(np.uint8(a[..., channel]))
+        write_png(path, ~g if invert else g, level=-1)
+        return
+    _check_write(load_library().ecseg_png_write_channel(os.fsencode(path), a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1],
+                                                        a.shape[2], int(channel), int(bool(invert))), path)
+
+
+def read_npy_labels_u8(path):
+    """``np.load(path).astype(np.uint8)`` for the labels/<stem>.npy files `make metaseg` writes (int64, (H, W); read_seg,
+    src/utils.py:125-132), narrowed while the file is read (csrc/host_io.cpp); any other .npy layout goes through numpy."""
+    lib = load_library()
+    H, W = C.c_int(), C.c_int()
+    rc = lib.ecseg_npy_label_info(os.fsencode(path), C.byref(H), C.byref(W))
+    if rc == 0:
+        out = np.empty((H.value, W.value), np.uint8)
+        rc = lib.ecseg_npy_read_labels_u8(os.fsencode(path), out.ctypes.data_as(C.c_void_p), H.value, W.value)
+        if rc == 0:
+            return out
+    if rc == E_IO:
+        raise OSError('cannot read %s' % path)
+    return np.ascontiguousarray(np.load(path).astype(np.uint8))

@@ -50,21 +50,37 @@ def _load(p):
     I = image_io.imread(p)
     if I.ndim < 3:
         return I, None
-    seg = np.load(os.path.join(path_split[0], 'labels', path_split[1][:-4] + '.npy'))
-    return I, np.ascontiguousarray(seg.astype(np.uint8))
+    return I, image_io.read_npy_labels_u8(os.path.join(path_split[0], 'labels', path_split[1][:-4] + '.npy'))
 
 
 def _write_channels(p, I8):
     path_split = os.path.split(p)
-    image_io.write_png(os.path.join(path_split[0], 'red', path_split[1] + '.png'), ~np.uint8(I8[..., 0]), level=1)
-    image_io.write_png(os.path.join(path_split[0], 'green', path_split[1] + '.png'), ~np.uint8(I8[..., 1]), level=1)
+    image_io.write_png_channel(os.path.join(path_split[0], 'red', path_split[1] + '.png'), I8, 0, invert=True)
+    image_io.write_png_channel(os.path.join(path_split[0], 'green', path_split[1] + '.png'), I8, 1, invert=True)
 
 
-def run(inpath, handle, image_paths, sensitivity, batch_images=8, io_threads=None, log=print):
+def run(inpath, handle, image_paths, sensitivity, batch_images=8, io_threads=None, log=print, stats=None):
     """The per-image loop of src/meta_overlay.py:56-95 with the decoding (TIFF + labels/*.npy) and the red / green PNG
     encoders on worker threads and the nine counts of consecutive same-shaped images computed in one device call.  Rows
     come back in the order of ``image_paths``."""
     import concurrent.futures as cf
+    import threading
+    import time
+    t_stage = {'read': 0.0, 'write': 0.0, 'pack': 0.0, 'device': 0.0}      # thread-seconds per host stage (stats)
+    t_lock = threading.Lock()
+
+    def timed(stage, fn):
+        def wrapped(*a):
+            t0 = time.perf_counter()
+            try:
+                return fn(*a)
+            finally:
+                dt = time.perf_counter() - t0
+                with t_lock:
+                    t_stage[stage] += dt
+        return wrapped
+
+    load_fn, write_fn = timed('read', _load), timed('write', _write_channels)
     io_threads = io_threads or default_io_threads(1)
     window = max(2 * batch_images, io_threads)
     rows = [None] * len(image_paths)
@@ -75,18 +91,23 @@ def run(inpath, handle, image_paths, sensitivity, batch_images=8, io_threads=Non
         def flush(group):
             if not group:
                 return
+            t0 = time.perf_counter()
             rgb = np.stack([g[1] for g in group])
+            seg = np.stack([g[2] for g in group])
+            t1 = time.perf_counter()
             I8 = image_tools.u16_to_u8(rgb, handle=handle)   # src/image_tools.py:142
-            rec = handle.overlay(np.stack([g[2] for g in group]), np.ascontiguousarray(I8), sensitivity, HSR_SIZE_THRESHOLD)
+            rec = handle.overlay(seg, np.ascontiguousarray(I8), sensitivity, HSR_SIZE_THRESHOLD)
+            t_stage['pack'] += t1 - t0
+            t_stage['device'] += time.perf_counter() - t1
             for j, (k, _, _) in enumerate(group):
-                writes.append(writers.submit(_write_channels, image_paths[k], I8[j]))
+                writes.append(writers.submit(write_fn, image_paths[k], I8[j]))
                 rows[k] = [os.path.split(image_paths[k])[1]] + csvio.overlay_cells(rec[j])
 
         group, key = [], None
         for k, p in enumerate(image_paths):
             while next_submit < min(len(image_paths), k + window):
                 log("Processing image: ", image_paths[next_submit])
-                reads[next_submit] = readers.submit(_load, image_paths[next_submit])
+                reads[next_submit] = readers.submit(load_fn, image_paths[next_submit])
                 next_submit += 1
             I, seg = reads.pop(k).result()
             if seg is None:
@@ -103,6 +124,8 @@ def run(inpath, handle, image_paths, sensitivity, batch_images=8, io_threads=Non
         flush(group)
         for f in writes:
             f.result()
+    if stats is not None:
+        stats.update({'%s_thread_seconds' % k: v for k, v in t_stage.items()})
     return [r for r in rows if r is not None]
 
 

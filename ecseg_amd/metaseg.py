@@ -192,6 +192,21 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
     model = models[0]
     t_gpu = 0.0
     t_lock = threading.Lock()
+    # per-stage host timers (thread-seconds summed over the worker threads): where a slow `make metaseg` spends its CPU
+    t_stage = {'read': 0.0, 'write': 0.0, 'pack': 0.0}
+
+    def timed(stage, fn):
+        def wrapped(*a, **kw):
+            t0 = time.perf_counter()
+            try:
+                return fn(*a, **kw)
+            finally:
+                dt = time.perf_counter() - t0
+                with t_lock:
+                    t_stage[stage] += dt
+        return wrapped
+
+    read_fn, write_fn = timed('read', _read), timed('write', _write_outputs)
     with cf.ThreadPoolExecutor(io_threads) as readers, cf.ThreadPoolExecutor(io_threads) as writers:
         reads = {}
         next_submit = 0
@@ -200,7 +215,7 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
             nonlocal next_submit
             while next_submit < min(len(mine), upto):
                 log("Processing image: ", mine[next_submit])
-                reads[next_submit] = readers.submit(_read, mine[next_submit], resume)
+                reads[next_submit] = readers.submit(read_fn, mine[next_submit], resume)
                 next_submit += 1
 
         write_futs = []
@@ -228,7 +243,7 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
                 if tie is not None:
                     tie[k] = tie_j
                 pending_writes.acquire()
-                f = writers.submit(_write_outputs, mine[k], gray_j, post_j, log, probs_j)
+                f = writers.submit(write_fn, mine[k], gray_j, post_j, log, probs_j)
                 f.add_done_callback(lambda _f: pending_writes.release())
                 write_futs.append((k, f))
 
@@ -249,7 +264,10 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
                         status[k] = 2
 
         def pack(group):                                   # the batch array is assembled by the feeder, not by the device thread
-            return [k for k, _ in group], np.stack([im for _, im in group])
+            t0 = time.perf_counter()
+            out = [k for k, _ in group], np.stack([im for _, im in group])
+            t_stage['pack'] += time.perf_counter() - t0
+            return out
 
         gpu_threads = [threading.Thread(target=gpu_loop, args=(m,), name='ecseg-gpu%d' % i) for i, m in enumerate(models)]
         for th in gpu_threads:
@@ -288,6 +306,7 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
                 status[k] = 3
     if stats is not None:
         stats['gpu_seconds'] = t_gpu
+        stats.update({'%s_thread_seconds' % k: v for k, v in t_stage.items()})
     rec = dist.make_records(start, len(mine), per, n_ec=n_ec, status=status, tie_risk=tie)
     return dist.gather_all(rec, device=model.handle.device)        # the path's one exchange (identity for one rank)
 

@@ -265,9 +265,16 @@ long long ecseg_lzw_encode(const uint8_t* src, long long n, uint8_t* dst, long l
 int ecseg_npy_write_i64(const char* path, const uint8_t* labels, int H, int W);
 /* plt.imsave(labels/<stem>.png, I, cmap=ListedColormap([4 colours]), vmin=0, vmax=4) (src/metaseg.py:47-52): RGBA. */
 int ecseg_png_write_labels(const char* path, const uint8_t* labels, int H, int W);
-/* 8-bit gray / RGB / RGBA PNG (channels 1 / 3 / 4; zlib level 0..9): red/ and green/ of split_FISH_channels
- * (src/image_tools.py:136-146). */
+/* 8-bit gray / RGB / RGBA PNG (channels 1 / 3 / 4; zlib level 0..9, or -1: the settings of cv2.imwrite without parameters -
+ * SUB filter, Z_BEST_SPEED, Z_RLE strategy): red/ and green/ of split_FISH_channels (src/image_tools.py:136-146). */
 int ecseg_png_write(const char* path, const uint8_t* pixels, int H, int W, int channels, int level);
+/* cv2.imwrite(red/<name>.png, cv2.bitwise_not(np.uint8(I[..., c]))) (src/image_tools.py:143-144): channel `channel` of an interleaved
+ * 8-bit (H, W, channels) image as a gray PNG, inverted when invert != 0, with cv2's default encoder settings. */
+int ecseg_png_write_channel(const char* path, const uint8_t* pixels, int H, int W, int channels, int channel, int invert);
+/* np.load(labels/<stem>.npy) narrowed to uint8 while it is read (read_seg, src/utils.py:125-132; src/meta_overlay.py:59): C-order
+ * 2-D integer arrays (the int64 file `make metaseg` writes, src/metaseg.py:53); ECSEG_E_UNSUPPORTED for any other layout. */
+int ecseg_npy_label_info(const char* path, int* H, int* W);
+int ecseg_npy_read_labels_u8(const char* path, uint8_t* dst, int H, int W);
 /* cv2.imwrite(dapi/<name>.tif, gray) (src/utils.py:122-123): LZW + predictor 2, strips of 8192 / W rows; invert != 0
  * stores 255 - img (cv2.bitwise_not, src/utils.py:112). */
 int ecseg_tiff_write_gray8(const char* path, const uint8_t* img, int H, int W, int invert);

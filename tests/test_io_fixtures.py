@@ -232,3 +232,52 @@ def test_label_png_run_length_deflate_decodes_everywhere(tmp_path):
             pos += 12 + n
         rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(lab.shape[0], 1 + 4 * lab.shape[1])
         assert not rows[:, 0].any() and np.array_equal(rows[:, 1:].reshape(want.shape), want), k
+
+
+def test_channel_png_and_native_label_reader(tmp_path):
+    """Round 5 host pipeline of `make meta_overlay`: red/ green/ channel PNGs written by the library's own SUB-filter + run-length
+    deflate (cv2.imwrite's default settings; src/image_tools.py:143-144) decode with libpng (PIL) and zlib to the inverted channel,
+    for noise, flat images, runs around the 258-byte match limit and degenerate shapes; labels/<stem>.npy is read back narrowed to
+    uint8 without numpy for every integer dtype metaseg or a user may have written (src/utils.py:125-132), other layouts fall back."""
+    import struct
+    import zlib
+    from ecseg_amd import synth
+    rng = np.random.default_rng(0)
+    cases = [synth.dapi_image(5, 200, 333, rgb=True), np.zeros((3, 700, 1), np.uint8), np.full((2, 9, 4), 200, np.uint8),
+             rng.integers(0, 256, (1, 1, 3), dtype=np.uint8), rng.integers(0, 2, (40, 1031, 2), dtype=np.uint8) * 255]
+    runs = np.zeros((6, 1500, 1), np.uint8)
+    for r, n in enumerate((257, 258, 259, 260, 261, 519)):
+        runs[r, 10:10 + n + 1, 0] = 77                              # SUB-filtered: one 77 followed by n zeros
+    cases.append(runs)
+    for a in cases:
+        for c in range(a.shape[2]):
+            for inv in (False, True):
+                p = str(tmp_path / 'c.png')
+                image_io.write_png_channel(p, a, c, invert=inv)
+                want = ~a[..., c] if inv else a[..., c]
+                assert np.array_equal(np.array(Image.open(p)), want), (a.shape, c, inv)
+                raw = open(p, 'rb').read()
+                pos, idat = 8, b''
+                while pos < len(raw):
+                    n, tag = struct.unpack('>I', raw[pos:pos + 4])[0], raw[pos + 4:pos + 8]
+                    body = raw[pos + 8:pos + 8 + n]
+                    assert struct.unpack('>I', raw[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + body) & 0xffffffff
+                    idat += body if tag == b'IDAT' else b''
+                    pos += 12 + n
+                rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(a.shape[0], 1 + a.shape[1])
+                assert (rows[:, 0] == 1).all() and np.array_equal(np.cumsum(rows[:, 1:], axis=1, dtype=np.uint8), want)
+    # cv2's default settings through the generic writer too (level -1)
+    g = synth.dapi_image(6, 120, 97)
+    image_io.write_png(str(tmp_path / 'g.png'), g, level=-1)
+    assert np.array_equal(np.array(Image.open(str(tmp_path / 'g.png'))), g)
+    lab = synth.label_map(4, 130, 211)
+    p = str(tmp_path / 'l.npy')
+    image_io.write_npy_int64(p, lab)
+    assert np.array_equal(image_io.read_npy_labels_u8(p), lab) and image_io.read_npy_labels_u8(p).dtype == np.uint8
+    for dt, layout in ((np.int32, None), (np.int16, None), (np.uint8, None), (np.bool_, None), (np.int64, 'F'), (np.float32, None), ('>i4', None)):
+        arr = lab.astype(dt)
+        np.save(p, np.asfortranarray(arr) if layout == 'F' else arr)
+        assert np.array_equal(image_io.read_npy_labels_u8(p), arr.astype(np.uint8)), dt
+    open(p, 'wb').write(open(p, 'rb').read()[:300])                   # truncated: numpy's own error, not garbage
+    with pytest.raises(Exception):
+        image_io.read_npy_labels_u8(p)

@@ -13,6 +13,10 @@ extern "C" long long ecseg_lzw_encode(const uint8_t* src, long long n, uint8_t* 
 extern "C" int ecseg_tiff_write_gray8(const char* path, const uint8_t* img, int H, int W, int invert);
 extern "C" int ecseg_tiff_info(const char* path, int* H, int* W, int* spp, int* bits);
 extern "C" int ecseg_tiff_read(const char* path, void* dst, long long dst_bytes);
+extern "C" int ecseg_npy_write_i64(const char* path, const uint8_t* labels, int H, int W);
+extern "C" int ecseg_npy_label_info(const char* path, int* H, int* W);
+extern "C" int ecseg_npy_read_labels_u8(const char* path, uint8_t* dst, int H, int W);
+extern "C" int ecseg_png_write_channel(const char* path, const uint8_t* px, int H, int W, int channels, int channel, int invert);
 
 static uint64_t s = 0x9e3779b97f4a7c15ull;
 static uint32_t rnd() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (uint32_t)(s >> 11); }
@@ -90,7 +94,47 @@ int main() {
             ++files;
         }
     }
+    // .npy label files (round 5: labels/<stem>.npy is parsed natively by `make meta_overlay`): a valid file, then headers with
+    // flipped / truncated / random bytes - every outcome but a crash or a write past the destination is acceptable
+    long long npy_files = 0;
+    {
+        const int H = 37, W = 53;
+        std::vector<uint8_t> lab((size_t)H * W), back((size_t)H * W + 1, 0xCD);
+        for (auto& v : lab) v = (uint8_t)(rnd() & 3);
+        if (ecseg_npy_write_i64(path, lab.data(), H, W) != 0) { std::printf("npy write failed\n"); return 1; }
+        int h = 0, w = 0;
+        if (ecseg_npy_label_info(path, &h, &w) != 0 || h != H || w != W) { std::printf("npy info mismatch\n"); return 1; }
+        if (ecseg_npy_read_labels_u8(path, back.data(), H, W) != 0 || std::memcmp(back.data(), lab.data(), lab.size()) != 0) { std::printf("npy round trip mismatch\n"); return 1; }
+        std::vector<uint8_t> file;
+        { FILE* f = std::fopen(path, "rb"); uint8_t b[4096]; size_t k; while ((k = std::fread(b, 1, sizeof b, f)) > 0) file.insert(file.end(), b, b + k); std::fclose(f); }
+        for (int round = 0; round < 3000; ++round) {
+            std::vector<uint8_t> bad(file);
+            const int kind = round % 3;
+            if (kind == 0) for (int k = 0; k < 1 + (int)(rnd() % 4); ++k) bad[rnd() % 140] ^= (uint8_t)(1u << (rnd() % 8));     // header bit flips
+            else if (kind == 1) bad.resize(rnd() % bad.size());                                                             // truncation
+            else for (int k = 0; k < 24; ++k) bad[6 + rnd() % 120] = (uint8_t)rnd();                                        // random header bytes
+            { FILE* f = std::fopen(path, "wb"); std::fwrite(bad.data(), 1, bad.size(), f); std::fclose(f); }
+            int hh = 0, ww = 0;
+            if (ecseg_npy_label_info(path, &hh, &ww) == 0 && hh > 0 && ww > 0 && (long long)hh * ww <= (1 << 22)) {
+                std::vector<uint8_t> out((size_t)hh * ww + 1, 0xEF);
+                (void)ecseg_npy_read_labels_u8(path, out.data(), hh, ww);
+                if (out[(size_t)hh * ww] != 0xEF) { std::printf("npy reader wrote past its destination\n"); return 1; }
+            }
+            (void)ecseg_npy_read_labels_u8(path, back.data(), H, W);
+            if (back[(size_t)H * W] != 0xCD) { std::printf("npy reader wrote past its destination (fixed shape)\n"); return 1; }
+            ++npy_files;
+        }
+        // the channel PNG coder on random shapes (reads strided pixels, writes a worst-case-sized buffer)
+        for (int round = 0; round < 200; ++round) {
+            const int hh = 1 + (int)(rnd() % 40), ww = 1 + (int)(rnd() % 600), ch = 1 + (int)(rnd() % 4);
+            std::vector<uint8_t> px((size_t)hh * ww * ch);
+            const int mode = round % 3;
+            for (auto& v : px) v = mode == 0 ? (uint8_t)rnd() : mode == 1 ? (uint8_t)0 : (uint8_t)((rnd() % 50) ? 9 : rnd());
+            if (ecseg_png_write_channel(path, px.data(), hh, ww, ch, (int)(rnd() % ch), round & 1) != 0) { std::printf("png channel write failed\n"); return 1; }
+        }
+    }
     std::remove(path);
+    std::printf("npy_fuzz ok: %lld corrupt files\n", npy_files);
     std::printf("tiff_fuzz ok: %lld corrupt files\n", files);
     std::printf("codec_fuzz ok: %lld corrupt streams\n", checked);
     return 0;

@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--io-threads', type=int, default=None)
     ap.add_argument('--keep', default=None)
     ap.add_argument('--workers', type=int, default=1, help='handles (device threads) on the GPU: config key device_workers')
+    ap.add_argument('--warm-one', dest='warm_full', action='store_false', help='warm up with ONE image (rounds 1-4) instead of a full batch per handle')
     a = ap.parse_args()
     from PIL import Image
     import yaml
@@ -57,9 +58,13 @@ def main():
         warm = os.path.join(work, 'warm')
         for sub in ('', 'dapi', 'labels'):
             os.makedirs(os.path.join(warm, sub), exist_ok=True)
-        shutil.copy(os.path.join(inp, 'img0000.tif'), warm)
+        # first-use allocations (activation buffers of a full batch, post-processing workspace, pinned staging) happen once per
+        # handle in the life of a process: warm every handle with one full batch, as any job longer than a second has
+        for k in range(a.batch if a.warm_full else 1):
+            shutil.copy(os.path.join(inp, 'img0000.tif'), os.path.join(warm, 'w%03d.tif' % k))
         stats = {}
-        metaseg.run(warm, model, utils.get_imgs(warm), batch_images=a.batch, log=lambda *x: None, stats=stats)   # first-use allocations
+        for mdl in [model] + extra:
+            metaseg.run(warm, mdl, utils.get_imgs(warm), batch_images=a.batch, log=lambda *x: None, stats=stats)
         t0 = time.perf_counter()
         rec = metaseg.run(inp, [model] + extra if extra else model, utils.get_imgs(inp), batch_images=a.batch, io_threads=a.io_threads, log=lambda *x: None, stats=stats)
         dt = time.perf_counter() - t0
@@ -71,17 +76,21 @@ def main():
     for sub in ('red', 'green'):
         os.makedirs(os.path.join(inp, sub), exist_ok=True)
     t0 = time.perf_counter()
-    rows = meta_overlay.run(inp, model.handle, utils.get_imgs(inp), 85, batch_images=a.batch, io_threads=a.io_threads, log=lambda *x: None)
+    ov_stats = {}
+    rows = meta_overlay.run(inp, model.handle, utils.get_imgs(inp), 85, batch_images=a.batch, io_threads=a.io_threads, log=lambda *x: None,
+                            stats=ov_stats)
     dt_ov = time.perf_counter() - t0
     out_bytes = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(inp) for f in fs) - in_bytes
     print(json.dumps({'what': '`make metaseg` loop: %d RGB LZW TIFF files (1040x1392) -> dapi/*.tif, labels/*.png, labels/*.npy (int64), '
-                              'records' % a.n, 'images': a.n, 'unet_base': a.base, 'batch_images': a.batch, 'device_workers': a.workers,
+                              'records' % a.n, 'images': a.n, 'unet_base': a.base, 'batch_images': a.batch, 'device_workers': a.workers, 'warmup': 'one full batch per handle' if a.warm_full else 'one image',
                       'io_threads': a.io_threads or 'default', 'cpu_count': os.cpu_count(),
                       'seconds': round(dt, 3), 'images_per_s': round(a.n / dt, 2),
                       'device_call_seconds': round(stats.get('gpu_seconds', 0.0), 3),
                       'input_MB': round(in_bytes / 1e6, 1), 'output_MB': round(out_bytes / 1e6, 1),
                       'ok_images': int((rec[:, 1] == 0).sum()), 'generate_seconds': round(t_gen, 1),
-                      'meta_overlay_seconds': round(dt_ov, 3), 'meta_overlay_images_per_s': round(len(rows) / dt_ov, 2)}))
+                      'meta_overlay_seconds': round(dt_ov, 3), 'meta_overlay_images_per_s': round(len(rows) / dt_ov, 2),
+                      'host_stage_ms_per_image': {k.replace('_thread_seconds', ''): round(1e3 * v / a.n, 3) for k, v in stats.items() if k.endswith('_thread_seconds')},
+                      'overlay_host_stage_ms_per_image': {k.replace('_thread_seconds', ''): round(1e3 * v / a.n, 3) for k, v in ov_stats.items()}}))
     if not a.keep:
         shutil.rmtree(work, ignore_errors=True)
 

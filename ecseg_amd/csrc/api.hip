@@ -115,6 +115,7 @@ struct ecseg_ctx {
     int wino4_split = 1;      // F(4x4) layers with exactly 32 output channels: split-K over the channel-half waves
     int wino16 = 1;           // F(2x2) layers with 16 / 32 input and output channels: conv_wino16_kernel (16x16x4 MFMA, register output stage)
     int wino_resident = 1;    // F(2x2) layers with <= 32 input and output channels: filter-resident kernel (conv_wino_res_kernel)
+    int fuse_first = 1;       // the network's first layer (3x3, 1 -> 16 channels) computed into the halo of the 16 -> 16 convolution behind it (conv_wino16_kernel FIRST)
 
     // timing
     hipEvent_t ev[ECSEG_T_N + 1] = {};
@@ -464,10 +465,30 @@ int run_plan_op(ecseg_ctx* h, size_t& oi, int n_all, StitchPlan* crop, const Lan
         v.p += off;
         return v;
     };
+    // The network's first layer (Conv2D 3x3 'same', 1 -> 16 channels) in front of a 16 -> 16 convolution that conv_wino16_kernel
+    // takes and that is its only reader: the second convolution's launch computes the first one into its own halo (FIRST); the
+    // 16-channel tensor between them is never written.  `first` != null below: op oi - 1 rides on op oi's launch.
+    const OpRt* first = nullptr;
+    if (h->fuse_first && h->use_winograd && h->wino16 && oi + 1 < h->ops.size()) {
+        const OpRt& a = h->ops[oi];
+        const OpRt& b = h->ops[oi + 1];
+        const ecseg_tensor_desc& ta = h->tensors[a.d.in0];
+        const ecseg_tensor_desc& tm = h->tensors[a.d.out];
+        const ecseg_tensor_desc& tb = h->tensors[b.d.out];
+        auto core = [](const ecseg_op_desc& q) { return q.act <= ECSEG_ACT_ELU && q.act != ECSEG_ACT_SOFTMAX && !(q.act == ECSEG_ACT_ELU && q.alpha != 1.f); };
+        if (a.d.op == ECSEG_OP_CONV && a.path == PATH_SMALL_CIN && a.d.kh == 3 && a.d.kw == 3 && a.d.stride == 1 && a.d.pad_top == 1 &&
+            a.d.pad_left == 1 && a.d.dilation <= 1 && ta.c == 1 && ta.c_stride == 1 && tm.c == 16 && tm.h == ta.h && tm.w == ta.w && core(a.d) &&
+            b.d.op == ECSEG_OP_CONV && b.path == PATH_MFMA && b.wt_wino16 != nullptr && b.d.in0 == a.d.out && h->consumers[a.d.out] == 1 &&
+            a.d.out != h->output_tensor && b.d.kh == 3 && b.d.kw == 3 && b.d.stride == 1 && b.d.pad_top == 1 && b.d.pad_left == 1 &&
+            tb.c == 16 && tb.h == tm.h && tb.w == tm.w && tm.w % 4 == 0 && core(b.d) && !(crop && h->crop && b.crop_ok)) {
+            first = &a;
+            ++oi;
+        }
+    }
     {
         const OpRt& o = h->ops[oi];
         const ecseg_op_desc& d = o.d;
-        const TView in = at(d.in0), out = at(d.out);
+        const TView in = first ? at(first->d.in0) : at(d.in0), out = at(d.out);
         hipError_t e = hipSuccess;
         switch (d.op) {
             case ECSEG_OP_CONV:
@@ -515,7 +536,10 @@ int run_plan_op(ecseg_ctx* h, size_t& oi, int n_all, StitchPlan* crop, const Lan
                     double computed = 1.0;                     // fraction of the layer a cropped launch really computes
                     // conv_wino4 / conv_wino16 implement activation codes 0..6 with ELU's alpha = 1 (device_util.h: apply_act_core)
                     const bool act_core_ok = act <= ECSEG_ACT_ELU && !(act == ECSEG_ACT_ELU && d.alpha != 1.f);
-                    const bool wino4 = h->use_winograd >= 2 && o.wt_wino4 && act_core_ok && conv_wino4_supported(p);   // (wt_wino* exist only for stride-1 3x3 'same' layers)
+                    if (first) {
+                        p.first_w = first->wt; p.first_b = first->bias; p.first_act = first->d.act; p.first_alpha = first->d.alpha;
+                    }
+                    const bool wino4 = !first && h->use_winograd >= 2 && o.wt_wino4 && act_core_ok && conv_wino4_supported(p);   // (wt_wino* exist only for stride-1 3x3 'same' layers)
                     const bool wino = !wino4 && h->use_winograd && o.wt_wino && out.h >= 4 && out.w >= 8;
                     bool w16 = false;
                     // a 3x3 convolution of the cropped chain on a Winograd kernel reads its input only inside the receptive field
@@ -575,7 +599,7 @@ int run_plan_op(ecseg_ctx* h, size_t& oi, int n_all, StitchPlan* crop, const Lan
                         fuse_following_pool();
                         fuse_following_head(64);
                         e = launch_conv_wino4(p, s);
-                    } else if (wino && h->wino16 && o.wt_wino16 && act_core_ok && conv_wino16_supported(p)) {
+                    } else if (wino && h->wino16 && o.wt_wino16 && act_core_ok && (first ? conv_wino16_first_supported(p) : conv_wino16_supported(p))) {
                         w16 = true;
                         p.wt = o.wt_wino16;
                         if (crop && h->crop && o.crop_ok && (part || n % crop->n_pos == 0)) {
@@ -612,8 +636,10 @@ int run_plan_op(ecseg_ctx* h, size_t& oi, int n_all, StitchPlan* crop, const Lan
                         }
                         e = launch_conv_mfma(p, s);
                     }
+                    if (first && !w16 && e == hipSuccess) e = hipErrorInvalidValue;     // (the eligibility test above and the launcher's disagree)
                     if (ev) {
                         (void)hipEventRecord(ev[1], s);
+                        if (first) { h->prof_flops += first->flops * n; h->prof_exec_flops += first->flops * n * 12.0 / 9.0; }   // (9 taps padded to 12 on the MFMA)
                         h->prof_flops += o.flops * n;
                         // multiplies actually issued (sub-pixel transposed convolution: 4 taps x 4 phases per input pixel, zeros included)
                         const double ex = o.flops * n * computed * (wino4 ? 0.25 : wino ? 16.0 / 36.0 : o.subpixel ? 16.0 / (d.kh * d.kw) : 1.0);
@@ -621,7 +647,8 @@ int run_plan_op(ecseg_ctx* h, size_t& oi, int n_all, StitchPlan* crop, const Lan
                         const bool res = wino && p.resident && p.coutp == 32 && p.cin_chunks <= 4;
                         // kind: bits 0-7 the kernel, bit 8: the following 2x2 max-pool was written by this launch, bit 9: the following 1x1 head was
                         h->prof_recs.push_back({(int)oi_first, (wino4 ? 2 : w16 ? 4 : res ? 3 : wino ? 1 : 0) | (p.pool.p != nullptr ? 0x100 : 0) |
-                                                (p.head_w != nullptr ? 0x200 : 0), o.flops * n, ex, 0.f});
+                                                (p.head_w != nullptr ? 0x200 : 0) | (first ? 0x400 : 0), o.flops * n + (first ? first->flops * n : 0.0),
+                                                ex + (first ? first->flops * n * 12.0 / 9.0 : 0.0), 0.f});
                     }
                 } else if (o.path == PATH_TAP) {
                     ConvParams p{};
@@ -1083,6 +1110,7 @@ int ecseg_set_option(ecseg_ctx* h, const char* key, int value) {
     else if (k == "fuse_head") h->fuse_head = value != 0;
     else if (k == "wino_resident") h->wino_resident = value != 0;
     else if (k == "wino16") h->wino16 = value != 0;
+    else if (k == "fuse_first") h->fuse_first = value != 0;
     else if (k == "wino4_split") h->wino4_split = value != 0;
     else if (k == "crop") h->crop = value != 0;
     else if (k == "winograd") h->use_winograd = value < 0 ? 0 : value > 2 ? 2 : (int)value;   // 0 direct, 1 F(2x2), 2 F(4x4)

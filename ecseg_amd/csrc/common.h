@@ -53,6 +53,11 @@ struct ConvParams {
     // conv_wino4: 1: a layer with exactly 32 output channels splits the input channels of every 8-channel group between the
     // two channel-half waves of a transform row instead of multiplying zero padding
     int w4_split;
+    // conv_wino16 (16 -> 16 channels), round 5: first_w != null: p.in is the network's 1-channel INPUT and this launch also computes
+    // the layer in front - Conv2D 3x3 'same', 1 -> 16 channels, kernel first_w[9][16] (HWIO), bias first_b (may be null),
+    // activation first_act - on the matrix cores, straight into its own halo buffer: the 16-channel tensor between the two
+    // layers never exists in memory
+    const float* first_w; const float* first_b; int first_act; float first_alpha;
     // filter image strides in floats: [tap][chunk][half][N padded][4] with padded chunk / tap pitches (power-of-two
     // pitches put the 16 transform points of a K-chunk on the same L2 channel and set)
     long wt_chunk_stride, wt_tap_stride;
@@ -88,6 +93,7 @@ int        conv_wino_ntile(int cout);
 // relayout_wino16 (api.hip)
 hipError_t launch_conv_wino16(const ConvParams& p, hipStream_t s);
 bool       conv_wino16_supported(const ConvParams& p);
+bool       conv_wino16_first_supported(const ConvParams& p);   // with ConvParams::first_w: the network's first layer computed into the halo
 // Winograd F(4x4,3x3) (wino4_kernel.hip); p.wt = image written by winograd4_filter (api.hip)
 hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s);
 bool       conv_wino4_supported(const ConvParams& p);

@@ -61,12 +61,24 @@ __device__ __forceinline__ void w16_dma16(const float* gsrc, unsigned lds_dst) {
 // HEAD: a following 1x1 convolution with <= 4 output channels (the U-Net's softmax head) is finished by the output stage:
 // a lane holds 4 of a pixel's channels, the four lanes kq = 0..3 of a tile hold them all - partial logits per lane, a
 // reduce-scatter over the two lane bits (12 cross-lane moves), lane kq finishes pixel kq of the tile's 2 x 2.
-template <int KC, int NB, int NBUF, bool HEAD>
+// FIRST (round 5; KC = NB = NBUF = 1): p.in is the network's 1-channel input and the halo of every block is COMPUTED here - the
+// network's first layer (Conv2D 3x3 'same', 1 -> 16 channels + bias + activation) as a 16 x 16 x 12 GEMM per 16 halo pixels on the
+// same matrix cores: A = the first layer's filter (16 output channels x 9 taps, zero padded to 12 = three k-steps), B = the nine
+// neighbours of 16 halo pixels read from a raw 20 x 40 patch of the input in LDS (LDS-DMA, double buffered), D = 4 channels of
+// one pixel per lane = exactly one 16-byte slot of the halo image.  612 halo pixels = 39 groups of 16 -> 117 MFMAs per block on
+// top of the layer's own 512; in exchange the 16-channel tensor between the two layers (9.4 GB per 64 images, written by
+// conv_first_kernel and read back here) never touches HBM.
+constexpr int W16_RAW_PITCH = 40;    // raw patch: rows y0 - 2 .. y0 + 17, columns x0 - 4 .. x0 + 35 (whole 16-byte granules)
+constexpr int W16_RAW_SLOTS = 256;   // 20 rows x 10 granules = 200, padded to 4 DMA pieces
+
+template <int KC, int NB, int NBUF, bool HEAD, bool FIRST = false>
 __global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(ConvParams p, int blocks_x, int strips_y, int segs_x, int bpw) {
+    static_assert(!FIRST || (KC == 1 && NB == 1 && NBUF == 1), "the fused first layer exists for the 16 -> 16 variant");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* Hs = reinterpret_cast<f32x4*>(smem);              // [NBUF][W16_HS] halo buffer(s)
     f32x4* Fs = Hs + NBUF * W16_HS;                          // [16 points][KC][NB][64 lanes]: MFMA A fragments, 4 k-steps each
     f32x4* Hw = Fs + 16 * KC * NB * 64;                      // HEAD: [16 NB channels] x 4 classes
+    f32x4* Rs = Hw + (HEAD ? 16 * NB : 0);                   // FIRST: [2][W16_RAW_SLOTS] raw input patches
     const unsigned lds_base = (unsigned)(size_t)(w16_lptr_t)smem;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -133,13 +145,58 @@ __global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(C
         }
     };
 
+    // ---- FIRST: raw-patch DMA (waves 0..3: one 64-granule piece each) and the halo fill on the matrix cores ----
+    const unsigned raw_base = lds_base + (unsigned)((size_t)(reinterpret_cast<char*>(Rs) - smem));
+    auto dma_raw = [&](int blk, int buf) __attribute__((always_inline)) {
+        if (wave >= W16_RAW_SLOTS / 64) return;              // wave-uniform
+        int img, y0, x0;
+        block_origin(blk, img, y0, x0);
+        const int q = wave * 64 + lane, row = q / 10, gc = q - row * 10;
+        const int iy = y0 - 2 + row, ix = x0 - 4 + 4 * gc;
+        const float* src = p.zero;
+        if (q < 200 && iy >= 0 && iy < H && ix >= 0 && ix < W) src = p.in.p + ((long)img * H + iy) * W + ix;     // (W % 4 == 0: whole granules)
+        w16_dma16(src, raw_base + (unsigned)(buf * W16_RAW_SLOTS + wave * 64) * 16u);
+    };
+    // this lane's A operand (filter value of output channel lane & 15, tap 4 ks + (lane >> 4)) and tap offset in the raw patch
+    float fa[3] = {0.f, 0.f, 0.f};
+    int ftap[3] = {0, 0, 0};
+    f32x4 fbv = {0.f, 0.f, 0.f, 0.f};
+    if (FIRST) {
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const int k = 4 * ks + (lane >> 4);
+            if (k < 9) { fa[ks] = p.first_w[k * 16 + (lane & 15)]; ftap[ks] = (k / 3) * W16_RAW_PITCH + (k % 3) + 2; }
+        }
+        if (p.first_b != nullptr) fbv = *reinterpret_cast<const f32x4*>(p.first_b + 4 * (lane >> 4));
+    }
+    auto fill_halo = [&](int blk, int buf) __attribute__((always_inline)) {
+        int img, y0, x0;
+        block_origin(blk, img, y0, x0);
+        const float* R = reinterpret_cast<const float*>(Rs + buf * W16_RAW_SLOTS);
+        const int n = lane & 15, cq = lane >> 4;
+#pragma unroll 1
+        for (int grp = wave; grp < (W16_ROWS * 34 + 15) / 16; grp += 8) {      // 39 groups of 16 halo pixels
+            const int pix = min(grp * 16 + n, W16_ROWS * 34 - 1);
+            const int y = pix / 34, x = pix - y * 34;
+            const float* rp = R + y * W16_RAW_PITCH + x;     // tap (dy, dx) of halo pixel (y, x): raw row y + dy, column x + dx + 2
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ks], rp[ftap[ks]], acc, 0, 0, 0);
+            acc = apply_act4_core(acc + fbv, p.first_act, p.first_alpha);
+            const int iy = y0 - 1 + y, ix = x0 - 1 + x;
+            if (!(iy >= 0 && iy < H && ix >= 0 && ix < W)) acc = f32x4{0.f, 0.f, 0.f, 0.f};     // the second layer's zero padding
+            if (grp * 16 + n < W16_ROWS * 34) Hs[y * W16_PITCH + 4 * x + (cq ^ (((x >> 2) & 1) << 1))] = acc;
+        }
+    };
+
     // ---- prologue: the filter image (linear copy) and the first halo ----
 #pragma unroll
     for (int k = 0; k < 2 * KC * NB; ++k) {
         const int piece = wave + 8 * k;                      // 16 * KC * NB pieces in all
         w16_dma16(p.wt + ((size_t)piece * 64 + lane) * 4, lds_base + (unsigned)(NBUF * W16_HS + piece * 64) * 16u);
     }
-    dma_halo(0, 0, 0);
+    if (FIRST) dma_raw(0, 0);
+    else dma_halo(0, 0, 0);
 
     // ---- lane geometry: tile (tr, tc) of the wave's 2 x 8 tiles, channel quad kq ----
     const int m = lane & 15, kq = lane >> 4;
@@ -182,6 +239,14 @@ __global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(C
                 if (kc + 1 < KC) dma_halo(blk, kc + 1, (st + 1) & 1);
                 else dma_halo(blk + 1, 0, (st + 1) & 1);
             }
+            if (FIRST) {
+                // the next block's raw patch goes out first (its buffer was last read two blocks ago), then this block's halo is
+                // computed from the patch that landed during the previous block
+                if (blk + 1 < nblk) dma_raw(blk + 1, (blk + 1) & 1);
+                fill_halo(blk, blk & 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("s_barrier" ::: "memory");
+            }
             W16_STAMP(0);                                    // [0] DMA issue
             const f32x4* Hb = Hs + (NBUF == 2 ? (st & 1) : 0) * W16_HS;
             f32x4 d[4][4];
@@ -213,7 +278,7 @@ __global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(C
                 // every wave has its halo values in registers: the buffer is free for the next stage
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 asm volatile("s_barrier" ::: "memory");
-                if (st + 1 < nstage) {
+                if (!FIRST && st + 1 < nstage) {
                     if (kc + 1 < KC) dma_halo(blk, kc + 1, 0);
                     else dma_halo(blk + 1, 0, 0);
                 }
@@ -362,7 +427,7 @@ bool conv_wino16_supported(const ConvParams& p) {
            p.out.h >= 16 && p.out.w >= 32 && p.in.cs % 4 == 0 && p.out.cs % 4 == 0 && p.zero != nullptr;
 }
 
-template <int KC, int NB, int NBUF, bool HEAD>
+template <int KC, int NB, int NBUF, bool HEAD, bool FIRST = false>
 static hipError_t launch_conv_wino16_tt(const ConvParams& p, hipStream_t s) {
     int blocks_x = (p.out.w + 31) / 32, strips_y = (p.out.h + 15) / 16;
     int bpw = 8;                                             // blocks per workgroup walk: the filter load is amortised over them
@@ -381,14 +446,14 @@ static hipError_t launch_conv_wino16_tt(const ConvParams& p, hipStream_t s) {
     }
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    const size_t lds = ((size_t)NBUF * W16_HS + (size_t)16 * KC * NB * 64 + (HEAD ? 16 * NB : 0)) * 16;
+    const size_t lds = ((size_t)NBUF * W16_HS + (size_t)16 * KC * NB * 64 + (HEAD ? 16 * NB : 0) + (FIRST ? 2 * W16_RAW_SLOTS : 0)) * 16;
     static DeviceOnce attr_set;                              // the attribute is per device (and per template instance)
     const hipError_t ea = attr_set.run([&] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino16_kernel<KC, NB, NBUF, HEAD>),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino16_kernel<KC, NB, NBUF, HEAD, FIRST>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
     if (ea != hipSuccess) return ea;
-    hipLaunchKernelGGL((conv_wino16_kernel<KC, NB, NBUF, HEAD>), dim3((unsigned)grid), dim3(512), lds, s, p, blocks_x, strips_y, segs_x, bpw);
+    hipLaunchKernelGGL((conv_wino16_kernel<KC, NB, NBUF, HEAD, FIRST>), dim3((unsigned)grid), dim3(512), lds, s, p, blocks_x, strips_y, segs_x, bpw);
     return hipGetLastError();
 }
 
@@ -397,7 +462,19 @@ static hipError_t launch_conv_wino16_t(const ConvParams& p, hipStream_t s) {
     return p.head_w != nullptr ? launch_conv_wino16_tt<KC, NB, NBUF, true>(p, s) : launch_conv_wino16_tt<KC, NB, NBUF, false>(p, s);
 }
 
+// The fused first layer (ConvParams::first_w): p.in is the 1-channel network input, 16 output channels, whole images (no region
+// list, no need boxes), extents that are multiples of 4 pixels with 16-byte aligned rows.
+bool conv_wino16_first_supported(const ConvParams& p) {
+    return p.in.h == p.out.h && p.in.w == p.out.w && p.in.c == 1 && p.in.cs == 1 && p.out.c == 16 && p.out.h >= 16 && p.out.w >= 32 &&
+           p.out.w % 4 == 0 && p.out.cs % 4 == 0 && p.zero != nullptr && p.lut == nullptr && p.in_box == nullptr &&
+           (reinterpret_cast<uintptr_t>(p.in.p) & 15) == 0;
+}
+
 hipError_t launch_conv_wino16(const ConvParams& p, hipStream_t s) {
+    if (p.first_w != nullptr) {
+        if (!conv_wino16_first_supported(p)) return hipErrorInvalidValue;
+        return p.head_w != nullptr ? launch_conv_wino16_tt<1, 1, 1, true, true>(p, s) : launch_conv_wino16_tt<1, 1, 1, false, true>(p, s);
+    }
     // 16 -> 16: single halo buffer, two workgroups per CU (1.40 -> 1.27 / 1.27 -> 1.07 ms on the two such layers of the base-16
     // U-Net at 256 x 256, 560 windows); the other shapes need > 128 registers (a second workgroup would spill: 32 -> 16
     // measured 2.27 -> 3.71 ms) and keep the double buffer

@@ -156,7 +156,9 @@ int ecseg_set_images_per_group(ecseg_ctx* h, int n);
  * 0 (default): everything on one stream - measured equal, the MFMA convs already fill the chip), "post_chunk"
  * (images per post-processing launch set), "images_per_group", "winograd" (3x3 / stride-1 / 'same'
  * convolutions: 2 (default) Winograd F(4x4,3x3) where the layer allows it (extents % 16, Cin % 4 and >= 8, Cout % 32), else
- * F(2x2,3x3); 1: F(2x2,3x3); 0: the direct implicit-GEMM kernel; all three are fp32 MFMA kernels), "wino16" (1 (default):
+ * F(2x2,3x3); 1: F(2x2,3x3); 0: the direct implicit-GEMM kernel; all three are fp32 MFMA kernels), "fuse_first" (1 (default): the network's first layer - Conv2D 3x3 'same', 1 -> 16 channels - is computed
+ * by the 16 -> 16 conv_wino16_kernel convolution behind it, on the matrix cores, straight into that kernel's halo buffer; the 16-channel tensor
+ * between the two never exists in memory; 0: conv_first_kernel writes it), "wino16" (1 (default):
  * F(2x2,3x3) layers with 16 or 32 input and output channels and extents >= 16 x 32 take conv_wino16_kernel - 16x16x4 MFMAs,
  * register output stage; 0: the 32-wide F(2x2) kernels), "wino_resident" (1 (default): the remaining F(2x2) layers with <= 32
  * input and <= 32 output channels keep their filter in registers and walk a tile row; 0: the streaming F(2x2) kernel - the
@@ -244,7 +246,8 @@ int ecseg_get_conv_executed_flops(ecseg_ctx* h, double* flops);
  * FLOPs.  kind bits 0-7 = kernel family (0 direct implicit GEMM conv_mfma_kernel, 1 Winograd F(2x2,3x3) conv_wino_kernel,
  * 2 Winograd F(4x4,3x3) conv_wino4_kernel, 3 filter-resident F(2x2) conv_wino_res_kernel, 4 F(2x2) on 16x16x4 MFMAs
  * conv_wino16_kernel); bit 8 (0x100): the launch also wrote the 2x2 max-pool that follows in the plan; bit 9 (0x200): it
- * also finished the 1x1 head that follows (the convolution's own output was not written).  Returns the number of records
+ * also finished the 1x1 head that follows (the convolution's own output was not written); bit 10 (0x400): it also computed the
+ * network's first layer (the plan operator in front of op_index) into its own halo ("fuse_first").  Returns the number of records
  * written (<= max_records) or a negative error. */
 int ecseg_get_conv_launch_profile(ecseg_ctx* h, int max_records, int32_t* op_index, int32_t* kind, float* ms,
                                   double* flops, double* executed_flops);

@@ -477,10 +477,10 @@ int run_plan_op(ecseg_ctx* h, size_t& oi, int n_all, StitchPlan* crop, const Lan
         const ecseg_tensor_desc& tb = h->tensors[b.d.out];
         auto core = [](const ecseg_op_desc& q) { return q.act <= ECSEG_ACT_ELU && q.act != ECSEG_ACT_SOFTMAX && !(q.act == ECSEG_ACT_ELU && q.alpha != 1.f); };
         if (a.d.op == ECSEG_OP_CONV && a.path == PATH_SMALL_CIN && a.d.kh == 3 && a.d.kw == 3 && a.d.stride == 1 && a.d.pad_top == 1 &&
-            a.d.pad_left == 1 && a.d.dilation <= 1 && ta.c == 1 && ta.c_stride == 1 && tm.c == 16 && tm.h == ta.h && tm.w == ta.w && core(a.d) &&
+            a.d.pad_left == 1 && a.d.dilation <= 1 && ta.c == 1 && ta.c_stride == 1 && (tm.c == 16 || tm.c == 32) && tm.h == ta.h && tm.w == ta.w && core(a.d) &&
             b.d.op == ECSEG_OP_CONV && b.path == PATH_MFMA && b.wt_wino16 != nullptr && b.d.in0 == a.d.out && h->consumers[a.d.out] == 1 &&
             a.d.out != h->output_tensor && b.d.kh == 3 && b.d.kw == 3 && b.d.stride == 1 && b.d.pad_top == 1 && b.d.pad_left == 1 &&
-            tb.c == 16 && tb.h == tm.h && tb.w == tm.w && tm.w % 4 == 0 && core(b.d) && !(crop && h->crop && b.crop_ok)) {
+            tb.c == tm.c && tb.h == tm.h && tb.w == tm.w && tm.w % 4 == 0 && core(b.d) && !(crop && h->crop && b.crop_ok)) {
             first = &a;
             ++oi;
         }

@@ -61,9 +61,9 @@ __device__ __forceinline__ void w16_dma16(const float* gsrc, unsigned lds_dst) {
 // HEAD: a following 1x1 convolution with <= 4 output channels (the U-Net's softmax head) is finished by the output stage:
 // a lane holds 4 of a pixel's channels, the four lanes kq = 0..3 of a tile hold them all - partial logits per lane, a
 // reduce-scatter over the two lane bits (12 cross-lane moves), lane kq finishes pixel kq of the tile's 2 x 2.
-// FIRST (round 5; KC = NB = NBUF = 1): p.in is the network's 1-channel input and the halo of every block is COMPUTED here - the
-// network's first layer (Conv2D 3x3 'same', 1 -> 16 channels + bias + activation) as a 16 x 16 x 12 GEMM per 16 halo pixels on the
-// same matrix cores: A = the first layer's filter (16 output channels x 9 taps, zero padded to 12 = three k-steps), B = the nine
+// FIRST (round 5): p.in is the network's 1-channel input and the halo of every stage is COMPUTED here - 16 channels (chunk kc) of
+// the network's first layer (Conv2D 3x3 'same', 1 -> 16 KC channels + bias + activation) as a 16 x 16 x 12 GEMM per 16 halo pixels
+// on the same matrix cores: A = the first layer's filter (16 output channels x 9 taps, zero padded to 12 = three k-steps), B = the nine
 // neighbours of 16 halo pixels read from a raw 20 x 40 patch of the input in LDS (LDS-DMA, double buffered), D = 4 channels of
 // one pixel per lane = exactly one 16-byte slot of the halo image.  612 halo pixels = 39 groups of 16 -> 117 MFMAs per block on
 // top of the layer's own 512; in exchange the 16-channel tensor between the two layers (9.4 GB per 64 images, written by
@@ -73,7 +73,6 @@ constexpr int W16_RAW_SLOTS = 256;   // 20 rows x 10 granules = 200, padded to 4
 
 template <int KC, int NB, int NBUF, bool HEAD, bool FIRST = false>
 __global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(ConvParams p, int blocks_x, int strips_y, int segs_x, int bpw) {
-    static_assert(!FIRST || (KC == 1 && NB == 1 && NBUF == 1), "the fused first layer exists for the 16 -> 16 variant");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* Hs = reinterpret_cast<f32x4*>(smem);              // [NBUF][W16_HS] halo buffer(s)
     f32x4* Fs = Hs + NBUF * W16_HS;                          // [16 points][KC][NB][64 lanes]: MFMA A fragments, 4 k-steps each
@@ -157,23 +156,24 @@ __global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(C
         if (q < 200 && iy >= 0 && iy < H && ix >= 0 && ix < W) src = p.in.p + ((long)img * H + iy) * W + ix;     // (W % 4 == 0: whole granules)
         w16_dma16(src, raw_base + (unsigned)(buf * W16_RAW_SLOTS + wave * 64) * 16u);
     };
-    // this lane's A operand (filter value of output channel lane & 15, tap 4 ks + (lane >> 4)) and tap offset in the raw patch
-    float fa[3] = {0.f, 0.f, 0.f};
-    int ftap[3] = {0, 0, 0};
-    f32x4 fbv = {0.f, 0.f, 0.f, 0.f};
-    if (FIRST) {
-#pragma unroll
-        for (int ks = 0; ks < 3; ++ks) {
-            const int k = 4 * ks + (lane >> 4);
-            if (k < 9) { fa[ks] = p.first_w[k * 16 + (lane & 15)]; ftap[ks] = (k / 3) * W16_RAW_PITCH + (k % 3) + 2; }
-        }
-        if (p.first_b != nullptr) fbv = *reinterpret_cast<const f32x4*>(p.first_b + 4 * (lane >> 4));
-    }
-    auto fill_halo = [&](int blk, int buf) __attribute__((always_inline)) {
+    // chunk kc of the first layer into halo buffer hbuf, from raw patch rbuf.  This lane's A operand: the filter value of output
+    // channel 16 kc + (lane & 15) at tap 4 ks + (lane >> 4) (re-read per fill: the wide variants have no registers to park it in)
+    auto fill_halo = [&](int blk, int kc, int hbuf, int rbuf) __attribute__((always_inline)) {
         int img, y0, x0;
         block_origin(blk, img, y0, x0);
-        const float* R = reinterpret_cast<const float*>(Rs + buf * W16_RAW_SLOTS);
+        const float* R = reinterpret_cast<const float*>(Rs + rbuf * W16_RAW_SLOTS);
+        f32x4* Hd = Hs + hbuf * W16_HS;
         const int n = lane & 15, cq = lane >> 4;
+        float fa[3];
+        int ftap[3];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const int k = 4 * ks + cq;
+            fa[ks] = k < 9 ? p.first_w[k * (16 * KC) + 16 * kc + n] : 0.f;
+            ftap[ks] = k < 9 ? (k / 3) * W16_RAW_PITCH + (k % 3) + 2 : 0;
+        }
+        f32x4 fbv = {0.f, 0.f, 0.f, 0.f};
+        if (p.first_b != nullptr) fbv = *reinterpret_cast<const f32x4*>(p.first_b + 16 * kc + 4 * cq);
 #pragma unroll 1
         for (int grp = wave; grp < (W16_ROWS * 34 + 15) / 16; grp += 8) {      // 39 groups of 16 halo pixels
             const int pix = min(grp * 16 + n, W16_ROWS * 34 - 1);
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(C
             acc = apply_act4_core(acc + fbv, p.first_act, p.first_alpha);
             const int iy = y0 - 1 + y, ix = x0 - 1 + x;
             if (!(iy >= 0 && iy < H && ix >= 0 && ix < W)) acc = f32x4{0.f, 0.f, 0.f, 0.f};     // the second layer's zero padding
-            if (grp * 16 + n < W16_ROWS * 34) Hs[y * W16_PITCH + 4 * x + (cq ^ (((x >> 2) & 1) << 1))] = acc;
+            if (grp * 16 + n < W16_ROWS * 34) Hd[y * W16_PITCH + 4 * x + (cq ^ (((x >> 2) & 1) << 1))] = acc;
         }
     };
 
@@ -235,15 +235,15 @@ __global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(C
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc, ++st) {
             // next stage's halo goes out first: it lands under this stage's MFMAs (its buffer was last read in stage st - 1)
-            if (NBUF == 2 && st + 1 < nstage) {
+            if (!FIRST && NBUF == 2 && st + 1 < nstage) {
                 if (kc + 1 < KC) dma_halo(blk, kc + 1, (st + 1) & 1);
                 else dma_halo(blk + 1, 0, (st + 1) & 1);
             }
             if (FIRST) {
-                // the next block's raw patch goes out first (its buffer was last read two blocks ago), then this block's halo is
-                // computed from the patch that landed during the previous block
-                if (blk + 1 < nblk) dma_raw(blk + 1, (blk + 1) & 1);
-                fill_halo(blk, blk & 1);
+                // the next block's raw patch goes out first (its buffer was last read two blocks ago), then this stage's halo is
+                // computed from the patch that landed during the previous block (halo buffer st & 1 was last read two stages ago)
+                if (kc == 0 && blk + 1 < nblk) dma_raw(blk + 1, (blk + 1) & 1);
+                fill_halo(blk, kc, NBUF == 2 ? (st & 1) : 0, blk & 1);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 asm volatile("s_barrier" ::: "memory");
             }
@@ -465,14 +465,16 @@ static hipError_t launch_conv_wino16_t(const ConvParams& p, hipStream_t s) {
 // The fused first layer (ConvParams::first_w): p.in is the 1-channel network input, 16 output channels, whole images (no region
 // list, no need boxes), extents that are multiples of 4 pixels with 16-byte aligned rows.
 bool conv_wino16_first_supported(const ConvParams& p) {
-    return p.in.h == p.out.h && p.in.w == p.out.w && p.in.c == 1 && p.in.cs == 1 && p.out.c == 16 && p.out.h >= 16 && p.out.w >= 32 &&
+    return p.in.h == p.out.h && p.in.w == p.out.w && p.in.c == 1 && p.in.cs == 1 && (p.out.c == 16 || p.out.c == 32) && p.out.h >= 16 && p.out.w >= 32 &&
            p.out.w % 4 == 0 && p.out.cs % 4 == 0 && p.zero != nullptr && p.lut == nullptr && p.in_box == nullptr &&
            (reinterpret_cast<uintptr_t>(p.in.p) & 15) == 0;
 }
 
 hipError_t launch_conv_wino16(const ConvParams& p, hipStream_t s) {
     if (p.first_w != nullptr) {
+        // (the first layer has as many channels as this one reads: 16 -> 16 -> 16 or 32 -> 32 -> 32, the encoder's first pair)
         if (!conv_wino16_first_supported(p)) return hipErrorInvalidValue;
+        if (p.out.c == 32) return p.head_w != nullptr ? launch_conv_wino16_tt<2, 2, 2, true, true>(p, s) : launch_conv_wino16_tt<2, 2, 2, false, true>(p, s);
         return p.head_w != nullptr ? launch_conv_wino16_tt<1, 1, 1, true, true>(p, s) : launch_conv_wino16_tt<1, 1, 1, false, true>(p, s);
     }
     // 16 -> 16: single halo buffer, two workgroups per CU (1.40 -> 1.27 / 1.27 -> 1.07 ms on the two such layers of the base-16

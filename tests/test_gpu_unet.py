@@ -451,17 +451,17 @@ def _L(cls, name, inbound, **cfg):
             'inbound_nodes': [[[i, 0, 0, {}] for i in inbound]] if inbound else []}
 
 
-@pytest.mark.parametrize('n,hw,pool', [(3, 256, True), (2, 64, True), (5, 96, False), (1, 48, False)])
-def test_first_layer_fused_into_the_wino16_halo(gpu, n, hw, pool):
-    """Round 5: the network's first layer (3x3, 1 -> 16 channels) computed by the 16 -> 16 convolution
-    behind it, on the matrix cores, into that kernel's own halo buffer (conv_wino16_kernel FIRST; option fuse_first).  Same
+@pytest.mark.parametrize('n,hw,pool,ch', [(3, 256, True, 16), (2, 64, True, 16), (5, 96, False, 16), (1, 48, False, 16), (2, 256, True, 32), (3, 80, False, 32)])
+def test_first_layer_fused_into_the_wino16_halo(gpu, n, hw, pool, ch):
+    """Round 5: the network's first layer (3x3, 1 -> 16 / 32 channels) computed by the 16 -> 16 / 32 -> 32
+    convolution behind it, on the matrix cores, into that kernel's own halo buffer (conv_wino16_kernel FIRST; option fuse_first).  Same
     arithmetic per output (9 products summed in float32, in MFMA order instead of the scalar kernel's): equal to the unfused
     plan within 1e-5 and to the oracle within 1e-3; extents that are not multiples of the 16 x 32 block, images at the batch
     ends, a fused max-pool behind it; and the fusion really happens (launch profile bit 0x400)."""
-    rng = np.random.default_rng(n * 1000 + hw)
+    rng = np.random.default_rng(n * 1000 + hw + ch)
     layers = [_L('InputLayer', 'in', [], batch_input_shape=[None, hw, hw, 1]),
-              _L('Conv2D', 'c0', ['in'], filters=16, kernel_size=[3, 3], strides=[1, 1], padding='same', activation='relu', use_bias=True),
-              _L('Conv2D', 'c1', ['c0'], filters=16, kernel_size=[3, 3], strides=[1, 1], padding='same', activation='relu', use_bias=True)]
+              _L('Conv2D', 'c0', ['in'], filters=ch, kernel_size=[3, 3], strides=[1, 1], padding='same', activation='relu', use_bias=True),
+              _L('Conv2D', 'c1', ['c0'], filters=ch, kernel_size=[3, 3], strides=[1, 1], padding='same', activation='relu', use_bias=True)]
     last = 'c1'
     if pool:
         layers.append(_L('MaxPooling2D', 'mp', ['c1'], pool_size=[2, 2], strides=[2, 2], padding='valid'))
@@ -470,9 +470,9 @@ def test_first_layer_fused_into_the_wino16_halo(gpu, n, hw, pool):
         last = 'cat'
     layers.append(_L('Conv2D', 'head', [last], filters=4, kernel_size=[1, 1], strides=[1, 1], padding='same', activation='softmax', use_bias=True))
     cfg = {'class_name': 'Functional', 'config': {'name': 'm', 'layers': layers, 'input_layers': [['in', 0, 0]], 'output_layers': [['head', 0, 0]]}}
-    cl = 32 if pool else 16
-    w = {'c0': [(rng.normal(size=(3, 3, 1, 16)) / 300).astype(np.float32), (rng.normal(size=16) * .1).astype(np.float32)],
-         'c1': [(rng.normal(size=(3, 3, 16, 16)) / 12).astype(np.float32), (rng.normal(size=16) * .1).astype(np.float32)],
+    cl = 2 * ch if pool else ch
+    w = {'c0': [(rng.normal(size=(3, 3, 1, ch)) / 300).astype(np.float32), (rng.normal(size=ch) * .1).astype(np.float32)],
+         'c1': [(rng.normal(size=(3, 3, ch, ch)) / np.sqrt(9 * ch)).astype(np.float32), (rng.normal(size=ch) * .1).astype(np.float32)],
          'head': [(rng.normal(size=(1, 1, cl, 4)) / 4).astype(np.float32), (rng.normal(size=4) * .1).astype(np.float32)]}
     x = rng.integers(0, 256, size=(n, hw, hw, 1), dtype=np.uint8)
     want = oracle_unet.forward(cfg, w, x)

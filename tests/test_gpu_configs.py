@@ -110,9 +110,17 @@ def test_bench_model_full_size_labels_vs_cpu_oracle(bench_model):
     img = synth.dapi_image(900)
     o_post, o_raw, o_probs, pos = oracle_pipeline.segment_gray(bench_model.model_config, bench_model.weights, img, batch=7,
                                                                return_intermediate=True)
-    post, nec, raw = bench_model.segment(img, want_raw=True)
+    raw, post, nec, tie, probs = bench_model.handle.segment_images(img[None], want_raw=True, want_tie_risk=True, want_probs=True)
+    raw, post, nec = raw[0], post[0], int(nec[0])
     diff = raw != o_raw
     assert int(diff.sum()) <= MAX_RAW_MISMATCH_PX_PER_IMAGE, int(diff.sum())
+    # the device's own tie-risk set (pixels whose two largest quantised probabilities differ by <= 1, from ITS stitched
+    # probabilities) bounds the disagreement: its size is what ecseg_segment_images_ex reports per image, it is at least the
+    # mismatch count, and every differing pixel lies inside it
+    qd = np.sort(quant.quantise_u8(probs[0].astype(np.float64)).astype(int), axis=-1)
+    tie_set = ((qd[..., -1] - qd[..., -2]) <= 1) & (probs[0].max(axis=-1) > 0)      # (never-written canvas pixels hold no probabilities)
+    assert int(tie[0]) == int(tie_set.sum()) and int(tie[0]) >= int(diff.sum())
+    assert not (diff & ~tie_set).any(), int((diff & ~tie_set).sum())
     if diff.any():
         q = np.sort(quant.quantise_u8(tiling.stitch(o_probs, pos))[diff].astype(int), axis=-1)
         assert (q[:, -1] - q[:, -2] <= 1).all()
@@ -256,43 +264,48 @@ def _truth_fixture(golden_dir, tag):
 
 @pytest.mark.parametrize('tag', ['random_base64', 'smooth_base64'])
 def test_labels_vs_float64_adjudicator(golden_dir, tag):
-    """Who is right where float32 evaluations disagree.  tests/golden/label_truth_<tag>.npz holds, for two
-    full-size images of a seeded base-64 model, every pixel whose FLOAT64 probabilities lie within 2.55e-5 of a change of the
-    quantised argmax, with the float64 label (tools/label_truth.py, tools/make_label_fixture.py; the largest float32 error
-    measured anywhere is 1.5e-5).  (a) Off those pixels the device - all three 3x3 kernels - and the float32 CPU oracle must
-    agree EXACTLY.  (b) On them the device may be wrong in no more pixels than measured per kernel, and in no more than the
-    float32 oracle itself plus a small allowance: the device is no further from the truth than the thing it is compared with."""
+    """Who is right where float32 evaluations disagree (32 images in the suite since round 5).
+    tests/golden/label_truth_<tag>.npz holds, for 32 full-size images of a seeded base-64 model, every pixel whose FLOAT64
+    probabilities lie within 2.55e-5 of a change of the quantised argmax, with the float64 label (tools/label_truth.py,
+    tools/make_label_fixture.py; the largest float32 error measured anywhere is 1.5e-5), the CRC-32 of the float64 label image
+    with those hard pixels blanked, and how often the float32 CPU oracle itself is wrong on them.  (a) OFF the hard pixels the
+    device - all three 3x3 kernels - must reproduce the float64 labels exactly (CRC; the float32 oracle does, in all 32 images:
+    `oracle32_off_hard_px`).  (b) ON them the device may be wrong in no more pixels per image than measured per kernel, and over
+    the 32 images in no more than the float32 oracle plus a small allowance: the device is no further from the truth than the
+    thing it is compared with.  (c) Clean-up and count are exact functions of the device's raw labels."""
     if not os.path.exists(os.path.join(golden_dir, 'label_truth_%s.npz' % tag)):
         pytest.skip('fixture %s not built' % tag)
+    import zlib
     from ecseg_amd._lib import Handle
     z, cfg, weights = _truth_fixture(golden_dir, tag)
     n = int(z['images'])
+    assert n >= 32 and int(z['oracle32_off_hard_px'].sum()) == 0
     imgs = np.stack([synth.dapi_image(int(z['seed0']) + i) for i in range(n)])
-    refs = [oracle_pipeline.segment_gray(cfg, weights, im, batch=7, return_intermediate=True)[1] for im in imgs]
     bound = MAX_WRONG_PX_PER_IMAGE_SMOOTH if tag.startswith('smooth') else MAX_WRONG_PX_PER_IMAGE
+    oracle_wrong = int(z['oracle32_wrong_on_hard_px'].sum())
     hnd = Handle(0)
     try:
         hnd.load_plan(keras_plan.build_plan(cfg, weights))
-        oracle_wrong = 0
-        hard, truth = [], []
-        for i in range(n):
-            hard.append(z['idx_%d' % i].astype(np.int64)); truth.append(z['truth_%d' % i])
-            oracle_wrong += int((refs[i].ravel()[hard[i]] != truth[i]).sum())
+        hard = [z['idx_%d' % i].astype(np.int64) for i in range(n)]
+        truth = [z['truth_%d' % i] for i in range(n)]
         for mode in (2, 1, 0):
             hnd.set_option('winograd', mode)
             raw, post, nec = hnd.segment_images(imgs, want_raw=True)
-            wrong = 0
+            wrong, crc_bad = 0, []
             for i in range(n):
-                easy = np.ones(raw[i].size, bool)
-                easy[hard[i]] = False
-                # (one pixel of slack: the float32 oracle's own worst error, 2.6e-5 on the smooth model, reaches the hard-set bound)
-                off = int((raw[i].ravel()[easy] != refs[i].ravel()[easy]).sum())
-                assert off <= 1, (tag, mode, i, off, 'device != oracle off the hard pixels')
-                w = int((raw[i].ravel()[hard[i]] != truth[i]).sum())
+                flat = raw[i].ravel().copy()
+                w = int((flat[hard[i]] != truth[i]).sum())
                 assert w <= bound[mode], (tag, mode, i, w)
                 wrong += w
-                assert np.array_equal(post[i], postproc.meta_inference(raw[i]))          # integer stages: exact on the device's labels
-            assert wrong <= oracle_wrong + 2 + n, (tag, mode, wrong, oracle_wrong)
+                flat[hard[i]] = 255
+                if zlib.crc32(flat.tobytes()) & 0xffffffff != int(z['crc_easy'][i]):
+                    crc_bad.append(i)
+                if i % 8 == 0:           # integer stages: exact on the device's labels (the oracle's clean-up takes ~0.5 s per image)
+                    assert np.array_equal(post[i], postproc.meta_inference(raw[i]))
+                    assert nec[i] == postproc.count_cc(post[i] == 3)[0]
+            # (one image of slack: the float32 oracle's own worst error on the smooth model, 2.6e-5, reaches the hard-set margin)
+            assert len(crc_bad) <= (1 if tag.startswith('smooth') else 0), (tag, mode, crc_bad, 'device != float64 off the hard pixels')
+            assert wrong <= oracle_wrong + 2 + n // 4, (tag, mode, wrong, oracle_wrong)
     finally:
         hnd.set_option('winograd', 2)
         hnd.close()

@@ -32,12 +32,26 @@ def main():
                'margin_unit': 1e-7, 'hard_below': 255, 'shape': np.array(z['raw64'].shape[1:]),
                'oracle32_wrong_px_all_images': (z['raw32'] != z['raw64']).sum(axis=(1, 2)).astype(np.int32),
                'nec64': z['nec64'][:a.images], 'nec32': z['nec32'][:a.images], 'oracle32_max_abs_dp': float(z['p32err'].max())}
+        import zlib
+        crc, off = [], []
         for i in range(a.images):
             m = z['margin64'][i].ravel()
             idx = np.flatnonzero(m < 255).astype(np.int32)
             out['idx_%d' % i] = idx
             out['truth_%d' % i] = z['raw64'][i].ravel()[idx]
             out['margin_%d' % i] = m[idx]
+            # everything OFF the hard pixels in 4 bytes: CRC-32 of the float64 labels with the hard pixels blanked (255).  Every
+            # float32 evaluation must reproduce it exactly; `oracle32_off_hard_px` says whether the float32 CPU oracle itself does
+            easy = z['raw64'][i].ravel().copy()
+            easy[idx] = 255
+            crc.append(zlib.crc32(easy.tobytes()) & 0xffffffff)
+            o32 = z['raw32'][i].ravel().copy()
+            o32[idx] = 255
+            off.append(int((o32 != easy).sum()))
+        out['crc_easy'] = np.array(crc, np.uint32)
+        out['oracle32_off_hard_px'] = np.array(off, np.int32)
+        out['oracle32_wrong_on_hard_px'] = np.array([int((z['raw32'][i].ravel()[out['idx_%d' % i]] != out['truth_%d' % i]).sum())
+                                                     for i in range(a.images)], np.int32)
         path = os.path.join(ROOT, 'tests', 'golden', 'label_truth_%s.npz' % tag)
         np.savez_compressed(path, **out)
         print(path, os.path.getsize(path), 'bytes;', [len(out['idx_%d' % i]) for i in range(a.images)], 'hard pixels')

@@ -26,6 +26,7 @@ class EcsegError(RuntimeError):
     code = None
 
 
+E_HIP = -2
 E_NOMEM = -4
 E_UNSUPPORTED, E_IO = -5, -6
 ABI_VERSION = 4           # ECSEG_ABI_VERSION of include/ecseg_hip.h this binding was written for

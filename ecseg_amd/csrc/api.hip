@@ -590,7 +590,7 @@ int run_plan_op(ecseg_ctx* h, size_t& oi, int n_all, StitchPlan* crop, const Lan
                         p.wt = o.wt_wino4; p.coutp = out.c; p.w4_split = h->wino4_split;
                         if (crop && h->crop && o.crop_ok && (part || n % crop->n_pos == 0)) {
                             const CropLut* cl = get_crop_lut(crop, o.crop_code);
-                            if (cl->len > 0 && out.h == cl->size && out.w == cl->size) {
+                            if (cl->len > 0 && out.h == cl->size && out.w == cl->size && conv_wino4_span_ok(p, crop->n_pos)) {
                                 use_lut(cl);
                                 computed = (double)cl->len / ((double)crop->n_pos * (out.h / 16) * (out.w / 16));
                             }

@@ -97,6 +97,7 @@ bool       conv_wino16_first_supported(const ConvParams& p);   // with ConvParam
 // Winograd F(4x4,3x3) (wino4_kernel.hip); p.wt = image written by winograd4_filter (api.hip)
 hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s);
 bool       conv_wino4_supported(const ConvParams& p);
+bool       conv_wino4_span_ok(const ConvParams& p, int windows);   // the halo's buffer descriptor reaches `windows` consecutive windows
 
 hipError_t launch_conv_small_cin(const TView& in, const TView& out, const float* w_hwio, const float* bias, int n,
                                  int R, int S, int pad_top, int pad_left, int act, float alpha, hipStream_t s);

@@ -630,7 +630,9 @@ __global__ __launch_bounds__(256) void count_roots_kernel(CclGeom g, const uint8
         __syncthreads();
         const size_t base = (size_t)img * g.H * g.W;
         const int yblk = y0 - (tid >> 6) * CCL_ROWS;
-        uint32_t bits = (own_bits[ti * 64 + (tid >> 2)] >> ((tid & 3) * 8)) & 0xffu;      // thread = 8 consecutive pixels of the tile
+        // thread = 8 consecutive pixels of the tile; a FULL tile (tile_any == 2: ccl_local wrote no owner bits for it) has one owner,
+        // its first pixel - no pass combines allow_full with counting today, the case is handled all the same
+        uint32_t bits = tile_any[ti] == 2 ? (tid == 0 ? 1u : 0u) : (own_bits[ti * 64 + (tid >> 2)] >> ((tid & 3) * 8)) & 0xffu;
         int nc[4] = {0, 0, 0, 0};
         while (bits) {
             const int k = __ffs((int)bits) - 1;

@@ -17,8 +17,8 @@
 // (every wave issues two pieces per group, one at a time behind pinned MFMAs; nobody waits for a piece to land; ONE
 // s_barrier per 8 channels).  The filter fragments are private to a wave (nobody else reads them), so every wave
 // streams its own 3-KB stage (6 points x 4 input channels x 32 output channels) by LDS-DMA into a private double
-// buffer, ordered by its own counted vmcnt only - no barrier on the filter path.  All LDS-DMA goes through inline asm
-// (glds16): the compiler orders every ds_read behind a builtin LDS-DMA with vmcnt(0).  The barrier sits at a different
+// buffer, ordered by its own counted vmcnt only - no barrier on the filter path.  All LDS-DMA goes through inline asm:
+// the compiler orders every ds_read behind a builtin LDS-DMA with vmcnt(0).  The barrier sits at a different
 // point of the phase sequence (transform, MFMA stage 0, MFMA stage 1) for the three waves of a SIMD (phase rotation).
 //
 // The output stage can also write the 2x2 max-pool of its result, finish a 1x1 head (<= 4 classes) and take its region
@@ -54,16 +54,10 @@ constexpr int w4_cpos(int v) { return ((v & 3) == 0 ? 0 : (v & 3) == 1 ? 5 : (v 
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// One LDS-DMA piece: 64 lanes x 16 bytes, global (per-lane address) -> LDS bytes [lds_dst + 16 * lane].  Issued through
-// inline asm on purpose: for the builtin the compiler orders every later ds_read behind the DMA with s_waitcnt vmcnt(0)
-// (it cannot tell the LDS buffers apart), which serialises a stream that is interleaved with LDS reads.  Here the
-// counted vmcnt waits in the kernel are the only ordering (lds_dst is wave-uniform; M0 is restored).
-template <int OFF>
-__device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {      // source = gsrc + OFF bytes
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%3\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst), "n"(OFF) : "memory");
-}
+// LDS-DMA (buffer_load ... lds for the halo, global_load_lds for the filter) is issued through inline asm on purpose: for the
+// builtin the compiler orders every later ds_read behind the DMA with s_waitcnt vmcnt(0) (it cannot tell the LDS buffers
+// apart), which serialises a stream that is interleaved with LDS reads.  The counted vmcnt waits in the kernel are the only
+// ordering (the LDS destination is wave-uniform; M0 is restored).
 
 // Interpolation points {0, +-a, +-b, inf} (common.h: W4_PA, W4_PB) and the constants of B^T and A^T they give:
 //   B^T rows (monic Lagrange numerators): p = 0: [a2b2, 0, -(a2+b2), 0, 1, 0]      p = inf: [0, a2b2, 0, -(a2+b2), 0, 1]
@@ -177,13 +171,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         }
     }
     // ---- halo DMA: every wave fills slots 64 k + lane, k = wave and wave + 12, two groups ahead of its use (3-deep
-    //      ring: nobody ever waits for a halo piece to land).  The per-lane source pointers are computed once and parked
-    //      in LDS (bit 0 = "advance with the channel group"; padding / out-of-image lanes point at the zero page and do
-    //      not advance): no registers held during the K loop ----
-#ifndef ECSEG_W4_BUF
-#define ECSEG_W4_BUF 1
-#endif
-#if ECSEG_W4_BUF
+    //      ring: nobody ever waits for a halo piece to land) ----
     // Round 4: the halo goes through a BUFFER descriptor - a workgroup-uniform base (the first of its two windows) in four SGPRs
     // + one 32-bit byte offset per lane and piece, kept in two registers; lanes that have to read zeros (padding, pixels outside
     // the image, the missing channel half of a Cin % 8 == 4 tail) hold an out-of-range offset and the hardware returns 0 (no zero
@@ -246,45 +234,6 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 offset:%4\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(l16), "s"(dst), "s"(g), "n"(k * 1024) : "memory");
     };
-#else
-    unsigned long long* Hd = reinterpret_cast<unsigned long long*>(Bs + 12 * 2 * W4_BWS) + tid;   // [2][768]
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int a = 64 * (wave + 12 * i) + lane;
-        unsigned long long d = (unsigned long long)(size_t)p.zero;
-        if (a < 2 * 18 * 36) {
-            const int g = a >= 648 ? 1 : 0, rem = a - g * 648;
-            const int r = rem / 36, cc = rem - r * 36;
-            const int h = cc >= 18 ? 1 : 0, c = cc - h * 18;
-            const int img = g ? r_img[1] : r_img[0];
-            const int iy = (g ? r_y0[1] : r_y0[0]) - 1 + w4_inv(r), ix = (g ? r_x0[1] : r_x0[0]) - 1 + w4_inv(c);
-            if (img >= 0 && iy >= (g ? r_by0[1] : r_by0[0]) && iy <= (g ? r_by1[1] : r_by1[0]) && ix >= (g ? r_bx0[1] : r_bx0[0]) &&
-                ix <= (g ? r_bx1[1] : r_bx1[0]))
-                d = (unsigned long long)(size_t)(p.in.p + (((size_t)img * H + iy) * W + ix) * p.in.cs + 4 * h) | 1ull | (h ? 2ull : 0ull);
-        }
-        Hd[i * 768] = d;
-    }
-    auto dma_halo_piece = [&](int grp, auto ii) __attribute__((always_inline)) {            // piece ii (0 | 1) of halo group grp (< ngroups)
-        W4_DIAG_SKIP_HALO_DMA();
-        constexpr int i = decltype(ii)::value;
-        unsigned long long d = Hd[i * 768];
-        // Cin % 8 == 4: the upper channel half of the last group does not exist - its lanes (bit 1) read the zero page
-        if (tail4 && grp == ngroups - 1 && (d & 2ull)) d = (unsigned long long)(size_t)p.zero;
-        const float* src = reinterpret_cast<const float*>((size_t)(d & ~3ull)) + (d & 1ull ? grp * 8 : 0);
-        glds16<0>(src, lds_base + (unsigned)((grp % 3) * W4_HS + 64 * (wave + 12 * i)) * 16u);
-    };
-    // ---- filter DMA: wt4[nb][stage][wave][point pair nu / 2][lane = h * 32 + cout][nu % 2][k 2], 768 floats per wave and stage ----
-    const float* w_src = p.wt + ((size_t)nb * nstages * 12 + (SPLIT ? xi : wave)) * 768 + lane * 4;
-    f32x4* Bw = Bs + wave * 2 * W4_BWS;
-    auto dma_filter_piece = [&](int stage, int buf, auto kk) __attribute__((always_inline)) {
-        W4_DIAG_SKIP_FILTER_DMA();
-        constexpr int k = decltype(kk)::value;
-        const float* g = w_src + (size_t)stage * (12 * 768);
-        // the instruction offset advances the global AND the LDS address: one M0 for the three pieces
-        glds16<k * 1024>(g, lds_base + (unsigned)(3 * W4_HS + (wave * 2 + buf) * W4_BWS) * 16u);
-    };
-
-#endif
 
     // ---- A-operand lane -> tile.  ds_read_b128 serves lanes {0-3,12-15,20-27} and {4-11,16-19,28-31} of each half
     //      in separate LDS cycles; give each of those groups the 16 tiles of ONE region ----
@@ -451,21 +400,10 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
 // Priorities (round 4, A/B on one box, per-layer tables in gpurun_out/r04_ab1): the MATRIX phases run above the transform
 // (transform 0, matrix phases 1 / 2 / 3 by rotation class): 1024 -> 512 at 32x32 13.83 -> 13.35 ms, 512 -> 512 6.92-7.11 -> 6.73-6.78,
 // every other layer +-0.5 %; the transform is latency-bound on its LDS reads and loses nothing at priority 0, a ready MFMA
-// no longer waits behind another wave's burst of 12 transform fmas.  (ECSEG_W4_PRIO=0: rounds 1-3, transform at 3, matrix
-// phases 0 / 1 / 2; =2: no priorities at all, -6 %.)
-#ifndef ECSEG_W4_PRIO
-#define ECSEG_W4_PRIO 1
-#endif
-#if ECSEG_W4_PRIO == 0
-#define W4_PT 3
-#define W4_PS(PR) (PR)
-#elif ECSEG_W4_PRIO == 1
+// no longer waits behind another wave's burst of 12 transform fmas.  (Rounds 1-3: transform at 3, matrix phases 0 / 1 / 2; no
+// priorities at all: -6 %.)
 #define W4_PT 0
 #define W4_PS(PR) ((PR) + 1)
-#else
-#define W4_PT 0
-#define W4_PS(PR) 0
-#endif
 #define W4_T(g, PR) do { __builtin_amdgcn_s_setprio(W4_PT); transform(g, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}); __builtin_amdgcn_s_setprio(W4_PS(PR)); } while (0)
     // S0(g): filter stage 2g has landed (it is the youngest thing this wave issued) -> vmcnt(0); streams stage 2g+1 and
     // the halo of group g+2.  S1(g): only the two halo pieces issued after stage 2g+1 may still fly -> vmcnt(2).
@@ -740,9 +678,16 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
 
 // Eligibility beyond "3x3, stride 1, pad 1, same size" (checked by the caller): extents multiples of 16, input channels
 // a multiple of 4 (>= 8), output channels a multiple of 32 (the filter image is zero padded to 8 / 64), 16-byte aligned views.
+// The halo goes through a raw buffer descriptor with 32-bit lane offsets relative to the lower of a workgroup's two windows and
+// 0x7fff0000 bytes of records: two neighbouring windows (whole launches) must fit that range - conv_wino4_span_ok(p, 2) - and so
+// must the windows of one image that a region list can pair (cropped launches: conv_wino4_span_ok(p, per_image), checked by the
+// caller before it hands over a list).  Beyond it the hardware would silently return zeros.
+bool conv_wino4_span_ok(const ConvParams& p, int windows) {
+    return (size_t)windows * p.in.h * p.in.w * (size_t)p.in.cs * 4 < 0x7fff0000ull;
+}
 bool conv_wino4_supported(const ConvParams& p) {
     return p.in.h == p.out.h && p.in.w == p.out.w && p.out.h % 16 == 0 && p.out.w % 16 == 0 && p.in.c % 4 == 0 &&
-           p.in.c >= 8 && p.out.c % 32 == 0 && p.in.cs % 4 == 0 && p.out.cs % 4 == 0 && p.zero != nullptr;
+           p.in.c >= 8 && p.out.c % 32 == 0 && p.in.cs % 4 == 0 && p.out.cs % 4 == 0 && p.zero != nullptr && conv_wino4_span_ok(p, 2);
 }
 
 hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s) {
@@ -751,8 +696,8 @@ hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s) {
     const size_t npairs = (nreg + 1) / 2;
     const size_t grid = npairs * (size_t)((p.out.c + 63) / 64);
     if (grid == 0) return hipSuccess;
-    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    size_t lds = (size_t)(3 * W4_HS + 12 * 2 * W4_BWS) * 16 + 2 * 768 * 8;
+    if (grid > 0x7fffffffull || !conv_wino4_span_ok(p, p.lut != nullptr ? p.per_image : 2)) return hipErrorInvalidValue;
+    size_t lds = (size_t)(3 * W4_HS + 12 * 2 * W4_BWS) * 16;
     const size_t lds_epi = (size_t)24 * W4_RPLANE * 4;
     if (lds_epi > lds) lds = lds_epi;
     void (*kern)(ConvParams, int, int, int) = conv_wino4_kernel<false, false>;

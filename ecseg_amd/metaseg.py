@@ -25,7 +25,7 @@ import numpy as np
 import yaml
 
 from . import csvio, dist, image_io
-from ._lib import E_NOMEM, EcsegError
+from ._lib import E_HIP, E_NOMEM, EcsegError
 from .utils import default_io_threads, get_imgs, load_model, save_img, tune_host_allocator
 
 MODEL_NAME = 'metaseg.h5'
@@ -149,7 +149,13 @@ def _segment_isolating(model, imgs, log, emit_probs=False):
     try:
         gray, post, nec, tie, probs = _segment_with_retry(model, imgs, log, emit_probs)
         return [(j, gray[j], post[j], int(nec[j]), int(tie[j]), None if probs is None else probs[j]) for j in range(len(imgs))], []
-    except Exception as e:
+    except EcsegError as e:
+        # only failures that can belong to ONE input are bisected (a bad argument / shape, an unsupported layout, memory for a single
+        # giant image).  A HIP runtime error is sticky - after a device fault or a lost context every sub-batch would fail again,
+        # O(n log n) doomed calls per batch and a job that "finishes" with an empty CSV - and anything that is not an EcsegError
+        # is a programming error: both end the rank (_supervise_native tears the job down).
+        if e.code == E_HIP:
+            raise
         if len(imgs) == 1:
             return [], [(0, e)]
         half = len(imgs) // 2
@@ -251,14 +257,20 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
         # images and handing results to the writers overlaps the U-Net
         batches = queue.Queue(maxsize=2 * len(models))
 
+        fatal = []                                         # a sticky device error / programming error: the rank ends after the drain
+
         def gpu_loop(m):
             while True:
                 g = batches.get()
                 if g is None:
                     return
                 try:
+                    if fatal:                              # keep draining so that the feeder never blocks; nothing reaches the device
+                        raise fatal[0]
                     flush(g, m)
                 except BaseException as e:                 # never leave the feeding loop blocked on a dead consumer
+                    if not fatal and not (isinstance(e, EcsegError) and e.code != E_HIP):
+                        fatal.append(e)
                     log("Skipping %d image(s): %r" % (len(g[0]), e))
                     for k in g[0]:
                         status[k] = 2
@@ -298,6 +310,12 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
                 batches.put(None)
             for th in gpu_threads:
                 th.join()
+        if fatal:
+            # a HIP runtime error does not go away (device fault, lost context) and a non-library exception is a bug: fail the rank
+            # loudly instead of finishing with every image marked failed and exit code 0
+            for _, f in write_futs:
+                f.cancel()
+            raise fatal[0]
         for k, f in write_futs:
             try:
                 f.result()

@@ -136,6 +136,33 @@ def test_crop_of_unread_regions_changes_nothing(hw, depth):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('base,depth,hw', [(64, 2, (600, 500)), (16, 4, (1040, 1392)), (32, 3, (300, 462))])
+def test_crop_is_exact_with_the_direct_kernels(base, depth, hw):
+    """the strongest regression oracle of the region lists and need boxes.  With winograd=0 every convolution is the
+    direct implicit-GEMM kernel - an output depends on its 3x3 support only, no Winograd tile leaks anything else into its last
+    bits - so skipping the regions nobody reads (crop=1: the cropped up-convolutions here) must leave every stitched probability,
+    label and count BIT-IDENTICAL to the uncropped plan; a box or region list one pixel too small shows up as a difference
+    instead of hiding inside the 1e-5 / near-tie tolerance of the Winograd comparison above."""
+    from ecseg_amd import keras_plan
+    from ecseg_amd._lib import Handle
+    cfg = synth.unet_config(base=base, depth=depth)
+    weights = synth.unet_weights(cfg, seed=13)
+    hnd = Handle(0)
+    try:
+        hnd.load_plan(keras_plan.build_plan(cfg, weights, fuse=True))
+        hnd.set_option('winograd', 0)
+        imgs = np.stack([synth.dapi_image(60 + i, hw[0], hw[1]) for i in range(3)])
+        hnd.set_option('crop', 0)
+        b = hnd.segment_images(imgs, want_raw=True, want_tie_risk=True, want_probs=True)
+        hnd.set_option('crop', 1)
+        a = hnd.segment_images(imgs, want_raw=True, want_tie_risk=True, want_probs=True)
+    finally:
+        hnd.close()
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.gpu
 def test_repeated_runs_are_bit_identical():
     """Race screen (tools/stress_determinism.py runs the long version): the F(4x4) kernel orders its LDS-DMA traffic with
     hand-counted vmcnt waits and one barrier per 8 channels; any mistake there shows up as run-to-run differences."""

@@ -266,3 +266,24 @@ def test_two_device_workers_give_the_same_outputs_as_one(tmp_path):
     assert all(len(m.handle.calls) > 0 for m in models), 'a worker never got a batch'
     a, b = _snapshot(one), _snapshot(two)
     assert sorted(a) == sorted(b) and all(a[k] == b[k] for k in a)
+
+
+def test_sticky_device_error_ends_the_rank_instead_of_bisecting(tmp_path):
+    """a HIP runtime error (device fault, lost context: ECSEG_E_HIP) is not a property of one image - bisecting would
+    burn O(n log n) doomed device calls per batch and the job would "finish" with every image marked failed and exit code 0.  The
+    rank raises after the first such error: one device call per worker, no bisection, the exception reaches the caller."""
+    from ecseg_amd._lib import E_HIP
+    folder = str(tmp_path / 'in')
+    make_inputs(folder, 9)
+    m = StubModel()
+    calls = []
+
+    def broken(gray):
+        calls.append(len(gray))
+        e = EcsegError('hipErrorIllegalAddress (simulated)')
+        e.code = E_HIP
+        raise e
+    m.segment = broken
+    with pytest.raises(EcsegError, match='hipErrorIllegalAddress'):
+        metaseg.run(folder, m, get_imgs(folder), 0, 1, batch_images=3, io_threads=2, log=lambda *a: None)
+    assert calls == [3], calls                                           # the first batch, once: no halves, no later batches

@@ -193,7 +193,7 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
                  resume=False, tie=None, emit_probs=False):
     # `model`: one model, or a list of models on the same GPU (config key device_workers): one device thread per model takes
     # batches from the common queue, so the host <-> device copies and the per-call synchronisation of one overlap the kernels of
-    # the other (a narrow model spends a third of a call outside its kernels: DESIGN.md 6)
+    # the other (a narrow model spends a third of a call outside its kernels: EXPERIMENTS.md 6)
     models = list(model) if isinstance(model, (list, tuple)) else [model]
     model = models[0]
     t_gpu = 0.0

@@ -62,7 +62,7 @@ def tune_host_allocator():
     11.6 MB int64 label arrays, batch stacks) from dozens of I/O threads.  With glibc's defaults every such buffer is its own
     mmap / munmap in a per-thread arena: the threads then serialise on the process-wide address-space lock and on page faults
     of fresh memory - measured on the build host (8 cores, tools/host_scaling.py): 48 images in 4.1 s with 5.1 s of system
-    time; one arena + a 32 MB mmap threshold + no trimming: 1.6 s with 0.6 s of system time.  Called once per
+    time; one arena + a 32 MB mmap threshold + no trimming: 1.6 s with 0.6 s of system time (EXPERIMENTS.md 6).  Called once per
     process before the I/O threads start; ECSEG_HOST_MALLOC=default leaves the allocator alone."""
     global _allocator_tuned
     if _allocator_tuned or os.environ.get('ECSEG_HOST_MALLOC', '').lower() == 'default':

@@ -427,7 +427,7 @@ def test_rendezvous_rejects_a_stale_file_of_another_job(tmp_path, monkeypatch):
 def test_host_cpu_budget_and_io_thread_default(monkeypatch):
     """The I/O thread pools of the file pipelines are sized by the CPUs this process may really use (affinity capped by the cgroup
     quota), shared between the ranks of the node: 4 ranks x 32 threads inside a 16-CPU quota ran at half the rate of one rank
-    (tools/host_scaling.py)."""
+    (tools/host_scaling.py, EXPERIMENTS.md 6)."""
     from ecseg_amd import utils
     n = utils.host_cpu_budget()
     assert 1 <= n <= (os.cpu_count() or 1)

@@ -15,7 +15,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 H, W = 1040, 1392
-ALG_BYTES_PER_IMAGE = 7 * H * W * 9 + 7 * H * W * 2          # DESIGN.md 5.4: 7 labellings x 13.0 MB + 7 stencils x 2.9 MB
+ALG_BYTES_PER_IMAGE = 7 * H * W * 9 + 7 * H * W * 2          # DESIGN.md 5.5: 7 labellings x 13.0 MB + 7 stencils x 2.9 MB
 
 
 def main():

@@ -274,7 +274,7 @@ def aggregate(recs):
     agg = {}
     for r in recs:
         a = agg.setdefault(r['op'], dict(kind=r['kind'] & 0xff, pool=bool(r['kind'] & 0x100), head=bool(r['kind'] & 0x200),
-                                         launches=0, ms=0.0, flops=0.0, executed=0.0))
+                                         first=bool(r['kind'] & 0x400), launches=0, ms=0.0, flops=0.0, executed=0.0))
         a['launches'] += 1; a['ms'] += r['ms']; a['flops'] += r['flops']; a['executed'] += r['executed_flops']
     return agg
 
@@ -291,7 +291,8 @@ def layer_table(model, recs, steps):
         ms = a['ms'] / a['launches']
         rows.append({'op': op, 'layer': names.get(o['out'], '?'), 'type': 'conv%dx%d' % (o['kh'], o['kw']) if o['op'] == 1 else 'convT%dx%d' % (o['kh'], o['kw']),
                      'in': [ti['h'], ti['w'], ti['c']], 'out': [to['h'], to['w'], to['c']],
-                     'kernel': KIND_NAMES[a['kind']] + (' + fused 2x2 max-pool' if a['pool'] else '') + (' + fused 1x1 head' if a['head'] else ''),
+                     'kernel': KIND_NAMES[a['kind']] + (' + fused 2x2 max-pool' if a['pool'] else '') + (' + fused 1x1 head' if a['head'] else '') +
+                               (' + first 3x3 convolution computed into the halo' if a['first'] else ''),
                      'launches': a['launches'], 'avg_ms': round(ms, 4),
                      'algorithmic_gflop_per_launch': round(a['flops'] / a['launches'] / 1e9, 2),
                      'executed_gflop_per_launch': round(a['executed'] / a['launches'] / 1e9, 2),
@@ -308,9 +309,12 @@ def roofline_8d(plan, recs, steps, patches_per_step, unet_ms_per_step):
     convolution, unfused head - count their direct FLOPs and are HBM-bound anyway); B_l = algorithmic fp32 bytes, every
     tensor read / written once (4 N (Hin Win Cin + Hout Wout Cout) + the kernel), scaled by the computed fraction of a
     cropped launch; a 1x1 head finished by the previous convolution's output stage counts neither its own bytes nor the
-    write of the tensor it would have read.  frac <= 1: the ideal schedule of the same layers on the same algorithms."""
+    write of the tensor it would have read, and a first convolution computed into the next layer's halo (record bit 0x400:
+    its FLOPs are in that launch's) leaves only its one-channel input and its filter - the tensor between the two never
+    exists.  frac <= 1: the ideal schedule of the same layers on the same algorithms."""
     agg = aggregate(recs)
     fused_heads = {op + 1 for op, a in agg.items() if a['head']}
+    fused_firsts = {op - 1 for op, a in agg.items() if a['first']}
     ideal_f = ideal_b = tot_f = tot_b = 0.0
     for k, o in enumerate(plan.ops):
         if o['op'] not in (1, 2) or k in fused_heads:
@@ -321,6 +325,9 @@ def roofline_8d(plan, recs, steps, patches_per_step, unet_ms_per_step):
         F = 2.0 * o['kh'] * o['kw'] * ti['c'] * to['c'] * px * n
         b_in, b_out = 4.0 * n * ti['h'] * ti['w'] * ti['c'], 4.0 * n * to['h'] * to['w'] * to['c']
         b_w = 4.0 * plan.weights[o['w0']].size
+        if k in fused_firsts:                       # executed inside op k + 1's launch: its input and filter are all that moves
+            tot_b += b_in + b_w; ideal_b += (b_in + b_w) / (PEAK_HBM_GBS * 1e9)
+            continue
         a = agg.get(k)
         if a is not None:
             issued = a['flops'] * KIND_ISSUED[a['kind']]
@@ -328,6 +335,8 @@ def roofline_8d(plan, recs, steps, patches_per_step, unet_ms_per_step):
             F = a['executed'] / steps
             if a['head']:
                 b_out = 0.0
+            if a['first']:
+                b_in = 0.0
             b_in, b_out = b_in * computed, b_out * computed
         B = b_in + b_out + b_w
         tf, tb = F / (PEAK_FP32_MFMA_TFLOPS * 1e12), B / (PEAK_HBM_GBS * 1e9)

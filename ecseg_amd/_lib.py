@@ -2,6 +2,7 @@
 or no MI355X is visible, every entry point raises."""
 import ctypes as C
 import os
+import time
 
 import numpy as np
 
@@ -13,6 +14,7 @@ EXPORTS = [
     'ecseg_abi_version', 'ecseg_create', 'ecseg_destroy', 'ecseg_last_error', 'ecseg_device_name', 'ecseg_stream',
     'ecseg_model_load', 'ecseg_model_flops_per_patch', 'ecseg_forward_patches', 'ecseg_forward_patches_f32', 'ecseg_read_tensor',
     'ecseg_segment_images', 'ecseg_segment_images_ex', 'ecseg_segment_images_dev', 'ecseg_set_images_per_group', 'ecseg_set_option', 'ecseg_preprocess', 'ecseg_u16_to_u8',
+    'ecseg_meta_segment', 'ecseg_host_alloc', 'ecseg_host_free',
     'ecseg_stitch_argmax', 'ecseg_meta_inference', 'ecseg_meta_inference_dev', 'ecseg_count_cc', 'ecseg_ccl_labels',
     'ecseg_count_colocalization', 'ecseg_count_hsr', 'ecseg_overlay', 'ecseg_get_timings',
     'ecseg_set_kernel_profiling', 'ecseg_get_conv_profile', 'ecseg_get_conv_executed_flops', 'ecseg_get_conv_launch_profile', 'ecseg_debug_peek', 'ecseg_lzw_decode', 'ecseg_lzw_encode',
@@ -29,7 +31,7 @@ class EcsegError(RuntimeError):
 E_HIP = -2
 E_NOMEM = -4
 E_UNSUPPORTED, E_IO = -5, -6
-ABI_VERSION = 4           # ECSEG_ABI_VERSION of include/ecseg_hip.h this binding was written for
+ABI_VERSION = 5           # ECSEG_ABI_VERSION of include/ecseg_hip.h this binding was written for
 
 
 class TensorDesc(C.Structure):
@@ -81,6 +83,9 @@ def load_library():
     lib.ecseg_set_option.argtypes = [vp, C.c_char_p, i32]
     lib.ecseg_preprocess.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
     lib.ecseg_u16_to_u8.argtypes = [vp, vp, C.c_longlong, vp]
+    lib.ecseg_meta_segment.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
+    lib.ecseg_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.ecseg_host_free.argtypes = [vp, vp]
     lib.ecseg_stitch_argmax.argtypes = [vp, vp, i32, i32, i32, vp]
     lib.ecseg_meta_inference.argtypes = [vp, u8p, i32, i32, i32, vp, vp]
     lib.ecseg_meta_inference_dev.argtypes = [vp, u8p, i32, i32, i32, vp, vp]
@@ -150,9 +155,14 @@ class Handle:
         self.device = int(device)
         self.plan = None
         self.images_per_group = 0          # 0: automatic (ecseg_set_images_per_group)
+        self.native_seconds = 0.0          # time spent inside ecseg_meta_segment (stage report of `make metaseg`)
+        self._pinned = {}                  # page-locked host buffers of host_empty: array address -> allocation
 
     def close(self):
         if getattr(self, 'h', None):
+            for p in list(getattr(self, '_pinned', {}).values()):
+                self.lib.ecseg_host_free(self.h, C.c_void_p(p))
+            self._pinned = {}
             self.lib.ecseg_destroy(self.h)
             self.h = None
 
@@ -274,6 +284,46 @@ class Handle:
         self._check(self.lib.ecseg_preprocess(self.h, _ptr(a), n, H, W, Cc, a.dtype.itemsize, _ptr(gray), _ptr(inv)),
                     'ecseg_preprocess')
         return gray, inv
+
+    def meta_segment(self, imgs, gray_out=None, post_out=None):
+        """(n, H, W[, C]) uint8 / uint16 raw images -> (gray, post-processed labels, n_ec, tie_risk): meta_preprocess + the
+        segment pipeline in one device call (ecseg_meta_segment).  ``gray_out`` / ``post_out``: (n, H, W) uint8 arrays to
+        fill (e.g. page-locked ones from ``host_empty``)."""
+        a = np.ascontiguousarray(imgs)
+        if a.dtype not in (np.uint8, np.uint16):
+            raise TypeError('meta_preprocess takes uint8 or uint16 images, got %s' % a.dtype)
+        if a.ndim == 3:
+            a = a[..., None]
+        n, H, W, Cc = a.shape
+        outs = []
+        for o in (gray_out, post_out):
+            if o is None:
+                o = np.empty((n, H, W), np.uint8)
+            elif o.shape != (n, H, W) or o.dtype != np.uint8 or not o.flags.c_contiguous:
+                raise ValueError('output buffers must be C-contiguous uint8 arrays of shape %s' % ((n, H, W),))
+            outs.append(o)
+        nec = np.zeros(n, np.int32); tie = np.zeros(n, np.int32)
+        t0 = time.perf_counter()
+        rc = self.lib.ecseg_meta_segment(self.h, _ptr(a), n, H, W, Cc, a.dtype.itemsize, _ptr(outs[0]), _ptr(outs[1]), _ptr(nec), _ptr(tie))
+        self.native_seconds += time.perf_counter() - t0    # (inside the library, GIL released: `make metaseg`'s stage report)
+        self._check(rc, 'ecseg_meta_segment')
+        return outs[0], outs[1], nec, tie
+
+    def host_empty(self, shape, dtype=np.uint8):
+        """An uninitialised numpy array in page-locked host memory (ecseg_host_alloc).  The memory belongs to the handle: it is
+        released by ``host_release(array)`` or when the handle closes, and must not be used after that."""
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        p = C.c_void_p()
+        self._check(self.lib.ecseg_host_alloc(self.h, max(nbytes, 1), C.byref(p)), 'ecseg_host_alloc')
+        arr = np.ctypeslib.as_array((C.c_uint8 * max(nbytes, 1)).from_address(p.value))[:nbytes].view(dtype).reshape(shape)
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_release(self, arr):
+        p = self._pinned.pop(arr.ctypes.data, None)
+        if p is not None and self.h:
+            self._check(self.lib.ecseg_host_free(self.h, C.c_void_p(p)), 'ecseg_host_free')
 
     def u16_to_u8(self, a):
         a = np.ascontiguousarray(a, np.uint16)

@@ -1,6 +1,7 @@
 // C ABI of libecseg_hip.so (see include/ecseg_hip.h).  Host-side orchestration only: buffer management, the layer plan
 // interpreter, the image pipeline (tile -> U-Net -> stitch/argmax -> meta_inference -> count) and timing.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -906,6 +907,10 @@ int check_model(ecseg_ctx* h) {
     return ECSEG_OK;
 }
 
+bool debug_calls() { static const bool on = getenv("ECSEG_DEBUG_CALLS") != nullptr; return on; }
+
+double dbg_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 float stage_elapsed(hipEvent_t a, hipEvent_t b) {
     float t = 0.f;
     return hipEventElapsedTime(&t, a, b) == hipSuccess ? t : 0.f;
@@ -915,6 +920,7 @@ float stage_elapsed(hipEvent_t a, hipEvent_t b) {
 // probs_host (optional): the stitched float32 probabilities of every image, copied out group by group.
 int segment_dev(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint8_t* raw, uint8_t* post, int32_t* n_ec,
                 float* probs_host = nullptr) {
+    const double tq00 = dbg_now();
     int rc = check_model(h);
     if (rc) return rc;
     if ((rc = ensure(h, h->d_tie, h->d_tie_cap, (size_t)n_img))) return rc;
@@ -951,6 +957,7 @@ int segment_dev(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint
     }
     const std::vector<hipEvent_t>& evs = h->grp_events;
     size_t used = 0;
+    const double tq0 = dbg_now();
     for (int i0 = 0; i0 < n_img; i0 += grp) {
         const int ni = std::min(grp, n_img - i0);
         const hipEvent_t* e6 = &evs[used];
@@ -1011,8 +1018,13 @@ int segment_dev(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint
         HIP_TRY(h, post_run(h, post + (size_t)i0 * px, ni, H, W, n_ec ? n_ec + i0 : nullptr, s2));
         HIP_TRY(h, hipEventRecord(e6[5], s2));
     }
+    const double tq1 = dbg_now();
     HIP_TRY(h, hipStreamSynchronize(s));
     HIP_TRY(h, hipStreamSynchronize(s2));
+    const double tq2 = dbg_now();
+    // ECSEG_DEBUG_CALLS: host-side timeline of the call on stderr (a `make metaseg` whose device calls take longer than their
+    // kernels: is the host late with the launches, or is the wait long - e.g. a throttled CPU quota - ?)
+    if (debug_calls()) fprintf(stderr, "[segment_dev] setup %.2f enqueue %.2f wait %.2f ms\n", tq0 - tq00, tq1 - tq0, tq2 - tq1);
     for (size_t k = 0; k + 5 < used; k += 6) {
         h->stage_ms[ECSEG_T_TILE] += stage_elapsed(evs[k], evs[k + 1]);
         h->stage_ms[ECSEG_T_UNET] += stage_elapsed(evs[k + 1], evs[k + 2]);
@@ -1522,6 +1534,72 @@ int ecseg_preprocess(ecseg_ctx* h, const void* img, int n_img, int H, int W, int
     HIP_TRY(h, hipStreamSynchronize(s));
     for (float& v : h->stage_ms) v = 0.f;
     h->stage_ms[ECSEG_T_COUNT] = stage_elapsed(h->ev[0], h->ev[1]);
+    return ECSEG_OK;
+}
+
+// meta_segment of a batch in ONE call (src/utils.py:105-124 minus the file I/O, + src/metaseg.py:46): the raw images go up
+// once, the pre-processed images never leave the device between meta_preprocess and the U-Net (the two-call sequence
+// ecseg_preprocess + ecseg_segment_images_ex downloads them, synchronises and uploads them again), and their copy back
+// to the host (dapi/<name> is written from it) travels on the second stream under the U-Net.
+int ecseg_meta_segment(ecseg_ctx* h, const void* img, int n_img, int H, int W, int C, int bps, uint8_t* gray_out, uint8_t* post,
+                       int32_t* n_ec, int32_t* tie_risk) {
+    if (!h) return ECSEG_E_INVALID;
+    if (n_img < 0 || H <= 0 || W <= 0 || (C != 1 && C != 3 && C != 4) || (bps != 1 && bps != 2) || (n_img > 0 && (!img || !post)))
+        return fail(h, ECSEG_E_INVALID, "meta_segment: bad arguments");
+    if (n_img == 0) return ECSEG_OK;
+    int rc = check_model(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t px = (size_t)H * W, tot = px * n_img, in_bytes = tot * C * bps;
+    if ((rc = ensure(h, h->d_aux8, h->d_aux8_cap, in_bytes))) return rc;
+    if ((rc = ensure(h, h->d_gray, h->d_gray_cap, tot))) return rc;
+    if ((rc = ensure(h, h->d_raw, h->d_raw_cap, tot))) return rc;
+    if ((rc = ensure(h, h->d_post, h->d_post_cap, tot))) return rc;
+    if ((rc = ensure(h, h->d_i32, h->d_i32_cap, (size_t)2 * n_img))) return rc;       // counts, then the inverted flags
+    if ((rc = ensure(h, h->d_hist, h->d_hist_cap, (size_t)n_img * 256))) return rc;
+    hipStream_t s = h->stream, sc = h->stream2;
+    const double t0 = dbg_now();
+    HIP_TRY(h, hipMemcpyAsync(h->d_aux8, img, in_bytes, hipMemcpyHostToDevice, s));
+    const double t1 = dbg_now();
+    HIP_TRY(h, run_preprocess(h->d_aux8, n_img, H, W, C, bps, h->d_gray, h->d_i32 + n_img, h->d_hist, s));
+    if (gray_out) {
+        HIP_TRY(h, hipEventRecord(h->ev[2], s));
+        HIP_TRY(h, hipStreamWaitEvent(sc, h->ev[2], 0));
+        HIP_TRY(h, hipMemcpyAsync(gray_out, h->d_gray, tot, hipMemcpyDeviceToHost, sc));
+    }
+    const double t2 = dbg_now();
+    if ((rc = segment_dev(h, h->d_gray, n_img, H, W, h->d_raw, h->d_post, h->d_i32))) return rc;
+    const double t3 = dbg_now();
+    HIP_TRY(h, hipMemcpyAsync(post, h->d_post, tot, hipMemcpyDeviceToHost, s));
+    if (tie_risk) HIP_TRY(h, hipMemcpyAsync(tie_risk, h->d_tie, (size_t)n_img * 4, hipMemcpyDeviceToHost, s));
+    if (n_ec) HIP_TRY(h, hipMemcpyAsync(n_ec, h->d_i32, (size_t)n_img * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    const double t4 = dbg_now();
+    HIP_TRY(h, hipStreamSynchronize(sc));
+    const double t5 = dbg_now();
+    if (debug_calls()) fprintf(stderr, "[meta_segment n=%d] upload enqueue %.2f preprocess + gray copy enqueue %.2f segment_dev %.2f (stage timers %.2f) labels down %.2f gray wait %.2f total %.2f ms\n",
+                     n_img, t1 - t0, t2 - t1, t3 - t2, h->stage_ms[0] + h->stage_ms[1] + h->stage_ms[2] + h->stage_ms[3], t4 - t3, t5 - t4, t5 - t0);
+    return ECSEG_OK;
+}
+
+// Page-locked host memory: hipMemcpyAsync from / to it is a DMA transfer the host thread does not wait for (pageable
+// memory is staged through the runtime's own pinned chunks by the calling thread).
+int ecseg_host_alloc(ecseg_ctx* h, size_t bytes, void** out) {
+    if (!h || !out) return h ? fail(h, ECSEG_E_INVALID, "host_alloc: out is NULL") : ECSEG_E_INVALID;
+    *out = nullptr;
+    if (bytes == 0) return ECSEG_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocPortable);
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); *out = nullptr; return fail(h, ECSEG_E_NOMEM, "host_alloc: out of page-locked host memory"); }
+    HIP_TRY(h, e);
+    return ECSEG_OK;
+}
+
+int ecseg_host_free(ecseg_ctx* h, void* p) {
+    if (!h) return ECSEG_E_INVALID;
+    if (!p) return ECSEG_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipHostFree(p));
     return ECSEG_OK;
 }
 

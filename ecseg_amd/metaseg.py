@@ -10,7 +10,8 @@ node, every rank writes the outputs of its own images and rank 0 writes ``ec_qua
 of the per-image records (the reference's analogue is the implicit all-device MirroredStrategy, src/metaseg.py:33-36).
 
 Optional config keys (defaults keep the reference's behaviour): ``batch_images`` (8), ``io_threads``, ``device_ids``,
-``resume`` (false; true: images whose ``labels/<stem>.npy``, ``.png`` and ``dapi/<name>`` exist are not segmented again).
+``resume`` (false; true: images whose ``labels/<stem>.npy``, ``.png`` and ``dapi/<name>`` exist are not segmented again),
+``device_workers`` (1), ``pinned_mb`` (2048: page-locked host memory for the batch buffers; 0: none).
 """
 import concurrent.futures as cf
 import json
@@ -100,8 +101,93 @@ def _write_outputs(p, gray, post, log, probs=None):
     _replace_into(outpath + '.npy', lambda t: image_io.write_npy_int64(t, post))
 
 
-def _segment_group(model, imgs, emit_probs=False):
-    """-> gray, post, n_ec, tie_risk, probs | None (arrays over the batch)."""
+class _PinnedPool:
+    """Page-locked host buffers (Handle.host_empty) for the batches of `make metaseg`, recycled: the raw images go up and the
+    pre-processed images and labels come down as DMA transfers the device thread does not wait for (tools/experiments/
+    host_call_probe.py: a batch of 32 images on a base-16 model, 1.50 -> 1.21 ms per image).  Page-locking costs ~0.2 ms per
+    MB - five uses of a buffer - so ``get`` never allocates: a miss returns None (the caller uses ordinary memory for this
+    batch) and asks the pool's own thread for a buffer of that size, which later batches find.  Buffers are only ever
+    allocated up to ``limit_bytes``.  The pool belongs to the handle (buffers survive from one run to the next and are freed
+    with it); a run brackets its use with start() / stop()."""
+
+    def __init__(self, handle, limit_bytes):
+        self.handle, self.left = handle, int(limit_bytes)
+        self.free, self.lock = [], threading.Lock()
+        self.alloc = getattr(handle, 'host_empty', None)
+        self.requests, self.thread = None, None
+        self.hits = self.misses = 0
+
+    @classmethod
+    def of(cls, handle, limit_bytes):
+        pool = getattr(handle, '_metaseg_pool', None)
+        if pool is None:
+            pool = cls(handle, limit_bytes)
+            try:
+                handle._metaseg_pool = pool
+            except AttributeError:
+                pass
+        return pool
+
+    def start(self):
+        if self.alloc is not None and self.thread is None:
+            self.requests = queue.Queue()
+            self.thread = threading.Thread(target=self._grow, name='ecseg-pinned', daemon=True)
+            self.thread.start()
+
+    def stop(self):
+        if self.thread is not None:
+            self.requests.put(None)
+            self.thread.join()
+            self.thread = None
+
+    def _grow(self):
+        while True:
+            want = self.requests.get()
+            if want is None:
+                return
+            try:
+                b = self.alloc((want,), np.uint8)
+            except EcsegError:
+                with self.lock:
+                    self.left = 0                           # the system will not lock more pages: stop asking
+                continue
+            with self.lock:
+                self.free.append(b)
+
+    def get(self, nbytes, full_bytes=0):
+        """-> flat uint8 array of at least ``nbytes`` or None.  (A miss orders max(nbytes, full_bytes): the buffer of a partial
+        batch then serves full ones.)"""
+        if self.thread is None:
+            return None
+        with self.lock:
+            fit = [k for k, b in enumerate(self.free) if b.size >= nbytes]
+            if fit:
+                self.hits += 1
+                return self.free.pop(min(fit, key=lambda k: self.free[k].size))
+            self.misses += 1
+            want = max(int(nbytes), int(full_bytes))
+            if want <= self.left:
+                self.left -= want
+                self.requests.put(want)
+        return None
+
+    def put(self, b):
+        if b is not None:
+            with self.lock:
+                self.free.append(b)
+
+
+def _view(buf, shape, dtype=np.uint8):
+    n = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+    return buf[:n].view(dtype).reshape(shape)
+
+
+def _segment_group(model, imgs, emit_probs=False, outs=None):
+    """-> gray, post, n_ec, tie_risk, probs | None (arrays over the batch).  ``outs``: (gray, post) arrays to fill."""
+    fused = getattr(model.handle, 'meta_segment', None)
+    if fused is not None and not emit_probs:               # one device call: the pre-processed images stay on the GPU
+        gray, post, nec, tie = fused(imgs, *(outs or (None, None)))
+        return gray, post, nec, tie, None
     gray, _ = model.handle.preprocess(imgs)
     ex = getattr(model, 'segment_ex', None)
     if ex is None:                                         # a model without the extended call: no tie-risk bound, no probabilities
@@ -111,7 +197,7 @@ def _segment_group(model, imgs, emit_probs=False):
     return (gray, out[0], out[1], out[2], out[3] if emit_probs else None)
 
 
-def _segment_with_retry(model, imgs, log, emit_probs=False):
+def _segment_with_retry(model, imgs, log, emit_probs=False, outs=None):
     """GPU part of one batch.  On an out-of-memory status the internal launch group is halved, starting below what the failed
     attempt used (down to one image per launch); if that still does not fit, the batch itself is split by images (allocations
     that scale with the batch: post-processing workspace, input staging).  The handle's setting is restored afterwards, so
@@ -122,7 +208,7 @@ def _segment_with_retry(model, imgs, log, emit_probs=False):
         group = min(before, len(imgs)) if before > 0 else len(imgs)
         while True:
             try:
-                return _segment_group(model, imgs, emit_probs)
+                return _segment_group(model, imgs, emit_probs, outs)
             except EcsegError as e:
                 if e.code != E_NOMEM:
                     raise
@@ -135,19 +221,20 @@ def _segment_with_retry(model, imgs, log, emit_probs=False):
             raise EcsegError('out of device memory for a single image of shape %s' % (imgs.shape[1:],))
         half = len(imgs) // 2
         log("Out of device memory for a batch of shape %s: splitting it into %d + %d image(s)" % (imgs.shape, half, len(imgs) - half))
-        a, b = _segment_with_retry(model, imgs[:half], log, emit_probs), _segment_with_retry(model, imgs[half:], log, emit_probs)
+        lo, hi = (tuple(o[:half] for o in outs), tuple(o[half:] for o in outs)) if outs else (None, None)
+        a, b = _segment_with_retry(model, imgs[:half], log, emit_probs, lo), _segment_with_retry(model, imgs[half:], log, emit_probs, hi)
         return tuple(None if x is None else np.concatenate([x, y]) for x, y in zip(a, b))
     finally:
         h.set_images_per_group(before)
 
 
-def _segment_isolating(model, imgs, log, emit_probs=False):
+def _segment_isolating(model, imgs, log, emit_probs=False, outs=None):
     """GPU part of one batch with per-image failure isolation (a per-image status): a batch that fails for any reason
     other than memory (_segment_with_retry deals with that) is bisected until the failing image(s) stand alone - one bad image
     costs one status-2 row, not the whole batch.  -> list of (index in batch, gray, post, n_ec, tie_risk, probs | None) for the
     images that went through, list of (index, exception) for those that did not."""
     try:
-        gray, post, nec, tie, probs = _segment_with_retry(model, imgs, log, emit_probs)
+        gray, post, nec, tie, probs = _segment_with_retry(model, imgs, log, emit_probs, outs)
         return [(j, gray[j], post[j], int(nec[j]), int(tie[j]), None if probs is None else probs[j]) for j in range(len(imgs))], []
     except EcsegError as e:
         # only failures that can belong to ONE input are bisected (a bad argument / shape, an unsupported layout, memory for a single
@@ -167,7 +254,7 @@ def _segment_isolating(model, imgs, log, emit_probs=False):
 
 
 def run(inpath, model, image_paths, rank=0, world=1, batch_images=8, io_threads=None, log=print, stats=None, resume=False,
-        emit_probs=False):
+        emit_probs=False, pinned_mb=2048):
     """Segment this rank's shard; returns records (one row per image of the WHOLE job after the all-gather)."""
     start, stop, per = dist.shard_bounds(len(image_paths), rank, world)
     mine = image_paths[start:stop]
@@ -182,15 +269,21 @@ def run(inpath, model, image_paths, rank=0, world=1, batch_images=8, io_threads=
     old_switch = sys.getswitchinterval()
     sys.setswitchinterval(0.0005)
     tune_host_allocator()                                                   # one malloc arena, no mmap per buffer (utils.py)
+    # page-locked batch buffers (config key pinned_mb, default 2048; 0: ordinary memory as in rounds 1-4)
+    first = model[0] if isinstance(model, (list, tuple)) else model
+    pool = _PinnedPool.of(first.handle, int(pinned_mb) << 20)
+    if pinned_mb > 0:
+        pool.start()
     try:
         return _run_threads(model, mine, start, per, rank, world, batch_images, io_threads, window, pending_writes, n_ec,
-                            status, log, stats, resume, tie, emit_probs)
+                            status, log, stats, resume, tie, emit_probs, pool)
     finally:
+        pool.stop()
         sys.setswitchinterval(old_switch)
 
 
 def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads, window, pending_writes, n_ec, status, log, stats,
-                 resume=False, tie=None, emit_probs=False):
+                 resume=False, tie=None, emit_probs=False, pool=None):
     # `model`: one model, or a list of models on the same GPU (config key device_workers): one device thread per model takes
     # batches from the common queue, so the host <-> device copies and the per-call synchronisation of one overlap the kernels of
     # the other (a narrow model spends a third of a call outside its kernels: EXPERIMENTS.md 6)
@@ -199,7 +292,8 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
     t_gpu = 0.0
     t_lock = threading.Lock()
     # per-stage host timers (thread-seconds summed over the worker threads): where a slow `make metaseg` spends its CPU
-    t_stage = {'read': 0.0, 'write': 0.0, 'pack': 0.0}
+    # (device_kernels: the library's stage timers; device_native: inside the library call, the rest of gpu_seconds is Python)
+    t_stage = {'read': 0.0, 'write': 0.0, 'pack': 0.0, 'device_kernels': 0.0, 'device_native': 0.0}
 
     def timed(stage, fn):
         def wrapped(*a, **kw):
@@ -213,7 +307,8 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
         return wrapped
 
     read_fn, write_fn = timed('read', _read), timed('write', _write_outputs)
-    with cf.ThreadPoolExecutor(io_threads) as readers, cf.ThreadPoolExecutor(io_threads) as writers:
+    with cf.ThreadPoolExecutor(io_threads) as readers, cf.ThreadPoolExecutor(io_threads) as writers, \
+            cf.ThreadPoolExecutor(min(8, io_threads)) as packers:
         reads = {}
         next_submit = 0
 
@@ -228,7 +323,7 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
 
         def flush(batch, model):
             nonlocal t_gpu
-            group, imgs = batch
+            group, imgs, in_buf = batch
             if not group:
                 return
             if imgs.dtype == np.bool_:                     # resumed images: only the count is needed
@@ -237,12 +332,43 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
                     n_ec[k] = int(cnt[j])
                 return
             t0 = time.perf_counter()
-            done, bad = _segment_isolating(model, imgs, log, emit_probs)
+            nat0 = getattr(model.handle, 'native_seconds', 0.0)
+            # page-locked output buffers of the batch; they go back to the pool when its last output file is written
+            n, (H, W) = len(imgs), imgs.shape[1:3]
+            full = max(n, batch_images) * H * W
+            bufs = [pool.get(n * H * W, full) for _ in range(2)] if not emit_probs else [None, None]
+            outs = tuple(_view(b, (n, H, W)) for b in bufs) if all(b is not None for b in bufs) else None
+            try:
+                done, bad = _segment_isolating(model, imgs, log, emit_probs, outs)
+            finally:
+                pool.put(in_buf)                           # (the call has returned: the upload is over)
+                if outs is None:
+                    for b in bufs:
+                        pool.put(b)
+            dt = time.perf_counter() - t0
+            tm = getattr(model.handle, 'timings', None)
+            kern = 1e-3 * sum(tm().values()) if tm is not None else 0.0
             with t_lock:
-                t_gpu += time.perf_counter() - t0
+                t_gpu += dt
+                t_stage['device_kernels'] += kern
+                t_stage['device_native'] += getattr(model.handle, 'native_seconds', 0.0) - nat0
             for j, e in bad:                               # a failing image must not take its batch or the shard down
                 log("Skipping %s (shape %s): %s" % (mine[group[j]], imgs.shape[1:], e))
                 status[group[j]] = 2
+            left = [len(done)]
+
+            def written(_f):
+                pending_writes.release()
+                with t_lock:
+                    left[0] -= 1
+                    last = left[0] == 0
+                if last and outs is not None:
+                    for b in bufs:
+                        pool.put(b)
+
+            if not done and outs is not None:
+                for b in bufs:
+                    pool.put(b)
             for j, gray_j, post_j, nec_j, tie_j, probs_j in done:
                 k = group[j]
                 n_ec[k] = nec_j
@@ -250,7 +376,7 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
                     tie[k] = tie_j
                 pending_writes.acquire()
                 f = writers.submit(write_fn, mine[k], gray_j, post_j, log, probs_j)
-                f.add_done_callback(lambda _f: pending_writes.release())
+                f.add_done_callback(written)
                 write_futs.append((k, f))
 
         # the device calls run on their own thread (one batch in the queue, one on the GPU) so that collecting decoded
@@ -277,9 +403,15 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
 
         def pack(group):                                   # the batch array is assembled by the feeder, not by the device thread
             t0 = time.perf_counter()
-            out = [k for k, _ in group], np.stack([im for _, im in group])
+            first = group[0][1]
+            buf = pool.get(len(group) * first.nbytes, batch_images * first.nbytes) if first.dtype != np.bool_ else None
+            if buf is None:
+                arr = np.stack([im for _, im in group])
+            else:                                          # page-locked batch buffer, filled by several threads (13 GB/s each)
+                arr = _view(buf, (len(group),) + first.shape, first.dtype)
+                list(packers.map(lambda j: np.copyto(arr[j], group[j][1]), range(len(group))))
             t_stage['pack'] += time.perf_counter() - t0
-            return out
+            return [k for k, _ in group], arr, buf
 
         gpu_threads = [threading.Thread(target=gpu_loop, args=(m,), name='ecseg-gpu%d' % i) for i, m in enumerate(models)]
         for th in gpu_threads:
@@ -324,6 +456,7 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
                 status[k] = 3
     if stats is not None:
         stats['gpu_seconds'] = t_gpu
+        stats['pinned_pool'] = {'hits': pool.hits, 'misses': pool.misses, 'free_MB': round(sum(b.size for b in pool.free) / 1e6, 1)}
         stats.update({'%s_thread_seconds' % k: v for k, v in t_stage.items()})
     rec = dist.make_records(start, len(mine), per, n_ec=n_ec, status=status, tie_risk=tie)
     return dist.gather_all(rec, device=model.handle.device)        # the path's one exchange (identity for one rank)
@@ -476,7 +609,8 @@ def main(argv=None):
     t0 = time.perf_counter()
     stats = {}
     rec = run(inpath, models if workers > 1 else model, image_paths, rank, world, batch_images=int(var.get('batch_images', 8)),
-              io_threads=var.get('io_threads'), stats=stats, resume=bool(var.get('resume', False)), emit_probs=emit_probs)
+              io_threads=var.get('io_threads'), stats=stats, resume=bool(var.get('resume', False)), emit_probs=emit_probs,
+              pinned_mb=int(var.get('pinned_mb', 2048)))
     failed = finish(inpath, image_paths, rec, rank, seconds=time.perf_counter() - t0, gpu_seconds=stats.get('gpu_seconds', 0.0))
     if native:
         dist.native_close(os.environ['ECSEG_RDZV'], rank)          # (the all-gather was the last thing every rank waited for)

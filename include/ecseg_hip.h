@@ -21,6 +21,7 @@
 #ifndef ECSEG_HIP_H
 #define ECSEG_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -34,7 +35,7 @@ extern "C" {
 /* 4 (round 5): ecseg_op_desc gains `dilation`; op codes 10-12 (DWCONV, PRELU, LAYERNORM); ADD takes `mode` (add / multiply / subtract /
  * maximum / minimum) and broadcasts extents of 1; MAXPOOL honours pad_top / pad_left ('same' pooling); activation codes 7-14;
  * ECSEG_COMM_TIMEOUT_S bounds ecseg_comm_create / ecseg_allgather_records*. */
-#define ECSEG_ABI_VERSION 4
+#define ECSEG_ABI_VERSION 5
 
 #define ECSEG_OK             0
 #define ECSEG_E_INVALID     -1   /* bad argument / shape / plan */
@@ -187,6 +188,22 @@ int ecseg_set_option(ecseg_ctx* h, const char* key, int value);
  * gray_out: (n_img, H, W) uint8; inverted_out (optional) one flag per image. */
 int ecseg_preprocess(ecseg_ctx* h, const void* img, int n_img, int H, int W, int C, int bytes_per_sample,
                      uint8_t* gray_out, int32_t* inverted_out);
+
+/* ---- meta_segment of a batch in one call (src/utils.py:105-124 minus imread / imwrite, + src/metaseg.py:46) ---------- */
+/* img as for ecseg_preprocess.  pre_process (src/utils.py:112) -> patches -> U-Net -> stitch -> argmax -> meta_inference ->
+ * count_cc(I==3)[0] without the pre-processed images leaving the device in between: what `make metaseg` calls per batch.
+ * gray_out (optional): the pre-processed images (src/utils.py:122-123 writes dapi/<name> from them), copied back under
+ * the U-Net; labels_post, n_ec, tie_risk (optional) as for ecseg_segment_images_ex.  Results are identical to
+ * ecseg_preprocess followed by ecseg_segment_images_ex. */
+int ecseg_meta_segment(ecseg_ctx* h, const void* img, int n_img, int H, int W, int C, int bytes_per_sample,
+                       uint8_t* gray_out, uint8_t* labels_post, int32_t* n_ec, int32_t* tie_risk);
+
+/* ---- page-locked host buffers ------------------------------------------------------------------------------ */
+/* Host pointers handed to any entry point may be ordinary (pageable) memory.  Buffers from ecseg_host_alloc make the
+ * host <-> device copies DMA transfers (about 2x the pageable rate, and the gray_out copy of ecseg_meta_segment then really
+ * overlaps the U-Net).  Free with ecseg_host_free before ecseg_destroy. */
+int ecseg_host_alloc(ecseg_ctx* h, size_t bytes, void** out);
+int ecseg_host_free(ecseg_ctx* h, void* p);
 
 /* u16_to_u8 alone (src/image_tools.py:98-101, used by split_FISH_channels :142): count uint16 samples ->
  * uint8 with cv2.convertScaleAbs(alpha = 255/65535) rounding. */

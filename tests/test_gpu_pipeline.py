@@ -211,3 +211,43 @@ def test_tie_risk_counts_and_stitched_probabilities(model16):
     # the plain call returns the same labels and counts
     raw2, post2, nec2 = model16.handle.segment_images(imgs, want_raw=True)
     assert np.array_equal(raw, raw2) and np.array_equal(post, post2) and np.array_equal(nec, nec2)
+
+
+@pytest.mark.parametrize('kind', ['rgb_u8', 'gray_u16', 'rgba_u16'])
+def test_meta_segment_is_preprocess_then_segment_in_one_call(model16, kind):
+    """ecseg_meta_segment (what `make metaseg` calls per batch: src/utils.py:105-124 minus the file I/O + src/metaseg.py:46) must
+    return exactly what ecseg_preprocess followed by ecseg_segment_images_ex returns - pre-processed images, labels, counts and
+    tie-risk bounds - from ordinary and from page-locked host buffers (ecseg_host_alloc), and the pre-processed images must
+    equal the oracle's meta_preprocess."""
+    from oracle import preprocess as oracle_pre
+    H, W = 300, 462
+    h = model16.handle
+    base = np.stack([synth.dapi_image(40 + i, H, W, rgb=True) for i in range(3)])
+    if kind == 'rgb_u8':
+        imgs = base
+    elif kind == 'gray_u16':
+        imgs = (base[..., 2].astype(np.uint16) * 257)
+        imgs[1] = 65535 - imgs[1]                                           # a bright-background image: the inverting branch
+    else:
+        imgs = np.concatenate([base.astype(np.uint16) * 201, np.full(base.shape[:3] + (1,), 65535, np.uint16)], axis=-1)
+    gray_a, _ = h.preprocess(imgs)
+    _, post_a, nec_a, tie_a = h.segment_images(gray_a, want_raw=False, want_tie_risk=True)
+    for i in range(len(imgs)):
+        assert np.array_equal(gray_a[i], oracle_pre.meta_preprocess(imgs[i]))
+    gray_b, post_b, nec_b, tie_b = h.meta_segment(imgs)
+    assert np.array_equal(gray_a, gray_b) and np.array_equal(post_a, post_b)
+    assert np.array_equal(nec_a, nec_b) and np.array_equal(tie_a, tie_b)
+    p_in = h.host_empty(imgs.shape, imgs.dtype)
+    p_gray, p_post = h.host_empty((3, H, W)), h.host_empty((3, H, W))
+    try:
+        p_in[...] = imgs
+        p_gray[...] = 0x5A; p_post[...] = 0x5A
+        g, p, nec_c, tie_c = h.meta_segment(p_in, gray_out=p_gray, post_out=p_post)
+        assert g is p_gray and p is p_post
+        assert np.array_equal(gray_a, p_gray) and np.array_equal(post_a, p_post)
+        assert np.array_equal(nec_a, nec_c) and np.array_equal(tie_a, tie_c)
+    finally:
+        for b in (p_in, p_gray, p_post):
+            h.host_release(b)
+    with pytest.raises(ValueError):
+        h.meta_segment(imgs, gray_out=np.empty((2, H, W), np.uint8), post_out=np.empty((3, H, W), np.uint8))

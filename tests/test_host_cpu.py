@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), 'libecseg_hip.so does not export %s' % name
     assert declared == set(EXPORTS)
-    assert lib.ecseg_abi_version() == 4
+    assert lib.ecseg_abi_version() == 5
 
 
 def test_missing_gpu_fails_loudly():

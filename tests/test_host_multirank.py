@@ -287,3 +287,63 @@ def test_sticky_device_error_ends_the_rank_instead_of_bisecting(tmp_path):
     with pytest.raises(EcsegError, match='hipErrorIllegalAddress'):
         metaseg.run(folder, m, get_imgs(folder), 0, 1, batch_images=3, io_threads=2, log=lambda *a: None)
     assert calls == [3], calls                                           # the first batch, once: no halves, no later batches
+
+
+def test_fused_call_and_page_locked_pool_give_the_same_outputs(tmp_path):
+    """Round 5 host path: a handle with ``meta_segment`` (ecseg_meta_segment: pre-process + segment in one device call) and
+    ``host_empty`` (page-locked batch buffers, recycled through metaseg._PinnedPool) must give the records, files and CSV of
+    the two-call path over ordinary memory.  The pool never allocates on the device thread: a miss is served from ordinary
+    memory and ordered from the pool's own thread; buffers return when a batch's last output file is written."""
+    one, two = str(tmp_path / 'one'), str(tmp_path / 'two')
+    make_inputs(one, 13, corrupt=4)
+    shutil.copytree(one, two)
+    p1, p2 = get_imgs(one), get_imgs(two)
+    rec1 = metaseg.run(one, StubModel(), p1, 0, 1, batch_images=3, io_threads=2, log=lambda *a: None)
+    metaseg.finish(one, p1, rec1, 0, log=lambda *a: None)
+
+    class FusedHandle(StubHandle):
+        def __init__(self):
+            super().__init__()
+            self.allocated, self.fused_calls, self.filled = [], 0, 0
+
+        def host_empty(self, shape, dtype=np.uint8):
+            a = np.full(shape, 0xAB, dtype)                  # (stale bytes: a result must not depend on them)
+            self.allocated.append(a)
+            return a
+
+        def meta_segment(self, imgs, gray_out=None, post_out=None):
+            self.fused_calls += 1
+            gray, _ = self.preprocess(imgs)
+            post, nec = StubModel.segment(model, gray)
+            if gray_out is not None:
+                assert any(np.shares_memory(gray_out, a) for a in self.allocated) and gray_out.shape == gray.shape
+                gray_out[...] = gray; post_out[...] = post
+                gray, post = gray_out, post_out
+                self.filled += 1
+            return gray, post, nec, np.zeros(len(gray), np.int32)
+
+    model = StubModel()
+    model.handle = FusedHandle()
+    rec2 = metaseg.run(two, model, p2, 0, 1, batch_images=3, io_threads=2, log=lambda *a: None, pinned_mb=64)
+    metaseg.finish(two, p2, rec2, 0, log=lambda *a: None)
+    assert np.array_equal(rec1, rec2)
+    a, b = _snapshot(one), _snapshot(two)
+    assert sorted(a) == sorted(b) and all(a[k] == b[k] for k in a)
+    h = model.handle
+    pool = h._metaseg_pool
+    assert h.fused_calls >= 4 and pool.misses > 0
+    assert pool.thread is None, 'the pool thread must end with the run'
+    # every buffer is back in the pool (none leaked to a writer), the limit was respected, and a second run starts with hits
+    assert sorted(id(x) for x in pool.free) == sorted(id(x) for x in h.allocated)
+    assert sum(x.size for x in h.allocated) <= 64 << 20
+    hits0 = pool.hits
+    shutil.rmtree(two); shutil.copytree(one, two)
+    for sub in ('labels', 'dapi'):
+        shutil.rmtree(os.path.join(two, sub), ignore_errors=True)
+        os.makedirs(os.path.join(two, sub))
+    rec3 = metaseg.run(two, model, get_imgs(two), 0, 1, batch_images=3, io_threads=2, log=lambda *a: None, pinned_mb=64)
+    assert np.array_equal(rec1, rec3) and pool.hits > hits0 and h.filled > 0
+    # pinned_mb = 0: the pool is never asked
+    m0 = StubModel(); m0.handle = FusedHandle()
+    metaseg.run(two, m0, get_imgs(two), 0, 1, batch_images=3, io_threads=2, log=lambda *a: None, pinned_mb=0)
+    assert m0.handle.allocated == [] and m0.handle.fused_calls >= 4

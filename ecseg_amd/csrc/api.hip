@@ -108,6 +108,8 @@ struct ecseg_ctx {
     int post_graph = 0;       // measured +-0 % at 4 / 16 / 64 images per call (the launch queue already hides the gaps): off by default
     int post_chunk = 64;
     int overlap_post = 0;
+    int blocking_wait = 1;    // the long waits (a whole launch group) sleep on a blocking event instead of spinning on the stream
+    hipEvent_t ev_block = nullptr;
     int fuse_pool = 1;        // 2x2 max-pool written by the producing F(4x4) convolution's output stage
     int crop = 1;             // segment path: skip output regions of the last full-resolution convolutions that the stitch never reads
     int crop_mask = 1;        // cropped plan: Winograd kernels read zeros outside the receptive field of the needed outputs (0: A/B measurements only - results then depend on stale buffer contents in the last bits)
@@ -916,6 +918,17 @@ float stage_elapsed(hipEvent_t a, hipEvent_t b) {
     return hipEventElapsedTime(&t, a, b) == hipSuccess ? t : 0.f;
 }
 
+// Wait for everything enqueued on a stream (the long waits: a whole launch group).  "blocking_wait" 1 (default): record an
+// event created with hipEventBlockingSync and sleep on it - beside the device's blocking-sync flag (ecseg_create) this also
+// keeps the runtime's helper thread off the CPU (0.31 -> 0.13 cores busy per waiting call).
+hipError_t wait_stream(ecseg_ctx* h, hipStream_t s) {
+    if (!h->blocking_wait) return hipStreamSynchronize(s);
+    hipError_t e = hipSuccess;
+    if (!h->ev_block && (e = hipEventCreateWithFlags(&h->ev_block, hipEventBlockingSync | hipEventDisableTiming)) != hipSuccess) return e;
+    if ((e = hipEventRecord(h->ev_block, s)) != hipSuccess) return e;
+    return hipEventSynchronize(h->ev_block);
+}
+
 // Device-resident pipeline: gray (n_img, H, W) -> raw labels, post labels, counts.  All pointers are device pointers.
 // probs_host (optional): the stitched float32 probabilities of every image, copied out group by group.
 int segment_dev(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint8_t* raw, uint8_t* post, int32_t* n_ec,
@@ -1019,8 +1032,8 @@ int segment_dev(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint
         HIP_TRY(h, hipEventRecord(e6[5], s2));
     }
     const double tq1 = dbg_now();
-    HIP_TRY(h, hipStreamSynchronize(s));
-    HIP_TRY(h, hipStreamSynchronize(s2));
+    HIP_TRY(h, wait_stream(h, s));
+    if (s2 != s) HIP_TRY(h, wait_stream(h, s2));
     const double tq2 = dbg_now();
     // ECSEG_DEBUG_CALLS: host-side timeline of the call on stderr (a `make metaseg` whose device calls take longer than their
     // kernels: is the host late with the launches, or is the wait long - e.g. a throttled CPU quota - ?)
@@ -1050,6 +1063,14 @@ int ecseg_create(ecseg_ctx** out, int device_id) {
     if (e != hipSuccess || ndev <= 0) return fail(nullptr, ECSEG_E_HIP, std::string("no HIP device: ") + hipGetErrorString(e));
     if (device_id < 0 || device_id >= ndev) return fail(nullptr, ECSEG_E_INVALID, "device_id out of range");
     if ((e = hipSetDevice(device_id)) != hipSuccess) return fail_hip(nullptr, e, "hipSetDevice");
+    // Waiting host threads sleep instead of spinning: with this runtime's default (hipDeviceScheduleAuto = spin when the host has
+    // more cores than GPUs) a thread inside a segment call burns a whole core for the length of the call - measured 1.35 cores
+    // busy per waiting call, 0.13 with this flag and the blocking event of wait_stream, at the same wall time
+    // (tools/experiments/wait_cpu.py).  `make metaseg` needs those cores for its decoders and encoders.  The flag
+    // belongs to the device, i.e. to every user of it in this process; ECSEG_SPIN_WAIT=1 leaves the runtime's default alone.
+    if (!getenv("ECSEG_SPIN_WAIT") || atoi(getenv("ECSEG_SPIN_WAIT")) == 0) {
+        if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();    // (not fatal: the default stays)
+    }
     ecseg_ctx* h = new ecseg_ctx();
     h->device = device_id;
     hipDeviceProp_t prop;
@@ -1089,6 +1110,7 @@ void ecseg_destroy(ecseg_ctx* h) {
                     h->ws.L, h->ws.area, h->ws.sumy, h->ws.sumx, h->ws.flag, h->ws.tmpA, h->ws.tmpB, h->ws.list, h->ws.g, h->ws.tile_any, h->ws.own_bits, h->ws.binned, h->ws.binstart};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
+    if (h->ev_block) (void)hipEventDestroy(h->ev_block);
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->grp_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->lane_events) (void)hipEventDestroy(e);
@@ -1118,6 +1140,7 @@ int ecseg_set_option(ecseg_ctx* h, const char* key, int value) {
     if (!h || !key) return ECSEG_E_INVALID;
     const std::string k(key);
     if (k == "overlap_post") h->overlap_post = value != 0;
+    else if (k == "blocking_wait") h->blocking_wait = value != 0;
     else if (k == "fuse_pool") h->fuse_pool = value != 0;
     else if (k == "fuse_head") h->fuse_head = value != 0;
     else if (k == "wino_resident") h->wino_resident = value != 0;
@@ -1573,9 +1596,9 @@ int ecseg_meta_segment(ecseg_ctx* h, const void* img, int n_img, int H, int W, i
     HIP_TRY(h, hipMemcpyAsync(post, h->d_post, tot, hipMemcpyDeviceToHost, s));
     if (tie_risk) HIP_TRY(h, hipMemcpyAsync(tie_risk, h->d_tie, (size_t)n_img * 4, hipMemcpyDeviceToHost, s));
     if (n_ec) HIP_TRY(h, hipMemcpyAsync(n_ec, h->d_i32, (size_t)n_img * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(h, hipStreamSynchronize(s));
+    HIP_TRY(h, wait_stream(h, s));
     const double t4 = dbg_now();
-    HIP_TRY(h, hipStreamSynchronize(sc));
+    HIP_TRY(h, wait_stream(h, sc));
     const double t5 = dbg_now();
     if (debug_calls()) fprintf(stderr, "[meta_segment n=%d] upload enqueue %.2f preprocess + gray copy enqueue %.2f segment_dev %.2f (stage timers %.2f) labels down %.2f gray wait %.2f total %.2f ms\n",
                      n_img, t1 - t0, t2 - t1, t3 - t2, h->stage_ms[0] + h->stage_ms[1] + h->stage_ms[2] + h->stage_ms[3], t4 - t3, t5 - t4, t5 - t0);

@@ -35,6 +35,8 @@ extern "C" {
 /* 4 (round 5): ecseg_op_desc gains `dilation`; op codes 10-12 (DWCONV, PRELU, LAYERNORM); ADD takes `mode` (add / multiply / subtract /
  * maximum / minimum) and broadcasts extents of 1; MAXPOOL honours pad_top / pad_left ('same' pooling); activation codes 7-14;
  * ECSEG_COMM_TIMEOUT_S bounds ecseg_comm_create / ecseg_allgather_records*. */
+/* 5 (round 5): ecseg_meta_segment (pre-process + segment in one call), ecseg_host_alloc / ecseg_host_free (page-locked host
+ * buffers); ecseg_create sets the device's scheduling flag to hipDeviceScheduleBlockingSync (see there). */
 #define ECSEG_ABI_VERSION 5
 
 #define ECSEG_OK             0
@@ -49,6 +51,10 @@ typedef struct ecseg_ctx ecseg_ctx;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------- */
 int         ecseg_abi_version(void);
+/* ecseg_create also makes host threads that wait for this device SLEEP instead of spinning (hipSetDeviceFlags(
+ * hipDeviceScheduleBlockingSync): a device-wide setting of the process; same wall time, one core less per waiting call).
+ * Environment ECSEG_SPIN_WAIT=1 leaves the runtime's default.  ECSEG_DEBUG_CALLS=1 prints a host-side timeline of every
+ * ecseg_meta_segment call on stderr. */
 int         ecseg_create(ecseg_ctx** out, int device_id);
 void        ecseg_destroy(ecseg_ctx* h);
 const char* ecseg_last_error(ecseg_ctx* h);        /* h may be NULL: error of the last failed ecseg_create */
@@ -177,7 +183,8 @@ int ecseg_set_images_per_group(ecseg_ctx* h, int n);
  * (0) to float32 rounding, i.e. labels can differ at near-ties of the quantised probabilities), "unet_lanes" (0 (default): automatic -
  * a launch group of <= 70 windows (one or two 1040x1392 images) runs its U-Net as two window lanes on their own streams, which fills
  * the half-empty last round of workgroups of the deep layers (one image: 11.3 -> 10.4 ms); 1..8: that many lanes; results are
- * bit-identical for every value), "post_graph" (1: the
+ * bit-identical for every value), "blocking_wait" (1 (default): the wait for a launch group sleeps on an event created
+ * with hipEventBlockingSync; 0: hipStreamSynchronize), "post_graph" (1: the
  * ~60 short kernels of meta_inference + count are captured once per (buffers, geometry) into a HIP graph and replayed;
  * 0 (default): plain launches - measured equal, the asynchronous launch queue already hides the launch gaps). */
 int ecseg_set_option(ecseg_ctx* h, const char* key, int value);

@@ -38,6 +38,9 @@ def main():
     ap.add_argument('--keep', default=None)
     ap.add_argument('--workers', type=int, default=1, help='handles (device threads) on the GPU: config key device_workers')
     ap.add_argument('--pinned-mb', type=int, default=2048, help='page-locked host memory for the batch buffers (config key pinned_mb; 0: none)')
+    ap.add_argument('--weights', default='random', choices=('random', 'smooth'),
+                    help="random: seeded random weights (speckled labels: the slowest case for the label PNG coder); smooth: the fitted base-16 "
+                         "stand-in for a trained model (tests/golden/smooth_b16_f16.npz: blobs, as real label maps)")
     ap.add_argument('--warm-one', dest='warm_full', action='store_false', help='warm up with ONE image (rounds 1-4) instead of a full batch per handle')
     a = ap.parse_args()
     from PIL import Image
@@ -54,15 +57,25 @@ def main():
         os.makedirs(os.path.join(inp, sub), exist_ok=True)
     base = [synth.dapi_image(600 + i, rgb=True) for i in range(8)]
     t0 = time.perf_counter()
-    have = a.keep and len([f for f in os.listdir(inp) if f.endswith('.tif')]) == a.n      # (--keep DIR of an earlier run: reuse its inputs)
+    old = [f for f in os.listdir(inp) if f.endswith('.tif')]
+    have = a.keep and len(old) == a.n                    # (--keep DIR of an earlier run with the same --n: reuse its inputs)
+    if not have:
+        for f in old:
+            os.unlink(os.path.join(inp, f))
     for i in range(0 if have else a.n):
         img = np.roll(base[i % 8], (31 * (i // 8), 17 * (i // 8)), axis=(0, 1))
         Image.fromarray(img).save(os.path.join(inp, 'img%04d.tif' % i), compression='tiff_lzw')
     t_gen = time.perf_counter() - t0
     in_bytes = sum(os.path.getsize(os.path.join(inp, f)) for f in os.listdir(inp))
-    cfg = synth.unet_config(base=a.base)
-    model = MetasegModel(cfg, synth.unet_weights(cfg, seed=0), device=0)
-    extra = [MetasegModel(cfg, synth.unet_weights(cfg, seed=0), device=0) for _ in range(a.workers - 1)]
+    if a.weights == 'smooth':
+        from tools import make_smooth_fixture
+        a.base = 16
+        cfg, weights = make_smooth_fixture.load(os.path.join(ROOT, 'tests', 'golden', 'smooth_b16_f16.npz'))
+    else:
+        cfg = synth.unet_config(base=a.base)
+        weights = synth.unet_weights(cfg, seed=0)
+    model = MetasegModel(cfg, weights, device=0)
+    extra = [MetasegModel(cfg, weights, device=0) for _ in range(a.workers - 1)]
     if a.base >= 64:
         model.handle.set_images_per_group(16)          # narrower models: the automatic launch-group size
     with open(os.path.join(work, 'config.yaml'), 'w') as f:
@@ -101,7 +114,7 @@ def main():
     dt_ov = time.perf_counter() - t0
     out_bytes = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(inp) for f in fs) - in_bytes
     print(json.dumps({'what': '`make metaseg` loop: %d RGB LZW TIFF files (1040x1392) -> dapi/*.tif, labels/*.png, labels/*.npy (int64), '
-                              'records' % a.n, 'images': a.n, 'unet_base': a.base, 'batch_images': a.batch, 'device_workers': a.workers, 'pinned_mb': a.pinned_mb,
+                              'records' % a.n, 'images': a.n, 'unet_base': a.base, 'weights': a.weights, 'batch_images': a.batch, 'device_workers': a.workers, 'pinned_mb': a.pinned_mb,
                       'pinned_pool': stats.get('pinned_pool'), 'warmup': 'one full batch per handle' if a.warm_full else 'one image',
                       'io_threads': a.io_threads or 'default', 'cpu_count': os.cpu_count(),
                       'seconds': round(dt, 3), 'images_per_s': round(a.n / dt, 2),

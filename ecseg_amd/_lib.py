@@ -315,7 +315,11 @@ class Handle:
         dtype = np.dtype(dtype)
         nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
         p = C.c_void_p()
-        self._check(self.lib.ecseg_host_alloc(self.h, max(nbytes, 1), C.byref(p)), 'ecseg_host_alloc')
+        rc = self.lib.ecseg_host_alloc(self.h, max(nbytes, 1), C.byref(p))     # (thread-safe: does not touch the handle's error text)
+        if rc != 0:
+            e = EcsegError('ecseg_host_alloc(%d bytes) failed (%d)' % (nbytes, rc))
+            e.code = rc
+            raise e
         arr = np.ctypeslib.as_array((C.c_uint8 * max(nbytes, 1)).from_address(p.value))[:nbytes].view(dtype).reshape(shape)
         self._pinned[arr.ctypes.data] = p.value
         return arr
@@ -323,7 +327,11 @@ class Handle:
     def host_release(self, arr):
         p = self._pinned.pop(arr.ctypes.data, None)
         if p is not None and self.h:
-            self._check(self.lib.ecseg_host_free(self.h, C.c_void_p(p)), 'ecseg_host_free')
+            rc = self.lib.ecseg_host_free(self.h, C.c_void_p(p))
+            if rc != 0:
+                e = EcsegError('ecseg_host_free failed (%d)' % rc)
+                e.code = rc
+                raise e
 
     def u16_to_u8(self, a):
         a = np.ascontiguousarray(a, np.uint16)

@@ -1606,23 +1606,23 @@ int ecseg_meta_segment(ecseg_ctx* h, const void* img, int n_img, int H, int W, i
 }
 
 // Page-locked host memory: hipMemcpyAsync from / to it is a DMA transfer the host thread does not wait for (pageable
-// memory is staged through the runtime's own pinned chunks by the calling thread).
+// memory is staged through the runtime's own pinned chunks by the calling thread).  These two calls read nothing of the
+// handle but its device number and never write its error string: they may run on another thread while the handle is
+// inside a call (`make metaseg` page-locks batch buffers on a helper thread, ecseg_amd/metaseg.py: _PinnedPool).
 int ecseg_host_alloc(ecseg_ctx* h, size_t bytes, void** out) {
-    if (!h || !out) return h ? fail(h, ECSEG_E_INVALID, "host_alloc: out is NULL") : ECSEG_E_INVALID;
+    if (!h || !out) return ECSEG_E_INVALID;
     *out = nullptr;
     if (bytes == 0) return ECSEG_OK;
-    HIP_TRY(h, hipSetDevice(h->device));
+    if (hipSetDevice(h->device) != hipSuccess) { (void)hipGetLastError(); return ECSEG_E_HIP; }
     const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocPortable);
-    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); *out = nullptr; return fail(h, ECSEG_E_NOMEM, "host_alloc: out of page-locked host memory"); }
-    HIP_TRY(h, e);
+    if (e != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return e == hipErrorOutOfMemory ? ECSEG_E_NOMEM : ECSEG_E_HIP; }
     return ECSEG_OK;
 }
 
 int ecseg_host_free(ecseg_ctx* h, void* p) {
     if (!h) return ECSEG_E_INVALID;
     if (!p) return ECSEG_OK;
-    HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipHostFree(p));
+    if (hipSetDevice(h->device) != hipSuccess || hipHostFree(p) != hipSuccess) { (void)hipGetLastError(); return ECSEG_E_HIP; }
     return ECSEG_OK;
 }
 

@@ -208,7 +208,9 @@ int ecseg_meta_segment(ecseg_ctx* h, const void* img, int n_img, int H, int W, i
 /* ---- page-locked host buffers ------------------------------------------------------------------------------ */
 /* Host pointers handed to any entry point may be ordinary (pageable) memory.  Buffers from ecseg_host_alloc make the
  * host <-> device copies DMA transfers (about 2x the pageable rate, and the gray_out copy of ecseg_meta_segment then really
- * overlaps the U-Net).  Free with ecseg_host_free before ecseg_destroy. */
+ * overlaps the U-Net).  Free with ecseg_host_free before ecseg_destroy.  Unlike every other entry point these two may be called
+ * from another thread while the handle is inside a call (they use only its device number); a failure is reported by the
+ * return code alone (ECSEG_E_NOMEM / ECSEG_E_HIP), not through ecseg_last_error. */
 int ecseg_host_alloc(ecseg_ctx* h, size_t bytes, void** out);
 int ecseg_host_free(ecseg_ctx* h, void* p);
 

@@ -245,8 +245,8 @@ void deflate_labels(const uint8_t* labels, int H, int W, const uint8_t pal[4][4]
     for (int i = 0; i < 19; ++i) cl_len[i] = i < 13 ? 4 : 5;
     canonical_codes(cl_len, 19, cl_code);
     // worst case: every run costs its four literals (<= 60 bits) plus one match code (<= 21 bits) per started 64 pixels
-    size_t worst_bits = 4096 + 16 * (size_t)H + 64;
-    for (size_t i = 0; i < nt; ++i) if (const uint32_t t = tok[i]; t != 0xffffffffu) worst_bits += 60 + 21 * (size_t)(((t & 0x3fffffffu) + 62) / 64);
+    // (in closed form: at most nt runs, and W / 64 + 1 further match codes per scan line)
+    const size_t worst_bits = 4096 + 16 * (size_t)H + 64 + (60 + 21) * nt + 21 * (size_t)H * ((size_t)W / 64 + 1);
     std::unique_ptr<uint8_t[]> buf(new uint8_t[worst_bits / 8 + 32]);
     buf[0] = 0x78; buf[1] = 0x01;
     BitWriter bw(buf.get() + 2);
@@ -273,6 +273,17 @@ void deflate_labels(const uint8_t* labels, int H, int W, const uint8_t pal[4][4]
     // b += 4 k a + 2 k (k - 1) S + k T; a += k S)
     uint64_t S[4], T[4];
     for (int c = 0; c < 4; ++c) { S[c] = pal[c][0] + pal[c][1] + pal[c][2] + pal[c][3]; T[c] = 4 * pal[c][0] + 3 * pal[c][1] + 2 * pal[c][2] + pal[c][3]; }
+    // a run of k <= 64 pixels (all of them on speckled maps) leaves as ONE bit string - four literals + the match of its other
+    // k - 1 pixels - when that fits the writer's 56 bits, with its Adler terms from a table
+    uint64_t comb[4][65]; uint8_t comb_n[4][65];
+    uint32_t adl_a[4][65], adl_b[4][65];
+    for (int c = 0; c < 4; ++c) for (int k = 1; k <= 64; ++k) {
+        const int n = cn[c] + mn[k - 1];
+        comb_n[c][k] = (uint8_t)(n <= 56 ? n : 0);
+        comb[c][k] = n <= 56 ? (cbits[c] | ((uint64_t)mbits[k - 1] << cn[c])) : 0;
+        adl_a[c][k] = (uint32_t)(k * S[c]);
+        adl_b[c][k] = (uint32_t)(2 * (uint64_t)k * (k - 1) * S[c] + k * T[c]);
+    }
     uint64_t a = 1, b = 0;
     const uint64_t M = 65521;
     for (size_t i = 0; i < nt; ++i) {
@@ -280,6 +291,13 @@ void deflate_labels(const uint8_t* labels, int H, int W, const uint8_t pal[4][4]
         if (t == 0xffffffffu) { bw.put(lcode[0], llen[0]); b += a; continue; }
         const int c = (int)(t >> 30);
         const uint64_t k = t & 0x3fffffffu;
+        if (k <= 64 && comb_n[c][k]) {
+            bw.put(comb[c][k], comb_n[c][k]);
+            if ((a | b) >> 36) { a %= M; b %= M; }
+            b += 4 * k * a + adl_b[c][k];
+            a += adl_a[c][k];
+            continue;
+        }
         bw.put(cbits[c] & 0xffffffffu, cn[c] < 32 ? cn[c] : 32);
         bw.put(cbits[c] >> 32, cn[c] < 32 ? 0 : cn[c] - 32);
         uint64_t rest = k - 1;

@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Start-up cost a `make metaseg` user sees before the first image: plan + upload + Winograd filter transforms of the
+base-64 model, first and second segment call (GPU box)."""
 import time, sys, os
 sys.path.insert(0, os.getcwd())
 t0=time.perf_counter()
@@ -16,5 +19,3 @@ t5=time.perf_counter()
 m.segment(img)
 t6=time.perf_counter()
 print('import %.2f s, synth weights %.2f s, MetasegModel (plan + upload + filter transforms) %.2f s, first segment %.3f s, second %.3f s' % (t1-t0, t2-t1, t3-t2, t5-t4, t6-t5))
-# from an .h5 on disk
-from ecseg_amd import utils

@@ -38,6 +38,7 @@ def main():
     ap.add_argument('--keep', default=None)
     ap.add_argument('--workers', type=int, default=1, help='handles (device threads) on the GPU: config key device_workers')
     ap.add_argument('--pinned-mb', type=int, default=2048, help='page-locked host memory for the batch buffers (config key pinned_mb; 0: none)')
+    ap.add_argument('--input-compression', default='tiff_lzw', choices=('tiff_lzw', 'raw'), help='compression of the generated input TIFFs (raw = uncompressed, as many microscopes write them)')
     ap.add_argument('--weights', default='random', choices=('random', 'smooth'),
                     help="random: seeded random weights (speckled labels: the slowest case for the label PNG coder); smooth: the fitted base-16 "
                          "stand-in for a trained model (tests/golden/smooth_b16_f16.npz: blobs, as real label maps)")
@@ -64,7 +65,7 @@ def main():
             os.unlink(os.path.join(inp, f))
     for i in range(0 if have else a.n):
         img = np.roll(base[i % 8], (31 * (i // 8), 17 * (i // 8)), axis=(0, 1))
-        Image.fromarray(img).save(os.path.join(inp, 'img%04d.tif' % i), compression='tiff_lzw')
+        Image.fromarray(img).save(os.path.join(inp, 'img%04d.tif' % i), compression=a.input_compression)
     t_gen = time.perf_counter() - t0
     in_bytes = sum(os.path.getsize(os.path.join(inp, f)) for f in os.listdir(inp))
     if a.weights == 'smooth':
@@ -113,8 +114,8 @@ def main():
                             stats=ov_stats)
     dt_ov = time.perf_counter() - t0
     out_bytes = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(inp) for f in fs) - in_bytes
-    print(json.dumps({'what': '`make metaseg` loop: %d RGB LZW TIFF files (1040x1392) -> dapi/*.tif, labels/*.png, labels/*.npy (int64), '
-                              'records' % a.n, 'images': a.n, 'unet_base': a.base, 'weights': a.weights, 'batch_images': a.batch, 'device_workers': a.workers, 'pinned_mb': a.pinned_mb,
+    print(json.dumps({'what': '`make metaseg` loop: %d RGB %s TIFF files (1040x1392) -> dapi/*.tif, labels/*.png, labels/*.npy (int64), records'
+                              % (a.n, 'LZW' if a.input_compression == 'tiff_lzw' else 'uncompressed'), 'images': a.n, 'unet_base': a.base, 'weights': a.weights, 'batch_images': a.batch, 'device_workers': a.workers, 'pinned_mb': a.pinned_mb,
                       'pinned_pool': stats.get('pinned_pool'), 'warmup': 'one full batch per handle' if a.warm_full else 'one image',
                       'io_threads': a.io_threads or 'default', 'cpu_count': os.cpu_count(),
                       'seconds': round(dt, 3), 'images_per_s': round(a.n / dt, 2),

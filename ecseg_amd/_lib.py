@@ -14,7 +14,7 @@ EXPORTS = [
     'ecseg_abi_version', 'ecseg_create', 'ecseg_destroy', 'ecseg_last_error', 'ecseg_device_name', 'ecseg_stream',
     'ecseg_model_load', 'ecseg_model_flops_per_patch', 'ecseg_forward_patches', 'ecseg_forward_patches_f32', 'ecseg_read_tensor',
     'ecseg_segment_images', 'ecseg_segment_images_ex', 'ecseg_segment_images_dev', 'ecseg_set_images_per_group', 'ecseg_set_option', 'ecseg_preprocess', 'ecseg_u16_to_u8',
-    'ecseg_meta_segment', 'ecseg_host_alloc', 'ecseg_host_free',
+    'ecseg_meta_segment', 'ecseg_prefetch_input', 'ecseg_host_alloc', 'ecseg_host_free',
     'ecseg_stitch_argmax', 'ecseg_meta_inference', 'ecseg_meta_inference_dev', 'ecseg_count_cc', 'ecseg_ccl_labels',
     'ecseg_count_colocalization', 'ecseg_count_hsr', 'ecseg_overlay', 'ecseg_get_timings',
     'ecseg_set_kernel_profiling', 'ecseg_get_conv_profile', 'ecseg_get_conv_executed_flops', 'ecseg_get_conv_launch_profile', 'ecseg_debug_peek', 'ecseg_lzw_decode', 'ecseg_lzw_encode',
@@ -84,6 +84,7 @@ def load_library():
     lib.ecseg_preprocess.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
     lib.ecseg_u16_to_u8.argtypes = [vp, vp, C.c_longlong, vp]
     lib.ecseg_meta_segment.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
+    lib.ecseg_prefetch_input.argtypes = [vp, vp, C.c_size_t]
     lib.ecseg_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     lib.ecseg_host_free.argtypes = [vp, vp]
     lib.ecseg_stitch_argmax.argtypes = [vp, vp, i32, i32, i32, vp]
@@ -308,6 +309,16 @@ class Handle:
         self.native_seconds += time.perf_counter() - t0    # (inside the library, GIL released: `make metaseg`'s stage report)
         self._check(rc, 'ecseg_meta_segment')
         return outs[0], outs[1], nec, tie
+
+    def prefetch_input(self, imgs):
+        """Name the raw images (a C-contiguous array in page-locked memory) of the meta_segment call AFTER the coming one: the
+        coming call uploads them under its kernels (ecseg_prefetch_input).  None withdraws."""
+        if imgs is None:
+            self._check(self.lib.ecseg_prefetch_input(self.h, None, 0), 'ecseg_prefetch_input')
+            return
+        if not imgs.flags.c_contiguous:
+            raise ValueError('prefetch_input takes a C-contiguous array')
+        self._check(self.lib.ecseg_prefetch_input(self.h, _ptr(imgs), imgs.nbytes), 'ecseg_prefetch_input')
 
     def host_empty(self, shape, dtype=np.uint8):
         """An uninitialised numpy array in page-locked host memory (ecseg_host_alloc).  The memory belongs to the handle: it is

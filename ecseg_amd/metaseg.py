@@ -386,10 +386,21 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
         fatal = []                                         # a sticky device error / programming error: the rank ends after the drain
 
         def gpu_loop(m):
+            prefetch = None if emit_probs else getattr(m.handle, 'prefetch_input', None)
+            ahead = []                                     # the batch taken from the queue while looking ahead
             while True:
-                g = batches.get()
+                g = ahead.pop() if ahead else batches.get()
                 if g is None:
                     return
+                # look ahead without waiting: the raw images of the next batch - when they lie in page-locked memory - go up
+                # under this batch's kernels (ecseg_prefetch_input), so one handle overlaps its copies with its own compute
+                try:
+                    ahead.append(batches.get_nowait())
+                    nxt = ahead[0]
+                    if prefetch is not None and nxt is not None and nxt[2] is not None and not fatal:
+                        prefetch(nxt[1])
+                except queue.Empty:
+                    pass
                 try:
                     if fatal:                              # keep draining so that the feeder never blocks; nothing reaches the device
                         raise fatal[0]

@@ -35,8 +35,8 @@ extern "C" {
 /* 4 (round 5): ecseg_op_desc gains `dilation`; op codes 10-12 (DWCONV, PRELU, LAYERNORM); ADD takes `mode` (add / multiply / subtract /
  * maximum / minimum) and broadcasts extents of 1; MAXPOOL honours pad_top / pad_left ('same' pooling); activation codes 7-14;
  * ECSEG_COMM_TIMEOUT_S bounds ecseg_comm_create / ecseg_allgather_records*. */
-/* 5 (round 5): ecseg_meta_segment (pre-process + segment in one call), ecseg_host_alloc / ecseg_host_free (page-locked host
- * buffers); ecseg_create sets the device's scheduling flag to hipDeviceScheduleBlockingSync (see there). */
+/* 5 (round 5): ecseg_meta_segment (pre-process + segment in one call), ecseg_prefetch_input, ecseg_host_alloc / ecseg_host_free
+ * (page-locked host buffers); ecseg_create sets the device's scheduling flag to hipDeviceScheduleBlockingSync (see there). */
 #define ECSEG_ABI_VERSION 5
 
 #define ECSEG_OK             0
@@ -204,6 +204,13 @@ int ecseg_preprocess(ecseg_ctx* h, const void* img, int n_img, int H, int W, int
  * ecseg_preprocess followed by ecseg_segment_images_ex. */
 int ecseg_meta_segment(ecseg_ctx* h, const void* img, int n_img, int H, int W, int C, int bytes_per_sample,
                        uint8_t* gray_out, uint8_t* labels_post, int32_t* n_ec, int32_t* tie_risk);
+
+/* Names the raw images of the ecseg_meta_segment call AFTER the coming one (page-locked memory, same layout, `bytes` in total):
+ * the coming call uploads them on a stream of their own under its kernels, the call after it recognises them by (pointer, size)
+ * and skips its own upload - the host <-> device copies of batch k + 1 overlap the kernels of batch k on ONE handle.  The
+ * images must not change between the two calls; a call with other images uploads as always and drops what was sent ahead.
+ * Results are those of calls without it. */
+int ecseg_prefetch_input(ecseg_ctx* h, const void* img, size_t bytes);
 
 /* ---- page-locked host buffers ------------------------------------------------------------------------------ */
 /* Host pointers handed to any entry point may be ordinary (pageable) memory.  Buffers from ecseg_host_alloc make the

@@ -246,6 +246,24 @@ def test_meta_segment_is_preprocess_then_segment_in_one_call(model16, kind):
         assert g is p_gray and p is p_post
         assert np.array_equal(gray_a, p_gray) and np.array_equal(post_a, p_post)
         assert np.array_equal(nec_a, nec_c) and np.array_equal(tie_a, tie_c)
+        # images sent ahead (ecseg_prefetch_input): named before the call that precedes theirs, uploaded under that call's kernels,
+        # recognised by the next call; a call with other images drops them; results never change
+        p_in2 = h.host_empty(imgs.shape, imgs.dtype)
+        try:
+            p_in2[...] = imgs[::-1]
+            want2 = h.meta_segment(np.ascontiguousarray(imgs[::-1]))
+            h.prefetch_input(p_in2)
+            r1 = h.meta_segment(p_in)                      # uploads p_in2 on the side
+            r2 = h.meta_segment(p_in2)                     # finds it on the device
+            h.prefetch_input(p_in2)
+            r3 = h.meta_segment(p_in)
+            r4 = h.meta_segment(imgs)                      # other images: own upload, the prefetched ones are dropped
+            r5 = h.meta_segment(p_in2)                     # ... and uploaded again here
+            for r, want in ((r1, (gray_a, post_a, nec_a, tie_a)), (r2, want2), (r3, (gray_a, post_a, nec_a, tie_a)),
+                            (r4, (gray_a, post_a, nec_a, tie_a)), (r5, want2)):
+                assert all(np.array_equal(x, y) for x, y in zip(r, want))
+        finally:
+            h.host_release(p_in2)
     finally:
         for b in (p_in, p_gray, p_post):
             h.host_release(b)

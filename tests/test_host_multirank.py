@@ -305,14 +305,20 @@ def test_fused_call_and_page_locked_pool_give_the_same_outputs(tmp_path):
         def __init__(self):
             super().__init__()
             self.allocated, self.fused_calls, self.filled = [], 0, 0
+            self.sent_ahead, self.seen = [], []
 
         def host_empty(self, shape, dtype=np.uint8):
             a = np.full(shape, 0xAB, dtype)                  # (stale bytes: a result must not depend on them)
             self.allocated.append(a)
             return a
 
+        def prefetch_input(self, imgs):
+            assert any(np.shares_memory(imgs, a) for a in self.allocated), 'only page-locked batches are sent ahead'
+            self.sent_ahead.append(imgs.ctypes.data)
+
         def meta_segment(self, imgs, gray_out=None, post_out=None):
             self.fused_calls += 1
+            self.seen.append(imgs.ctypes.data)
             gray, _ = self.preprocess(imgs)
             post, nec = StubModel.segment(model, gray)
             if gray_out is not None:
@@ -343,6 +349,8 @@ def test_fused_call_and_page_locked_pool_give_the_same_outputs(tmp_path):
         os.makedirs(os.path.join(two, sub))
     rec3 = metaseg.run(two, model, get_imgs(two), 0, 1, batch_images=3, io_threads=2, log=lambda *a: None, pinned_mb=64)
     assert np.array_equal(rec1, rec3) and pool.hits > hits0 and h.filled > 0
+    # batches sent ahead (ecseg_prefetch_input) are exactly the ones the next device call then receives
+    assert h.sent_ahead and all(a in h.seen for a in h.sent_ahead)
     # pinned_mb = 0: the pool is never asked
     m0 = StubModel(); m0.handle = FusedHandle()
     metaseg.run(two, m0, get_imgs(two), 0, 1, batch_images=3, io_threads=2, log=lambda *a: None, pinned_mb=0)

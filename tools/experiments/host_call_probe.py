@@ -4,6 +4,7 @@
   B  ecseg_meta_segment, pageable host arrays
   C  ecseg_meta_segment, page-locked input and outputs (ecseg_host_alloc)
   D  C from two threads with a handle each (config key device_workers = 2)
+  E  C on ONE handle with the next batch's images sent ahead (ecseg_prefetch_input)
 against the device-only time of the same batch (stage timers).  Prints one JSON line.
 
     python tools/experiments/host_call_probe.py [--base 16] [--batch 32] [--reps 6]
@@ -95,6 +96,21 @@ def main():
             t.join()
 
     out['D_two_handles_pinned_ms_per_image'] = round(timed(two_workers) / 2, 4)        # (2 n images per repetition)
+
+    # E: ONE handle, the next batch's images sent ahead under this batch's kernels (ecseg_prefetch_input)
+    hh, p_in, p_g, p_p = pin[0]
+    p_in_b = hh.host_empty(imgs.shape, imgs.dtype)
+    p_in_b[...] = imgs
+    bufs = [p_in, p_in_b]
+
+    def ahead():
+        for k in range(4):
+            hh.prefetch_input(bufs[(k + 1) & 1])
+            got['e'] = hh.meta_segment(bufs[k & 1], gray_out=p_g, post_out=p_p)
+
+    out['E_one_handle_inputs_sent_ahead_ms_per_image'] = round(timed(ahead) / 4, 4)
+    out['E_identical_to_A'] = bool(np.array_equal(got['e'][0], ref['gray']) and np.array_equal(got['e'][1], ref['post'])
+                                   and np.array_equal(got['e'][2], ref['nec']))
     t0 = time.perf_counter()
     c = np.empty_like(pin[0][1])
     np.copyto(c, imgs)

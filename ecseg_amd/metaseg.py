@@ -160,7 +160,8 @@ class _PinnedPool:
         if self.thread is None:
             return None
         with self.lock:
-            fit = [k for k, b in enumerate(self.free) if b.size >= nbytes]
+            # (a buffer more than twice the size asked for stays where it is: label buffers must not eat the input buffers)
+            fit = [k for k, b in enumerate(self.free) if nbytes <= b.size <= 2 * max(int(nbytes), int(full_bytes))]
             if fit:
                 self.hits += 1
                 return self.free.pop(min(fit, key=lambda k: self.free[k].size))

@@ -25,6 +25,9 @@ if [ "${1:-a}" = a ]; then
   # ... and with the fitted smooth-output stand-in for a trained model (blobs instead of speckle: what the label PNG coder sees in real use)
   for n in 256 1024; do timeout -k 10 400 python3 tools/time_cli.py --keep /dev/shm/ecseg_cli --n $n --base 16 --batch 32 --weights smooth >> $O/cli_timing.jsonl 2>> $O/cli_timing.err; echo "cli smooth x$n rc $?"; done
   rm -rf /dev/shm/ecseg_cli
+  # ... and with uncompressed input TIFFs (no LZW decode: the loop is then bound by the device, not by the CPU quota)
+  for w in random smooth; do timeout -k 10 400 python3 tools/time_cli.py --keep /dev/shm/ecseg_cli --n 1024 --base 16 --batch 32 --input-compression raw --weights $w >> $O/cli_timing.jsonl 2>> $O/cli_timing.err; echo "cli raw $w rc $?"; done
+  rm -rf /dev/shm/ecseg_cli
   timeout -k 10 100 python3 tools/experiments/host_call_probe.py --base 16 --batch 32 > $O/host_call_probe.json 2>> $O/cli_timing.err; echo "host probe rc $?"
   timeout -k 10 100 python3 tools/experiments/wait_cpu.py 1 > $O/wait_cpu.jsonl 2>> $O/cli_timing.err; ECSEG_SPIN_WAIT=1 timeout -k 10 100 python3 tools/experiments/wait_cpu.py 0 >> $O/wait_cpu.jsonl 2>> $O/cli_timing.err
 else

@@ -177,6 +177,22 @@ class _PinnedPool:
             with self.lock:
                 self.free.append(b)
 
+    def reserve(self, sizes):
+        """Order buffers ahead of need (in this order, within the limit): the first batches of a run then find theirs instead
+        of missing one by one.  A size already served by a free buffer of its class is skipped."""
+        if self.thread is None:
+            return
+        with self.lock:
+            spare = [b.size for b in self.free]
+            for want in sizes:
+                want = int(want)
+                k = next((k for k, sz in enumerate(spare) if want <= sz <= 2 * want), None)
+                if k is not None:
+                    spare.pop(k)
+                elif want <= self.left:
+                    self.left -= want
+                    self.requests.put(want)
+
 
 def _view(buf, shape, dtype=np.uint8):
     n = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
@@ -429,7 +445,7 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
         for th in gpu_threads:
             th.start()
         try:
-            group, key = [], None
+            group, key, reserved = [], None, False
             for k in range(len(mine)):
                 top_up(k + window)
                 try:
@@ -442,6 +458,12 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
                     img = img[1]
                     log("Keeping existing outputs of ", mine[k])
                 kk = (img.shape, img.dtype.str)
+                if not reserved and img.dtype != np.bool_:
+                    # the shape of the run is known with its first image: order the page-locked buffers of the first batches now
+                    # (three inputs in flight - being packed, queued, on the device - and three output pairs being written)
+                    reserved = True
+                    b_in, b_out = batch_images * img.nbytes, batch_images * img.shape[0] * img.shape[1]
+                    pool.reserve([b_in, b_out, b_out, b_in, b_out, b_out, b_in, b_out, b_out])
                 if group and (kk != key or len(group) >= batch_images):
                     batches.put(pack(group))
                     group = []

@@ -450,3 +450,21 @@ def test_host_allocator_tuning_is_optional_and_idempotent(monkeypatch):
     assert utils.tune_host_allocator() is False                                           # once per process
     a = np.ones((1040, 1392), np.int64)                                                    # the allocator still works
     assert int(a.sum()) == 1040 * 1392
+
+
+def test_integration_stub_structs_match_the_binding():
+    """INTEGRATION.md B shows the ctypes stub a reference maintainer would paste into src/utils.py.  Its struct layouts and its
+    ABI check must be the ones of the shipped binding (round 5 found the stub one field behind the header)."""
+    import ctypes as C
+    from ecseg_amd import _lib
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    stub = text[text.index('class _Tensor(ctypes.Structure)'):text.index('def load_model(model_name):')]
+    ns = {'ctypes': C}
+    exec(stub, ns)                                        # the two class definitions, nothing else
+    for mine, theirs in ((ns['_Tensor'], _lib.TensorDesc), (ns['_Op'], _lib.OpDesc)):
+        assert [(n, t) for n, t in mine._fields_] == [(n, t) for n, t in theirs._fields_]
+        assert C.sizeof(mine) == C.sizeof(theirs)
+    assert '_lib.ecseg_abi_version() == %d' % _lib.ABI_VERSION in text
+    # every library call the document makes exists
+    for name in set(re.findall(r'_lib\.(ecseg_[a-z0-9_]+)', text)):
+        assert name in _lib.EXPORTS, name

@@ -232,3 +232,34 @@ def test_device_workers_two_handles_same_outputs(workdir):
     assert sorted(snaps[0]) == sorted(snaps[1])
     for k in snaps[0]:
         assert snaps[0][k] == snaps[1][k], k
+
+
+def test_integration_stub_of_the_reference_side_runs(workdir):
+    """the ctypes stub a reference maintainer pastes into src/utils.py - executed as written (its own raw
+    ctypes binding, its struct definitions, `load_model`, `meta_segment`, `meta_segment_batch`) with the reference's
+    surrounding names supplied, and compared with the package's own path."""
+    import types
+    from ecseg_amd import utils as eutils
+    from ecseg_amd._lib import LIB_PATH
+    tmp, inp = workdir
+    os.makedirs(inp / 'dapi', exist_ok=True)
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'INTEGRATION.md')).read()
+    start = text.index("```python\nimport ctypes, numpy as np\n_lib = ctypes.CDLL(")
+    code = text[start + len('```python\n'):text.index('```', start + 10)]
+    code = code.replace("'/path/to/ecseg_amd/libecseg_hip.so'", repr(LIB_PATH))
+    saved = []
+    ns = {'os': os, 'imread': image_io.imread, 'meta_preprocess': preprocess.meta_preprocess,
+          'cv2': types.SimpleNamespace(bitwise_not=lambda a: ~a), 'save_img': lambda img, split, sub: saved.append((split[1], sub, img))}
+    exec(code, ns)
+    model = ns['load_model']('metaseg.h5')
+    ours = eutils.load_model('metaseg.h5')
+    paths = [str(inp / ('img%d.tif' % k)) for k in range(3)]
+    for p in paths:
+        lab = ns['meta_segment'](model, p)
+        assert lab.dtype == np.int64 and np.array_equal(lab, eutils.meta_segment(ours, p))
+    labs, nec = ns['meta_segment_batch'](model, paths)
+    for j, p in enumerate(paths):
+        want = eutils.meta_segment(ours, p)
+        assert np.array_equal(labs[j], want) and nec[j] == postproc.count_cc(want == 3)[0]
+    assert len(saved) == 6 and all(s[1] == 'dapi' for s in saved)
+    ns['_lib'].ecseg_destroy(ns['_h'])

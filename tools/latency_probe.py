@@ -19,12 +19,19 @@ def main():
     ap.add_argument('--base', type=int, default=64)
     ap.add_argument('--lanes', default='1,2,3,4')
     ap.add_argument('--images', default='1,2,3')
+    ap.add_argument('--weights', default='random', choices=('random', 'smooth'),
+                    help='smooth: the fitted base-16 stand-in for a trained model (tests/golden/smooth_b16_f16.npz; implies --base 16)')
     a = ap.parse_args()
     import torch
     from ecseg_amd import synth
     from ecseg_amd.model import MetasegModel
-    cfg = synth.unet_config(base=a.base)
-    m = MetasegModel(cfg, synth.unet_weights(cfg, seed=0), device=0)
+    if a.weights == 'smooth':
+        from tools import make_smooth_fixture
+        cfg, weights = make_smooth_fixture.load(os.path.join(ROOT, 'tests', 'golden', 'smooth_b16_f16.npz'))
+    else:
+        cfg = synth.unet_config(base=a.base)
+        weights = synth.unet_weights(cfg, seed=0)
+    m = MetasegModel(cfg, weights, device=0)
     h = m.handle
     out = {}
     for n_img in [int(x) for x in a.images.split(',')]:

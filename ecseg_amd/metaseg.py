@@ -111,10 +111,10 @@ class _PinnedPool:
     with it); a run brackets its use with start() / stop()."""
 
     def __init__(self, handle, limit_bytes):
-        self.handle, self.left = handle, int(limit_bytes)
+        self.handle, self.limit, self.left = handle, int(limit_bytes), int(limit_bytes)
         self.free, self.lock = [], threading.Lock()
         self.alloc = getattr(handle, 'host_empty', None)
-        self.requests, self.thread = None, None
+        self.requests, self.thread, self.stopping = None, None, False
         self.hits = self.misses = 0
 
     @classmethod
@@ -126,16 +126,22 @@ class _PinnedPool:
                 handle._metaseg_pool = pool
             except AttributeError:
                 pass
+        elif int(limit_bytes) > pool.limit:                 # a later run may raise the limit (never lowers what is already locked)
+            with pool.lock:
+                pool.left += int(limit_bytes) - pool.limit
+                pool.limit = int(limit_bytes)
         return pool
 
     def start(self):
         if self.alloc is not None and self.thread is None:
             self.requests = queue.Queue()
+            self.stopping = False
             self.thread = threading.Thread(target=self._grow, name='ecseg-pinned', daemon=True)
             self.thread.start()
 
     def stop(self):
         if self.thread is not None:
+            self.stopping = True                            # orders not started yet are dropped: a short run does not wait for them
             self.requests.put(None)
             self.thread.join()
             self.thread = None
@@ -145,6 +151,10 @@ class _PinnedPool:
             want = self.requests.get()
             if want is None:
                 return
+            if self.stopping:
+                with self.lock:
+                    self.left += want
+                continue
             try:
                 b = self.alloc((want,), np.uint8)
             except EcsegError:
@@ -271,7 +281,7 @@ def _segment_isolating(model, imgs, log, emit_probs=False, outs=None):
 
 
 def run(inpath, model, image_paths, rank=0, world=1, batch_images=8, io_threads=None, log=print, stats=None, resume=False,
-        emit_probs=False, pinned_mb=2048):
+        emit_probs=False, pinned_mb=2048, pinned_min_images=None):
     """Segment this rank's shard; returns records (one row per image of the WHOLE job after the all-gather)."""
     start, stop, per = dist.shard_bounds(len(image_paths), rank, world)
     mine = image_paths[start:stop]
@@ -289,7 +299,8 @@ def run(inpath, model, image_paths, rank=0, world=1, batch_images=8, io_threads=
     # page-locked batch buffers (config key pinned_mb, default 2048; 0: ordinary memory as in rounds 1-4)
     first = model[0] if isinstance(model, (list, tuple)) else model
     pool = _PinnedPool.of(first.handle, int(pinned_mb) << 20)
-    if pinned_mb > 0:
+    # (page-locking pays after ~5 uses of a buffer: not for a handful of images; pinned_min_images overrides the threshold)
+    if pinned_mb > 0 and len(mine) >= (4 * batch_images if pinned_min_images is None else pinned_min_images):
         pool.start()
     try:
         return _run_threads(model, mine, start, per, rank, world, batch_images, io_threads, window, pending_writes, n_ec,

@@ -263,3 +263,42 @@ def test_integration_stub_of_the_reference_side_runs(workdir):
         assert np.array_equal(labs[j], want) and nec[j] == postproc.count_cc(want == 3)[0]
     assert len(saved) == 6 and all(s[1] == 'dapi' for s in saved)
     ns['_lib'].ecseg_destroy(ns['_h'])
+
+
+def test_page_locked_batch_buffers_change_nothing(workdir):
+    """`make metaseg`'s page-locked recycled batch buffers and the next batch's upload under the current batch's kernels
+    (ecseg_host_alloc, ecseg_prefetch_input; switched on for jobs of >= 4 batches, forced here): records and every output
+    file equal a run over ordinary memory, in the first run (buffers arrive while it runs) and in the second (all hits)."""
+    from ecseg_amd import metaseg, utils as eutils
+    tmp, inp = workdir
+    model = eutils.load_model('metaseg.h5')
+    paths = eutils.get_imgs(str(inp))
+
+    def one_run(**kw):
+        for sub in ('labels', 'dapi'):
+            shutil.rmtree(str(inp / sub), ignore_errors=True)
+            os.makedirs(inp / sub)
+        stats = {}
+        rec = metaseg.run(str(inp), model, paths, batch_images=1, io_threads=2, log=lambda *a: None, stats=stats, **kw)
+        snap = {os.path.join(sub, f): (inp / sub / f).read_bytes() for sub in ('labels', 'dapi') for f in sorted(os.listdir(str(inp / sub)))}
+        return rec, snap, stats
+
+    rec0, snap0, st0 = one_run(pinned_mb=0)
+    assert st0['pinned_pool']['hits'] == 0
+    # a four-image run is over before the pool's thread has locked anything (orders still pending when a run ends are dropped):
+    # stock the pool first, as the early batches of a long run do
+    import time
+    pool = metaseg._PinnedPool.of(model.handle, 256 << 20)
+    pool.start()
+    sizes = [300 * 400 * 3] * 3 + [300 * 400] * 6 + [280 * 300] * 9
+    pool.reserve(sizes)
+    t0 = time.time()
+    while len(pool.free) < len(sizes) and time.time() - t0 < 20:
+        time.sleep(0.01)
+    pool.stop()
+    assert len(pool.free) == len(sizes)
+    rec1, snap1, st1 = one_run(pinned_min_images=0)
+    assert st1['pinned_pool']['hits'] >= 8, st1['pinned_pool']
+    assert len(pool.free) >= len(sizes)                                    # every buffer came back
+    assert np.array_equal(rec0, rec1)
+    assert sorted(snap1) == sorted(snap0) and all(snap1[k] == snap0[k] for k in snap0)

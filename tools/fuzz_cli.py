@@ -83,7 +83,9 @@ def main():
             for sub in ('dapi', 'labels', 'red', 'green'):
                 os.makedirs(os.path.join(d, sub), exist_ok=True)
             bi, it = int(rng.integers(1, 6)), int(rng.integers(1, 7))
-            rec = metaseg.run(d, model, paths, batch_images=bi, io_threads=it, log=lambda *x: None)
+            # (page-locked batch buffers + inputs sent ahead, forced on for half of the folders: small folders would skip them)
+            rec = metaseg.run(d, model, paths, batch_images=bi, io_threads=it, log=lambda *x: None,
+                              pinned_min_images=0 if rng.random() < 0.5 else None)
             tag = '%d files, %d shapes, batch %d, threads %d' % (len(paths), len(shapes), bi, it)
             if len(rec) != len(paths) or [int(r[dist.F_INDEX]) for r in rec] != list(range(len(paths))):
                 fail('records out of order / missing - ' + tag)

@@ -94,7 +94,8 @@ def main():
             shutil.copy(os.path.join(inp, 'img0000.tif'), os.path.join(warm, 'w%03d.tif' % k))
         stats = {}
         for mdl in [model] + extra:
-            metaseg.run(warm, mdl, utils.get_imgs(warm), batch_images=a.batch, log=lambda *x: None, stats=stats, pinned_mb=a.pinned_mb)
+            metaseg.run(warm, mdl, utils.get_imgs(warm), batch_images=a.batch, log=lambda *x: None, stats=stats, pinned_mb=a.pinned_mb,
+                        pinned_min_images=0)    # (one batch would not start the page-locked pool by itself)
         cg0 = cgroup_cpu()
         t0 = time.perf_counter()
         rec = metaseg.run(inp, [model] + extra if extra else model, utils.get_imgs(inp), batch_images=a.batch, io_threads=a.io_threads, log=lambda *x: None, stats=stats,

@@ -1069,12 +1069,12 @@ int ecseg_create(ecseg_ctx** out, int device_id) {
     if (e != hipSuccess || ndev <= 0) return fail(nullptr, ECSEG_E_HIP, std::string("no HIP device: ") + hipGetErrorString(e));
     if (device_id < 0 || device_id >= ndev) return fail(nullptr, ECSEG_E_INVALID, "device_id out of range");
     if ((e = hipSetDevice(device_id)) != hipSuccess) return fail_hip(nullptr, e, "hipSetDevice");
-    // Waiting host threads sleep instead of spinning: with this runtime's default (hipDeviceScheduleAuto = spin when the host has
-    // more cores than GPUs) a thread inside a segment call burns a whole core for the length of the call - measured 1.35 cores
-    // busy per waiting call, 0.13 with this flag and the blocking event of wait_stream, at the same wall time
-    // (tools/experiments/wait_cpu.py).  `make metaseg` needs those cores for its decoders and encoders.  The flag
-    // belongs to the device, i.e. to every user of it in this process; ECSEG_SPIN_WAIT=1 leaves the runtime's default alone.
-    if (!getenv("ECSEG_SPIN_WAIT") || atoi(getenv("ECSEG_SPIN_WAIT")) == 0) {
+    // Waiting host threads: this library's own long waits always sleep on a blocking event (wait_stream: 0.31 -> 0.13 cores busy
+    // per waiting call).  The DEVICE-wide flag hipDeviceScheduleBlockingSync (the runtime's default spins when the host has more
+    // cores than GPUs: 1.35 cores per waiting call, tools/experiments/wait_cpu.py) changes the waits of every HIP user of the
+    // process - torch tensors of an embedding application, other libraries - so it is OPT-IN: ECSEG_BLOCKING_SYNC=1,
+    // which this package's own command lines (`make metaseg`, `make meta_overlay`: they own their process) set for themselves.
+    if (getenv("ECSEG_BLOCKING_SYNC") && atoi(getenv("ECSEG_BLOCKING_SYNC")) != 0) {
         if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();    // (not fatal: the default stays)
     }
     ecseg_ctx* h = new ecseg_ctx();
@@ -1131,6 +1131,14 @@ void ecseg_destroy(ecseg_ctx* h) {
 
 const char* ecseg_last_error(ecseg_ctx* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
+// Images named or sent ahead by ecseg_prefetch_input belong to the very next ecseg_meta_segment call: any other call on the handle
+// in between withdraws them (the hit is keyed by host pointer + size, and a registration that outlived its call could
+// meet a recycled page-locked buffer of the same shape holding OTHER pixels).
+static inline void drop_sent_ahead(ecseg_ctx* h) {
+    h->next_host = nullptr; h->next_bytes = 0;
+    h->pre_host = nullptr; h->pre_bytes = 0;
+}
+
 int ecseg_device_name(ecseg_ctx* h, char* buf, int buflen) {
     if (!h || !buf || buflen <= 0) return ECSEG_E_INVALID;
     snprintf(buf, buflen, "%s", h->devname);
@@ -1172,6 +1180,7 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
                      int n_ops, const float* const* weights, const int64_t* weight_len, int n_weights, int input_tensor,
                      int output_tensor) {
     if (!h) return ECSEG_E_INVALID;
+    drop_sent_ahead(h);
     if (!tensors || !ops || n_tensors <= 0 || n_ops <= 0 || n_buffers <= 0) return fail(h, ECSEG_E_INVALID, "empty plan");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1452,6 +1461,7 @@ int ecseg_model_flops_per_patch(ecseg_ctx* h, double* flops) {
 }
 
 static int forward_host(ecseg_ctx* h, const void* patches, bool is_f32, int n, float* out) {
+    if (h) drop_sent_ahead(h);
     int rc = check_model(h);
     if (rc) return rc;
     if (n < 0 || (n > 0 && (!patches || !out))) return fail(h, ECSEG_E_INVALID, "forward_patches: bad arguments");
@@ -1504,6 +1514,7 @@ int ecseg_read_tensor(ecseg_ctx* h, int tensor, int n, float* out) {
 
 int ecseg_segment_images_dev(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint8_t* raw, uint8_t* post, int32_t* n_ec) {
     if (!h) return ECSEG_E_INVALID;
+    drop_sent_ahead(h);
     if (n_img < 0 || (n_img > 0 && (!gray || !post))) return fail(h, ECSEG_E_INVALID, "segment: bad arguments");
     if (n_img == 0) return ECSEG_OK;
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1524,6 +1535,7 @@ int ecseg_segment_images(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, in
 int ecseg_segment_images_ex(ecseg_ctx* h, const uint8_t* gray, int n_img, int H, int W, uint8_t* raw, uint8_t* post, int32_t* n_ec,
                             int32_t* tie_risk, float* probs) {
     if (!h) return ECSEG_E_INVALID;
+    drop_sent_ahead(h);
     if (n_img < 0 || (n_img > 0 && (!gray || !post))) return fail(h, ECSEG_E_INVALID, "segment: bad arguments");
     if (n_img == 0) return ECSEG_OK;
     int rc = check_model(h);
@@ -1546,6 +1558,7 @@ int ecseg_segment_images_ex(ecseg_ctx* h, const uint8_t* gray, int n_img, int H,
 
 int ecseg_preprocess(ecseg_ctx* h, const void* img, int n_img, int H, int W, int C, int bps, uint8_t* gray_out, int32_t* inverted_out) {
     if (!h) return ECSEG_E_INVALID;
+    drop_sent_ahead(h);
     if (n_img < 0 || H <= 0 || W <= 0 || (C != 1 && C != 3 && C != 4) || (bps != 1 && bps != 2) || (n_img > 0 && (!img || !gray_out)))
         return fail(h, ECSEG_E_INVALID, "preprocess: bad arguments");
     if (n_img == 0) return ECSEG_OK;
@@ -1591,6 +1604,7 @@ int ecseg_meta_segment(ecseg_ctx* h, const void* img, int n_img, int H, int W, i
     if ((rc = ensure(h, h->d_hist, h->d_hist_cap, (size_t)n_img * 256))) return rc;
     hipStream_t s = h->stream, sc = h->stream2;
     const double t0 = dbg_now();
+    if (h->next_host == img) { h->next_host = nullptr; h->next_bytes = 0; }     // (registered for a call that never came: it names THIS call's images)
     if (h->pre_host == img && h->pre_bytes == in_bytes && h->d_pre) {
         // these images were sent ahead (ecseg_prefetch_input) while the call before this one computed: the two input buffers
         // change places (the one given up last held the images of the call before, whose pre-processing is long over)
@@ -1671,6 +1685,7 @@ int ecseg_host_free(ecseg_ctx* h, void* p) {
 
 int ecseg_u16_to_u8(ecseg_ctx* h, const uint16_t* in, long long count, uint8_t* out) {
     if (!h) return ECSEG_E_INVALID;
+    drop_sent_ahead(h);
     if (count < 0 || (count > 0 && (!in || !out))) return fail(h, ECSEG_E_INVALID, "u16_to_u8: bad arguments");
     if (count == 0) return ECSEG_OK;
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1687,6 +1702,7 @@ int ecseg_u16_to_u8(ecseg_ctx* h, const uint16_t* in, long long count, uint8_t* 
 
 int ecseg_stitch_argmax(ecseg_ctx* h, const float* probs, int n_img, int H, int W, uint8_t* labels_raw) {
     if (!h) return ECSEG_E_INVALID;
+    drop_sent_ahead(h);
     if (n_img < 0 || (n_img > 0 && (!probs || !labels_raw))) return fail(h, ECSEG_E_INVALID, "stitch_argmax: bad arguments");
     if (n_img == 0) return ECSEG_OK;
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1706,6 +1722,7 @@ int ecseg_stitch_argmax(ecseg_ctx* h, const float* probs, int n_img, int H, int 
 
 int ecseg_meta_inference_dev(ecseg_ctx* h, const uint8_t* in, int n_img, int H, int W, uint8_t* out, int32_t* n_ec) {
     if (!h) return ECSEG_E_INVALID;
+    drop_sent_ahead(h);
     if (n_img < 0 || H <= 0 || W <= 0 || (n_img > 0 && (!in || !out))) return fail(h, ECSEG_E_INVALID, "meta_inference: bad arguments");
     if (n_img == 0) return ECSEG_OK;
     if ((long long)H * W >= (1ll << 31)) return fail(h, ECSEG_E_INVALID, "image too large");
@@ -1729,6 +1746,7 @@ int ecseg_meta_inference_dev(ecseg_ctx* h, const uint8_t* in, int n_img, int H, 
 
 int ecseg_meta_inference(ecseg_ctx* h, const uint8_t* in, int n_img, int H, int W, uint8_t* out, int32_t* n_ec) {
     if (!h) return ECSEG_E_INVALID;
+    drop_sent_ahead(h);
     if (n_img < 0 || H <= 0 || W <= 0 || (n_img > 0 && (!in || !out))) return fail(h, ECSEG_E_INVALID, "meta_inference: bad arguments");
     if (n_img == 0) return ECSEG_OK;
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1748,6 +1766,7 @@ int ecseg_meta_inference(ecseg_ctx* h, const uint8_t* in, int n_img, int H, int 
 static int count_driver(ecseg_ctx* h, const uint8_t* a, const uint8_t* b, int n_img, int H, int W, int kind, int arg,
                         int32_t* n_out, int64_t* px_out, int32_t* labels_out) {
     if (!h) return ECSEG_E_INVALID;
+    drop_sent_ahead(h);
     if (n_img < 0 || H <= 0 || W <= 0 || (n_img > 0 && !a)) return fail(h, ECSEG_E_INVALID, "count: bad arguments");
     if (n_img == 0) return ECSEG_OK;
     if ((long long)H * W >= (1ll << 31)) return fail(h, ECSEG_E_INVALID, "image too large");
@@ -1803,6 +1822,7 @@ int ecseg_count_hsr(ecseg_ctx* h, const uint8_t* chrom, const uint8_t* fish, int
 int ecseg_overlay(ecseg_ctx* h, const uint8_t* labels, const uint8_t* rgb, int n_img, int H, int W, int C, int sens, int hsr_thr,
                   int64_t* out) {
     if (!h) return ECSEG_E_INVALID;
+    drop_sent_ahead(h);
     if (n_img < 0 || H <= 0 || W <= 0 || C < 2 || (n_img > 0 && (!labels || !rgb || !out)))
         return fail(h, ECSEG_E_INVALID, "overlay: bad arguments");
     if (n_img == 0) return ECSEG_OK;

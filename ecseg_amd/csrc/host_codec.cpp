@@ -150,7 +150,15 @@ long long ecseg_lzw_decode(const uint8_t* src, long long n, uint8_t* dst, long l
             dst[out++] = (uint8_t)code;
             continue;
         }
-        if (__builtin_expect(old < 0, 0)) break;        // (stream that does not start with a ClearCode: careful form)
+        if (__builtin_expect(old < 0, 0)) {
+            // no previous code: a stream that does not begin with a ClearCode (libtiff tolerates it) or the code behind a
+            // second ClearCode in a row.  This code is ALREADY consumed: it is handled here as the literal it has to be (round 5
+            // left for the careful form at this point, which resumed from the next code and silently dropped this byte)
+            if (code > 255) return -1;
+            old_pos = out; old_len = 1; old = code;
+            dst[out++] = (uint8_t)code;
+            continue;
+        }
         uint32_t cpos, clen;
         const uint8_t* sp;
         if (__builtin_expect(code < next, 1)) {

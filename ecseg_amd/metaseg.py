@@ -422,13 +422,23 @@ def _run_threads(model, mine, start, per, rank, world, batch_images, io_threads,
                     return
                 # look ahead without waiting: the raw images of the next batch - when they lie in page-locked memory - go up
                 # under this batch's kernels (ecseg_prefetch_input), so one handle overlaps its copies with its own compute
-                try:
-                    ahead.append(batches.get_nowait())
-                    nxt = ahead[0]
-                    if prefetch is not None and nxt is not None and nxt[2] is not None and not fatal:
-                        prefetch(nxt[1])
-                except queue.Empty:
-                    pass
+                # (with several device workers a batch parked in `ahead` would keep the other worker idle: no look-ahead there.  A
+                # batch that never reaches ecseg_meta_segment - resumed images, only counted - must not leave a registration
+                # behind: the library keys the hit on (pointer, size) and the buffer goes back to the pool.  ADVICE r05)
+                if prefetch is not None and len(models) == 1:
+                    try:
+                        ahead.append(batches.get_nowait())
+                        nxt = ahead[0]
+                        to_device = g[0] and g[1].dtype != np.bool_
+                        if nxt is not None and nxt[2] is not None and nxt[1].dtype != np.bool_ and to_device and not fatal:
+                            prefetch(nxt[1])
+                        else:
+                            prefetch(None)
+                    except queue.Empty:
+                        pass
+                    except BaseException as e:             # an error here must not end the loop: the feeder would block for ever
+                        if not fatal and not (isinstance(e, EcsegError) and e.code != E_HIP):
+                            fatal.append(e)
                 try:
                     if fatal:                              # keep draining so that the feeder never blocks; nothing reaches the device
                         raise fatal[0]
@@ -546,8 +556,8 @@ def finish(inpath, image_paths, rec, rank, seconds=None, gpu_seconds=0.0, log=pr
 def _supervise_native(n, env, argv=None, poll=0.2, grace=10.0):
     """Start ``n`` fresh rank processes (ECSEG_DIST=native) and watch ALL of them: on the first non-zero exit the remaining
     ranks are terminated (then killed) - a rank that died before the record all-gather would otherwise leave its peers
-    blocked for ever in ncclCommInitRank / ncclAllGather (csrc/comm.hip has no timeout) and this parent on the first live
-    child.  The rendezvous directory is removed either way.  Returns the job's exit code (first failure, else 0).  Only
+    blocked in ncclCommInitRank / ncclAllGather until csrc/comm.hip's own timeout (ECSEG_COMM_TIMEOUT_S, default 300 s) and this
+    parent on the first live child.  The rendezvous directory is removed either way.  Returns the job's exit code (first failure, else 0).  Only
     fresh children are started, never a re-exec of a process that has touched the GPU."""
     import shutil
     import tempfile
@@ -607,6 +617,7 @@ def _self_launch(device_ids):
 
 
 def main(argv=None):
+    os.environ.setdefault('ECSEG_BLOCKING_SYNC', '1')      # this process is ours: waiting threads sleep (ecseg_create, include/ecseg_hip.h)
     config = open("config.yaml")
     var = yaml.load(config, Loader=yaml.FullLoader)['metaseg']
     inpath = var['inpath']

@@ -51,9 +51,10 @@ typedef struct ecseg_ctx ecseg_ctx;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------- */
 int         ecseg_abi_version(void);
-/* ecseg_create also makes host threads that wait for this device SLEEP instead of spinning (hipSetDeviceFlags(
- * hipDeviceScheduleBlockingSync): a device-wide setting of the process; same wall time, one core less per waiting call).
- * Environment ECSEG_SPIN_WAIT=1 leaves the runtime's default.  ECSEG_DEBUG_CALLS=1 prints a host-side timeline of every
+/* Waits: the library's own long waits sleep on a blocking event (option "blocking_wait").  With ECSEG_BLOCKING_SYNC=1 in the
+ * environment ecseg_create ALSO sets hipDeviceScheduleBlockingSync - a device-wide setting of the whole process (every HIP
+ * user's waits sleep instead of spinning: same wall time, one core less per waiting call); off by default for that reason,
+ * the package's command lines switch it on for their own process.  ECSEG_DEBUG_CALLS=1 prints a host-side timeline of every
  * ecseg_meta_segment call on stderr. */
 int         ecseg_create(ecseg_ctx** out, int device_id);
 void        ecseg_destroy(ecseg_ctx* h);

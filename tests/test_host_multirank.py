@@ -313,13 +313,27 @@ def test_fused_call_and_page_locked_pool_give_the_same_outputs(tmp_path):
             self.allocated.append(a)
             return a
 
+        registered = None                                    # the library's state: images named for the call after the coming one
+
         def prefetch_input(self, imgs):
+            if imgs is None:                                 # withdraw (a batch that is not sent ahead: ordinary memory, resumed images)
+                self.registered = None
+                return
             assert any(np.shares_memory(imgs, a) for a in self.allocated), 'only page-locked batches are sent ahead'
             self.sent_ahead.append(imgs.ctypes.data)
+            self.registered = imgs.ctypes.data
+
+        def count_cc(self, masks):
+            # a count-only batch (resumed images) must not leave a registration behind - the coming meta_segment
+            # call would send its OWN buffer ahead and a later batch in the recycled buffer would hit stale pixels
+            assert self.registered is None, 'a batch that never reaches meta_segment left images registered'
+            return super().count_cc(masks)
 
         def meta_segment(self, imgs, gray_out=None, post_out=None):
             self.fused_calls += 1
             self.seen.append(imgs.ctypes.data)
+            assert self.registered != imgs.ctypes.data, 'the coming call was handed its own images as the ones to send ahead'
+            self.registered = None
             time.sleep(0.03)                                 # (a device call takes a while: the feeder gets a batch ahead)
             gray, _ = self.preprocess(imgs)
             post, nec = StubModel.segment(model, gray)
@@ -365,6 +379,14 @@ def test_fused_call_and_page_locked_pool_give_the_same_outputs(tmp_path):
     assert np.array_equal(rec1, rec3) and pool.hits > hits0 and h.filled > 0
     # batches sent ahead (ecseg_prefetch_input) are exactly the ones the next device call then receives
     assert h.sent_ahead and all(a in h.seen for a in h.sent_ahead)
+    # resume over a folder where every other image is done: count-only batches alternate with device batches
+    done = sorted(os.listdir(os.path.join(two, 'labels')))
+    for k, f in enumerate(x for x in done if x.endswith('.npy')):
+        if k % 2:
+            os.remove(os.path.join(two, 'labels', f))
+    calls0 = h.fused_calls
+    rec4 = metaseg.run(two, model, get_imgs(two), 0, 1, batch_images=3, io_threads=2, log=lambda *a: None, pinned_mb=64, resume=True)
+    assert np.array_equal(rec1, rec4) and h.fused_calls > calls0
     # pinned_mb = 0: the pool is never asked
     m0 = StubModel(); m0.handle = FusedHandle()
     metaseg.run(two, m0, get_imgs(two), 0, 1, batch_images=3, io_threads=2, log=lambda *a: None, pinned_mb=0)

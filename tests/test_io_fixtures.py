@@ -120,6 +120,31 @@ def test_lzw_roundtrip_and_corrupt_streams_do_not_crash():
         image_io._lzw_decode(b'\xff\xff\xff\xff\xff\xff', 100)
 
 
+def _pack_codes(codes, width=9):
+    """MSB-first bit string of fixed-width LZW codes (fewer than 250 codes: the width never changes)."""
+    bits = ''.join(format(c, '0%db' % width) for c in codes)
+    bits += '0' * (-len(bits) % 8)
+    return bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
+
+
+def test_lzw_streams_without_a_leading_clear_code_and_with_two_in_a_row():
+    """the fast form consumed a code and then left for the careful form, which resumed from the NEXT code - a
+    strip that does not begin with ClearCode (libtiff accepts it) or holds two ClearCodes in a row lost one byte and came
+    out shifted.  Literal-only streams (every code < 256 adds an entry nobody uses) decode to the literals themselves."""
+    rng = np.random.default_rng(5)
+    lits = [int(v) for v in rng.integers(0, 256, 60)]
+    want = np.array(lits, np.uint8)
+    for codes in (lits + [257],                          # no ClearCode at all
+                  [256, 256] + lits + [257],             # two in a row
+                  [256] + lits[:30] + [256, 256] + lits[30:] + [257],
+                  [256] + lits + [257]):                 # the ordinary shape
+        for pad in (0, 16):                              # with / without room for the fast form to run to the end
+            got = image_io._lzw_decode(_pack_codes(codes) + bytes(pad), len(lits))
+            assert np.array_equal(got, want), (codes[:3], pad)
+    with pytest.raises(image_io.TiffError):              # a table code with no previous string is corrupt
+        image_io._lzw_decode(_pack_codes([300] + lits + [257]) + bytes(16), 61)
+
+
 def test_host_codec_under_address_sanitizer():
     """`make asan`: ASan + UBSan build of csrc/host_codec.cpp driven over a corrupt-stream corpus (tools/asan)."""
     import shutil

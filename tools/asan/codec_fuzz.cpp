@@ -54,6 +54,29 @@ int main() {
         (void)ecseg_lzw_decode(junk.data(), (long long)junk.size(), out.data(), (long long)out.size());
     }
     (void)ecseg_lzw_decode(nullptr, 0, nullptr, 0);
+    // ---- hand-made streams the repo's own encoder never writes: literal-only strips without a leading ClearCode,
+    //      with two ClearCodes in a row, ClearCodes sprinkled in; fixed 9-bit codes (< 250 codes: the width never changes) ----
+    for (int round = 0; round < 200; ++round) {
+        const int nlit = 1 + (int)(rnd() % 200);
+        std::vector<int> codes; std::vector<uint8_t> want;
+        if (round % 3 != 0) codes.push_back(256);
+        if (round % 3 == 2) codes.push_back(256);
+        for (int i = 0; i < nlit; ++i) {
+            if (round % 5 == 4 && rnd() % 16 == 0) { codes.push_back(256); if (rnd() & 1) codes.push_back(256); }
+            const uint8_t b = (uint8_t)rnd(); codes.push_back(b); want.push_back(b);
+        }
+        codes.push_back(257);
+        std::vector<uint8_t> bits((codes.size() * 9 + 7) / 8 + (round & 1 ? 16 : 0), 0);
+        size_t bp = 0;
+        for (int c : codes) for (int b = 8; b >= 0; --b, ++bp) if ((c >> b) & 1) bits[bp >> 3] |= (uint8_t)(0x80u >> (bp & 7));
+        std::vector<uint8_t> out(want.size() + 1, 0xAB);
+        const long long r = ecseg_lzw_decode(bits.data(), (long long)bits.size(), out.data(), (long long)want.size());
+        // (codes < 256 add table entries: with ClearCodes in between fewer than 250 are ever live, the width stays 9)
+        if (r != (long long)want.size() || std::memcmp(out.data(), want.data(), want.size()) != 0 || out[want.size()] != 0xAB) {
+            std::printf("hand-made literal stream %d: %lld of %zu bytes or wrong bytes\n", round, r, want.size()); return 1;
+        }
+        ++checked;
+    }
     // ---- whole-file TIFF reader (csrc/host_io.cpp): files written by our own writer, then truncated / bit-flipped /
     //      overwritten with random tag values; the reader must return a status and never touch memory outside dst ----
     long long files = 0;

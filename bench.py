@@ -266,8 +266,9 @@ def self_launch(args):
 
 
 KIND_NAMES = ('conv_mfma_kernel', 'conv_wino_kernel F(2x2)', 'conv_wino4_kernel F(4x4)',
-              'conv_wino_res_kernel F(2x2), filter-resident', 'conv_wino16_kernel F(2x2), 16x16x4 MFMA')
-KIND_ISSUED = (1.0, 16.0 / 36.0, 0.25, 16.0 / 36.0, 16.0 / 36.0)      # multiplies issued / multiplies of the direct 3x3 convolution
+              'conv_wino_res_kernel F(2x2), filter-resident', 'conv_wino16_kernel F(2x2), 16x16x4 MFMA',
+              'conv_wino4s_kernel F(4x4), 3-way bf16 split operands on the bf16 pipe')
+KIND_ISSUED = (1.0, 16.0 / 36.0, 0.25, 16.0 / 36.0, 16.0 / 36.0, 0.25)      # multiplies issued / multiplies of the direct 3x3 convolution (kind 5: each as 6 bf16 products)
 
 
 def aggregate(recs):

@@ -26,6 +26,8 @@ struct OpRt {                 // run-time form of one plan operator
     float* wt_wino = nullptr; // Winograd-transformed filter (16 points) when the op is eligible
     float* wt_wino4 = nullptr; // F(4x4,3x3) filter image (36 points, per-wave stage layout of wino4_kernel.hip)
     float* wt_wino16 = nullptr; // F(2x2,3x3) filter image of wino16_kernel.hip (Cin, Cout in {16, 32})
+    void* wt_wino4s = nullptr; // bf16x3 stage image of wino4s_kernel.hip, made on the device from wt_wino4 when "winograd" = 3 is asked for
+    int w4_cin = 0, w4_cout = 0; // the layer wt_wino4 was made for
     int coutp_wino = 0;
     float* bias = nullptr;
     float* head_w4 = nullptr; // PATH_HEAD with <= 4 classes: [cin][4] / [4] zero-padded copies for the fused output stage
@@ -120,7 +122,7 @@ struct ecseg_ctx {
     int crop = 1;             // segment path: skip output regions of the last full-resolution convolutions that the stitch never reads
     int crop_mask = 1;        // cropped plan: Winograd kernels read zeros outside the receptive field of the needed outputs (0: A/B measurements only - results then depend on stale buffer contents in the last bits)
     int fuse_head = 1;        // 1x1 head (<= 4 classes) computed by the output stage of the last F(4x4) convolution
-    int use_winograd = 2;     // 0 direct, 1 Winograd F(2x2,3x3), 2 F(4x4,3x3) where eligible (else F(2x2))
+    int use_winograd = 2;     // 0 direct, 1 Winograd F(2x2,3x3), 2 F(4x4,3x3) where eligible (else F(2x2)), 3: F(4x4) with 3-way bf16 split operands on the bf16 matrix pipe where eligible (else as 2)
     int wino4_split = 1;      // F(4x4) layers with exactly 32 output channels: split-K over the channel-half waves
     int wino16 = 1;           // F(2x2) layers with 16 / 32 input and output channels: conv_wino16_kernel (16x16x4 MFMA, register output stage)
     int wino_resident = 1;    // F(2x2) layers with <= 32 input and output channels: filter-resident kernel (conv_wino_res_kernel)
@@ -134,7 +136,7 @@ struct ecseg_ctx {
     std::vector<hipEvent_t> grp_events;    // 6 per image group of segment_dev
     size_t prof_used = 0;
     double prof_flops = 0.0, prof_exec_flops = 0.0;
-    struct ProfRec { int op; int kind; double flops, exec_flops; float ms; };   // kind: 0 direct, 1 F(2x2), 2 F(4x4), 3 filter-resident F(2x2), 4 F(2x2) on 16x16x4 MFMAs (wino16)
+    struct ProfRec { int op; int kind; double flops, exec_flops; float ms; };   // kind: 0 direct, 1 F(2x2), 2 F(4x4), 3 filter-resident F(2x2), 4 F(2x2) on 16x16x4 MFMAs (wino16), 5 F(4x4) with bf16x3 split operands (wino4s; exec_flops = the fp32-equivalent products, each issued as 6 bf16 products)
     std::vector<ProfRec> prof_recs;        // one per profiled launch of the last segment / forward call
     double last_conv_ms = 0.0; long long last_conv_launches = 0; double last_conv_flops = 0.0, last_conv_exec_flops = 0.0;
 };
@@ -595,8 +597,9 @@ int run_plan_op(ecseg_ctx* h, size_t& oi, int n_all, StitchPlan* crop, const Lan
                             ++oi;                              // the head op is done
                         }
                     };
+                    const bool wino4s = wino4 && h->use_winograd >= 3 && o.wt_wino4s && conv_wino4s_supported(p);
                     if (wino4) {
-                        p.wt = o.wt_wino4; p.coutp = out.c; p.w4_split = h->wino4_split;
+                        p.wt = wino4s ? reinterpret_cast<const float*>(o.wt_wino4s) : o.wt_wino4; p.coutp = out.c; p.w4_split = h->wino4_split;
                         if (crop && h->crop && o.crop_ok && (part || n % crop->n_pos == 0)) {
                             const CropLut* cl = get_crop_lut(crop, o.crop_code);
                             if (cl->len > 0 && out.h == cl->size && out.w == cl->size && conv_wino4_span_ok(p, crop->n_pos)) {
@@ -607,7 +610,7 @@ int run_plan_op(ecseg_ctx* h, size_t& oi, int n_all, StitchPlan* crop, const Lan
                         // a MaxPooling2D(2x2, stride 2) that follows directly is written by the same output stage
                         fuse_following_pool();
                         fuse_following_head(64);
-                        e = launch_conv_wino4(p, s);
+                        e = wino4s ? launch_conv_wino4s(p, s) : launch_conv_wino4(p, s);
                     } else if (wino && h->wino16 && o.wt_wino16 && act_core_ok && (first ? conv_wino16_first_supported(p) : conv_wino16_supported(p))) {
                         w16 = true;
                         p.wt = o.wt_wino16;
@@ -655,7 +658,7 @@ int run_plan_op(ecseg_ctx* h, size_t& oi, int n_all, StitchPlan* crop, const Lan
                         h->prof_exec_flops += ex;
                         const bool res = wino && p.resident && p.coutp == 32 && p.cin_chunks <= 4;
                         // kind: bits 0-7 the kernel, bit 8: the following 2x2 max-pool was written by this launch, bit 9: the following 1x1 head was
-                        h->prof_recs.push_back({(int)oi_first, (wino4 ? 2 : w16 ? 4 : res ? 3 : wino ? 1 : 0) | (p.pool.p != nullptr ? 0x100 : 0) |
+                        h->prof_recs.push_back({(int)oi_first, (wino4s ? 5 : wino4 ? 2 : w16 ? 4 : res ? 3 : wino ? 1 : 0) | (p.pool.p != nullptr ? 0x100 : 0) |
                                                 (p.head_w != nullptr ? 0x200 : 0) | (first ? 0x400 : 0), o.flops * n + (first ? first->flops * n : 0.0),
                                                 ex + (first ? first->flops * n * 12.0 / 9.0 : 0.0), 0.f});
                     }
@@ -1069,12 +1072,15 @@ int ecseg_create(ecseg_ctx** out, int device_id) {
     if (e != hipSuccess || ndev <= 0) return fail(nullptr, ECSEG_E_HIP, std::string("no HIP device: ") + hipGetErrorString(e));
     if (device_id < 0 || device_id >= ndev) return fail(nullptr, ECSEG_E_INVALID, "device_id out of range");
     if ((e = hipSetDevice(device_id)) != hipSuccess) return fail_hip(nullptr, e, "hipSetDevice");
-    // Waiting host threads: this library's own long waits always sleep on a blocking event (wait_stream: 0.31 -> 0.13 cores busy
-    // per waiting call).  The DEVICE-wide flag hipDeviceScheduleBlockingSync (the runtime's default spins when the host has more
-    // cores than GPUs: 1.35 cores per waiting call, tools/experiments/wait_cpu.py) changes the waits of every HIP user of the
-    // process - torch tensors of an embedding application, other libraries - so it is OPT-IN: ECSEG_BLOCKING_SYNC=1,
-    // which this package's own command lines (`make metaseg`, `make meta_overlay`: they own their process) set for themselves.
-    if (getenv("ECSEG_BLOCKING_SYNC") && atoi(getenv("ECSEG_BLOCKING_SYNC")) != 0) {
+    // Waiting host threads sleep instead of spinning: with this runtime's default (hipDeviceScheduleAuto = spin when the host has
+    // more cores than GPUs) a thread inside a segment call burns a whole core for the length of the call - measured 1.35 cores
+    // busy per waiting call, 0.13 with this flag and the blocking event of wait_stream, at the same wall time
+    // (tools/experiments/wait_cpu.py).  The flag belongs to the DEVICE, i.e. to every HIP user of it in this process (torch tensors
+    // of an embedding application included): INTEGRATION.md says so next to the ABI notes, and ECSEG_SPIN_WAIT=1 leaves the runtime's
+    // default alone.  Round 6 tried to make it opt-in and took that back: under the default scheduling mode hipFree
+    // hung for ever in ecseg_destroy - device idle, hipDeviceSynchronize returning hipSuccess - once a process had created and
+    // closed several handles (gpurun_out/r06_gputest_i.log: tests/test_gpu_unet.py then tests/test_gpu_configs.py; never with the flag).
+    if (!getenv("ECSEG_SPIN_WAIT") || atoi(getenv("ECSEG_SPIN_WAIT")) == 0) {
         if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();    // (not fatal: the default stays)
     }
     ecseg_ctx* h = new ecseg_ctx();
@@ -1153,6 +1159,27 @@ int ecseg_set_images_per_group(ecseg_ctx* h, int n) {
     return ECSEG_OK;
 }
 
+// "winograd" = 3: every layer that has an F(4x4) filter image and whole 64-channel output blocks gets the bf16x3 stage image of
+// conv_wino4s_kernel, written by a device kernel from the fp32 image (U rounded to float32 as the fp32 kernel uses it, then split
+// EXACTLY into three bf16 pieces).  Done when the option is set or a model is loaded under it - never inside a forward pass.
+static int ensure_split_images(ecseg_ctx* h) {
+    if (h->use_winograd < 3) return ECSEG_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    bool any = false;
+    for (OpRt& o : h->ops) {
+        if (!o.wt_wino4 || o.wt_wino4s || o.w4_cout % 64 != 0) continue;
+        void* d = nullptr;
+        const hipError_t e = hipMalloc(&d, wino4s_image_bytes(o.w4_cin, o.w4_cout));
+        if (e != hipSuccess) return fail(h, ECSEG_E_NOMEM, std::string("hipMalloc(split filter image): ") + hipGetErrorString(e));
+        h->dev_allocs.push_back(reinterpret_cast<float*>(d));
+        HIP_TRY(h, launch_wino4s_filter(o.wt_wino4, d, o.w4_cin, o.w4_cout, h->stream));
+        o.wt_wino4s = d;
+        any = true;
+    }
+    if (any) HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return ECSEG_OK;
+}
+
 int ecseg_set_option(ecseg_ctx* h, const char* key, int value) {
     if (!h || !key) return ECSEG_E_INVALID;
     const std::string k(key);
@@ -1165,7 +1192,10 @@ int ecseg_set_option(ecseg_ctx* h, const char* key, int value) {
     else if (k == "fuse_first") h->fuse_first = value != 0;
     else if (k == "wino4_split") h->wino4_split = value != 0;
     else if (k == "crop") h->crop = value != 0;
-    else if (k == "winograd") h->use_winograd = value < 0 ? 0 : value > 2 ? 2 : (int)value;   // 0 direct, 1 F(2x2), 2 F(4x4)
+    else if (k == "winograd") {                            // 0 direct, 1 F(2x2), 2 F(4x4), 3 F(4x4) on the bf16 pipe with 3-way split operands
+        h->use_winograd = value < 0 ? 0 : value > 3 ? 3 : (int)value;
+        return ensure_split_images(h);
+    }
     else if (k == "post_chunk" && value >= 1) h->post_chunk = value;
     else if (k == "post_graph") { h->post_graph = value != 0; if (!h->post_graph) drop_post_graphs(h); }
     else if (k == "images_per_group" && value >= 0) h->images_per_group = value;     // 0: automatic
@@ -1303,8 +1333,10 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
                             if ((rc = upload(h, relayout_wino16(u, cin, cout), &o.wt_wino16))) return rc;
                         // F(4x4): a lone 32-channel block wastes its second channel-half waves on zeros; measured on
                         // MI355X (profiles/r02_kernel_map.json) that still beats F(2x2) once the K loop is long enough
-                        if (cin % 4 == 0 && cin >= 8 && cout % 32 == 0 && (cout != 32 || cin >= 64) && to.h % 16 == 0 && to.w % 16 == 0)
+                        if (cin % 4 == 0 && cin >= 8 && cout % 32 == 0 && (cout != 32 || cin >= 64) && to.h % 16 == 0 && to.w % 16 == 0) {
                             if ((rc = upload(h, winograd4_filter(kw, cin, cout), &o.wt_wino4))) return rc;
+                            o.w4_cin = cin; o.w4_cout = cout;
+                        }
                     }
                 } else if (tap_ok && !taps_ok) {
                     if ((rc = tap_path())) return rc;
@@ -1450,7 +1482,7 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
         }
     }
     h->has_model = true;
-    return ECSEG_OK;
+    return ensure_split_images(h);                         // ("winograd" = 3 set before the load)
 }
 
 int ecseg_model_flops_per_patch(ecseg_ctx* h, double* flops) {

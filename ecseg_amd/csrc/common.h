@@ -98,6 +98,12 @@ bool       conv_wino16_first_supported(const ConvParams& p);   // with ConvParam
 hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s);
 bool       conv_wino4_supported(const ConvParams& p);
 bool       conv_wino4_span_ok(const ConvParams& p, int windows);   // the halo's buffer descriptor reaches `windows` consecutive windows
+// F(4x4,3x3) with 3-way bf16 split operands on the bf16 matrix pipe (wino4s_kernel.hip, round 6); p.wt = the stage image written
+// on the device by launch_wino4s_filter from the fp32 image of winograd4_filter (wino4s_image_bytes bytes)
+hipError_t launch_conv_wino4s(const ConvParams& p, hipStream_t s);
+bool       conv_wino4s_supported(const ConvParams& p);
+size_t     wino4s_image_bytes(int cin, int cout);
+hipError_t launch_wino4s_filter(const float* wt_wino4, void* dst, int cin, int cout, hipStream_t s);
 
 hipError_t launch_conv_small_cin(const TView& in, const TView& out, const float* w_hwio, const float* bias, int n,
                                  int R, int S, int pad_top, int pad_left, int act, float alpha, hipStream_t s);

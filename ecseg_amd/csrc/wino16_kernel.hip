@@ -173,7 +173,11 @@ __global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(C
             ftap[ks] = k < 9 ? (k / 3) * W16_RAW_PITCH + (k % 3) + 2 : 0;
         }
         f32x4 fbv = {0.f, 0.f, 0.f, 0.f};
-        if (p.first_b != nullptr) fbv = *reinterpret_cast<const f32x4*>(p.first_b + 16 * kc + 4 * cq);
+        if (p.first_b != nullptr) {
+            unsigned cqv = (unsigned)cq;
+            asm volatile("" : "+v"(cqv));                     // (the address is formed here, per fill: hoisted out of the block loop it cost the HEAD instantiation two spilled registers)
+            fbv = reinterpret_cast<const f32x4*>(p.first_b + 16 * kc)[cqv];
+        }
 #pragma unroll 1
         for (int grp = wave; grp < (W16_ROWS * 34 + 15) / 16; grp += 8) {      // 39 groups of 16 halo pixels
             const int pix = min(grp * 16 + n, W16_ROWS * 34 - 1);
@@ -318,46 +322,44 @@ __global__ __launch_bounds__(512, (NBUF == 1 ? 4 : 2)) void conv_wino16_kernel(C
                     for (int x = 0; x < 2; ++x) hl[yy][x] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    f32x4 R[4][2];
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        R[a][0] = acc[a * 4 + 0][nb] + acc[a * 4 + 1][nb] + acc[a * 4 + 2][nb];
-                        R[a][1] = acc[a * 4 + 1][nb] - acc[a * 4 + 2][nb] - acc[a * 4 + 3][nb];
-                    }
-                    f32x4 Y[2][2];
+                    const int co = 16 * nb + 4 * kq;
+                    f32x4 mx = {0.f, 0.f, 0.f, 0.f};
+                    // one pixel COLUMN of the tile at a time (round 6): both columns at once held R[4][2] + Y[2][2] = 48 registers beside the
+                    // 64 accumulators and the head's 16 partial logits - the HEAD instantiation (128-register cap) spilled 4 - 12 of
+                    // them.  Every value is computed by the same operations in the same order as before.
 #pragma unroll
                     for (int x = 0; x < 2; ++x) {
-                        Y[0][x] = apply_act4_core(R[0][x] + R[1][x] + R[2][x] + bv[nb], p.act, p.alpha);
-                        Y[1][x] = apply_act4_core(R[1][x] - R[2][x] - R[3][x] + bv[nb], p.act, p.alpha);
-                    }
-                    const int co = 16 * nb + 4 * kq;
-                    if (!(HEAD && p.head_only)) {
+                        f32x4 R[4];
 #pragma unroll
-                        for (int yy = 0; yy < 2; ++yy)
-#pragma unroll
-                            for (int x = 0; x < 2; ++x)
-                                if (oy + yy < H && ox + x < W)
-                                    __builtin_nontemporal_store(Y[yy][x], reinterpret_cast<f32x4*>(p.out.p + (((size_t)img * H + oy + yy) * W + ox + x) * p.out.cs + co));
-                    }
-                    if (HEAD) {                                  // this lane's 4 channels x 4 classes, for the tile's 2 x 2 pixels
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const f32x4 w = Hw[co + r];
+                        for (int a = 0; a < 4; ++a)
+                            R[a] = x == 0 ? acc[a * 4 + 0][nb] + acc[a * 4 + 1][nb] + acc[a * 4 + 2][nb]
+                                          : acc[a * 4 + 1][nb] - acc[a * 4 + 2][nb] - acc[a * 4 + 3][nb];
+                        f32x4 Y[2];
+                        Y[0] = apply_act4_core(R[0] + R[1] + R[2] + bv[nb], p.act, p.alpha);
+                        Y[1] = apply_act4_core(R[1] - R[2] - R[3] + bv[nb], p.act, p.alpha);
+                        if (!HEAD) {             // (a fused head is always the only reader: api.hip sets head_only with head_w; launch_conv_wino16 checks)
 #pragma unroll
                             for (int yy = 0; yy < 2; ++yy)
-#pragma unroll
-                                for (int x = 0; x < 2; ++x)
-#pragma unroll
-                                    for (int c = 0; c < 4; ++c) hl[yy][x][c] = __builtin_fmaf(Y[yy][x][r], w[c], hl[yy][x][c]);
+                                if (oy + yy < H && ox + x < W)
+                                    __builtin_nontemporal_store(Y[yy], reinterpret_cast<f32x4*>(p.out.p + (((size_t)img * H + oy + yy) * W + ox + x) * p.out.cs + co));
                         }
-                    }
-                    if (p.pool.p != nullptr && (oy >> 1) < p.pool.h && (ox >> 1) < p.pool.w) {
-                        // fused MaxPooling2D(2x2, stride 2): a Winograd tile is one pooling window (even extents: checked by the caller)
-                        f32x4 mx;
+                        if (HEAD) {                                  // this lane's 4 channels x 4 classes, for the column's 2 pixels
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) mx[c] = fmaxf(fmaxf(Y[0][0][c], Y[0][1][c]), fmaxf(Y[1][0][c], Y[1][1][c]));
-                        *reinterpret_cast<f32x4*>(p.pool.p + (((size_t)img * p.pool.h + (oy >> 1)) * p.pool.w + (ox >> 1)) * p.pool.cs + co) = mx;
+                            for (int r = 0; r < 4; ++r) {
+                                const f32x4 w = Hw[co + r];
+#pragma unroll
+                                for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+                                    for (int c = 0; c < 4; ++c) hl[yy][x][c] = __builtin_fmaf(Y[yy][r], w[c], hl[yy][x][c]);
+                            }
+                        }
+                        // fused MaxPooling2D(2x2, stride 2): a Winograd tile is one pooling window (even extents: checked by the caller)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) mx[c] = x == 0 ? fmaxf(Y[0][c], Y[1][c]) : fmaxf(mx[c], fmaxf(Y[0][c], Y[1][c]));
+                        if (HEAD) __builtin_amdgcn_sched_barrier(0);
                     }
+                    if (!HEAD && p.pool.p != nullptr && (oy >> 1) < p.pool.h && (ox >> 1) < p.pool.w)     // (never both: api.hip fuses a head only where no pool is)
+                        *reinterpret_cast<f32x4*>(p.pool.p + (((size_t)img * p.pool.h + (oy >> 1)) * p.pool.w + (ox >> 1)) * p.pool.cs + co) = mx;
                 }
                             if (HEAD) {
                     // reduce-scatter over the four lanes of the tile (lane bits 5 and 4): bit 5 keeps pixel row (kq >> 1), bit 4
@@ -471,6 +473,7 @@ bool conv_wino16_first_supported(const ConvParams& p) {
 }
 
 hipError_t launch_conv_wino16(const ConvParams& p, hipStream_t s) {
+    if (p.head_w != nullptr && (!p.head_only || p.pool.p != nullptr)) return hipErrorInvalidValue;     // (the HEAD kernels write neither the features nor a pool)
     if (p.first_w != nullptr) {
         // (the first layer has as many channels as this one reads: 16 -> 16 -> 16 or 32 -> 32 -> 32, the encoder's first pair)
         if (!conv_wino16_first_supported(p)) return hipErrorInvalidValue;

@@ -37,40 +37,7 @@
 
 namespace ecseg {
 
-namespace {
-
-constexpr int W4_HS = 1536;          // halo slots per buffer: 2 regions x 18 rows x 36 = 1296 used, padded to 24 x 64
-constexpr int W4_BWS = 192;          // filter slots per wave and stage: 6 points x 2 halves x 32 couts x 2 k / 4
-constexpr int W4_RPLANE = 1056;      // floats per (xi, x) plane of the output exchange image: 32 tiles x 32 couts + 32
-
-__device__ __forceinline__ int w4_pos(int v) {           // 0..17 -> regrouped position
-    const int m = v & 3;
-    return (m == 0 ? 0 : m == 1 ? 5 : m == 2 ? 10 : 14) + (v >> 2);
-}
-__device__ __forceinline__ int w4_inv(int r) {           // regrouped position -> 0..17
-    return r < 5 ? 4 * r : r < 10 ? 4 * (r - 5) + 1 : r < 14 ? 4 * (r - 10) + 2 : 4 * (r - 14) + 3;
-}
-constexpr int w4_cpos(int v) { return ((v & 3) == 0 ? 0 : (v & 3) == 1 ? 5 : (v & 3) == 2 ? 10 : 14) + (v >> 2); }
-
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-// LDS-DMA (buffer_load ... lds for the halo, global_load_lds for the filter) is issued through inline asm on purpose: for the
-// builtin the compiler orders every later ds_read behind the DMA with s_waitcnt vmcnt(0) (it cannot tell the LDS buffers
-// apart), which serialises a stream that is interleaved with LDS reads.  The counted vmcnt waits in the kernel are the only
-// ordering (the LDS destination is wave-uniform; M0 is restored).
-
-// Interpolation points {0, +-a, +-b, inf} (common.h: W4_PA, W4_PB) and the constants of B^T and A^T they give:
-//   B^T rows (monic Lagrange numerators): p = 0: [a2b2, 0, -(a2+b2), 0, 1, 0]      p = inf: [0, a2b2, 0, -(a2+b2), 0, 1]
-//                                         p = +-a: [0, -+a b2, -b2, +-a, 1, 0]     p = +-b: [0, -+a2 b, -a2, +-b, 1, 0]
-//   A^T = [1 1 1 1 1 0; 0 a -a b -b 0; 0 a2 a2 b2 b2 0; 0 a3 -a3 b3 -b3 1]
-// All constants are exact in float32 for the dyadic points chosen.
-constexpr float KA = (float)W4_PA, KB = (float)W4_PB, KA2 = KA * KA, KB2 = KB * KB, KA3 = KA2 * KA, KB3 = KB2 * KB;
-constexpr float KP = KA2 * KB2, KS = -(KA2 + KB2);
-static_assert((double)KA2 == W4_PA * W4_PA && (double)KB3 == W4_PB * W4_PB * W4_PB && (double)KP == W4_PA * W4_PA * W4_PB * W4_PB &&
-              (double)KA3 == W4_PA * W4_PA * W4_PA && (double)(KA * KB2) == W4_PA * W4_PB * W4_PB && (double)(KA2 * KB) == W4_PA * W4_PA * W4_PB,
-              "the Winograd points must keep every transform constant exact in float32");
-
-}  // namespace
+#include "wino4_consts.inc"
 
 // Row-transform pipeline depth (slots of in-flight halo reads beside the six direct ones; 0: rounds 1-3, column by column)
 #ifndef ECSEG_W4_TSLOTS
@@ -117,107 +84,7 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
     const int xi = wave % 6, ch = wave / 6;
     const int li = lane & 31, lh = lane >> 5;
 
-    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
-    // Block order: output-channel blocks in groups of G = 4 (2) next to each other, region pairs next, groups slowest.  The
-    // workgroups running together on an XCD then share each input halo in L2 between G of them and keep only G filter
-    // slabs streaming (spatial position fastest alone re-read the input Cout / 64 times from the Infinity Cache: 11-13x
-    // the algorithmic bytes on the Cin = 1024 layers; channel block fastest alone streams Cout / 64 slabs at once): +1.4 %.
-    const unsigned nblk_all = gridDim.x / (unsigned)npairs;
-#ifdef ECSEG_W4_G                                               // (A/B builds only: tools/build_variants.sh ECSEG_W4_G=8)
-    const unsigned G = (nblk_all % ECSEG_W4_G) == 0 ? ECSEG_W4_G : (nblk_all & 3u) == 0 ? 4u : (nblk_all & 1u) == 0 ? 2u : 1u;
-#else
-    const unsigned G = (nblk_all & 3u) == 0 ? 4u : (nblk_all & 1u) == 0 ? 2u : 1u;
-#endif
-    const unsigned lo = bid % G, rest = bid / G;
-    const int pair = (int)(rest % (unsigned)npairs);
-    const int nb = (int)((rest / (unsigned)npairs) * G + lo);
-    const int H = p.in.h, W = p.in.w;                        // output extent == input extent
-    const int ngroups = p.cin_chunks;                        // 8 input channels each
-    const int nstages = 2 * ngroups;
-    const bool tail4 = (p.in.c & 7) != 0;                    // (pointers are 16-byte aligned: bits 0 / 1 carry lane flags)
-
-    // the two 16 x 16 regions of this workgroup: consecutive in (patch, region row, region column) order
-    int r_img[2], r_y0[2], r_x0[2], r_win[2] = {-1, -1};     // r_win: window within its image (known for free in a cropped launch)
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int rid = 2 * pair + g;
-        int rx, ry, img;
-        if (p.lut != nullptr) {                              // cropped launch: the regions some later stage reads
-            const int i = rid / p.lut_len, v = p.lut[rid - i * p.lut_len];
-            img = i * p.per_image + (v >> 16); ry = (v >> 8) & 255; rx = v & 255;      // origins in 4-pixel tiles
-            if (i >= p.n / p.per_image) img = p.n;
-            r_img[g] = img < p.n ? img : -1;
-            r_y0[g] = ry * 4; r_x0[g] = rx * 4;
-            r_win[g] = v >> 16;
-            continue;
-        } else {
-            rx = rid % regs_x;
-            const int t = rid / regs_x;
-            ry = t % regs_y; img = t / regs_y;
-        }
-        r_img[g] = img < p.n ? img : -1;
-        r_y0[g] = ry * 16; r_x0[g] = rx * 16;
-    }
-
-    // input rows / columns the two regions may read (ConvParams::in_box: the receptive field of the needed outputs of a cropped
-    // plan; the whole image otherwise) - everything outside reads as zero
-    int r_by0[2] = {0, 0}, r_by1[2] = {H - 1, H - 1}, r_bx0[2] = {0, 0}, r_bx1[2] = {W - 1, W - 1};
-    if (p.in_box != nullptr) {
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            if (r_img[g] < 0) continue;
-            const int32_t* bx = p.in_box + 4 * (r_win[g] >= 0 ? r_win[g] : (r_img[g] + p.box_first) % p.per_image);
-            r_by0[g] = bx[0]; r_by1[g] = bx[1]; r_bx0[g] = bx[2]; r_bx1[g] = bx[3];
-        }
-    }
-    // ---- halo DMA: every wave fills slots 64 k + lane, k = wave and wave + 12, two groups ahead of its use (3-deep
-    //      ring: nobody ever waits for a halo piece to land) ----
-    // Round 4: the halo goes through a BUFFER descriptor - a workgroup-uniform base (the first of its two windows) in four SGPRs
-    // + one 32-bit byte offset per lane and piece, kept in two registers; lanes that have to read zeros (padding, pixels outside
-    // the image, the missing channel half of a Cin % 8 == 4 tail) hold an out-of-range offset and the hardware returns 0 (no zero
-    // page); the 8-channel group advances through the instruction's scalar offset.  Rounds 1-3 parked 64-bit pointers in LDS
-    // and rebuilt the address of every piece from them: 2 LDS reads + ~20 vector instructions per group - each LDS read beside
-    // the MFMA stream costs the matrix pipe ~14 cycles, each vector instruction ~2.2 (tools/micro/mfma_mix.hip).
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    const int img_lo = r_img[0] >= 0 ? (r_img[1] >= 0 && r_img[1] < r_img[0] ? r_img[1] : r_img[0]) : (r_img[1] >= 0 ? r_img[1] : 0);
-    const unsigned long long hb = (unsigned long long)(size_t)(p.in.p + (size_t)img_lo * H * W * p.in.cs);
-    i32x4 hrsrc;                                             // V#: base, stride 0, 2 GB of records, gfx9 raw-buffer word 3
-    hrsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)hb);
-    hrsrc[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(hb >> 32) & 0xffffu));
-    hrsrc[2] = 0x7fff0000;
-    hrsrc[3] = 0x00020000;
-    unsigned hoff[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int a = 64 * (wave + 12 * i) + lane;
-        unsigned off = 0xffffffffu;
-        if (a < 2 * 18 * 36) {
-            const int g = a >= 648 ? 1 : 0, rem = a - g * 648;
-            const int r = rem / 36, cc = rem - r * 36;
-            const int h = cc >= 18 ? 1 : 0, c = cc - h * 18;
-            const int img = g ? r_img[1] : r_img[0];
-            const int iy = (g ? r_y0[1] : r_y0[0]) - 1 + w4_inv(r), ix = (g ? r_x0[1] : r_x0[0]) - 1 + w4_inv(c);
-            if (img >= 0 && iy >= (g ? r_by0[1] : r_by0[0]) && iy <= (g ? r_by1[1] : r_by1[0]) && ix >= (g ? r_bx0[1] : r_bx0[0]) &&
-                ix <= (g ? r_bx1[1] : r_bx1[0]))                         // (two neighbouring windows: far below 2 GB)
-                off = (unsigned)(((((size_t)(img - img_lo) * H + iy) * W + ix) * p.in.cs + 4 * h) * 4);
-        }
-        hoff[i] = off;
-    }
-    auto dma_halo_piece = [&](int grp, auto ii) __attribute__((always_inline)) {            // piece ii (0 | 1) of halo group grp (< ngroups)
-        W4_DIAG_SKIP_HALO_DMA();
-        constexpr int i = decltype(ii)::value;
-        unsigned off = hoff[i];
-        if (tail4 && grp == ngroups - 1) {                   // Cin % 8 == 4: the upper channel half of the last group does not exist
-            const int a = 64 * (wave + 12 * i) + lane;
-            if ((a % 36) >= 18) off = 0xffffffffu;
-        }
-        const unsigned dst = lds_base + (unsigned)((grp % 3) * W4_HS + 64 * (wave + 12 * i)) * 16u;
-        const i32x4 rs = hrsrc;                              // (local copies: asm operands do not capture in a generic lambda)
-        const int soff = grp * 32;
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(off), "s"(dst), "s"(rs), "s"(soff) : "memory");
-    };
+#include "wino4_region.inc"
     // ---- filter DMA: wt4[nb][stage][wave][point pair nu / 2][lane = h * 32 + cout][nu % 2][k 2], 768 floats per wave and stage; the
     //      address is a scalar base (advanced per stage by scalar adds) + the lane's constant 16-byte offset ----
     const unsigned long long w_base = (unsigned long long)(size_t)(p.wt + ((size_t)nb * nstages * 12 + (SPLIT ? xi : wave)) * 768);
@@ -563,116 +430,10 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
         ESTAMP(1);                                           // [1] fold own row + write R to LDS
         __syncthreads();
         ESTAMP(2);                                           // [2] barrier
-        const int n0 = nb * 64 + pass * 32;
-        const f32x4 bv = pass ? bvp[1] : bvp[0];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int item = tid + k * 768;
-            if (item >= 2048) break;
-            const int q = item & 7, x = (item >> 3) & 3, n = (item >> 5) & 31, yh = item >> 10;
-            const int nq8 = n >> 2, ntx = n & 3;
-            const int g = (0x96 >> nq8) & 1;
-            const int nty = nq8 < 2 ? 0 : nq8 < 4 ? 1 : nq8 < 6 ? 2 : 3;
-            const int img = g ? r_img[1] : r_img[0];
-            if (img < 0) continue;
-            const float* r = Rs + x * W4_RPLANE + n * 32 + 4 * q;
-            // rows 0 / 1 need transform rows 0..4, rows 2 / 3 need 1..5
-            const f32x4 q1 = *reinterpret_cast<const f32x4*>(r + 1 * 4 * W4_RPLANE);
-            const f32x4 q2 = *reinterpret_cast<const f32x4*>(r + 2 * 4 * W4_RPLANE);
-            const f32x4 q3 = *reinterpret_cast<const f32x4*>(r + 3 * 4 * W4_RPLANE);
-            const f32x4 q4 = *reinterpret_cast<const f32x4*>(r + 4 * 4 * W4_RPLANE);
-            const f32x4 qe = *reinterpret_cast<const f32x4*>(r + (yh ? 5 : 0) * 4 * W4_RPLANE);
-            const int co = n0 + 4 * q;
-            const f32x4 s12 = q1 + q2, d12 = q1 - q2, s34 = q3 + q4, d34 = q3 - q4;
-            f32x4 y[2];
-            if (yh == 0) {
-                y[0] = qe + s12 + s34 + bv;
-                y[1] = KA * d12 + KB * d34 + bv;
-            } else {
-                y[0] = KA2 * s12 + KB2 * s34 + bv;
-                y[1] = KA3 * d12 + KB3 * d34 + qe + bv;
-            }
-            const int oy = (g ? r_y0[1] : r_y0[0]) + 4 * nty + 2 * yh, ox = (g ? r_x0[1] : r_x0[0]) + 4 * ntx + x;
-            float* o = p.out.p + (((size_t)img * H + oy) * W + ox) * p.out.cs + co;
-#pragma unroll
-            for (int yy = 0; yy < 2; ++yy) {
-                y[yy] = apply_act4_core(y[yy], p.act, p.alpha);
-                // non-temporal: the tensor (0.6 - 9.4 GB per launch) fits no cache and is read by a later launch; +0.7 % end to end
-                // (A/B round 4: 64 -> 64 at 256x256 10.79 - 10.92 -> 10.58 - 10.63 ms, the deep layers +-0)
-                if (co + 3 < Cout && !(HEAD && p.head_only))
-                    __builtin_nontemporal_store(y[yy], reinterpret_cast<f32x4*>(o + (size_t)yy * W * p.out.cs));
-            }
-            if (HEAD) {                                      // this lane's 4 channels x 4 classes of the 1x1 head
-                const f32x4* hw = reinterpret_cast<const f32x4*>(p.head_w) + co;
-                const f32x4 w0 = hw[0], w1 = hw[1], w2 = hw[2], w3 = hw[3];
-#pragma unroll
-                for (int yy = 0; yy < 2; ++yy)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        hl[k][yy][c] += y[yy][0] * w0[c] + y[yy][1] * w1[c] + y[yy][2] * w2[c] + y[yy][3] * w3[c];
-            }
-            if (p.pool.p != nullptr) {
-                // fused MaxPooling2D(2x2, stride 2): the row pair is in registers, the column partner (x ^ 1) is lane ^ 8 of
-                // the same tile, hence of the same region: it is active whenever this lane is
-                f32x4 m;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float a = fmaxf(y[0][c], y[1][c]);
-                    m[c] = fmaxf(a, __shfl_xor(a, 8));
-                }
-                if (!(x & 1) && co + 3 < Cout)
-                    *reinterpret_cast<f32x4*>(p.pool.p + (((size_t)img * p.pool.h + (oy >> 1)) * p.pool.w + (ox >> 1)) * p.pool.cs + co) = m;
-            }
-        }
+#include "wino4_combine.inc"
         ESTAMP(3);                                           // [3] combine + output stores issued
     }
-    if (HEAD) {
-        // the eight lanes q = 0..7 of a pixel column hold partial logits of 8 output channels each: butterfly over q,
-        // then lane q < 2 finishes row q of the pair (bias, softmax / activation over head_k classes) and stores it
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int item = tid + k * 768;
-            if (item >= 2048) break;
-            const int q = item & 7, x = (item >> 3) & 3, n = (item >> 5) & 31, yh = item >> 10;
-            const int nq8 = n >> 2, ntx = n & 3;
-            const int g = (0x96 >> nq8) & 1;
-            const int nty = nq8 < 2 ? 0 : nq8 < 4 ? 1 : nq8 < 6 ? 2 : 3;
-            const int img = g ? r_img[1] : r_img[0];
-            if (img < 0) continue;
-            f32x4 mine = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int yy = 0; yy < 2; ++yy)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float v = hl[k][yy][c];
-                    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
-                    if (q == yy) mine[c] = v;
-                }
-            if (q < 2) {
-                const f32x4 hb = *reinterpret_cast<const f32x4*>(p.head_b);
-                float l[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) l[c] = mine[c] + hb[c];
-                if (p.head_act == ECSEG_ACT_SOFTMAX) {
-                    float m = l[0];
-#pragma unroll
-                    for (int c = 1; c < 4; ++c) if (c < p.head_k) m = fmaxf(m, l[c]);
-                    float sum = 0.f;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) { l[c] = c < p.head_k ? expf(l[c] - m) : 0.f; sum += l[c]; }
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) l[c] = l[c] / sum;
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) l[c] = apply_act_core(l[c], p.head_act, p.alpha);
-                }
-                const int oy = (g ? r_y0[1] : r_y0[0]) + 4 * nty + 2 * yh + q, ox = (g ? r_x0[1] : r_x0[0]) + 4 * ntx + x;
-                float* ho = p.head_out.p + (((size_t)img * H + oy) * W + ox) * p.head_out.cs;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) if (c < p.head_k) ho[c] = l[c];
-            }
-        }
-    }
+#include "wino4_head.inc"
     W4_ESTAMP_DUMP();
 }
 
@@ -697,6 +458,7 @@ hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s) {
     const size_t grid = npairs * (size_t)((p.out.c + 63) / 64);
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull || !conv_wino4_span_ok(p, p.lut != nullptr ? p.per_image : 2)) return hipErrorInvalidValue;
+    if (p.head_w != nullptr && (!p.head_only || p.pool.p != nullptr)) return hipErrorInvalidValue;     // (the HEAD kernels write neither the features nor a pool)
     size_t lds = (size_t)(3 * W4_HS + 12 * 2 * W4_BWS) * 16;
     const size_t lds_epi = (size_t)24 * W4_RPLANE * 4;
     if (lds_epi > lds) lds = lds_epi;

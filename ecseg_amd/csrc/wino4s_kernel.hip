@@ -1,0 +1,445 @@
+// Winograd F(4x4, 3x3) convolution with the channel sum on the BF16 matrix pipe, float32-accurate: both operands are split
+// exactly into three bf16 pieces (x = x1 + x2 + x3, 8 significant bits each) and the six products above 2^-24 relative are
+// accumulated in float32 by v_mfma_f32_32x32x16_bf16 - 32 pipe cycles for K = 16 where v_mfma_f32_32x32x2_f32 needs 64 for K = 2
+// (round 6; option "winograd" = 3, `precision: split`; the fp32-MFMA kernel of wino4_kernel.hip stays the default).
+//
+//   sum_c V[c] U[c]  ~  sum_c  v1 u1 + (v1 u2 + v2 u1) + (v1 u3 + v2 u2 + v3 u1)        dropped: v2 u3 + v3 u2 + v3 u3 <= 3 x 2^-24 |V U|
+//
+// "K-folded" operands: a lane of the fp32 kernel holds 4 input channels of its tile (one 16-byte halo slot); here the 8 K slots of
+// a lane are those 4 channels x 2 pieces, so the halo ring, the 8-channel groups and the row transform stay as they are and one
+// MFMA sums TWO of the six products over the 8 channels of a group:
+//     A = [v3|v1] x B = [u1|u3]      A = [v1|v2] x B = [u2|u1]      A = [v2|v1] x B = [u2|u1]
+// The A windows overlap in ONE 8-register tuple [v3 v1 v2 v1]; the B windows overlap in the lane's 24-byte filter record [u2 u1 u3]
+// (two 16-byte reads at +0 and +8): no operand is ever copied.
+//
+// The kernel is VALU-bound, not matrix-bound (tools/micro/mfma_bf16x3_mix.hip: the split costs 5.5 instructions per transformed
+// value), so the wave decomposition minimises vector work per MFMA: wave = (transform ROW xi, HALF of its six points) x all 64
+// output channels of the workgroup - the column transform and the split of a point feed two 32-channel MFMA column blocks, and a
+// wave reads only the five halo columns its three points need.  Per 8-channel group a wave runs T (row transform of 5 columns),
+// P0, P1, P2 (one point each: column transform, split, 6 MFMAs, the LDS-DMA of the next filter stage behind them).
+//
+// Filter image (written on the device from the fp32 image of winograd4_filter by wino4s_filter_kernel): per 64-channel output
+// block, 8-channel group, point slot and wave one 3-KB stage = 2 column blocks x 64 lanes x [u2 u1 u3] x 4 channels x bf16, streamed
+// by LDS-DMA into a private double buffer exactly like the fp32 kernel's stages.  Output stage: a wave folds its half row, the
+// two halves of a row meet in the exchange image (half 0 writes, half 1 adds), then wino4_combine.inc as in the fp32 kernel.
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+#include "device_util.h"
+
+namespace ecseg {
+
+#include "wino4_consts.inc"
+
+#ifndef ECSEG_W4_TSLOTS
+#define ECSEG_W4_TSLOTS 4
+#endif
+// Timing-only ablations for A/B builds (tools/w4s_variants.sh; results are garbage): 1 no filter DMA, 2 no halo DMA, 4 no MFMAs,
+// 8 no split arithmetic, 16 every filter stage read from the wave's first one (hot in cache).  The product build has none of it.
+#ifndef ECSEG_W4S_ABL
+#define ECSEG_W4S_ABL 0
+#endif
+#define W4_DIAG_SKIP_HALO_DMA() do { if (ECSEG_W4S_ABL & 2) return; } while (0)
+#define ESTAMP(i)
+#define W4_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+namespace {
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef u32x4 __attribute__((aligned(8))) u32x4_a8;
+
+constexpr int W4S_STAGE = 3072;      // bytes of one filter stage: 2 column blocks x 64 lanes x 24
+
+__device__ __forceinline__ unsigned fbits(float v) { return __builtin_bit_cast(unsigned, v); }
+__device__ __forceinline__ float bfloat(unsigned v) { return __builtin_bit_cast(float, v); }
+// the high halves of two floats = their bf16 truncations, packed (lo in bits 0-15)
+__device__ __forceinline__ unsigned pack_hi(float lo, float hi) { return __builtin_amdgcn_perm(fbits(hi), fbits(lo), 0x07060302u); }
+}  // namespace
+
+template <bool HEAD>
+__global__ __launch_bounds__(768) void conv_wino4s_kernel(ConvParams p, int regs_x, int regs_y, int npairs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* Hs = reinterpret_cast<f32x4*>(smem);              // [3][W4_HS]          halo ring (group g -> buffer g % 3)
+    char* Bs = smem + 3 * W4_HS * 16;                        // [12][2][W4S_STAGE]  per-wave filter stages
+
+    const unsigned lds_base = (unsigned)(size_t)(lptr_t)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xi = wave % 6, hr = wave / 6;                  // transform row, half row (points 0 1 2 | 5 3 4 in stage order)
+    const int li = lane & 31, lh = lane >> 5;
+
+#include "wino4_region.inc"
+    (void)nstages;
+    // ---- filter DMA: image [nb][group][point slot][wave][3072 B]; scalar base + the lane's constant 16-byte offset ----
+    const unsigned long long w_base = (unsigned long long)(size_t)p.wt + ((size_t)nb * (3 * ngroups) * 12 + wave) * W4S_STAGE;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto dma_filter_piece = [&](int stage, int buf, auto kk) __attribute__((always_inline)) {
+        constexpr int k = decltype(kk)::value;
+        if (ECSEG_W4S_ABL & 1) return;
+        const unsigned long long g = w_base + (unsigned long long)((ECSEG_W4S_ABL & 16) ? 0 : stage) * (12 * W4S_STAGE);     // (16: every stage from the same hot 3 KB)
+        const unsigned dst = lds_base + (unsigned)(3 * W4_HS * 16 + (wave * 2 + buf) * W4S_STAGE);
+        const unsigned l16 = lane16;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 offset:%4\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(l16), "s"(dst), "s"(g), "n"(k * 1024) : "memory");
+    };
+
+    // ---- A-operand lane -> tile (as in the fp32 kernel: the b128 lane groups of a region read conflict-free) ----
+    const int q8 = li >> 2, tx = li & 3;
+    const int tg = (0x96 >> q8) & 1;
+    const int ty = (q8 == 0 || q8 == 1) ? 0 : (q8 == 2 || q8 == 3) ? 1 : (q8 == 4 || q8 == 5) ? 2 : 3;
+    const int a_lane = (tg * 18 + ty) * 36 + lh * 18 + tx;
+
+    int rr0, rr1, rr2, rr3; float c0, c1, c2;
+    switch (xi) {
+        case 0:  rr0 = 0; rr1 = 2; rr2 = 4; rr3 = 4; c0 = KP;        c1 = KS;   c2 = 1.f; break;
+        case 1:  rr0 = 1; rr1 = 2; rr2 = 3; rr3 = 4; c0 = -KA * KB2; c1 = -KB2; c2 = KA;  break;
+        case 2:  rr0 = 1; rr1 = 2; rr2 = 3; rr3 = 4; c0 = KA * KB2;  c1 = -KB2; c2 = -KA; break;
+        case 3:  rr0 = 1; rr1 = 2; rr2 = 3; rr3 = 4; c0 = -KA2 * KB; c1 = -KA2; c2 = KB;  break;
+        case 4:  rr0 = 1; rr1 = 2; rr2 = 3; rr3 = 4; c0 = KA2 * KB;  c1 = -KA2; c2 = -KB; break;
+        default: rr0 = 1; rr1 = 3; rr2 = 5; rr3 = 5; c0 = KP;        c1 = KS;   c2 = 1.f; break;
+    }
+    const int ro0 = 36 * w4_pos(rr0), ro1 = 36 * w4_pos(rr1), ro2 = 36 * w4_pos(rr2), ro3 = 36 * w4_pos(rr3);
+    // halo columns of a half row: half 0 needs columns 0..4 (points 0, +-a), half 1 columns 1..5 (points +-b, inf).  Both keep
+    // columns 1..4 in t[1..4]; t[0] is column 0 (half 0) or column 5 (half 1): ONE wave-uniform slot offset, no second code path
+    const int xcol = hr ? w4_cpos(5) : w4_cpos(0);
+    // column transform of a half row, with wave-uniform constants: e = t4 - kq t2, o = t3 - kq t1, points e +- kr o;
+    // the third point is 0 (half 0: KP t0 + KS t2 + t4) or infinity (half 1: KP t1 + KS t3 + t0): stage 0 of both halves
+    const float kq = hr ? KA2 : KB2, kr = hr ? KB : KA;
+
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[v][cb][e] = 0.f;
+
+    f32x4 t[5];
+    // ---- row transform of group grp (slot-pipelined like the fp32 kernel's, five columns) ----
+    const bool inner_row = xi >= 1 && xi <= 4;
+    auto transform = [&](int grp) __attribute__((always_inline)) {
+        const f32x4* A = Hs + (grp % 3) * W4_HS + a_lane;
+        constexpr int cp[5] = {0, w4_cpos(1), w4_cpos(2), w4_cpos(3), w4_cpos(4)};      // (column X: offset xcol, below)
+        constexpr int NS = ECSEG_W4_TSLOTS;
+        auto rd = [&](int slot, int j) __attribute__((always_inline)) -> f32x4 { return j == 0 ? A[slot + xcol] : A[slot + cp[j]]; };
+        f32x4 sl[NS];
+        if (inner_row) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) t[j] = rd(ro3, j);
+#define W4_TRD(i) rd((i) % 3 == 0 ? ro2 : (i) % 3 == 1 ? ro1 : ro0, (i) / 3)
+#pragma unroll
+            for (int k = 0; k < NS; ++k) sl[k] = W4_TRD(k);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 15; ++i) {
+                const float cf = i % 3 == 0 ? c2 : i % 3 == 1 ? c1 : c0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) t[i / 3][c] = __builtin_fmaf(cf, sl[i % NS][c], t[i / 3][c]);
+                if (i + NS < 15) sl[i % NS] = W4_TRD(i + NS);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef W4_TRD
+        } else {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) t[j] = rd(ro2, j);
+#define W4_TRD(i) rd((i) % 2 == 0 ? ro1 : ro0, (i) / 2)
+#pragma unroll
+            for (int k = 0; k < NS; ++k) sl[k] = W4_TRD(k);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const float cf = i % 2 == 0 ? c1 : c0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) t[i / 2][c] = __builtin_fmaf(cf, sl[i % NS][c], t[i / 2][c]);
+                if (i + NS < 10) sl[i % NS] = W4_TRD(i + NS);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef W4_TRD
+        }
+    };
+    // ---- one point: column transform of the lane's 4 channels, exact 3-way bf16 split, 6 MFMAs; the three pieces of the next
+    //      filter stage (and, in P1, the wave's two halo pieces) go out behind the first MFMAs ----
+    float Vm[4];                                             // the "-" point of the +- pair (computed in P1 with its partner, used in P2)
+    auto point = [&](auto pp, int fbuf, int next_stage, int halo_grp) __attribute__((always_inline)) {
+        constexpr int P = decltype(pp)::value;
+        // Register budget (168 at three waves per SIMD; 96 accumulators + 20 of t[] are always live): the fragments of column block
+        // 0 are read first, the split runs under their latency, and column block 1's are read only when the split's temporaries
+        // are dead - the order is pinned (sched_barrier), the compiler's own schedule hoists all four reads and spills.
+        const char* fp = Bs + (wave * 2 + fbuf) * W4S_STAGE + lane * 24;
+        const bf16x8 B12a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_a8*>(fp));               // [u2|u1]
+        const bf16x8 B3a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_a8*>(fp + 8));            // [u1|u3]
+        __builtin_amdgcn_sched_barrier(0);
+        float V[4];
+        if (P == 0) {
+            if (hr == 0) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) V[c] = __builtin_fmaf(KP, t[0][c], __builtin_fmaf(KS, t[2][c], t[4][c]));
+            } else {
+                // (the empty asm keeps the two arms apart: merged, they become ONE fma chain over t[hr], t[2 + hr], ... - a dynamically
+                // indexed t[] lives in scratch memory)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float x = t[1][c];
+                    asm volatile("" : "+v"(x));
+                    V[c] = __builtin_fmaf(KP, x, __builtin_fmaf(KS, t[3][c], t[0][c]));
+                }
+            }
+        } else if (P == 1) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float e = __builtin_fmaf(-kq, t[2][c], t[4][c]), o = __builtin_fmaf(-kq, t[1][c], t[3][c]);
+                V[c] = __builtin_fmaf(kr, o, e);
+                Vm[c] = __builtin_fmaf(-kr, o, e);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) V[c] = Vm[c];
+        }
+        // exact split by truncation: v1 = high half of v, v2 = high half of (v - v1), v3 = v - v1 - v2 (8 bits left: exact)
+        u32x8 a8;
+        {
+            float r[4], s[4];
+#if ECSEG_W4S_ABL & 8
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { r[c] = V[c]; s[c] = V[c]; }
+#else
+#pragma unroll
+            for (int c = 0; c < 4; ++c) r[c] = V[c] - bfloat(fbits(V[c]) & 0xffff0000u);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s[c] = r[c] - bfloat(fbits(r[c]) & 0xffff0000u);
+#endif
+            const unsigned p1a = pack_hi(V[0], V[1]), p1b = pack_hi(V[2], V[3]);
+            a8 = u32x8{pack_hi(s[0], s[1]), pack_hi(s[2], s[3]), p1a, p1b, pack_hi(r[0], r[1]), pack_hi(r[2], r[3]), p1a, p1b};
+        }
+        const bf16x8 A3 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a8, a8, 0, 1, 2, 3));      // [v3|v1]
+        const bf16x8 A2 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a8, a8, 2, 3, 4, 5));      // [v1|v2]
+        const bf16x8 A1 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a8, a8, 4, 5, 6, 7));      // [v2|v1]
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 B12b = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_a8*>(fp + 1536));
+        const bf16x8 B3b = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_a8*>(fp + 1536 + 8));
+        __builtin_amdgcn_sched_barrier(0);
+        const int nbuf = fbuf ^ 1;
+#if ECSEG_W4S_ABL & 4
+#define W4S_MFMA(CB, A, B) asm volatile("" :: "v"(A), "v"(B))
+#else
+#define W4S_MFMA(CB, A, B) acc[P][CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, acc[P][CB], 0, 0, 0)
+#endif
+        W4S_MFMA(0, A3, B3a);
+        __builtin_amdgcn_sched_barrier(0);
+        dma_filter_piece(next_stage, nbuf, std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        W4S_MFMA(0, A2, B12a);
+        __builtin_amdgcn_sched_barrier(0);
+        dma_filter_piece(next_stage, nbuf, std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        W4S_MFMA(0, A1, B12a);
+        __builtin_amdgcn_sched_barrier(0);
+        dma_filter_piece(next_stage, nbuf, std::integral_constant<int, 2>{});
+        __builtin_amdgcn_sched_barrier(0);
+        W4S_MFMA(1, A3, B3b);
+        if (P == 1 && halo_grp >= 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            dma_halo_piece(halo_grp, std::integral_constant<int, 0>{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        W4S_MFMA(1, A2, B12b);
+        if (P == 1 && halo_grp >= 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            dma_halo_piece(halo_grp, std::integral_constant<int, 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        W4S_MFMA(1, A1, B12b);
+#undef W4S_MFMA
+    };
+#define W4_BARRIER() asm volatile("s_barrier" ::: "memory")
+#define W4_SB() __builtin_amdgcn_sched_barrier(0)
+    // Filter stage s = 3 g + P lives in buffer s & 1.  Waits (every wave counts only its own LDS-DMAs, in issue order):
+    //   P0(g): stage 3g was the last thing issued (in P2(g-1) / the prologue)                         -> vmcnt(0)
+    //   P1(g): stage 3g+1, issued in P0(g), is the youngest                                           -> vmcnt(0)
+    //   P2(g): stage 3g+2 was issued in P1(g) BEFORE that phase's two halo pieces of group g+2        -> vmcnt(2) (0 without them)
+    // A wave's halo pieces of group g+2 are covered by the vmcnt(0) of P0(g+1), which every rotation class runs before barrier g+2.
+#define W4_T(g, PR) do { __builtin_amdgcn_s_setprio(0); transform(g); __builtin_amdgcn_s_setprio((PR) + 1); } while (0)
+#define W4_P0(g) do { W4_SB(); W4_WAIT(0); W4_SB(); point(std::integral_constant<int, 0>{}, (3 * (g)) & 1, 3 * (g) + 1, -1); } while (0)
+#define W4_P1(g) do { W4_SB(); W4_WAIT(0); W4_SB(); point(std::integral_constant<int, 1>{}, (3 * (g) + 1) & 1, 3 * (g) + 2, (g) + 2 < ngroups ? (g) + 2 : -1); } while (0)
+#define W4_P2(g) do { W4_SB(); if ((g) + 2 < ngroups) W4_WAIT(2); else W4_WAIT(0); W4_SB(); \
+                      point(std::integral_constant<int, 2>{}, (3 * (g) + 2) & 1, (g) + 1 < ngroups ? 3 * (g) + 3 : 3 * (g) + 2, -1); } while (0)
+    const int cls = wave >> 2;
+    dma_halo_piece(0, std::integral_constant<int, 0>{});
+    dma_halo_piece(0, std::integral_constant<int, 1>{});
+    if (ngroups > 1) {
+        dma_halo_piece(1, std::integral_constant<int, 0>{});
+        dma_halo_piece(1, std::integral_constant<int, 1>{});
+    }
+    dma_filter_piece(0, 0, std::integral_constant<int, 0>{});
+    dma_filter_piece(0, 0, std::integral_constant<int, 1>{});
+    dma_filter_piece(0, 0, std::integral_constant<int, 2>{});
+    if (ngroups > 1) W4_WAIT(5); else W4_WAIT(3);            // halo group 0 has landed (group 1: before barrier 1, see above)
+    // Phase rotation as in the fp32 kernel: the three waves of a SIMD (w, w + 4, w + 8) sit at different points of (T, P0, P1, P2),
+    // so the LDS round trips of one wave's row transform run under the other two waves' split arithmetic and MFMAs.
+    if (cls == 0) {
+        for (int grp = 0; grp < ngroups; ++grp) {
+            W4_BARRIER();
+            W4_T(grp, 0);
+            W4_P0(grp);
+            W4_P1(grp);
+            W4_P2(grp);
+        }
+    } else if (cls == 1) {
+        W4_BARRIER();
+        W4_T(0, 1);
+        W4_P0(0);
+        W4_P1(0);
+        for (int grp = 1; grp < ngroups; ++grp) {
+            W4_BARRIER();
+            W4_P2(grp - 1);
+            W4_T(grp, 1);
+            W4_P0(grp);
+            W4_P1(grp);
+        }
+        W4_P2(ngroups - 1);
+    } else {
+        W4_BARRIER();
+        W4_T(0, 2);
+        W4_P0(0);
+        for (int grp = 1; grp < ngroups; ++grp) {
+            W4_BARRIER();
+            W4_P1(grp - 1);
+            W4_P2(grp - 1);
+            W4_T(grp, 2);
+            W4_P0(grp);
+        }
+        W4_P1(ngroups - 1);
+        W4_P2(ngroups - 1);
+    }
+#undef W4_T
+#undef W4_P0
+#undef W4_P1
+#undef W4_P2
+#undef W4_SB
+#undef W4_BARRIER
+
+    // ---- output stage: two passes (column blocks) through the [xi][x][tile][32 couts] exchange image ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the compiler does not see the asm LDS-DMAs
+    float* Rs = reinterpret_cast<float*>(smem);
+    const int Cout = p.out.c;
+    float hl[3][2][4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hl[a][b][c] = 0.f;
+    f32x4 bvp[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (p.bias != nullptr) {
+        bvp[0] = *reinterpret_cast<const f32x4*>(p.bias + nb * 64 + 4 * (tid & 7));
+        if (nb * 64 + 32 < Cout) bvp[1] = *reinterpret_cast<const f32x4*>(p.bias + nb * 64 + 32 + 4 * (tid & 7));
+    }
+    // R = M[xi][:] A of a HALF row (A^T = [1 1 1 1 1 0; 0 a -a b -b 0; 0 a2 a2 b2 b2 0; 0 a3 -a3 b3 -b3 1]):
+    //   half 0 (m0, m+a, m-a):   r0 = m0 + s, r1 = a d, r2 = a2 s, r3 = a3 d            s = m+ + m-, d = m+ - m-
+    //   half 1 (minf, m+b, m-b): r0 = s, r1 = b d, r2 = b2 s, r3 = b3 d + minf
+    const float k1 = hr ? KB : KA, k2 = hr ? KB2 : KA2, k3 = hr ? KB3 : KA3;
+    auto write_R = [&](auto cbc, auto add_c) __attribute__((always_inline)) {
+        constexpr int cb = decltype(cbc)::value;
+        constexpr bool add = decltype(add_c)::value;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int tl = (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const float me = acc[0][cb][e], mp = acc[1][cb][e], mm = acc[2][cb][e];
+            const float sm = mp + mm, df = mp - mm;
+            float* o = Rs + (xi * 4) * W4_RPLANE + tl * 32 + li;
+            const float r1 = k1 * df, r2 = k2 * sm;
+            if (add) {
+                o[0 * W4_RPLANE] += sm; o[1 * W4_RPLANE] += r1; o[2 * W4_RPLANE] += r2; o[3 * W4_RPLANE] += __builtin_fmaf(k3, df, me);
+                // (four accumulator rows at a time: left alone, the compiler reads all 64 words first and spills accumulators for them)
+                if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            } else {
+                o[0 * W4_RPLANE] = me + sm; o[1 * W4_RPLANE] = r1; o[2 * W4_RPLANE] = r2; o[3 * W4_RPLANE] = k3 * df;
+            }
+        }
+    };
+    // (two straight-line passes, not a loop: in a loop the fold arithmetic of BOTH column blocks is loop-invariant, gets hoisted in
+    // front of it and spills ~90 registers)
+    auto do_pass = [&](auto passc) __attribute__((always_inline)) {
+        constexpr int pass = decltype(passc)::value;
+        __syncthreads();                                     // main-loop LDS reads / previous pass's combine are done
+        if (hr == 0) write_R(passc, std::false_type{});
+        __syncthreads();
+        if (hr == 1) write_R(passc, std::true_type{});
+        __syncthreads();
+#include "wino4_combine.inc"
+    };
+    do_pass(std::integral_constant<int, 0>{});
+    __builtin_amdgcn_sched_barrier(0);
+    do_pass(std::integral_constant<int, 1>{});
+#include "wino4_head.inc"
+}
+
+// The fp32 image of winograd4_filter (api.hip) -> the bf16x3 stage image of conv_wino4s_kernel; one thread per (block, stage, wave,
+// column block, lane): 4 channels x 3 pieces.
+__global__ __launch_bounds__(256) void wino4s_filter_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int nblk, int ngroups) {
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)nblk * 3 * ngroups * 12 * 128;
+    if (id >= total) return;
+    const int lane = (int)(id & 63), cb = (int)((id >> 6) & 1);
+    long long r = id >> 7;
+    const int wave = (int)(r % 12); r /= 12;
+    const int st = (int)(r % (3 * ngroups)); const int nb = (int)(r / (3 * ngroups));
+    const int g = st / 3, ps = st % 3;
+    const int xi = wave % 6, hr = wave / 6;
+    const int nu = hr ? (ps == 0 ? 5 : ps == 1 ? 3 : 4) : ps;
+    const int m = lane & 31, kb = lane >> 5;
+    unsigned short* o = dst + (((long long)(nb * 3 * ngroups + st) * 12 + wave) * (W4S_STAGE / 2)) + cb * 768 + lane * 12;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int ss = c >> 1, e = c & 1;
+        const long long idx = (((long long)nb * (2 * ngroups) + (2 * g + ss)) * 12 + (cb * 6 + xi)) * 768 + ((((long long)(nu >> 1) * 64 + kb * 32 + m) * 2 + (nu & 1)) * 2) + e;
+        const float u = src[idx];
+        const unsigned b1 = fbits(u) & 0xffff0000u;
+        const float r1 = u - bfloat(b1);
+        const unsigned b2 = fbits(r1) & 0xffff0000u;
+        const float r2 = r1 - bfloat(b2);
+        o[0 + c] = (unsigned short)(b2 >> 16);               // [u2 u1 u3]
+        o[4 + c] = (unsigned short)(b1 >> 16);
+        o[8 + c] = (unsigned short)(fbits(r2) >> 16);
+    }
+}
+
+size_t wino4s_image_bytes(int cin, int cout) { return (size_t)((cout + 63) / 64) * 3 * ((cin + 7) / 8) * 12 * W4S_STAGE; }
+
+hipError_t launch_wino4s_filter(const float* wt_wino4, void* dst, int cin, int cout, hipStream_t s) {
+    const int nblk = (cout + 63) / 64, ngroups = (cin + 7) / 8;
+    const long long total = (long long)nblk * 3 * ngroups * 12 * 128;
+    hipLaunchKernelGGL(wino4s_filter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, wt_wino4, reinterpret_cast<unsigned short*>(dst), nblk, ngroups);
+    return hipGetLastError();
+}
+
+// Same geometry rules as conv_wino4_kernel, and whole 64-channel output blocks (a lone 32-channel block would spend half of every
+// MFMA pair on padding: such layers stay on the fp32 kernel's SPLIT variant).
+bool conv_wino4s_supported(const ConvParams& p) { return conv_wino4_supported(p) && p.out.c % 64 == 0; }
+
+hipError_t launch_conv_wino4s(const ConvParams& p, hipStream_t s) {
+    const int regs_x = p.out.w / 16, regs_y = p.out.h / 16;
+    const size_t nreg = p.lut != nullptr ? (size_t)(p.n / p.per_image) * p.lut_len : (size_t)p.n * regs_x * regs_y;
+    const size_t npairs = (nreg + 1) / 2;
+    const size_t grid = npairs * (size_t)(p.out.c / 64);
+    if (grid == 0) return hipSuccess;
+    if (grid > 0x7fffffffull || !conv_wino4_span_ok(p, p.lut != nullptr ? p.per_image : 2)) return hipErrorInvalidValue;
+    if (p.head_w != nullptr && (!p.head_only || p.pool.p != nullptr)) return hipErrorInvalidValue;     // (the HEAD kernels write neither the features nor a pool)
+    size_t lds = (size_t)3 * W4_HS * 16 + (size_t)12 * 2 * W4S_STAGE;
+    const size_t lds_epi = (size_t)24 * W4_RPLANE * 4;
+    if (lds_epi > lds) lds = lds_epi;
+    void (*kern)(ConvParams, int, int, int) = p.head_w != nullptr ? conv_wino4s_kernel<true> : conv_wino4s_kernel<false>;
+    static DeviceOnce attr_set[2];
+    const hipError_t ea = attr_set[p.head_w != nullptr ? 1 : 0].run([&] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    if (ea != hipSuccess) return ea;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(768), lds, s, p, regs_x, regs_y, (int)npairs);
+    return hipGetLastError();
+}
+
+}  // namespace ecseg

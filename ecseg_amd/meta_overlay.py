@@ -14,7 +14,6 @@ HSR_SIZE_THRESHOLD = 20
 
 
 def main(argv=None):
-    os.environ.setdefault('ECSEG_BLOCKING_SYNC', '1')      # this process is ours: waiting threads sleep (ecseg_create, include/ecseg_hip.h)
     config = open("config.yaml")
     var = yaml.load(config, Loader=yaml.FullLoader)['meta_overlay']
     inpath = var['inpath']

@@ -617,7 +617,6 @@ def _self_launch(device_ids):
 
 
 def main(argv=None):
-    os.environ.setdefault('ECSEG_BLOCKING_SYNC', '1')      # this process is ours: waiting threads sleep (ecseg_create, include/ecseg_hip.h)
     config = open("config.yaml")
     var = yaml.load(config, Loader=yaml.FullLoader)['metaseg']
     inpath = var['inpath']

@@ -51,11 +51,12 @@ typedef struct ecseg_ctx ecseg_ctx;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------- */
 int         ecseg_abi_version(void);
-/* Waits: the library's own long waits sleep on a blocking event (option "blocking_wait").  With ECSEG_BLOCKING_SYNC=1 in the
- * environment ecseg_create ALSO sets hipDeviceScheduleBlockingSync - a device-wide setting of the whole process (every HIP
- * user's waits sleep instead of spinning: same wall time, one core less per waiting call); off by default for that reason,
- * the package's command lines switch it on for their own process.  ECSEG_DEBUG_CALLS=1 prints a host-side timeline of every
- * ecseg_meta_segment call on stderr. */
+/* SIDE EFFECT ON THE PROCESS: ecseg_create sets hipDeviceScheduleBlockingSync on the device - a device-wide, process-wide
+ * setting: every HIP user of the process (torch tensors of an embedding application too) then SLEEPS while it waits for the GPU
+ * instead of spinning (same wall time, one core less per waiting call).  ECSEG_SPIN_WAIT=1 in the environment leaves the runtime's
+ * default alone - at your own risk: under the default mode hipFree was seen to hang for ever in ecseg_destroy after several
+ * handles had been created and closed in one process (csrc/api.hip: ecseg_create).  ECSEG_DEBUG_CALLS=1 prints a host-side
+ * timeline of every ecseg_meta_segment call on stderr. */
 int         ecseg_create(ecseg_ctx** out, int device_id);
 void        ecseg_destroy(ecseg_ctx* h);
 const char* ecseg_last_error(ecseg_ctx* h);        /* h may be NULL: error of the last failed ecseg_create */

@@ -30,8 +30,8 @@ H, W = 1040, 1392
 # 2.4 on average (worst image 6); device direct 2.3 (6), F(2x2) 1.2 (4), F(4x4) 2.3 (5; 4.4 (10) with the textbook
 # interpolation points of rounds 1-2).  Every differing pixel lies within 2.5e-6 of a point where the quantised argmax
 # changes; "hard" pixels below are all those within 2.55e-5 (~0.08 % of an image).
-MAX_WRONG_PX_PER_IMAGE = {0: 12, 1: 8, 2: 10}     # kernel -> 2 x the worst image measured vs float64 (direct, F(2x2), F(4x4))
-MAX_WRONG_PX_PER_IMAGE_SMOOTH = {0: 4, 1: 4, 2: 4}
+MAX_WRONG_PX_PER_IMAGE = {0: 12, 1: 8, 2: 10, 3: 10}     # kernel -> 2 x the worst image measured vs float64 (direct, F(2x2), F(4x4), F(4x4) with bf16x3 split operands)
+MAX_WRONG_PX_PER_IMAGE_SMOOTH = {0: 4, 1: 4, 2: 4, 3: 4}
 MAX_RAW_MISMATCH_PX_PER_IMAGE = 14                # device F(4x4) vs the float32 ORACLE: 2 x the worst image measured (7)
 MAX_RAW_MISMATCH_PX_PER_IMAGE_SMOOTH = 3
 
@@ -70,7 +70,7 @@ def test_bench_model_probabilities_vs_oracle(bench_model):
     want = oracle_unet.forward(bench_model.model_config, bench_model.weights, x)
     h = bench_model.handle
     try:
-        for mode, tol in ((2, 1e-3), (1, 1e-3), (0, 1e-3)):
+        for mode, tol in ((3, 1e-3), (2, 1e-3), (1, 1e-3), (0, 1e-3)):
             h.set_option('winograd', mode)
             got = h.forward_patches(x)
             err = float(np.abs(got - want).max())
@@ -145,7 +145,7 @@ def test_smooth_output_model_labels_vs_cpu_oracle():
     hnd = Handle(0)
     try:
         hnd.load_plan(keras_plan.build_plan(cfg, weights))
-        for mode in (2, 1, 0):
+        for mode in (3, 2, 1, 0):
             hnd.set_option('winograd', mode)
             raw, post, nec = hnd.segment_images(imgs, want_raw=True)
             for i, (o_post, o_raw, o_probs, pos) in enumerate(refs):
@@ -288,7 +288,7 @@ def test_labels_vs_float64_adjudicator(golden_dir, tag):
         hnd.load_plan(keras_plan.build_plan(cfg, weights))
         hard = [z['idx_%d' % i].astype(np.int64) for i in range(n)]
         truth = [z['truth_%d' % i] for i in range(n)]
-        for mode in (2, 1, 0):
+        for mode in (3, 2, 1, 0):
             hnd.set_option('winograd', mode)
             raw, post, nec = hnd.segment_images(imgs, want_raw=True)
             wrong, crc_bad = 0, []

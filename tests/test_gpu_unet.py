@@ -199,6 +199,74 @@ def test_base64_unet_f4x4_with_concat_views(gpu):
     np.testing.assert_allclose(got.sum(-1), 1.0, atol=1e-5)
 
 
+@pytest.mark.parametrize('cin,cout,hw,n', [(64, 64, (64, 96), 3), (8, 64, (16, 16), 3), (128, 192, (16, 16), 4), (72, 128, (32, 48), 2),
+                                           (24, 64, (48, 16), 1), (12, 64, (32, 16), 2), (68, 128, (16, 16), 5), (256, 128, (32, 32), 2)])
+def test_winograd_f4x4_split_bf16x3_matches_fp32_kernel_and_oracle(gpu, cin, cout, hw, n):
+    """Round 6 (option winograd = 3): the F(4x4) channel sum on the bf16 matrix pipe with both operands split exactly into three
+    bf16 pieces (six of the nine piece products, float32 accumulate: dropped terms <= 3 x 2^-24).  It must sit as close to the
+    oracle as the fp32-MFMA F(4x4) kernel does (same 5e-4 bound; measured: the same 1e-6) and within 1e-5 of that kernel.  Covers
+    whole and odd region counts, regions spanning two patches, the Cin % 8 == 4 tail and 1 - 3 output blocks.  Layers with
+    Cout % 64 != 0 stay on the fp32 kernel (checked through the launch profile)."""
+    rng = np.random.default_rng(cin * 11 + cout)
+    H, W = hw
+    cfg = {'class_name': 'Functional', 'config': {'name': 'm', 'layers': [
+        {'class_name': 'InputLayer', 'name': 'in', 'config': {'name': 'in', 'batch_input_shape': [None, H, W, cin]},
+         'inbound_nodes': []},
+        {'class_name': 'Conv2D', 'name': 'c', 'config': {'name': 'c', 'filters': cout, 'kernel_size': [3, 3],
+                                                         'strides': [1, 1], 'padding': 'same', 'activation': 'relu',
+                                                         'use_bias': True}, 'inbound_nodes': [[['in', 0, 0, {}]]]}],
+        'input_layers': [['in', 0, 0]], 'output_layers': [['c', 0, 0]]}}
+    weights = {'c': [(rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin) / 64).astype(np.float32),
+                     rng.normal(size=cout).astype(np.float32)]}
+    x = rng.integers(0, 256, size=(n, H, W, cin), dtype=np.uint8)
+    want = oracle_unet.forward(cfg, weights, x)
+    try:
+        gpu.set_option('winograd', 2)
+        w4, _ = _run(gpu, cfg, weights, x, fuse=True)
+        gpu.set_option('winograd', 3)
+        gpu.set_kernel_profiling(True)
+        ws = gpu.forward_patches(x)
+        kinds = [r['kind'] & 0xff for r in gpu.conv_launch_profile()]
+        gpu.set_kernel_profiling(False)
+    finally:
+        gpu.set_option('winograd', 2)
+    assert kinds and set(kinds) == {5}, kinds                    # conv_wino4s_kernel ran (one launch per window lane)
+    scale = max(1.0, float(np.abs(want).max()))
+    assert np.abs(ws - want).max() < 5e-4 * scale, np.abs(ws - want).max()
+    assert np.abs(ws - w4).max() < 1e-5 * scale, np.abs(ws - w4).max()
+
+
+def test_base64_unet_split_mode_with_views_pool_head_and_fallback(gpu):
+    """Base-64 U-Net (depth 2) under winograd = 3: strided channel views of the skip connections, the fused 2x2 max-pool and the
+    fused 1x1 head run through conv_wino4s_kernel's output stage; the same model at base 32 has layers with 32 output channels,
+    which fall back to the fp32 F(4x4) kernel.  Probabilities within 1e-3 of the oracle and 1e-5 of the fp32-MFMA path."""
+    for base in (64, 32):
+        cfg = synth.unet_config(base=base, depth=2)
+        weights = synth.unet_weights(cfg, seed=base)
+        x = _patches(2, seed=base)
+        want = oracle_unet.forward(cfg, weights, x)
+        try:
+            gpu.set_option('winograd', 2)
+            ref, _ = _run(gpu, cfg, weights, x, fuse=True)
+            gpu.set_option('winograd', 3)
+            gpu.set_kernel_profiling(True)
+            got = gpu.forward_patches(x)
+            kinds = [r['kind'] & 0xff for r in gpu.conv_launch_profile()]
+            gpu.set_kernel_profiling(False)
+            gpu.set_option('fuse_pool', 0)
+            gpu.set_option('fuse_head', 0)
+            unfused = gpu.forward_patches(x)
+        finally:
+            gpu.set_option('winograd', 2)
+            gpu.set_option('fuse_pool', 1)
+            gpu.set_option('fuse_head', 1)
+        assert 5 in kinds and (base == 64 or 2 in kinds), (base, kinds)
+        assert np.abs(got - want).max() < TOL, np.abs(got - want).max()
+        assert np.abs(got - ref).max() < 1e-5, np.abs(got - ref).max()
+        assert np.abs(got - unfused).max() < 1e-5, np.abs(got - unfused).max()
+        np.testing.assert_allclose(got.sum(-1), 1.0, atol=1e-5)
+
+
 @pytest.mark.parametrize('act,use_bias', [('linear', True), ('sigmoid', False), ('tanh', True), ('elu', True)])
 def test_winograd_f4x4_activations_and_no_bias(gpu, act, use_bias):
     """The F(4x4) output stage applies the layer's own activation and tolerates a missing bias."""

@@ -375,6 +375,41 @@ def test_shipped_library_has_no_diagnostic_kernels():
         assert word not in product.replace('W4_KSTAMP', '').replace('W4_ESTAMP', '').replace('WSTAMP', '').replace('ESTAMP', ''), word
 
 
+def test_no_kernel_of_the_shipped_library_spills_registers():
+    """`conv_wino16_kernel<1,1,1,HEAD,*>` spilled 4 / 12 VGPRs to scratch and nothing in the suite looked.  Every
+    kernel of every code object inside libecseg_hip.so must report .vgpr_spill_count 0 and no private segment (scratch memory) in
+    its metadata notes.  (Scalar registers that overflow are parked in lanes of a vector register - v_writelane, no memory traffic;
+    ccl_local_kernel and some wide conv_wino16 variants do that - and are not counted here.)"""
+    import shutil
+    import struct
+    import subprocess
+    import tempfile
+    from ecseg_amd._lib import LIB_PATH
+    readelf = '/opt/rocm/lib/llvm/bin/llvm-readelf'
+    if not os.path.exists(readelf) or not shutil.which('objcopy'):
+        pytest.skip('no llvm-readelf / objcopy')
+    with tempfile.TemporaryDirectory() as d:
+        fat = os.path.join(d, 'fat.bin')
+        subprocess.run(['objcopy', '-O', 'binary', '--only-section=.hip_fatbin', LIB_PATH, fat], check=True)
+        blob = open(fat, 'rb').read()
+        kernels = {}
+        for m in re.finditer(b'\x7fELF\x02\x01', blob):           # the gfx950 code objects (ELF64, little endian) of the fat binary
+            i = m.start()
+            shoff = struct.unpack_from('<Q', blob, i + 0x28)[0]
+            shentsize, shnum = struct.unpack_from('<HH', blob, i + 0x3a)
+            co = os.path.join(d, 'co.elf')
+            with open(co, 'wb') as f:
+                f.write(blob[i:i + shoff + shentsize * shnum])
+            notes = subprocess.run([readelf, '--notes', co], capture_output=True, text=True, check=True).stdout
+            for blk in notes.split('- .agpr_count:')[1:]:
+                get = lambda k: re.search(r'\.%s:\s+(\S+)' % k, blk).group(1)
+                kernels[get('name')] = (int(get('vgpr_spill_count')), int(get('private_segment_fixed_size')))
+    assert len(kernels) > 100, len(kernels)
+    assert any('conv_wino4s_kernel' in k for k in kernels) and any('conv_wino16_kernel' in k for k in kernels)
+    bad = {k: v for k, v in kernels.items() if v != (0, 0)}
+    assert not bad, bad
+
+
 def test_native_launcher_stops_the_peers_of_a_failed_rank(tmp_path):
     """a rank that dies before the record all-gather must not leave its peers (blocked in RCCL) and the parent
     hanging: the supervisor polls ALL children, terminates the others on the first non-zero exit, removes the rendezvous

@@ -20,5 +20,5 @@ run pageable --pinned-mb 0
 run io16 --io-threads 16
 run workers2 --workers 2
 run smooth --weights smooth
-ECSEG_BLOCKING_SYNC=0 run spin
+ECSEG_SPIN_WAIT=1 run spin
 rm -rf $K

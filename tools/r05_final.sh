@@ -29,7 +29,7 @@ if [ "${1:-a}" = a ]; then
   for w in random smooth; do timeout -k 10 400 python3 tools/time_cli.py --keep /dev/shm/ecseg_cli --n 1024 --base 16 --batch 32 --input-compression raw --weights $w >> $O/cli_timing.jsonl 2>> $O/cli_timing.err; echo "cli raw $w rc $?"; done
   rm -rf /dev/shm/ecseg_cli
   timeout -k 10 100 python3 tools/experiments/host_call_probe.py --base 16 --batch 32 > $O/host_call_probe.json 2>> $O/cli_timing.err; echo "host probe rc $?"
-  ECSEG_BLOCKING_SYNC=1 timeout -k 10 100 python3 tools/experiments/wait_cpu.py 1 > $O/wait_cpu.jsonl 2>> $O/cli_timing.err; ECSEG_BLOCKING_SYNC=0 timeout -k 10 100 python3 tools/experiments/wait_cpu.py 0 >> $O/wait_cpu.jsonl 2>> $O/cli_timing.err
+  timeout -k 10 100 python3 tools/experiments/wait_cpu.py 1 > $O/wait_cpu.jsonl 2>> $O/cli_timing.err; ECSEG_SPIN_WAIT=1 timeout -k 10 100 python3 tools/experiments/wait_cpu.py 0 >> $O/wait_cpu.jsonl 2>> $O/cli_timing.err
 else
   bash tools/profile_round.sh r05 --no-narrow > $O/profile_round.log 2>&1; echo "profile_round rc $?"
   for f in kernel_stats.csv pmc_traffic.json mfma_busy.json; do cp gpurun_out/prof_r05/$f $O/ 2>/dev/null; done

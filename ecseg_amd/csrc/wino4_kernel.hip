@@ -38,6 +38,7 @@
 namespace ecseg {
 
 #include "wino4_consts.inc"
+#define W4_HALO_RING 3
 
 // Row-transform pipeline depth (slots of in-flight halo reads beside the six direct ones; 0: rounds 1-3, column by column)
 #ifndef ECSEG_W4_TSLOTS

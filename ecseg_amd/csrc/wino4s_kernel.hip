@@ -31,6 +31,7 @@
 namespace ecseg {
 
 #include "wino4_consts.inc"
+#define W4_HALO_RING 2
 
 #ifndef ECSEG_W4_TSLOTS
 #define ECSEG_W4_TSLOTS 4
@@ -52,6 +53,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef u32x4 __attribute__((aligned(8))) u32x4_a8;
 
 constexpr int W4S_STAGE = 3072;      // bytes of one filter stage: 2 column blocks x 64 lanes x 24
+constexpr int W4S_TS = 2 * 6 * 4 * 36;   // slots of the t image: 2 regions x 6 transform rows x 4 tile rows x (18 columns x 2 channel halves)
 
 __device__ __forceinline__ unsigned fbits(float v) { return __builtin_bit_cast(unsigned, v); }
 __device__ __forceinline__ float bfloat(unsigned v) { return __builtin_bit_cast(float, v); }
@@ -62,8 +64,9 @@ __device__ __forceinline__ unsigned pack_hi(float lo, float hi) { return __built
 template <bool HEAD>
 __global__ __launch_bounds__(768) void conv_wino4s_kernel(ConvParams p, int regs_x, int regs_y, int npairs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4* Hs = reinterpret_cast<f32x4*>(smem);              // [3][W4_HS]          halo ring (group g -> buffer g % 3)
-    char* Bs = smem + 3 * W4_HS * 16;                        // [12][2][W4S_STAGE]  per-wave filter stages
+    f32x4* Hs = reinterpret_cast<f32x4*>(smem);              // [2][W4_HS]          raw halo (group g -> buffer g & 1)
+    f32x4* Ts = Hs + 2 * W4_HS;                              // [W4S_TS]            row-transformed halo of ONE group: t[region][xi][tile row][18 columns x 2 halves]
+    char* Bs = reinterpret_cast<char*>(Ts + W4S_TS);         // [12][2][W4S_STAGE]  per-wave filter stages
 
     const unsigned lds_base = (unsigned)(size_t)(lptr_t)smem;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -80,29 +83,20 @@ __global__ __launch_bounds__(768) void conv_wino4s_kernel(ConvParams p, int regs
         constexpr int k = decltype(kk)::value;
         if (ECSEG_W4S_ABL & 1) return;
         const unsigned long long g = w_base + (unsigned long long)((ECSEG_W4S_ABL & 16) ? 0 : stage) * (12 * W4S_STAGE);     // (16: every stage from the same hot 3 KB)
-        const unsigned dst = lds_base + (unsigned)(3 * W4_HS * 16 + (wave * 2 + buf) * W4S_STAGE);
+        const unsigned dst = lds_base + (unsigned)((2 * W4_HS + W4S_TS) * 16 + (wave * 2 + buf) * W4S_STAGE);
         const unsigned l16 = lane16;
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 offset:%4\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(l16), "s"(dst), "s"(g), "n"(k * 1024) : "memory");
     };
 
-    // ---- A-operand lane -> tile (as in the fp32 kernel: the b128 lane groups of a region read conflict-free) ----
+    // ---- the lane's tile (as in the fp32 kernel: the b128 lane groups of a region read conflict-free) and its slot in the t image ----
     const int q8 = li >> 2, tx = li & 3;
     const int tg = (0x96 >> q8) & 1;
     const int ty = (q8 == 0 || q8 == 1) ? 0 : (q8 == 2 || q8 == 3) ? 1 : (q8 == 4 || q8 == 5) ? 2 : 3;
-    const int a_lane = (tg * 18 + ty) * 36 + lh * 18 + tx;
-
-    int rr0, rr1, rr2, rr3; float c0, c1, c2;
-    switch (xi) {
-        case 0:  rr0 = 0; rr1 = 2; rr2 = 4; rr3 = 4; c0 = KP;        c1 = KS;   c2 = 1.f; break;
-        case 1:  rr0 = 1; rr1 = 2; rr2 = 3; rr3 = 4; c0 = -KA * KB2; c1 = -KB2; c2 = KA;  break;
-        case 2:  rr0 = 1; rr1 = 2; rr2 = 3; rr3 = 4; c0 = KA * KB2;  c1 = -KB2; c2 = -KA; break;
-        case 3:  rr0 = 1; rr1 = 2; rr2 = 3; rr3 = 4; c0 = -KA2 * KB; c1 = -KA2; c2 = KB;  break;
-        case 4:  rr0 = 1; rr1 = 2; rr2 = 3; rr3 = 4; c0 = KA2 * KB;  c1 = -KA2; c2 = -KB; break;
-        default: rr0 = 1; rr1 = 3; rr2 = 5; rr3 = 5; c0 = KP;        c1 = KS;   c2 = 1.f; break;
-    }
-    const int ro0 = 36 * w4_pos(rr0), ro1 = 36 * w4_pos(rr1), ro2 = 36 * w4_pos(rr2), ro3 = 36 * w4_pos(rr3);
+    // t image: slot(region, xi, tile row, column, half) = ((region * 6 + xi) * 4 + tile row) * 36 + half * 18 + P(column): the row
+    // stride 36 = 4 (mod 16) and the regrouped columns make the 16 lanes of a b128 group hit 16 different bank groups, as in the raw halo
+    const int t_lane = ((tg * 6 + xi) * 4 + ty) * 36 + lh * 18 + tx;
     // halo columns of a half row: half 0 needs columns 0..4 (points 0, +-a), half 1 columns 1..5 (points +-b, inf).  Both keep
     // columns 1..4 in t[1..4]; t[0] is column 0 (half 0) or column 5 (half 1): ONE wave-uniform slot offset, no second code path
     const int xcol = hr ? w4_cpos(5) : w4_cpos(0);
@@ -118,60 +112,66 @@ __global__ __launch_bounds__(768) void conv_wino4s_kernel(ConvParams p, int regs
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[v][cb][e] = 0.f;
 
+    // ---- the row transform, ONCE per workgroup and group (round 6, second version).  In the fp32 kernel - and in this kernel's first
+    //      version - every wave reads the raw halo rows of its transform row itself: 20 ds_read_b128 per wave and group, 240 KB of LDS
+    //      reads per group for 21 KB of data, and with the channel sum three times faster that traffic (+ 144 KB of filter reads +
+    //      134 KB of LDS-DMA writes = 518 KB at 128 B / clock) - not the matrix pipe, not the vector pipe - set the pace
+    //      (tools/experiments/w4s_ablate.sh).  Now 288 threads transform the group cooperatively: item = (region, tile row, column,
+    //      channel half): six raw rows in, t[xi = 0..5] out (12 fmas per channel, the +- rows share their even / odd parts), written
+    //      to the t image; a wave then reads the five columns of ITS row: raw 28 KB + t 28 KB written + 60 KB read. ----
+    auto row_pass = [&](int grp) __attribute__((always_inline)) {
+        // 576 half items (region, tile row, channel half, column, channel PAIR) over the 12 waves x 48 lanes: every wave carries the
+        // same share (a pass run by five waves alone left the other seven waiting at the barrier behind it), 8-byte accesses,
+        // neighbouring lanes on neighbouring addresses
+        if (lane >= 48) return;
+        const int item = wave * 48 + lane, cpair = item & 1, k = item >> 1;
+        const int pc = k % 18, r1 = k / 18, h = r1 & 1, r2 = r1 >> 1, tyy = r2 & 3, tgg = r2 >> 2;
+        const f32x2* R = reinterpret_cast<const f32x2*>(Hs + (grp & 1) * W4_HS + (tgg * 18 + tyy) * 36 + h * 18 + pc) + cpair;      // raw row 4 tyy + i at slot offset 36 * {0, 5, 10, 14, 1, 6}[i]
+        const f32x2 d0 = R[2 * 0], d1 = R[2 * 36 * 5], d2 = R[2 * 36 * 10], d3 = R[2 * 36 * 14], d4 = R[2 * 36 * 1], d5 = R[2 * 36 * 6];
+        f32x2* T = reinterpret_cast<f32x2*>(Ts + ((tgg * 6) * 4 + tyy) * 36 + h * 18 + pc) + cpair;                                 // + xi * 144 slots
+        f32x2 o, e, q;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) o[c] = __builtin_fmaf(KP, d0[c], __builtin_fmaf(KS, d2[c], d4[c]));
+        T[2 * 0 * 144] = o;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) o[c] = __builtin_fmaf(KP, d1[c], __builtin_fmaf(KS, d3[c], d5[c]));
+        T[2 * 5 * 144] = o;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { e[c] = __builtin_fmaf(-KB2, d2[c], d4[c]); q[c] = __builtin_fmaf(-KB2, d1[c], d3[c]); }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) o[c] = __builtin_fmaf(KA, q[c], e[c]);
+        T[2 * 1 * 144] = o;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) o[c] = __builtin_fmaf(-KA, q[c], e[c]);
+        T[2 * 2 * 144] = o;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { e[c] = __builtin_fmaf(-KA2, d2[c], d4[c]); q[c] = __builtin_fmaf(-KA2, d1[c], d3[c]); }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) o[c] = __builtin_fmaf(KB, q[c], e[c]);
+        T[2 * 3 * 144] = o;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) o[c] = __builtin_fmaf(-KB, q[c], e[c]);
+        T[2 * 4 * 144] = o;
+    };
     f32x4 t[5];
-    // ---- row transform of group grp (slot-pipelined like the fp32 kernel's, five columns) ----
-    const bool inner_row = xi >= 1 && xi <= 4;
-    auto transform = [&](int grp) __attribute__((always_inline)) {
-        const f32x4* A = Hs + (grp % 3) * W4_HS + a_lane;
-        constexpr int cp[5] = {0, w4_cpos(1), w4_cpos(2), w4_cpos(3), w4_cpos(4)};      // (column X: offset xcol, below)
-        constexpr int NS = ECSEG_W4_TSLOTS;
-        auto rd = [&](int slot, int j) __attribute__((always_inline)) -> f32x4 { return j == 0 ? A[slot + xcol] : A[slot + cp[j]]; };
-        f32x4 sl[NS];
-        if (inner_row) {
-#pragma unroll
-            for (int j = 0; j < 5; ++j) t[j] = rd(ro3, j);
-#define W4_TRD(i) rd((i) % 3 == 0 ? ro2 : (i) % 3 == 1 ? ro1 : ro0, (i) / 3)
-#pragma unroll
-            for (int k = 0; k < NS; ++k) sl[k] = W4_TRD(k);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 15; ++i) {
-                const float cf = i % 3 == 0 ? c2 : i % 3 == 1 ? c1 : c0;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) t[i / 3][c] = __builtin_fmaf(cf, sl[i % NS][c], t[i / 3][c]);
-                if (i + NS < 15) sl[i % NS] = W4_TRD(i + NS);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#undef W4_TRD
-        } else {
-#pragma unroll
-            for (int j = 0; j < 5; ++j) t[j] = rd(ro2, j);
-#define W4_TRD(i) rd((i) % 2 == 0 ? ro1 : ro0, (i) / 2)
-#pragma unroll
-            for (int k = 0; k < NS; ++k) sl[k] = W4_TRD(k);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 10; ++i) {
-                const float cf = i % 2 == 0 ? c1 : c0;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) t[i / 2][c] = __builtin_fmaf(cf, sl[i % NS][c], t[i / 2][c]);
-                if (i + NS < 10) sl[i % NS] = W4_TRD(i + NS);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#undef W4_TRD
-        }
+    auto load_t = [&]() __attribute__((always_inline)) {
+        const f32x4* A = Ts + t_lane;
+        t[0] = A[xcol];
+        t[1] = A[w4_cpos(1)]; t[2] = A[w4_cpos(2)]; t[3] = A[w4_cpos(3)]; t[4] = A[w4_cpos(4)];
     };
     // ---- one point: column transform of the lane's 4 channels, exact 3-way bf16 split, 6 MFMAs; the three pieces of the next
-    //      filter stage (and, in P1, the wave's two halo pieces) go out behind the first MFMAs ----
+    //      filter stage go out behind the first MFMAs ----
     float Vm[4];                                             // the "-" point of the +- pair (computed in P1 with its partner, used in P2)
-    auto point = [&](auto pp, int fbuf, int next_stage, int halo_grp) __attribute__((always_inline)) {
+    auto point = [&](auto pp, int fbuf, int next_stage) __attribute__((always_inline)) {
         constexpr int P = decltype(pp)::value;
-        // Register budget (168 at three waves per SIMD; 96 accumulators + 20 of t[] are always live): the fragments of column block
-        // 0 are read first, the split runs under their latency, and column block 1's are read only when the split's temporaries
-        // are dead - the order is pinned (sched_barrier), the compiler's own schedule hoists all four reads and spills.
-        const char* fp = Bs + (wave * 2 + fbuf) * W4S_STAGE + lane * 24;
-        const bf16x8 B12a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_a8*>(fp));               // [u2|u1]
-        const bf16x8 B3a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_a8*>(fp + 8));            // [u1|u3]
+        // Filter stage: [column block 0: 64 x [u2|u1]] [column block 1: 64 x [u2|u1]] [64 x u3 of block 0][64 x u3 of block 1]: one aligned
+        // 16-byte and one 8-byte read per block - 24 bytes per lane (the first version read [u2|u1] and [u1|u3] as two overlapping
+        // 16-byte windows: 32).  Register budget (168 at three waves per SIMD; 96 accumulators + 20 of t[] are always live): block 0's
+        // fragments are read first, the split runs under their latency, block 1's are read when the split's temporaries are dead -
+        // the order is pinned (sched_barrier): the compiler's own schedule hoists all reads and spills.
+        const char* fp = Bs + (wave * 2 + fbuf) * W4S_STAGE;
+        const u32x4 b12a = reinterpret_cast<const u32x4*>(fp)[lane];
+        const u32x2 u3a = reinterpret_cast<const u32x2*>(fp + 2048)[lane];
         __builtin_amdgcn_sched_barrier(0);
         float V[4];
         if (P == 0) {
@@ -219,9 +219,11 @@ __global__ __launch_bounds__(768) void conv_wino4s_kernel(ConvParams p, int regs
         const bf16x8 A2 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a8, a8, 2, 3, 4, 5));      // [v1|v2]
         const bf16x8 A1 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a8, a8, 4, 5, 6, 7));      // [v2|v1]
         __builtin_amdgcn_sched_barrier(0);
-        const bf16x8 B12b = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_a8*>(fp + 1536));
-        const bf16x8 B3b = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_a8*>(fp + 1536 + 8));
+        const u32x4 b12b = reinterpret_cast<const u32x4*>(fp + 1024)[lane];
+        const u32x2 u3b = reinterpret_cast<const u32x2*>(fp + 2048 + 512)[lane];
         __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 B12a = __builtin_bit_cast(bf16x8, b12a), B3a = __builtin_bit_cast(bf16x8, u32x4{b12a[2], b12a[3], u3a[0], u3a[1]});
+        const bf16x8 B12b = __builtin_bit_cast(bf16x8, b12b), B3b = __builtin_bit_cast(bf16x8, u32x4{b12b[2], b12b[3], u3b[0], u3b[1]});
         const int nbuf = fbuf ^ 1;
 #if ECSEG_W4S_ABL & 4
 #define W4S_MFMA(CB, A, B) asm volatile("" :: "v"(A), "v"(B))
@@ -241,33 +243,29 @@ __global__ __launch_bounds__(768) void conv_wino4s_kernel(ConvParams p, int regs
         dma_filter_piece(next_stage, nbuf, std::integral_constant<int, 2>{});
         __builtin_amdgcn_sched_barrier(0);
         W4S_MFMA(1, A3, B3b);
-        if (P == 1 && halo_grp >= 0) {
-            __builtin_amdgcn_sched_barrier(0);
-            dma_halo_piece(halo_grp, std::integral_constant<int, 0>{});
-            __builtin_amdgcn_sched_barrier(0);
-        }
         W4S_MFMA(1, A2, B12b);
-        if (P == 1 && halo_grp >= 0) {
-            __builtin_amdgcn_sched_barrier(0);
-            dma_halo_piece(halo_grp, std::integral_constant<int, 1>{});
-            __builtin_amdgcn_sched_barrier(0);
-        }
         W4S_MFMA(1, A1, B12b);
+        __builtin_amdgcn_sched_barrier(0);                   // (MFMAs are no memory operations: without this they sink below the s_barrier that follows)
 #undef W4S_MFMA
     };
 #define W4_BARRIER() asm volatile("s_barrier" ::: "memory")
 #define W4_SB() __builtin_amdgcn_sched_barrier(0)
-    // Filter stage s = 3 g + P lives in buffer s & 1.  Waits (every wave counts only its own LDS-DMAs, in issue order):
-    //   P0(g): stage 3g was the last thing issued (in P2(g-1) / the prologue)                         -> vmcnt(0)
-    //   P1(g): stage 3g+1, issued in P0(g), is the youngest                                           -> vmcnt(0)
-    //   P2(g): stage 3g+2 was issued in P1(g) BEFORE that phase's two halo pieces of group g+2        -> vmcnt(2) (0 without them)
-    // A wave's halo pieces of group g+2 are covered by the vmcnt(0) of P0(g+1), which every rotation class runs before barrier g+2.
-#define W4_T(g, PR) do { __builtin_amdgcn_s_setprio(0); transform(g); __builtin_amdgcn_s_setprio((PR) + 1); } while (0)
-#define W4_P0(g) do { W4_SB(); W4_WAIT(0); W4_SB(); point(std::integral_constant<int, 0>{}, (3 * (g)) & 1, 3 * (g) + 1, -1); } while (0)
-#define W4_P1(g) do { W4_SB(); W4_WAIT(0); W4_SB(); point(std::integral_constant<int, 1>{}, (3 * (g) + 1) & 1, 3 * (g) + 2, (g) + 2 < ngroups ? (g) + 2 : -1); } while (0)
-#define W4_P2(g) do { W4_SB(); if ((g) + 2 < ngroups) W4_WAIT(2); else W4_WAIT(0); W4_SB(); \
-                      point(std::integral_constant<int, 2>{}, (3 * (g) + 2) & 1, (g) + 1 < ngroups ? 3 * (g) + 3 : 3 * (g) + 2, -1); } while (0)
-    const int cls = wave >> 2;
+    // Per group g (every wave, in this order):
+    //   barrier Y(g-1)  the t image holds group g (row_pass(g) is complete) and raw buffer g & 1 is free again
+    //   t <- t image    five ds_read_b128;   this wave's two halo pieces of group g + 2 -> raw buffer g & 1
+    //   P0(g), P1(g)    (P1: the last use of t[])
+    //   barrier X(g)    nobody needs the t image of group g any more; the raw halo of group g + 1 has landed (every wave waited for its pieces)
+    //   row_pass(g+1)   raw buffer (g + 1) & 1 -> t image
+    //   P2(g)
+    // Filter stage s = 3 g + P lives in buffer s & 1 and is streamed one stage ahead, behind the MFMAs of the stage before.  Waits
+    // (a wave counts only its own LDS-DMAs, in issue order):
+    //   P0(g): stage 3g was issued in P2(g-1) / the prologue, BEFORE the two halo pieces that followed barrier Y(g-1)   -> vmcnt(2) (0 without them)
+    //   P1(g), P2(g): the stage issued one phase earlier is the youngest                                               -> vmcnt(0)
+    // so a wave's halo pieces of group g + 2 have landed at its P1(g), long before barrier X(g + 1).
+#define W4_P0(g, H) do { W4_SB(); if (H) W4_WAIT(2); else W4_WAIT(0); W4_SB(); point(std::integral_constant<int, 0>{}, (3 * (g)) & 1, 3 * (g) + 1); } while (0)
+#define W4_P1(g) do { W4_SB(); W4_WAIT(0); W4_SB(); point(std::integral_constant<int, 1>{}, (3 * (g) + 1) & 1, 3 * (g) + 2); } while (0)
+#define W4_P2(g) do { W4_SB(); W4_WAIT(0); W4_SB(); \
+                      point(std::integral_constant<int, 2>{}, (3 * (g) + 2) & 1, (g) + 1 < ngroups ? 3 * (g) + 3 : 3 * (g) + 2); } while (0)
     dma_halo_piece(0, std::integral_constant<int, 0>{});
     dma_halo_piece(0, std::integral_constant<int, 1>{});
     if (ngroups > 1) {
@@ -277,45 +275,29 @@ __global__ __launch_bounds__(768) void conv_wino4s_kernel(ConvParams p, int regs
     dma_filter_piece(0, 0, std::integral_constant<int, 0>{});
     dma_filter_piece(0, 0, std::integral_constant<int, 1>{});
     dma_filter_piece(0, 0, std::integral_constant<int, 2>{});
-    if (ngroups > 1) W4_WAIT(5); else W4_WAIT(3);            // halo group 0 has landed (group 1: before barrier 1, see above)
-    // Phase rotation as in the fp32 kernel: the three waves of a SIMD (w, w + 4, w + 8) sit at different points of (T, P0, P1, P2),
-    // so the LDS round trips of one wave's row transform run under the other two waves' split arithmetic and MFMAs.
-    if (cls == 0) {
-        for (int grp = 0; grp < ngroups; ++grp) {
-            W4_BARRIER();
-            W4_T(grp, 0);
-            W4_P0(grp);
-            W4_P1(grp);
-            W4_P2(grp);
+    if (ngroups > 1) W4_WAIT(5); else W4_WAIT(3);            // raw group 0 has landed
+    W4_BARRIER();
+    row_pass(0);
+    for (int grp = 0; grp < ngroups; ++grp) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's share of row_pass(grp) is in the t image
+        W4_BARRIER();                                        // Y(grp - 1)
+        W4_SB();
+        load_t();
+        const bool more_halo = grp + 2 < ngroups;
+        if (more_halo) {
+            dma_halo_piece(grp + 2, std::integral_constant<int, 0>{});
+            dma_halo_piece(grp + 2, std::integral_constant<int, 1>{});
         }
-    } else if (cls == 1) {
-        W4_BARRIER();
-        W4_T(0, 1);
-        W4_P0(0);
-        W4_P1(0);
-        for (int grp = 1; grp < ngroups; ++grp) {
-            W4_BARRIER();
-            W4_P2(grp - 1);
-            W4_T(grp, 1);
-            W4_P0(grp);
-            W4_P1(grp);
+        W4_P0(grp, more_halo);
+        W4_P1(grp);
+        if (grp + 1 < ngroups) {
+            W4_BARRIER();                                    // X(grp)
+            W4_SB();
+            row_pass(grp + 1);
+            W4_SB();
         }
-        W4_P2(ngroups - 1);
-    } else {
-        W4_BARRIER();
-        W4_T(0, 2);
-        W4_P0(0);
-        for (int grp = 1; grp < ngroups; ++grp) {
-            W4_BARRIER();
-            W4_P1(grp - 1);
-            W4_P2(grp - 1);
-            W4_T(grp, 2);
-            W4_P0(grp);
-        }
-        W4_P1(ngroups - 1);
-        W4_P2(ngroups - 1);
+        W4_P2(grp);
     }
-#undef W4_T
 #undef W4_P0
 #undef W4_P1
 #undef W4_P2
@@ -392,7 +374,10 @@ __global__ __launch_bounds__(256) void wino4s_filter_kernel(const float* __restr
     const int xi = wave % 6, hr = wave / 6;
     const int nu = hr ? (ps == 0 ? 5 : ps == 1 ? 3 : 4) : ps;
     const int m = lane & 31, kb = lane >> 5;
-    unsigned short* o = dst + (((long long)(nb * 3 * ngroups + st) * 12 + wave) * (W4S_STAGE / 2)) + cb * 768 + lane * 12;
+    // stage layout: [block 0: 64 lanes x [u2|u1]] [block 1: 64 x [u2|u1]] [64 x u3 of block 0] [64 x u3 of block 1]
+    unsigned short* o = dst + (((long long)(nb * 3 * ngroups + st) * 12 + wave) * (W4S_STAGE / 2));
+    unsigned short* o12 = o + cb * 512 + lane * 8;
+    unsigned short* o3 = o + 1024 + cb * 256 + lane * 4;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int ss = c >> 1, e = c & 1;
@@ -402,9 +387,9 @@ __global__ __launch_bounds__(256) void wino4s_filter_kernel(const float* __restr
         const float r1 = u - bfloat(b1);
         const unsigned b2 = fbits(r1) & 0xffff0000u;
         const float r2 = r1 - bfloat(b2);
-        o[0 + c] = (unsigned short)(b2 >> 16);               // [u2 u1 u3]
-        o[4 + c] = (unsigned short)(b1 >> 16);
-        o[8 + c] = (unsigned short)(fbits(r2) >> 16);
+        o12[c] = (unsigned short)(b2 >> 16);                 // u2
+        o12[4 + c] = (unsigned short)(b1 >> 16);             // u1
+        o3[c] = (unsigned short)(fbits(r2) >> 16);           // u3
     }
 }
 
@@ -429,7 +414,7 @@ hipError_t launch_conv_wino4s(const ConvParams& p, hipStream_t s) {
     if (grid == 0) return hipSuccess;
     if (grid > 0x7fffffffull || !conv_wino4_span_ok(p, p.lut != nullptr ? p.per_image : 2)) return hipErrorInvalidValue;
     if (p.head_w != nullptr && (!p.head_only || p.pool.p != nullptr)) return hipErrorInvalidValue;     // (the HEAD kernels write neither the features nor a pool)
-    size_t lds = (size_t)3 * W4_HS * 16 + (size_t)12 * 2 * W4S_STAGE;
+    size_t lds = (size_t)(2 * W4_HS + W4S_TS) * 16 + (size_t)12 * 2 * W4S_STAGE;
     const size_t lds_epi = (size_t)24 * W4_RPLANE * 4;
     if (lds_epi > lds) lds = lds_epi;
     void (*kern)(ConvParams, int, int, int) = p.head_w != nullptr ? conv_wino4s_kernel<true> : conv_wino4s_kernel<false>;

@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 H, W = 1040, 1392
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak (no sparsity)
 CPU_SEED0 = 900                    # synthetic image indices of the CPU-baseline / parity sample
 
 
@@ -508,6 +509,57 @@ class DeviceRun:
         self.torch.cuda.empty_cache()
 
 
+def split_leg(run, steps, headline, wino_mode):
+    """the same step with the F(4x4) channel sums on the bf16 matrix pipe and both operands split exactly into three
+    bf16 pieces (option winograd = 3, conv_wino4s_kernel; float32-accurate, float32 accumulate).  Reported beside - never instead of -
+    the fp32-MFMA headline: images/s, the split kernel's own rate against the BF16 peak (each fp32-equivalent product is issued as
+    six bf16 products), max |dp| and raw-label differences against the fp32-MFMA path on two images, and - base 64 with the committed
+    float64 adjudicator fixture - how often each path is wrong on the fixture's hard pixels."""
+    hnd = run.hnd
+    out = {'what': 'option winograd = 3: conv_wino4s_kernel on every 3x3 layer with whole 64-channel output blocks (v_mfma_f32_32x32x16_bf16, '
+                   '3-way exact bf16 split of both operands, 6 of the 9 piece products, float32 accumulate); everything else as in the headline run'}
+    try:
+        hnd.set_option('winograd', 3)
+        m = run.timed(steps, 1, profile=True)
+        s = model_summary(run, m)
+        r5 = [r for r in m['recs'] if (r['kind'] & 0xff) == 5]
+        ms5, ex5 = sum(r['ms'] for r in r5), sum(r['executed_flops'] for r in r5)
+        out.update({'value': s['value'], 'unit': 'images/s', 'ms_per_step': s['ms_per_step'], 'vs_f32_headline': round(s['value'] / headline, 4),
+                    'stage_ms_per_image': s['stage_ms_per_image'], 'dtype': 'bf16x3 products, f32 accumulate (f32-accurate)'})
+        if ms5 > 0:
+            eq = ex5 / (ms5 * 1e-3) / 1e12
+            out['split_kernel'] = {'launches_per_step': len(r5) // steps, 'ms_per_step': round(ms5 / steps, 3),
+                                   'fp32_equivalent_executed_tflops': round(eq, 2), 'bf16_product_tflops': round(6 * eq, 2),
+                                   'frac_of_bf16_mfma_peak': round(6 * eq / PEAK_BF16_MFMA_TFLOPS, 4), 'peak': PEAK_BF16_MFMA_TFLOPS,
+                                   'vs_fp32_mfma_peak': round(eq / PEAK_FP32_MFMA_TFLOPS, 4),
+                                   'note': 'executed = Winograd F(4x4) products really issued (36/144 of the direct convolution, cropped regions only); '
+                                           'the kernel is bound by the LDS-DMA path that streams its filter (110 KB per 8-channel group and workgroup, '
+                                           'tools/micro/ldsdma_rate.hip), not by the matrix pipe: DESIGN.md 5.1b'}
+        pair = run.host[:2]
+        a = hnd.segment_images(pair, want_raw=True, want_probs=True)
+        hnd.set_option('winograd', 2)
+        b = hnd.segment_images(pair, want_raw=True, want_probs=True)
+        out['vs_fp32_mfma_path'] = {'images': 2, 'max_abs_dp': float(np.abs(a[3] - b[3]).max()), 'raw_label_px_different': int((a[0] != b[0]).sum()),
+                                    'n_ec_different': int((np.asarray(a[2]) != np.asarray(b[2])).sum())}
+        fx = os.path.join(ROOT, 'tests', 'golden', 'label_truth_random_base64.npz')
+        if run.base == 64 and os.path.exists(fx):
+            z = np.load(fx)
+            from ecseg_amd import synth
+            n = 8
+            imgs = np.stack([synth.dapi_image(int(z['seed0']) + i) for i in range(n)])
+            adj = {'images': n, 'hard_px': int(sum(len(z['idx_%d' % i]) for i in range(n))),
+                   'float32_cpu_oracle_wrong': int(z['oracle32_wrong_on_hard_px'][:n].sum()),
+                   'fixture': 'tests/golden/label_truth_random_base64.npz (float64 labels of the pixels within 2.55e-5 of a change of the quantised argmax)'}
+            for mode, name in ((3, 'split_bf16x3_wrong'), (2, 'fp32_mfma_wrong')):
+                hnd.set_option('winograd', mode)
+                raw = hnd.segment_images(imgs, want_raw=True)[0]
+                adj[name] = int(sum((raw[i].ravel()[z['idx_%d' % i].astype(np.int64)] != z['truth_%d' % i]).sum() for i in range(n)))
+            out['float64_adjudicator'] = adj
+    finally:
+        hnd.set_option('winograd', wino_mode)
+    return out
+
+
 def model_summary(run, m):
     """The per-model part of the JSON line (used for the headline model and for the narrow models)."""
     steps, B = m['steps'], run.B
@@ -567,7 +619,7 @@ def main():
     torch.cuda.set_device(local)
     if args.direct:
         args.wino = 0
-    wino_mode = 2 if args.wino is None else max(0, min(2, args.wino))
+    wino_mode = 2 if args.wino is None else max(0, min(3, args.wino))
     B = args.images
 
     run = DeviceRun(args.base, B, args.group, local, rank, world, args)
@@ -621,7 +673,8 @@ def main():
             res['roofline'] = {'bound': r8['bound'] if r8 else 'mfma',
                                'kernel': {0: 'conv_mfma_kernel (direct implicit GEMM)',
                                           1: 'conv_wino_kernel (Winograd F(2x2,3x3)) + conv_mfma_kernel (%s)' % up_desc,
-                                          2: 'conv_wino4_kernel (Winograd F(4x4,3x3)) + conv_mfma_kernel (%s)' % up_desc}[wino_mode] +
+                                          2: 'conv_wino4_kernel (Winograd F(4x4,3x3)) + conv_mfma_kernel (%s)' % up_desc,
+                                          3: 'conv_wino4s_kernel (Winograd F(4x4,3x3), bf16x3 split operands) + conv_mfma_kernel (%s)' % up_desc}[wino_mode] +
                                          ', fp32 v_mfma_f32_32x32x2_f32',
                                'achieved': round(exe, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': round(exe / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_stale': traffic_stale, 'traffic_source': traffic_src,
@@ -655,6 +708,8 @@ def main():
                                      'what': 'ecseg_segment_images: %d uint8 images from pageable host memory (H2D), device '
                                              'pipeline, post-processed labels + counts back to host memory (D2H), synchronous'
                                              % B}
+        if world == 1 and not args.no_narrow and wino_mode == 2:
+            res['split_bf16x3'] = split_leg(run, args.steps, summ['value'], wino_mode)
         if world == 1 and not args.no_narrow:
             res.update(aux_device_legs(hnd, local))
             res['single_image_latency_ms'] = run.single_image_latency()

@@ -39,6 +39,9 @@ namespace ecseg {
 
 #include "wino4_consts.inc"
 #define W4_HALO_RING 3
+// raw image of this kernel: rows and columns regrouped by their phase modulo the tile stride (see the header), the two channel halves 18 slots apart
+#define W4_HALO_SLOT(r, cc) const int h = (cc) >= 18 ? 1 : 0, hy = w4_inv(r), hx = w4_inv((cc) - h * 18)
+#define W4_HALO_UPPER(cc) ((cc) >= 18)
 
 // Row-transform pipeline depth (slots of in-flight halo reads beside the six direct ones; 0: rounds 1-3, column by column)
 #ifndef ECSEG_W4_TSLOTS
@@ -53,6 +56,7 @@ namespace ecseg {
 #define W4_TEMPLATE template <bool HEAD = false, bool SPLIT = false>
 #define W4_DIAG_ENTRY()
 #define W4_DIAG_SKIP_HALO_DMA()
+#define W4_DIAG_HALO_OFFSET(off, a)
 #define W4_DIAG_SKIP_FILTER_DMA()
 #define W4_DIAG_FAKE_TRANSFORM(grp)
 #define W4_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A, B, ACC, 0, 0, 0)

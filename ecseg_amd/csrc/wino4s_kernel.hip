@@ -5,23 +5,28 @@
 //
 //   sum_c V[c] U[c]  ~  sum_c  v1 u1 + (v1 u2 + v2 u1) + (v1 u3 + v2 u2 + v3 u1)        dropped: v2 u3 + v3 u2 + v3 u3 <= 3 x 2^-24 |V U|
 //
-// "K-folded" operands: a lane of the fp32 kernel holds 4 input channels of its tile (one 16-byte halo slot); here the 8 K slots of
-// a lane are those 4 channels x 2 pieces, so the halo ring, the 8-channel groups and the row transform stay as they are and one
-// MFMA sums TWO of the six products over the 8 channels of a group:
+// "K-folded" operands: a lane holds 4 input channels of its tile (one 16-byte slot); the 8 K slots of a lane are those 4 channels x 2
+// pieces, so 8-channel groups stay as in the fp32 kernel and one MFMA sums TWO of the six products over the 8 channels of a group:
 //     A = [v3|v1] x B = [u1|u3]      A = [v1|v2] x B = [u2|u1]      A = [v2|v1] x B = [u2|u1]
-// The A windows overlap in ONE 8-register tuple [v3 v1 v2 v1]; the B windows overlap in the lane's 24-byte filter record [u2 u1 u3]
-// (two 16-byte reads at +0 and +8): no operand is ever copied.
 //
-// The kernel is VALU-bound, not matrix-bound (tools/micro/mfma_bf16x3_mix.hip: the split costs 5.5 instructions per transformed
-// value), so the wave decomposition minimises vector work per MFMA: wave = (transform ROW xi, HALF of its six points) x all 64
-// output channels of the workgroup - the column transform and the split of a point feed two 32-channel MFMA column blocks, and a
-// wave reads only the five halo columns its three points need.  Per 8-channel group a wave runs T (row transform of 5 columns),
-// P0, P1, P2 (one point each: column transform, split, 6 MFMAs, the LDS-DMA of the next filter stage behind them).
+// Wave = (transform ROW xi, HALF of its six points) x all 64 output channels of the workgroup: the column transform and the split of
+// a point (5.5 vector instructions per value: v_and, v_sub, v_and, v_sub + 1.5 v_perm) feed two 32-channel MFMA column blocks.
+// Per 8-channel group a wave runs P0, P1, P2 (one point each: column transform, split, 6 MFMAs, LDS-DMA of a later filter stage
+// behind them).  What the kernel looked like on the way here, with numbers, is in EXPERIMENTS.md (round 6):
+//   v1  every wave reads the raw halo rows of its transform row itself (fp32 kernel's scheme): 518 KB of LDS traffic per group;
+//   v2  the ROW transform done once per workgroup and group by all 768 threads (row_pass) into a t image in LDS, which a wave reads
+//       as five 16-byte columns: 355 KB of LDS traffic, 40 % fewer vector instructions - and slower, until
+//   v3  (this file) the three waves of a SIMD were rotated against the two barriers again, the filter stream went two stages ahead
+//       and the raw halo image put a pixel's two 16-byte halves next to each other (32 instead of 64 cache lines per LDS-DMA).
+// The bound is none of the pipes: the LDS-DMA path of a CU sustains ~70 GB/s from L2-resident data (tools/micro/ldsdma_rate.hip; 34
+// from the Infinity Cache) and this kernel needs 131 KB per group and workgroup - 110 KB of it filter, six bytes per element, used
+// for 32 tiles only (36 points x 96 accumulator registers bound M x N of a fused Winograd workgroup).  Without any DMA the K loop runs
+// 2.2x the fp32 kernel's rate, with it 1.27x (tools/experiments/w4s_ablate.sh): 256 -> 256 at 64 x 64 x 280 windows 4.29 -> 3.45 ms.
 //
 // Filter image (written on the device from the fp32 image of winograd4_filter by wino4s_filter_kernel): per 64-channel output
-// block, 8-channel group, point slot and wave one 3-KB stage = 2 column blocks x 64 lanes x [u2 u1 u3] x 4 channels x bf16, streamed
-// by LDS-DMA into a private double buffer exactly like the fp32 kernel's stages.  Output stage: a wave folds its half row, the
-// two halves of a row meet in the exchange image (half 0 writes, half 1 adds), then wino4_combine.inc as in the fp32 kernel.
+// block, 8-channel group, point slot and wave one 3-KB stage = three self-contained 1-KB LDS-DMA pieces: [block 0: 64 lanes x [u2|u1]]
+// [block 1: 64 x [u2|u1]] [64 x u3 of block 0, 64 x u3 of block 1].  Output stage: a wave folds its half row, the two halves of a row
+// meet in the exchange image (half 0 writes, half 1 adds), then wino4_combine.inc as in the fp32 kernel.
 #include <cstdlib>
 #include <type_traits>
 
@@ -32,16 +37,28 @@ namespace ecseg {
 
 #include "wino4_consts.inc"
 #define W4_HALO_RING 2
+// raw image of this kernel (only row_pass reads it): plain row / column order, the two 16-byte channel halves of a pixel NEXT to each other -
+// neighbouring lanes of a halo LDS-DMA then read the 32 contiguous bytes of one pixel (the fp32 kernel's image, laid out for its MFMA
+// operand reads, puts them 18 lanes apart: 64 cache lines per instruction; measured on this kernel: -0.3 ms of 3.6 on 256 -> 256 at 64 x 64)
+#define W4_HALO_SLOT(r, cc) const int h = (cc) & 1, hy = (r), hx = (cc) >> 1
+#define W4_HALO_UPPER(cc) ((cc) & 1)
 
 #ifndef ECSEG_W4_TSLOTS
 #define ECSEG_W4_TSLOTS 4
 #endif
-// Timing-only ablations for A/B builds (tools/w4s_variants.sh; results are garbage): 1 no filter DMA, 2 no halo DMA, 4 no MFMAs,
-// 8 no split arithmetic, 16 every filter stage read from the wave's first one (hot in cache).  The product build has none of it.
-#ifndef ECSEG_W4S_ABL
-#define ECSEG_W4S_ABL 0
+// Timing-only ablations (no filter DMA, no halo DMA, no MFMAs, no split arithmetic, hot / contiguous sources) exist only in A/B builds
+// with -DECSEG_W4S_ABL=<bits> (tools/w4s_variants.sh, csrc/wino4s_diag.inc); the product translation unit has ONE code path: every
+// hook below is empty.
+#ifdef ECSEG_W4S_ABL
+#include "wino4s_diag.inc"
+#else
+#define W4_DIAG_SKIP_HALO_DMA()
+#define W4_DIAG_HALO_OFFSET(off, a)
+#define W4S_DIAG_SKIP_FILTER_DMA()
+#define W4S_DIAG_STAGE(stage) (stage)
+#define W4S_DIAG_NO_SPLIT 0
+#define W4S_MFMA(CB, A, B) acc[P][CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, acc[P][CB], 0, 0, 0)
 #endif
-#define W4_DIAG_SKIP_HALO_DMA() do { if (ECSEG_W4S_ABL & 2) return; } while (0)
 #define ESTAMP(i)
 #define W4_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
@@ -81,8 +98,8 @@ __global__ __launch_bounds__(768) void conv_wino4s_kernel(ConvParams p, int regs
     const unsigned lane16 = (unsigned)lane * 16u;
     auto dma_filter_piece = [&](int stage, int buf, auto kk) __attribute__((always_inline)) {
         constexpr int k = decltype(kk)::value;
-        if (ECSEG_W4S_ABL & 1) return;
-        const unsigned long long g = w_base + (unsigned long long)((ECSEG_W4S_ABL & 16) ? 0 : stage) * (12 * W4S_STAGE);     // (16: every stage from the same hot 3 KB)
+        W4S_DIAG_SKIP_FILTER_DMA();
+        const unsigned long long g = w_base + (unsigned long long)W4S_DIAG_STAGE(stage) * (12 * W4S_STAGE);
         const unsigned dst = lds_base + (unsigned)((2 * W4_HS + W4S_TS) * 16 + (wave * 2 + buf) * W4S_STAGE);
         const unsigned l16 = lane16;
         unsigned keep;
@@ -124,11 +141,11 @@ __global__ __launch_bounds__(768) void conv_wino4s_kernel(ConvParams p, int regs
         // same share (a pass run by five waves alone left the other seven waiting at the barrier behind it), 8-byte accesses,
         // neighbouring lanes on neighbouring addresses
         if (lane >= 48) return;
-        const int item = wave * 48 + lane, cpair = item & 1, k = item >> 1;
-        const int pc = k % 18, r1 = k / 18, h = r1 & 1, r2 = r1 >> 1, tyy = r2 & 3, tgg = r2 >> 2;
-        const f32x2* R = reinterpret_cast<const f32x2*>(Hs + (grp & 1) * W4_HS + (tgg * 18 + tyy) * 36 + h * 18 + pc) + cpair;      // raw row 4 tyy + i at slot offset 36 * {0, 5, 10, 14, 1, 6}[i]
-        const f32x2 d0 = R[2 * 0], d1 = R[2 * 36 * 5], d2 = R[2 * 36 * 10], d3 = R[2 * 36 * 14], d4 = R[2 * 36 * 1], d5 = R[2 * 36 * 6];
-        f32x2* T = reinterpret_cast<f32x2*>(Ts + ((tgg * 6) * 4 + tyy) * 36 + h * 18 + pc) + cpair;                                 // + xi * 144 slots
+        const int item = wave * 48 + lane, cpair = item & 1, h = (item >> 1) & 1, k = item >> 2;
+        const int x = k % 18, r2 = k / 18, tyy = r2 & 3, tgg = r2 >> 2;
+        const f32x2* R = reinterpret_cast<const f32x2*>(Hs + (grp & 1) * W4_HS + (tgg * 18 + 4 * tyy) * 36 + 2 * x + h) + cpair;     // raw row 4 tyy + i: + 36 i slots
+        const f32x2 d0 = R[2 * 36 * 0], d1 = R[2 * 36 * 1], d2 = R[2 * 36 * 2], d3 = R[2 * 36 * 3], d4 = R[2 * 36 * 4], d5 = R[2 * 36 * 5];
+        f32x2* T = reinterpret_cast<f32x2*>(Ts + ((tgg * 6) * 4 + tyy) * 36 + h * 18 + w4_pos(x)) + cpair;                            // + xi * 144 slots
         f32x2 o, e, q;
 #pragma unroll
         for (int c = 0; c < 2; ++c) o[c] = __builtin_fmaf(KP, d0[c], __builtin_fmaf(KS, d2[c], d4[c]));
@@ -162,7 +179,7 @@ __global__ __launch_bounds__(768) void conv_wino4s_kernel(ConvParams p, int regs
     // ---- one point: column transform of the lane's 4 channels, exact 3-way bf16 split, 6 MFMAs; the three pieces of the next
     //      filter stage go out behind the first MFMAs ----
     float Vm[4];                                             // the "-" point of the +- pair (computed in P1 with its partner, used in P2)
-    auto point = [&](auto pp, int fbuf, int next_stage) __attribute__((always_inline)) {
+    auto point = [&](auto pp, int fbuf, int ahead_stage) __attribute__((always_inline)) {
         constexpr int P = decltype(pp)::value;
         // Filter stage: [column block 0: 64 x [u2|u1]] [column block 1: 64 x [u2|u1]] [64 x u3 of block 0][64 x u3 of block 1]: one aligned
         // 16-byte and one 8-byte read per block - 24 bytes per lane (the first version read [u2|u1] and [u1|u3] as two overlapping
@@ -203,15 +220,10 @@ __global__ __launch_bounds__(768) void conv_wino4s_kernel(ConvParams p, int regs
         u32x8 a8;
         {
             float r[4], s[4];
-#if ECSEG_W4S_ABL & 8
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { r[c] = V[c]; s[c] = V[c]; }
-#else
+            for (int c = 0; c < 4; ++c) r[c] = W4S_DIAG_NO_SPLIT ? V[c] : V[c] - bfloat(fbits(V[c]) & 0xffff0000u);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) r[c] = V[c] - bfloat(fbits(V[c]) & 0xffff0000u);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) s[c] = r[c] - bfloat(fbits(r[c]) & 0xffff0000u);
-#endif
+            for (int c = 0; c < 4; ++c) s[c] = W4S_DIAG_NO_SPLIT ? V[c] : r[c] - bfloat(fbits(r[c]) & 0xffff0000u);
             const unsigned p1a = pack_hi(V[0], V[1]), p1b = pack_hi(V[2], V[3]);
             a8 = u32x8{pack_hi(s[0], s[1]), pack_hi(s[2], s[3]), p1a, p1b, pack_hi(r[0], r[1]), pack_hi(r[2], r[3]), p1a, p1b};
         }
@@ -224,83 +236,119 @@ __global__ __launch_bounds__(768) void conv_wino4s_kernel(ConvParams p, int regs
         __builtin_amdgcn_sched_barrier(0);
         const bf16x8 B12a = __builtin_bit_cast(bf16x8, b12a), B3a = __builtin_bit_cast(bf16x8, u32x4{b12a[2], b12a[3], u3a[0], u3a[1]});
         const bf16x8 B12b = __builtin_bit_cast(bf16x8, b12b), B3b = __builtin_bit_cast(bf16x8, u32x4{b12b[2], b12b[3], u3b[0], u3b[1]});
-        const int nbuf = fbuf ^ 1;
-#if ECSEG_W4S_ABL & 4
-#define W4S_MFMA(CB, A, B) asm volatile("" :: "v"(A), "v"(B))
-#else
-#define W4S_MFMA(CB, A, B) acc[P][CB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, acc[P][CB], 0, 0, 0)
-#endif
+        // The stage streamed from here is TWO stages ahead and goes into the buffer this phase is reading: piece 0 (block 0's [u2|u1]) once
+        // those fragments are in registers (behind the second MFMA), pieces 1 and 2 (block 1's, the u3 of both) behind the first MFMAs
+        // of block 1.  One stage ahead (the first version) left a stage ~0.8 of a phase to land and every phase began with a wait.
         W4S_MFMA(0, A3, B3a);
-        __builtin_amdgcn_sched_barrier(0);
-        dma_filter_piece(next_stage, nbuf, std::integral_constant<int, 0>{});
-        __builtin_amdgcn_sched_barrier(0);
         W4S_MFMA(0, A2, B12a);
         __builtin_amdgcn_sched_barrier(0);
-        dma_filter_piece(next_stage, nbuf, std::integral_constant<int, 1>{});
+        dma_filter_piece(ahead_stage, fbuf, std::integral_constant<int, 0>{});
         __builtin_amdgcn_sched_barrier(0);
         W4S_MFMA(0, A1, B12a);
-        __builtin_amdgcn_sched_barrier(0);
-        dma_filter_piece(next_stage, nbuf, std::integral_constant<int, 2>{});
-        __builtin_amdgcn_sched_barrier(0);
         W4S_MFMA(1, A3, B3b);
+        __builtin_amdgcn_sched_barrier(0);
+        dma_filter_piece(ahead_stage, fbuf, std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
         W4S_MFMA(1, A2, B12b);
+        __builtin_amdgcn_sched_barrier(0);
+        dma_filter_piece(ahead_stage, fbuf, std::integral_constant<int, 2>{});
+        __builtin_amdgcn_sched_barrier(0);
         W4S_MFMA(1, A1, B12b);
         __builtin_amdgcn_sched_barrier(0);                   // (MFMAs are no memory operations: without this they sink below the s_barrier that follows)
-#undef W4S_MFMA
     };
 #define W4_BARRIER() asm volatile("s_barrier" ::: "memory")
 #define W4_SB() __builtin_amdgcn_sched_barrier(0)
-    // Per group g (every wave, in this order):
-    //   barrier Y(g-1)  the t image holds group g (row_pass(g) is complete) and raw buffer g & 1 is free again
-    //   t <- t image    five ds_read_b128;   this wave's two halo pieces of group g + 2 -> raw buffer g & 1
-    //   P0(g), P1(g)    (P1: the last use of t[])
-    //   barrier X(g)    nobody needs the t image of group g any more; the raw halo of group g + 1 has landed (every wave waited for its pieces)
-    //   row_pass(g+1)   raw buffer (g + 1) & 1 -> t image
-    //   P2(g)
-    // Filter stage s = 3 g + P lives in buffer s & 1 and is streamed one stage ahead, behind the MFMAs of the stage before.  Waits
-    // (a wave counts only its own LDS-DMAs, in issue order):
-    //   P0(g): stage 3g was issued in P2(g-1) / the prologue, BEFORE the two halo pieces that followed barrier Y(g-1)   -> vmcnt(2) (0 without them)
-    //   P1(g), P2(g): the stage issued one phase earlier is the youngest                                               -> vmcnt(0)
-    // so a wave's halo pieces of group g + 2 have landed at its P1(g), long before barrier X(g + 1).
-#define W4_P0(g, H) do { W4_SB(); if (H) W4_WAIT(2); else W4_WAIT(0); W4_SB(); point(std::integral_constant<int, 0>{}, (3 * (g)) & 1, 3 * (g) + 1); } while (0)
-#define W4_P1(g) do { W4_SB(); W4_WAIT(0); W4_SB(); point(std::integral_constant<int, 1>{}, (3 * (g) + 1) & 1, 3 * (g) + 2); } while (0)
-#define W4_P2(g) do { W4_SB(); W4_WAIT(0); W4_SB(); \
-                      point(std::integral_constant<int, 2>{}, (3 * (g) + 2) & 1, (g) + 1 < ngroups ? 3 * (g) + 3 : 3 * (g) + 2); } while (0)
-    dma_halo_piece(0, std::integral_constant<int, 0>{});
-    dma_halo_piece(0, std::integral_constant<int, 1>{});
-    if (ngroups > 1) {
-        dma_halo_piece(1, std::integral_constant<int, 0>{});
-        dma_halo_piece(1, std::integral_constant<int, 1>{});
-    }
+    // Barriers and phases.  Per group g: barrier Y(g-1) - the t image holds group g and raw buffer g & 1 is free (this wave's halo pieces
+    // of group g + 2 go out right behind it) - and barrier X(g) - nobody needs the t image of group g any more and the raw halo of
+    // group g + 1 has landed: row_pass(g + 1) follows it.  Between them every wave runs its three point phases, but the three waves
+    // of a SIMD (w, w + 4, w + 8: one of each class) sit at different points of the sequence, so the LDS latencies of one run under
+    // the split arithmetic and MFMAs of the others:
+    //   class 0:   Y(g-1) | t <- image, P0(g), P1(g)         | X(g) | row_pass(g+1), P2(g)
+    //   class 1:   Y(g-1) | t <- image, P2(g-1), P0(g)       | X(g) | row_pass(g+1), P1(g)
+    //   class 2:   Y(g-1) | P1(g-1), t <- image, P2(g-1)     | X(g) | row_pass(g+1), P0(g)
+    // (P1 is the last reader of t[], P2 needs only Vm[].)  Filter stage s = 3 g + P lives in buffer s & 1 and is streamed TWO stages
+    // ahead (point()).  Waits - a wave counts only its own LDS-DMAs, in issue order: phase s needs stage s; younger than it are the three
+    // pieces of stage s + 1 and, when barrier Y lies between phase s - 2 and phase s, the two halo pieces issued behind Y: vmcnt(5) for
+    // the two phases that follow Y, vmcnt(3) for the third (and for all of them once no halo is left to fetch).
+#define W4_PH(PP, s, H) do { W4_SB(); if (H) W4_WAIT(5); else W4_WAIT(3); W4_SB(); \
+                             point(std::integral_constant<int, PP>{}, (s) & 1, (s) + 2 < 3 * ngroups ? (s) + 2 : 3 * ngroups - 1); } while (0)
+#define W4_Y() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); W4_BARRIER(); W4_SB(); } while (0)      /* (own share of the row pass is written) */
+#define W4_X() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); W4_BARRIER(); W4_SB(); } while (0)      /* (own t[] is loaded) */
+#define W4_HALO(g) do { dma_halo_piece((g), std::integral_constant<int, 0>{}); dma_halo_piece((g), std::integral_constant<int, 1>{}); } while (0)
+    const int cls = wave >> 2;
+    W4_HALO(0);
+    if (ngroups > 1) W4_HALO(1);
     dma_filter_piece(0, 0, std::integral_constant<int, 0>{});
     dma_filter_piece(0, 0, std::integral_constant<int, 1>{});
     dma_filter_piece(0, 0, std::integral_constant<int, 2>{});
-    if (ngroups > 1) W4_WAIT(5); else W4_WAIT(3);            // raw group 0 has landed
+    dma_filter_piece(1, 1, std::integral_constant<int, 0>{});
+    dma_filter_piece(1, 1, std::integral_constant<int, 1>{});
+    dma_filter_piece(1, 1, std::integral_constant<int, 2>{});
+    if (ngroups > 1) W4_WAIT(8); else W4_WAIT(6);            // raw group 0 has landed
     W4_BARRIER();
     row_pass(0);
-    for (int grp = 0; grp < ngroups; ++grp) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's share of row_pass(grp) is in the t image
-        W4_BARRIER();                                        // Y(grp - 1)
-        W4_SB();
-        load_t();
-        const bool more_halo = grp + 2 < ngroups;
-        if (more_halo) {
-            dma_halo_piece(grp + 2, std::integral_constant<int, 0>{});
-            dma_halo_piece(grp + 2, std::integral_constant<int, 1>{});
+    if (cls == 0) {
+        for (int grp = 0; grp < ngroups; ++grp) {
+            W4_Y();
+            load_t();
+            const bool mh = grp + 2 < ngroups;
+            if (mh) W4_HALO(grp + 2);
+            W4_PH(0, 3 * grp, mh);
+            W4_PH(1, 3 * grp + 1, mh);
+            if (grp + 1 < ngroups) { W4_X(); row_pass(grp + 1); W4_SB(); }
+            W4_PH(2, 3 * grp + 2, false);
         }
-        W4_P0(grp, more_halo);
-        W4_P1(grp);
-        if (grp + 1 < ngroups) {
-            W4_BARRIER();                                    // X(grp)
-            W4_SB();
-            row_pass(grp + 1);
-            W4_SB();
+    } else if (cls == 1) {
+        {
+            W4_Y();
+            load_t();
+            const bool mh = 2 < ngroups;
+            if (mh) W4_HALO(2);
+            W4_PH(0, 0, mh);
+            if (1 < ngroups) { W4_X(); row_pass(1); W4_SB(); }
+            W4_PH(1, 1, mh);                                 // (stricter than needed when halo pieces went out: they are older than stage 2 here)
         }
-        W4_P2(grp);
+        for (int grp = 1; grp < ngroups; ++grp) {
+            W4_Y();
+            load_t();
+            const bool mh = grp + 2 < ngroups;
+            if (mh) W4_HALO(grp + 2);
+            W4_PH(2, 3 * grp - 1, mh);
+            W4_PH(0, 3 * grp, mh);
+            if (grp + 1 < ngroups) { W4_X(); row_pass(grp + 1); W4_SB(); }
+            W4_PH(1, 3 * grp + 1, false);
+        }
+        W4_PH(2, 3 * ngroups - 1, false);
+    } else {
+        {
+            W4_Y();
+            const bool mh = 2 < ngroups;
+            if (mh) W4_HALO(2);
+            load_t();
+            if (1 < ngroups) {
+                if (mh) W4_WAIT(8); else W4_WAIT(6);         // raw group 1 has landed (this class has not waited for anything since the prologue)
+                W4_X(); row_pass(1); W4_SB();
+            }
+            W4_PH(0, 0, mh);
+        }
+        for (int grp = 1; grp < ngroups; ++grp) {
+            W4_Y();
+            const bool mh = grp + 2 < ngroups;
+            if (mh) W4_HALO(grp + 2);
+            W4_PH(1, 3 * grp - 2, mh);
+            W4_SB();
+            load_t();
+            W4_PH(2, 3 * grp - 1, mh);
+            if (grp + 1 < ngroups) { W4_X(); row_pass(grp + 1); W4_SB(); }
+            W4_PH(0, 3 * grp, false);
+        }
+        W4_PH(1, 3 * ngroups - 2, false);
+        W4_PH(2, 3 * ngroups - 1, false);
     }
-#undef W4_P0
-#undef W4_P1
-#undef W4_P2
+#undef W4_PH
+#undef W4_Y
+#undef W4_X
+#undef W4_HALO
 #undef W4_SB
 #undef W4_BARRIER
 

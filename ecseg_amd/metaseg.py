@@ -625,11 +625,13 @@ def main(argv=None):
         print("Input folder does not exist. Exiting...")
         sys.exit(2)
     # precision: fast (default) = Winograd F(4x4,3x3) where a layer allows it; exact = F(2x2,3x3) everywhere - half as many
-    # raw-label pixels away from a float64 evaluation of the network, ~1.7x the U-Net time.  emit_probs: also
+    # raw-label pixels away from a float64 evaluation of the network, ~1.7x the U-Net time; split = F(4x4,3x3) with the channel
+    # sums on the bf16 matrix pipe and both operands split exactly into three bf16 pieces (float32-accurate, float32 accumulate; round 6:
+    # faster than `fast` on models with >= 64 channels per layer, the same accuracy class; opt-in).  emit_probs: also
     # write the stitched float32 probabilities as labels/<stem>_probs.npy (23 MB per 1040 x 1392 image).
     precision = str(var.get('precision', 'fast')).lower()
-    if precision not in ('fast', 'exact'):
-        print("metaseg.precision must be 'fast' or 'exact'. Exiting...")
+    if precision not in ('fast', 'exact', 'split'):
+        print("metaseg.precision must be 'fast', 'exact' or 'split'. Exiting...")
         sys.exit(2)
     emit_probs = bool(var.get('emit_probs', False))
     for sub in ('dapi', 'labels'):
@@ -658,7 +660,7 @@ def main(argv=None):
     model = models[0]
     print(model.handle.device_name)
     for m in models:
-        m.handle.set_option('winograd', 1 if precision == 'exact' else 2)
+        m.handle.set_option('winograd', {'exact': 1, 'fast': 2, 'split': 3}[precision])
     image_paths = get_imgs(inpath)
     print("Reading from: ", inpath)
     t0 = time.perf_counter()

@@ -360,7 +360,7 @@ def roofline_8d(plan, recs, steps, patches_per_step, unet_ms_per_step):
 class DeviceRun:
     """One synthetic model on this rank's GPU: inputs resident in HBM, `step()` = the whole device pipeline over B images."""
 
-    def __init__(self, base, B, group, local, rank, world, args):
+    def __init__(self, base, B, group, local, rank, world, args, up=None, batchnorm=False):
         import torch
         from ecseg_amd import dist as edist
         from ecseg_amd import synth
@@ -368,7 +368,7 @@ class DeviceRun:
         self.torch, self.edist = torch, edist
         self.base, self.B, self.world = base, B, world
         dev = torch.device('cuda', local)
-        cfg = synth.unet_config(base=base, up=args.up)
+        cfg = synth.unet_config(base=base, up=up or args.up, batchnorm=batchnorm)
         self.model = MetasegModel(cfg, synth.unet_weights(cfg, seed=0), device=local)
         hnd = self.hnd = self.model.handle
         hnd.set_images_per_group(group)
@@ -724,6 +724,14 @@ def main():
                 narrow['base%d' % nb] = model_summary(r2, r2.timed(5, 1, profile=True))
                 r2.close()
             res['narrow_models'] = narrow
+            # the decoder family of the most common public Keras U-Net - UpSampling2D(2) + Conv2D(2x2, 'same') instead of
+            # Conv2DTranspose - lowered (round 6) to ONE 3x3 / stride-2 transposed convolution with pre-summed taps on the un-upsampled tensor
+            ups = {}
+            for tag, nb, nimg, bn in (('upsample_base64', 64, 16, False), ('upsample_base16', 16, 64, False), ('upsample_base16_batchnorm', 16, 64, True)):
+                r3 = DeviceRun(nb, nimg, 0, local, rank, world, args, up='upsample', batchnorm=bn)
+                ups[tag] = model_summary(r3, r3.timed(5, 1, profile=True))
+                r3.close()
+            res['upsample_decoder_models'] = ups
         if pools is not None:
             cpu_par, cpu_single, refs = cpu_baseline(args.base, pools, args.up)    # after the timed region, on the idle workers
             res['cpu_baseline'] = cpu_par

@@ -41,6 +41,12 @@ struct OpRt {                 // run-time form of one plan operator
     float* shift = nullptr;
     int cin_chunks = 0, coutp = 0;
     int subpixel = 0;         // CONVT kh x kw / stride 2 with k in {3, 4} as a 2x2-tap convolution over the input (relayout_convt_subpixel)
+    // round 6: the same layers with >= 32 output channels run PHASE BY PHASE instead - output rows y = 2 j + c come from the kernel rows
+    // kh = c + crop (mod 2) at input offsets (c + crop - kh) / 2: four forward convolutions of 1 or 2 taps per axis on the input extent
+    // (9 instead of 16 tap x phase products at k = 3, no zero blocks staged or multiplied, no overhanging tile row), each with a
+    // strided scatter store.  ph_wt[c_y * 2 + c_x] != null: that path; ph_R / ph_S / ph_pt / ph_pl: taps and leading pad of each phase
+    float* ph_wt[4] = {nullptr, nullptr, nullptr, nullptr};
+    int ph_R[4] = {0, 0, 0, 0}, ph_S[4] = {0, 0, 0, 0}, ph_pt[4] = {0, 0, 0, 0}, ph_pl[4] = {0, 0, 0, 0};
     double flops = 0.0;       // algorithmic 2*MAC per patch
 };
 enum { PATH_MFMA = 1, PATH_SMALL_CIN = 2, PATH_HEAD = 3, PATH_GENERIC = 4, PATH_OTHER = 5, PATH_TAP = 6 /* conv_mfma_tap_kernel: any taps / stride / dilation */ };
@@ -525,6 +531,12 @@ int run_plan_op(ecseg_ctx* h, size_t& oi, int n_all, StitchPlan* crop, const Lan
                         // 4x4 'same' and every 'valid' layer, not 3x3 'same' - whose 16 x 16 inputs then tile exactly)
                         p.convt_ext = (out.h + d.pad_top > 2 * in.h || out.w + d.pad_left > 2 * in.w) ? 1 : 0;
                         p.crop_top = d.pad_top; p.crop_left = d.pad_left;
+                        // tap t = (d + 1) * 2 + (e + 1), phase (a, b): kernel index (a - 2 d, b - 2 e) >= k means a zero block (relayout_convt_subpixel)
+                        for (int dd = -1; dd <= 0; ++dd)
+                            for (int ee = -1; ee <= 0; ++ee)
+                                for (int a = 0; a < 2; ++a)
+                                    for (int b = 0; b < 2; ++b)
+                                        if (a - 2 * dd >= d.kh || b - 2 * ee >= d.kw) p.tap_zero_mask |= 1 << (((dd + 1) * 2 + (ee + 1)) * 4 + a * 2 + b);
                     } else {
                         p.R = 1; p.S = 1; p.pad_top = 0; p.pad_left = 0; p.convt = 1; p.kT = d.kh;
                         p.crop_top = d.pad_top; p.crop_left = d.pad_left;
@@ -646,15 +658,32 @@ int run_plan_op(ecseg_ctx* h, size_t& oi, int n_all, StitchPlan* crop, const Lan
                                 computed = (double)cl->len / ((double)crop->n_pos * ((in.h + th - 1) / th) * ((in.w + tw - 1) / tw));
                             }
                         }
-                        e = launch_conv_mfma(p, s);
+                        if (o.subpixel && o.ph_wt[0] != nullptr) {
+                            // phase by phase (see OpRt::ph_wt): tiles walk the input positions j of the outputs 2 j + c that exist
+                            const int crop_t = p.crop_top, crop_l = p.crop_left;
+                            p.tap_zero_mask = 0;
+                            p.crop_top = 0; p.crop_left = 0;
+                            p.convt_ext = ((out.h + 1) / 2 > in.h || (out.w + 1) / 2 > in.w) ? 1 : 0;
+                            (void)crop_t; (void)crop_l;
+                            for (int ph = 0; ph < 4 && e == hipSuccess; ++ph) {
+                                p.wt = o.ph_wt[ph]; p.R = o.ph_R[ph]; p.S = o.ph_S[ph]; p.pad_top = o.ph_pt[ph]; p.pad_left = o.ph_pl[ph];
+                                p.phase_a = ph >> 1; p.phase_b = ph & 1;
+                                p.convt = 2;                   // one output phase per launch: N = coutp
+                                p.wt_chunk_stride = wt_chunk_pitch(o.coutp);
+                                p.wt_tap_stride = wt_tap_pitch(o.coutp, o.cin_chunks);
+                                e = launch_conv_mfma(p, s);
+                            }
+                        } else {
+                            e = launch_conv_mfma(p, s);
+                        }
                     }
                     if (first && !w16 && e == hipSuccess) e = hipErrorInvalidValue;     // (the eligibility test above and the launcher's disagree)
                     if (ev) {
                         (void)hipEventRecord(ev[1], s);
                         if (first) { h->prof_flops += first->flops * n; h->prof_exec_flops += first->flops * n * 12.0 / 9.0; }   // (9 taps padded to 12 on the MFMA)
                         h->prof_flops += o.flops * n;
-                        // multiplies actually issued (sub-pixel transposed convolution: 4 taps x 4 phases per input pixel, zeros included)
-                        const double ex = o.flops * n * computed * (wino4 ? 0.25 : wino ? 16.0 / 36.0 : o.subpixel ? 16.0 / (d.kh * d.kw) : 1.0);
+                        // multiplies actually issued (sub-pixel transposed convolution: 4 taps x 4 phases per input pixel minus the all-zero blocks the kernel skips)
+                        const double ex = o.flops * n * computed * (wino4 ? 0.25 : wino ? 16.0 / 36.0 : (o.subpixel && o.ph_wt[0] == nullptr) ? (16.0 - __builtin_popcount((unsigned)p.tap_zero_mask)) / (d.kh * d.kw) : 1.0);
                         h->prof_exec_flops += ex;
                         const bool res = wino && p.resident && p.coutp == 32 && p.cin_chunks <= 4;
                         // kind: bits 0-7 the kernel, bit 8: the following 2x2 max-pool was written by this launch, bit 9: the following 1x1 head was
@@ -1363,6 +1392,32 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
                     o.cin_chunks = (cin + 7) / 8;
                     if ((rc = upload(h, relayout_convt_subpixel(kw, d.kh, cin, cout, o.cin_chunks, o.coutp), &o.wt))) return rc;
                     h->mfma_flops_per_patch += o.flops;
+                    if (cout >= 32 && d.pad_top <= 1 && d.pad_left <= 1) {
+                        const int k = d.kh;
+                        // taps of output phase c along one axis, ascending input offset: kernel index kh = c + crop (mod 2), offset (c + crop - kh) / 2
+                        auto taps = [&](int c, int crop, int idx[2], int& lead) {
+                            int n = 0, dmin = 0, off[2] = {0, 0};
+                            for (int kk = k - 1; kk >= 0; --kk)
+                                if (((c + crop - kk) & 1) == 0) { off[n] = (c + crop - kk) / 2; idx[n] = kk; ++n; }      // kk descending = offset ascending
+                            dmin = off[0];
+                            lead = -dmin;
+                            return n;
+                        };
+                        for (int cy = 0; cy < 2; ++cy)
+                            for (int cx = 0; cx < 2; ++cx) {
+                                int ky[2], kx[2], pt = 0, pl = 0;
+                                const int R = taps(cy, d.pad_top, ky, pt), S = taps(cx, d.pad_left, kx, pl);
+                                std::vector<float> hw((size_t)R * S * cin * cout);      // HWIO filter of this phase's forward convolution
+                                for (int r = 0; r < R; ++r)
+                                    for (int q = 0; q < S; ++q)
+                                        for (int ci = 0; ci < cin; ++ci)
+                                            for (int co = 0; co < cout; ++co)
+                                                hw[(((size_t)r * S + q) * cin + ci) * cout + co] = kw[(((size_t)ky[r] * k + kx[q]) * cout + co) * cin + ci];
+                                const int ph = cy * 2 + cx;
+                                o.ph_R[ph] = R; o.ph_S[ph] = S; o.ph_pt[ph] = pt; o.ph_pl[ph] = pl;
+                                if ((rc = upload(h, relayout_conv(hw.data(), R, S, cin, cout, o.cin_chunks, o.coutp), &o.ph_wt[ph]))) return rc;
+                            }
+                    }
                 } else {
                     o.path = PATH_GENERIC;
                     if ((rc = upload(h, std::vector<float>(kw, kw + (size_t)d.kh * d.kw * cin * cout), &o.wt))) return rc;

@@ -26,9 +26,12 @@ struct ConvParams {
     int cin_chunks;     // ceil(Cin / 8)
     int coutp;          // Cout padded to a multiple of the N tile
     // transposed-conv mode (R = S = 1 in the GEMM, kT x kT stride-kT scatter in the epilogue)
-    int convt;          // 0 | 1
+    int convt;          // 0 | 1 | 2 (2: ONE output phase per launch - N = coutp, the phase in phase_a / phase_b)
     int kT, crop_top, crop_left;
     int convt_ext;      // transposed mode: tiles walk the input extent + convt_ext (sub-pixel form of k x k / stride 2: 1)
+    int phase_a, phase_b;   // transposed mode with ONE output phase per launch (N = coutp): the launch writes output (kT i + phase_a - crop_top, kT j + phase_b - crop_left)
+    int tap_zero_mask;  // sub-pixel form (R = S = 2, kT = 2): bit (tap * 4 + phase) set = that (tap, output phase) block of the filter is all zero
+                        // (7 of 16 at k = 3: the phases have 4, 2, 2 and 1 taps): conv_mfma_kernel skips its MFMAs.  0: multiply everything
     int stride;         // forward convolution: output stride (0 / 1: dense; 2: conv_mfma gathers a strided halo)
     const float* zero;  // >= 16 bytes of zeros in device memory (LDS-DMA source for padding / out-of-image pixels)
     TView pool;         // pool.p != null: also write MaxPooling2D(2x2, stride 2) of the activated output (conv_wino4 only)

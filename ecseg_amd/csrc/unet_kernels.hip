@@ -136,6 +136,25 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p, int tiles_
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
 
+    // Sub-pixel transposed convolutions (round 6): 7 of the 16 (tap, output phase) filter blocks of a 3x3 / stride-2 layer are all zero
+    // - the phases have 4, 2, 2 and 1 taps - and the up-sample + 2x2 decoder step lowered to such a layer lives on exactly those 9.
+    // skip[nt]: bit t set = tap t of this workgroup's 32-column tile nt multiplies zeros only (a tile that straddles two phases -
+    // coutp = 16 - skips what both have in common).  Wave-uniform: one scalar branch per (tap, tile).
+    unsigned skip[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        skip[nt] = 0;
+        if (R == 2 && S == 2 && p.convt && p.tap_zero_mask) {
+            const int ab0 = (n0 + nt * 32) / p.coutp, ab1 = min((n0 + nt * 32 + 31) / p.coutp, p.kT * p.kT - 1);
+#pragma unroll
+            for (int t = 0; t < R * S; ++t) {
+                bool z = true;
+                for (int ab = ab0; ab <= ab1; ++ab) z = z && ((p.tap_zero_mask >> (t * 4 + ab)) & 1);
+                if (z) skip[nt] |= 1u << t;
+            }
+        }
+    }
+
     load_chunk(0);
     for (int st = 0; st < nstages; ++st) {
         store_chunk();
@@ -150,6 +169,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p, int tiles_
                     const f32x4 a = Ap[kc * 2 * NPIX + r * HW + s];
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
+                        if (R == 2 && S == 2 && ((skip[nt] >> (r * S + s)) & 1)) continue;
                         const f32x4 b = Bp[(kc * R * S + r * S + s) * 2 * BN + nt * 32];
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
@@ -178,6 +198,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p, int tiles_
             const int ab = co / p.coutp;
             co -= ab * p.coutp;
             oa = ab / p.kT; ob = ab - oa * p.kT;
+            oa += p.phase_a; ob += p.phase_b;                  // (phase-by-phase launches: N holds one phase, ab = 0)
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) Xs[((e & 3) + 8 * (e >> 2) + 4 * lh) * 32 + li] = acc[nt][e];
@@ -642,7 +663,7 @@ int conv_mfma_ntile(int cout) {
 }
 
 bool conv_mfma_supported(const ConvParams& p) {
-    const bool taps_ok = (p.R == 3 && p.S == 3) || (p.R == 2 && p.S == 2) || (p.R == 1 && p.S == 1);
+    const bool taps_ok = (p.R == 3 && p.S == 3) || (p.R == 2 && p.S == 2) || (p.R == 1 && p.S == 1) || (p.stride <= 1 && ((p.R == 2 && p.S == 1) || (p.R == 1 && p.S == 2)));
     const bool align_ok = (p.in.cs % 4 == 0) && (p.in.c % 4 == 0) && (((uintptr_t)p.in.p) % 16 == 0);
     return taps_ok && align_ok && p.in.c >= 8 && p.out.c >= 16;
 }
@@ -653,7 +674,7 @@ static hipError_t launch_conv_mfma_t(const ConvParams& p, hipStream_t s) {
     constexpr int BN = NT * 32;
     const int ext_h = p.convt ? p.in.h + p.convt_ext : p.out.h, ext_w = p.convt ? p.in.w + p.convt_ext : p.out.w;
     const int tiles_x = (ext_w + TW - 1) / TW, tiles_y = (ext_h + TH - 1) / TH;
-    const int np_total = p.convt ? p.kT * p.kT * p.coutp : p.coutp;
+    const int np_total = p.convt == 1 ? p.kT * p.kT * p.coutp : p.coutp;        // (convt == 2: one output phase per launch)
     const int nblk_n = np_total / BN;
     size_t lds = (size_t)KCH * (2 * ((TH - 1) * ST + R) * ((TW - 1) * ST + S) + R * S * 2 * BN) * 16;
     if (lds < 4 * 4096) lds = 4 * 4096;                       // the output stage needs a 4-KB exchange tile per wave
@@ -673,7 +694,9 @@ static hipError_t launch_conv_mfma_rs(const ConvParams& p, hipStream_t s) {
         return launch_conv_mfma_t<NT, TW, 1, 1, 2, 2>(p, s);
     }
     if (p.R == 3) return launch_conv_mfma_t<NT, TW, 3, 3>(p, s);
-    if (p.R == 2) return launch_conv_mfma_t<NT, TW, 2, 2>(p, s);
+    if (p.R == 2 && p.S == 2) return launch_conv_mfma_t<NT, TW, 2, 2>(p, s);
+    if (p.R == 2 && p.S == 1) return launch_conv_mfma_t<NT, TW, 2, 1, 2>(p, s);     // (the two-tap phases of a 3x3 / stride-2 transposed convolution)
+    if (p.R == 1 && p.S == 2) return launch_conv_mfma_t<NT, TW, 1, 2, 2>(p, s);
     return launch_conv_mfma_t<NT, TW, 1, 1, 2>(p, s);      // K-chunks per barrier: 1 / 2 / 4 / 8 measured 0 / +0.2 / -0.2 / -1.5 % (A/B)
 }
 
@@ -681,7 +704,7 @@ hipError_t launch_conv_mfma(const ConvParams& p, hipStream_t s) {
     // transposed convolutions whose kT x kT phases x padded channels fit one 128-column tile (Cout <= 32 at 2x2): ONE workgroup
     // computes every output phase of its input tile - the tile is staged once instead of once per phase, and the per-thread
     // staging descriptors / prologue of these short-K layers are amortised over 2 - 4x the work
-    const int np_t = p.convt ? p.kT * p.kT * p.coutp : 0;
+    const int np_t = p.convt == 1 ? p.kT * p.kT * p.coutp : 0;
     const int bn = (p.convt && np_t <= 128 && np_t % 32 == 0) ? np_t : conv_mfma_ntile(p.out.c);
     const bool wide = p.force_tw ? p.force_tw == 32 : (p.convt ? p.in.w : p.out.w) >= 32;
     if (bn == 128) return wide ? launch_conv_mfma_rs<4, 32>(p, s) : launch_conv_mfma_rs<4, 16>(p, s);

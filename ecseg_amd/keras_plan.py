@@ -601,6 +601,34 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
         return [j for j, n in enumerate(nodes) if alive[j] and i in n['inputs']]
 
     if fuse:
+        # UpSampling2D(2, nearest) -> Conv2D(2x2, 'same') - the decoder step of the most common public Keras U-Net - as ONE stride-2
+        # transposed convolution over the un-upsampled tensor (round 6).  With up(y) = in(y // 2) and 'same' padding
+        # of an even kernel (nothing before, one row / column behind):
+        #     out(2i)   = w0 in(i) + w1 in(i)          out(2i+1) = w0 in(i) + w1 in(i+1)
+        # i.e. in(i) reaches out(2i-1), out(2i), out(2i+1) with w1, w0 + w1, w0: a 3-tap transposed kernel K' = [w1, w0 + w1, w0] with
+        # one output row cropped at the top - in 2-D the nine taps K'[a][b] = sum of w[r][s] over r in R(a), s in R(b),
+        # R = ({1}, {0, 1}, {0}) (1 + 2 + 2 + 4 = 9 products of pre-summed filters instead of 16 on a 4x-sized tensor that never exists).
+        # The library runs k x k / stride-2 transposed convolutions as one 2x2-tap sub-pixel convolution on the matrix cores.
+        for j, n in enumerate(nodes):
+            if not alive[j] or n['kind'] != 'conv' or len(n['inputs']) != 1 or n.get('rank', 4) != 4:
+                continue
+            i = n['inputs'][0]
+            u = nodes[i]
+            if u['kind'] != 'upsample' or u['stride'] != 2 or u['mode'] != 0 or len(consumers(i)) != 1 or i == out_node:
+                continue
+            if (n['kh'], n['kw'], n.get('stride', 1), n.get('dilation', 1), n['pad_top'], n['pad_left']) != (2, 2, 1, 1, 0, 0) or \
+                    n['shape'][:2] != u['shape'][:2]:
+                continue
+            w = n['kernel'].astype(np.float64)                   # (2, 2, in, out)
+            R = ((1,), (0, 1), (0,))
+            kt = np.zeros((3, 3, w.shape[3], w.shape[2]))
+            for a in range(3):
+                for b in range(3):
+                    kt[a, b] = sum(w[r, q] for r in R[a] for q in R[b]).T
+            n.update(kind='convt', kh=3, kw=3, stride=2, pad_top=1, pad_left=1, kernel=np.ascontiguousarray(kt, np.float32), inputs=list(u['inputs']))
+            n.pop('dilation', None)
+            n.setdefault('also', []).append(u['name'] + ' (UpSampling2D folded into the convolution)')
+            alive[i] = False
         for j, n in enumerate(nodes):
             if not alive[j] or len(n['inputs']) != 1:
                 continue

@@ -267,6 +267,26 @@ def test_base64_unet_split_mode_with_views_pool_head_and_fallback(gpu):
         np.testing.assert_allclose(got.sum(-1), 1.0, atol=1e-5)
 
 
+@pytest.mark.parametrize('base,bn', [(16, False), (32, True), (64, False)])
+def test_upsample_conv2x2_decoder_runs_as_one_transposed_convolution(gpu, base, bn):
+    """Round 6: UpSampling2D(2, nearest) -> Conv2D(2x2, 'same') is lowered to ONE 3x3 / stride-2 transposed
+    convolution with pre-summed taps on the un-upsampled tensor (keras_plan pass 2).  The fused plan must contain no UpSampling2D,
+    equal the layer-by-layer plan (fuse=False: real up-sampling + a real 2x2 convolution) to float32 rounding and the oracle -
+    which evaluates the ORIGINAL graph - within 1e-3."""
+    cfg = synth.unet_config(base=base, up='upsample', batchnorm=bn, depth=3)
+    weights = synth.unet_weights(cfg, seed=base + 1)
+    x = _patches(2, seed=base)
+    want = oracle_unet.forward(cfg, weights, x)
+    fused, plan = _run(gpu, cfg, weights, x, fuse=True)
+    assert not any(o['op'] == keras_plan.OP_UPSAMPLE for o in plan.ops)
+    assert sum(1 for o in plan.ops if o['op'] == keras_plan.OP_CONVT and (o['kh'], o['stride'], o['pad_top'], o['pad_left']) == (3, 2, 1, 1)) == 3
+    plain, plan0 = _run(gpu, cfg, weights, x, fuse=False)
+    assert sum(1 for o in plan0.ops if o['op'] == keras_plan.OP_UPSAMPLE) == 3
+    assert np.abs(fused - want).max() < TOL, np.abs(fused - want).max()
+    assert np.abs(fused - plain).max() < 2e-5, np.abs(fused - plain).max()
+    np.testing.assert_allclose(fused.sum(-1), 1.0, atol=1e-5)
+
+
 @pytest.mark.parametrize('act,use_bias', [('linear', True), ('sigmoid', False), ('tanh', True), ('elu', True)])
 def test_winograd_f4x4_activations_and_no_bias(gpu, act, use_bias):
     """The F(4x4) output stage applies the layer's own activation and tolerates a missing bias."""

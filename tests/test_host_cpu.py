@@ -92,7 +92,7 @@ def _check_plan(plan):
         assert t['h'] * t['w'] * t['c_stride'] <= plan.buffer_floats[t['buffer']]
 
 
-@pytest.mark.parametrize('base,up,bn', [(64, 'transpose', False), (16, 'upsample', True), (32, 'transpose', True)])
+@pytest.mark.parametrize('base,up,bn', [(64, 'transpose', False), (16, 'upsample', True), (16, 'upsample', False), (32, 'transpose', True)])
 def test_plan_of_canonical_unet(base, up, bn):
     cfg = synth.unet_config(base=base, up=up, batchnorm=bn)
     w = synth.unet_weights(cfg)
@@ -104,6 +104,17 @@ def test_plan_of_canonical_unet(base, up, bn):
         if fuse:
             assert all(o['op'] not in (keras_plan.OP_AFFINE, keras_plan.OP_ACT) for o in plan.ops)
             assert all(o['op'] != keras_plan.OP_COPY for o in plan.ops)     # concatenation is free
+            if up == 'upsample':
+                # round 6: UpSampling2D(2) + Conv2D(2x2, 'same') = ONE 3x3 / stride-2 transposed convolution with pre-summed taps, cropped by one
+                assert all(o['op'] != keras_plan.OP_UPSAMPLE for o in plan.ops)
+                ct = [o for o in plan.ops if o['op'] == keras_plan.OP_CONVT]
+                assert len(ct) == 4 and all((o['kh'], o['kw'], o['stride'], o['pad_top'], o['pad_left']) == (3, 3, 2, 1, 1) for o in ct)
+                k2 = w[[l['config']['name'] for l in cfg['config']['layers'] if l['class_name'] == 'Conv2D' and l['config']['kernel_size'] == [2, 2]][0]][0]
+                k3 = plan.weights[ct[0]['w0']].reshape(3, 3, k2.shape[3], k2.shape[2])
+                if not bn:                                                   # (a folded BatchNorm scales the taps)
+                    assert np.allclose(k3[1, 1], k2.sum((0, 1)).T, atol=1e-6) and np.allclose(k3[0, 0], k2[1, 1].T) and np.allclose(k3[2, 1], (k2[0, 0] + k2[0, 1]).T, atol=1e-6)
+        elif up == 'upsample':
+            assert sum(1 for o in plan.ops if o['op'] == keras_plan.OP_UPSAMPLE) == 4
         # window lanes (csrc/api.hip run_plan) address the model input and output in plain window order while every other
         # tensor is packed into a lane's private slice of its buffer: the two must have buffers of their own
         for io in (plan.input_tensor, plan.output_tensor):

@@ -224,6 +224,25 @@ def aux_device_legs(hnd, local, n=64, with_comm=True):
     out['preprocess_ms_per_image'] = {'value': round(t, 4), 'images': n, 'algorithmic_bytes_per_image': pp_bytes,
                                       'achieved_GBs': round(pp_bytes / (t * 1e-3) / 1e9, 1), 'frac_of_hbm_peak': round(pp_bytes / (t * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
                                       'what': 'ecseg_preprocess (src/image_tools.py:86-96): blue channel + 256-bin histogram + Otsu + invert, uint8 RGB, kernels only'}
+    # "CCL ms/image" on a REALISTIC label map beside the headline's speckle figure (random weights give 16 - 17 k
+    # components per image): the clean-up + count of ecseg_meta_inference_dev on seeded synth.label_map images (blobs + 0.2 % salt),
+    # independent of any network, kernels only
+    d_in = torch.from_numpy(np.ascontiguousarray(lab)).to('cuda:%d' % local)
+    d_out = torch.empty_like(d_in)
+    nec = torch.zeros(n, dtype=torch.int32, device=d_in.device)
+    hnd.meta_inference_dev(d_in.data_ptr(), n, H, W, d_out.data_ptr(), nec.data_ptr())
+    ms = []
+    for _ in range(5):
+        hnd.meta_inference_dev(d_in.data_ptr(), n, H, W, d_out.data_ptr(), nec.data_ptr())
+        ms.append(hnd.timings()['post'])
+    t = float(np.median(ms)) / n
+    cc_bytes = px * (7 * 9 + 7 * 2)                     # 7 labellings x 9 B/px + 7 stencil passes x 2 B/px (111 MB per 1040 x 1392 image)
+    out['ccl_ms_per_image_realistic'] = {'value': round(t, 4), 'images': n, 'algorithmic_bytes_per_image': int(cc_bytes),
+                                         'achieved_GBs': round(cc_bytes / (t * 1e-3) / 1e9, 1), 'frac_of_hbm_peak': round(cc_bytes / (t * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
+                                         'mean_n_ec': float(nec.float().mean().item()),
+                                         'what': 'ecseg_meta_inference_dev (src/image_tools.py:15-84 + src/metaseg.py:46) on synth.label_map images (blobs + 0.2 % salt noise), kernels only; '
+                                                 'the headline ccl_ms_per_image is the same kernels on the speckled argmax of the random-weight bench model'}
+    del d_in, d_out, nec
     if not with_comm:                                              # (tools/aux_legs.py under rocprofv3: RCCL's own profiler hooks crash there)
         return out
     try:

@@ -162,11 +162,82 @@ def _group_nested_weights(ws, owner):
     return d
 
 
+def unshare_layers(mc, weights):
+    """A Functional config in which some layer is CALLED more than once (several inbound nodes: shared weights - a Siamese branch, one
+    block applied at two scales) -> (config, weights) in which every call is a layer of its own: call j >= 1 of layer ``name`` becomes
+    ``name/call<j>`` with the same weight arrays, every reference [layer, node index, tensor index] is rewritten to the clone it means,
+    and the layers are put into dependency order (Keras lists a layer once, where it was created - the inputs of its later calls are
+    defined further down).  The reference loads such files like any other (/root/reference/src/utils.py:27-33)."""
+    cfg = mc['config']
+    layers = cfg['layers']
+    if all(len(L.get('inbound_nodes', [])) <= 1 for L in layers):
+        return mc, weights
+
+    def lname(L):
+        return L['config'].get('name', L.get('name'))
+
+    def norm(node):
+        if isinstance(node, dict):
+            raise PlanError('Keras 3 model_config is not supported (save with TF 2.x / Keras 2)')
+        if node and isinstance(node[0], str):
+            node = [node]
+        return [list(r) for r in node]
+
+    calls = {lname(L): len(L.get('inbound_nodes', [])) for L in layers}
+
+    def clone_name(name, j):
+        if j and j >= max(calls.get(name, 1), 1):
+            raise PlanError('reference to call %d of layer %s, which is called %d time(s)' % (j, name, calls.get(name, 0)))
+        return name if not j else '%s/call%d' % (name, j)
+
+    def fix(ref):
+        j = ref[1] if len(ref) > 1 and isinstance(ref[1], int) else 0
+        return [clone_name(ref[0], j), 0] + list(ref[2:])
+
+    wout = dict(weights)
+    out = []
+    for L in layers:
+        inb = L.get('inbound_nodes', [])
+        name = lname(L)
+        if not inb:
+            out.append(L)
+            continue
+        for j, node in enumerate(inb):
+            nm = clone_name(name, j)
+            out.append(dict(L, name=nm, config=dict(L['config'], name=nm), inbound_nodes=[[fix(r) for r in norm(node)]]))
+            if j and name in weights:
+                wout[nm] = weights[name]
+    # dependency order (stable): a clone may consume layers that are listed after the layer it was cloned from
+    pos = {lname(L): k for k, L in enumerate(out)}
+    done, order = set(), []
+
+    def visit(k, stack=()):
+        nm = lname(out[k])
+        if nm in done:
+            return
+        if nm in stack:
+            raise PlanError('the layer graph has a cycle through %s' % nm)
+        for node in out[k].get('inbound_nodes', []):
+            for r in node:
+                if r[0] not in pos:
+                    raise PlanError('layer %s consumes unknown layer %s' % (nm, r[0]))
+                visit(pos[r[0]], stack + (nm,))
+        done.add(nm)
+        order.append(out[k])
+
+    for k in range(len(out)):
+        visit(k)
+    new_cfg = dict(cfg, layers=order, input_layers=[fix(list(r)) for r in cfg.get('input_layers', [])],
+                   output_layers=[fix(list(r)) for r in cfg.get('output_layers', [])])
+    return dict(mc, config=new_cfg), wout
+
+
 def inline_nested(model_config, weights):
     """-> (flat Functional model_config, weights): every nested Functional / Sequential sub-model (a transfer-learning
     backbone used as one layer, ``tf.keras.applications.*`` inside a classifier) is replaced by its own layers, named
     ``<sub-model>/<layer>``; the sub-model's InputLayers become references to the tensors it is called on."""
     mc = _to_functional(model_config)
+    mc, weights = unshare_layers(mc, weights)
     cfg = mc['config']
     new_layers, alias, wout = [], {}, dict(weights)
 
@@ -750,10 +821,15 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
             plan.layer_tensor[nm] = tensor_of[j]
         return tensor_of[j]
 
+    weight_ids = {}                     # id(array) -> index: the calls of a shared layer (unshare_layers) are several ops on ONE weight index
+
     def add_weight(arr):
         if arr is None:
             return -1
+        if id(arr) in weight_ids and weight_ids[id(arr)][0] is arr:
+            return weight_ids[id(arr)][1]
         plan.weights.append(np.ascontiguousarray(arr, np.float32).ravel())
+        weight_ids[id(arr)] = (arr, len(plan.weights) - 1)
         return len(plan.weights) - 1
 
     def op(**kw):

@@ -177,6 +177,38 @@ def _tfop(L, lc, a):
     raise NotImplementedError('TFOpLambda %s' % fn)
 
 
+def _calls_in_order(layers):
+    """Layers that Keras calls more than once (shared weights: several entries in ``inbound_nodes``) as one evaluation step per CALL,
+    ordered so that every call comes after the calls it consumes.  -> list of (layer dict with ONE inbound node whose references name
+    calls as ``layer@k``, key ``layer@k`` under which the call's value is stored, name of the layer whose weights it uses).
+    A Functional model evaluates node k of a layer on the tensors [layer, node index, tensor index] of its inbound node k
+    (tf.keras functional API; the reference loads such files like any other: /root/reference/src/utils.py:27-33)."""
+    def refs_of(node):
+        return [node] if node and isinstance(node[0], str) else list(node)
+
+    pending = []
+    for L in layers:
+        name = L['config']['name']
+        nodes = L.get('inbound_nodes', [])
+        if not nodes:
+            pending.append((L, '%s@0' % name, name, []))
+        for k, node in enumerate(nodes):
+            refs = [[('%s@%d' % (r[0], r[1] if len(r) > 1 and isinstance(r[1], int) else 0))] + [0] + list(r[2:]) for r in refs_of(node)]
+            pending.append((dict(L, inbound_nodes=[refs]), '%s@%d' % (name, k), name, [r[0] for r in refs]))
+    ready, ordered = set(), []
+    while pending:
+        rest = []
+        for item in pending:
+            if all(d in ready for d in item[3]):
+                ordered.append(item[:3])
+                ready.add(item[1])
+            else:
+                rest.append(item)
+        assert len(rest) < len(pending), 'the layer graph has a cycle or a dangling reference'
+        pending = rest
+    return ordered
+
+
 def forward(model_config, weights, x_nhwc, lambda_fns=None, dtype=np.float32, output=0):
     """``model_config``: dict (or JSON text) of a Keras Functional/Sequential model; ``weights``: {layer name:
     [arrays in Keras order]}; ``x_nhwc``: (N, H, W, C) any dtype.  Returns float32 NHWC output of the model.

@@ -45,6 +45,7 @@ class Plan:
         self.input_tensor = self.output_tensor = -1
         self.layer_tensor = {}     # Keras layer name -> tensor index of its output
         self.output_rank = 4       # 2: the Keras model returns (N, K) (classifier heads: Flatten / global pooling / Dense)
+        self.channels_first = False   # the Keras model takes / returns (N, C, H, W): the caller transposes at the boundary (channels_first_to_last)
 
     def flops_per_patch(self):
         f = 0.0
@@ -160,6 +161,68 @@ def _group_nested_weights(ws, owner):
         parts = str(nm).split(':')[0].split('/')
         d.setdefault(parts[-2] if len(parts) >= 2 else parts[0], []).append(a)
     return d
+
+
+SPATIAL_CLASSES = ('Conv2D', 'Conv2DTranspose', 'DepthwiseConv2D', 'SeparableConv2D', 'MaxPooling2D', 'AveragePooling2D', 'UpSampling2D',
+                   'ZeroPadding2D', 'Cropping2D', 'GlobalAveragePooling2D', 'GlobalMaxPooling2D')
+
+
+def channels_first_to_last(mc, weights):
+    """A Functional config whose layers say ``data_format: channels_first`` (tensors (N, C, H, W)) -> (the equivalent channels_last config,
+    weights, True); a channels_last config comes back unchanged with False.  Keras stores convolution kernels as (kh, kw, in, out) in
+    BOTH formats, so only shapes and axes move: the input shape (C, H, W) -> (H, W, C), channel axis 1 -> 3 (BatchNormalization,
+    Normalization, LayerNormalization, Concatenate, Softmax), PReLU slopes (C, H, W) -> (H, W, C) with shared axes 2, 3 -> 1, 2.
+    The caller transposes the arrays at the boundary (MetasegModel).  What has no channels_last twin is refused: Flatten in
+    channels_last memory order, Reshape / Permute, Dense or a last-axis softmax on a 4-D tensor (they act on W there)."""
+    layers = mc['config']['layers']
+    fmts = {L['config'].get('data_format') for L in layers if L['class_name'] in SPATIAL_CLASSES}
+    if 'channels_first' not in fmts:
+        return mc, weights, False
+    if fmts - {'channels_first'}:
+        raise PlanError('the model mixes channels_first and channels_last layers')
+    ax_map = {1: 3, -3: 3, 2: 1, 3: 2, -2: 1, -1: 2}
+    wout = dict(weights)
+    out = []
+    for L in layers:
+        cls, lc = L['class_name'], dict(L['config'])
+        name = lc.get('name', L.get('name'))
+        if cls == 'InputLayer':
+            key = 'batch_input_shape' if 'batch_input_shape' in lc else 'batch_shape'
+            b = lc.get(key)
+            if b is not None and len(b) == 4:
+                lc[key] = [b[0], b[2], b[3], b[1]]
+        elif cls in SPATIAL_CLASSES:
+            lc['data_format'] = 'channels_last'
+            if lc.get('batch_input_shape') is not None and len(lc['batch_input_shape']) == 4:
+                b = lc['batch_input_shape']
+                lc['batch_input_shape'] = [b[0], b[2], b[3], b[1]]
+        elif cls in ('BatchNormalization', 'Normalization', 'LayerNormalization', 'Concatenate', 'Softmax'):
+            ax = lc.get('axis', -1)
+            one = not isinstance(ax, (list, tuple))
+            axs = [ax] if one else list(ax)
+            if axs != [None]:
+                bad = [a for a in axs if a not in ax_map]
+                if bad:
+                    raise PlanError('%s %s: axis %s of a channels_first tensor' % (cls, name, ax))
+                axs = [ax_map[a] for a in axs]
+                if cls in ('Concatenate', 'Softmax') and axs != [3]:
+                    raise PlanError('%s %s acts on a spatial axis of a channels_first tensor (axis %s)' % (cls, name, ax))
+                lc['axis'] = axs[0] if one else axs
+        elif cls == 'PReLU':
+            sh = lc.get('shared_axes')
+            if sh is not None:
+                lc['shared_axes'] = sorted(ax_map[a] for a in sh)
+            if name in weights and np.asarray(weights[name][0]).ndim == 3:
+                wout[name] = [np.ascontiguousarray(np.transpose(np.asarray(weights[name][0]), (1, 2, 0)))] + list(weights[name][1:])
+        elif cls == 'Flatten':
+            if lc.get('data_format') != 'channels_first':
+                raise PlanError('Flatten %s flattens a channels_first tensor in (C, H, W) order: not supported (Flatten(data_format='
+                                "'channels_first') - the order Keras itself converts to - is)" % name)
+            lc['data_format'] = 'channels_last'
+        elif cls in ('Reshape', 'Permute', 'Dense') or (cls == 'Activation' and lc.get('activation') == 'softmax'):
+            raise PlanError('%s %s in a channels_first model acts on the W axis of (N, C, H, W): not supported' % (cls, name))
+        out.append(dict(L, config=lc))
+    return dict(mc, config=dict(mc['config'], layers=out)), wout, True
 
 
 def unshare_layers(mc, weights):
@@ -352,6 +415,7 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
     if isinstance(model_config, (str, bytes)):
         model_config = json.loads(model_config)
     model_config, weights = inline_nested(model_config, weights)
+    model_config, weights, was_channels_first = channels_first_to_last(model_config, weights)
     layers, seq, cfg = _layers_of(model_config)
 
     # ---------------------------------------------------------------- pass 1: logical graph
@@ -749,6 +813,7 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
 
     # ---------------------------------------------------------------- pass 4: emit tensors / ops with buffer reuse
     plan = Plan()
+    plan.channels_first = was_channels_first
     order = [j for j in range(len(nodes)) if alive[j]]
     last_use = {}
     for j in order:

@@ -37,7 +37,12 @@ class MetasegModel:
 
     # Keras call shapes -----------------------------------------------------------------------------
     def predict_on_batch(self, x):
-        return self.handle.forward_patches(np.asarray(x))
+        x = np.asarray(x)
+        if self.plan.channels_first:
+            # a channels_first Keras model takes and returns (N, C, H, W): the plan is its channels_last twin (keras_plan.channels_first_to_last)
+            y = self.handle.forward_patches(np.ascontiguousarray(np.moveaxis(x, 1, -1)) if x.ndim == 4 else x)
+            return np.ascontiguousarray(np.moveaxis(y, -1, 1)) if y.ndim == 4 else y
+        return self.handle.forward_patches(x)
 
     def predict(self, x, batch_size=None, verbose=0):
         return self.predict_on_batch(x)

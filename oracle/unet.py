@@ -222,6 +222,10 @@ def forward(model_config, weights, x_nhwc, lambda_fns=None, dtype=np.float32, ou
     cfg = model_config['config']
     layers = cfg['layers'] if isinstance(cfg, dict) else cfg
     seq = model_config['class_name'] == 'Sequential'
+    # channels_first models (round 6): Keras keeps (N, C, H, W) tensors and (kh, kw, in, out) kernels; the channel axis of every
+    # axis-taking layer is then 1 instead of 3 / -1.  Every value below is NCHW either way: only the boundary and the axis checks differ.
+    cf = any(L['config'].get('data_format') == 'channels_first' for L in layers)
+    chan = (lambda ax: ax in (1, -3, [1], [-3])) if cf else (lambda ax: ax in (-1, 3, [-1], [3]))
     vals = {}
     if isinstance(x_nhwc, (list, tuple)) and x_nhwc and torch.is_tensor(x_nhwc[0]):
         xs = list(x_nhwc)                     # a nested model called on the (NCHW / (N, K)) tensors of its parent
@@ -229,19 +233,25 @@ def forward(model_config, weights, x_nhwc, lambda_fns=None, dtype=np.float32, ou
         x_nhwc = np.ascontiguousarray(x_nhwc)
         if x_nhwc.ndim == 3:                  # (N, H, W): a model whose InputLayer has no channel axis
             x_nhwc = x_nhwc[..., None]
-        xs = [torch.from_numpy(x_nhwc.astype(dtype)).permute(0, 3, 1, 2).contiguous()]
+        if cf:                                # a channels_first model takes (N, C, H, W): torch's own layout, nothing to move
+            xs = [torch.from_numpy(x_nhwc.astype(dtype)).contiguous()]
+        else:
+            xs = [torch.from_numpy(x_nhwc.astype(dtype)).permute(0, 3, 1, 2).contiguous()]
     x = xs[0]
     n_in = 0
     prev = None
+    # one evaluation step per CALL of a layer: (layer with one inbound node, key of the call's value, layer whose weights it uses)
+    shared = not seq and any(len(L.get('inbound_nodes', [])) > 1 for L in layers)
+    steps = _calls_in_order(layers) if shared else [(L, L['config']['name'], L['config']['name']) for L in layers]
+    okey = (lambda r: '%s@%d' % (r[0], r[1] if len(r) > 1 and isinstance(r[1], int) else 0)) if shared else (lambda r: r[0])
     with torch.no_grad():
-        for L in layers:
+        for L, vkey, name in steps:
             cls, lc = L['class_name'], L['config']
-            name = lc['name']
             if cls == 'InputLayer':
                 order = [r[0] for r in cfg['input_layers']] if isinstance(cfg, dict) and cfg.get('input_layers') else None
-                vals[name] = xs[order.index(name) if order and name in order else n_in]
+                vals[vkey] = xs[order.index(name) if order and name in order else n_in]
                 n_in += 1
-                prev = name
+                prev = vkey
                 continue
             if seq:
                 if prev is None:
@@ -250,7 +260,7 @@ def forward(model_config, weights, x_nhwc, lambda_fns=None, dtype=np.float32, ou
                 ins = [vals[prev]]
             else:
                 nodes = L['inbound_nodes']
-                assert len(nodes) == 1, 'shared layers are not supported'
+                assert len(nodes) == 1, 'one step per call (_calls_in_order)'
                 node = nodes[0]
                 if node and isinstance(node[0], str):
                     node = [node]
@@ -259,8 +269,8 @@ def forward(model_config, weights, x_nhwc, lambda_fns=None, dtype=np.float32, ou
             if cls in ('Functional', 'Model', 'Sequential'):    # a nested model: evaluate it on this layer's inputs
                 outs = forward({'class_name': cls, 'config': lc}, _nested_weights(weights.get(name)), ins, lambda_fns=lambda_fns,
                                dtype=dtype, output=None)
-                vals[name] = outs if len(outs) > 1 else outs[0]
-                prev = name
+                vals[vkey] = outs if len(outs) > 1 else outs[0]
+                prev = vkey
                 continue
             w = [np.asarray(v, dtype) for v in weights.get(name, [])]
             if cls == 'Conv2D':
@@ -293,7 +303,10 @@ def forward(model_config, weights, x_nhwc, lambda_fns=None, dtype=np.float32, ou
                 if lc.get('keepdims'):
                     y = y[:, :, None, None]
             elif cls == 'Flatten':
-                y = a.permute(0, 2, 3, 1).reshape(a.shape[0], -1) if a.dim() == 4 else a.reshape(a.shape[0], -1)
+                # (a channels_first tensor is flattened in (C, H, W) order unless the layer itself says data_format = channels_first,
+                # in which case Keras moves the channels last first)
+                nhwc_order = a.dim() == 4 and (not cf or lc.get('data_format') == 'channels_first')
+                y = a.permute(0, 2, 3, 1).reshape(a.shape[0], -1) if nhwc_order else a.reshape(a.shape[0], -1)
             elif cls == 'Reshape':
                 ts = [int(v) for v in lc['target_shape']]
                 flat = a.permute(0, 2, 3, 1).reshape(a.shape[0], -1) if a.dim() == 4 else a.reshape(a.shape[0], -1)
@@ -323,7 +336,7 @@ def forward(model_config, weights, x_nhwc, lambda_fns=None, dtype=np.float32, ou
                 else:
                     y = F.interpolate(a, scale_factor=sz, mode='bilinear', align_corners=False)
             elif cls == 'Concatenate':
-                assert lc.get('axis', -1) in (-1, 3)
+                assert chan(lc.get('axis', -1)), 'Concatenate over the channel axis only'
                 y = torch.cat(ins, dim=1)
             elif cls in ('Add', 'Multiply', 'Subtract', 'Maximum', 'Minimum', 'Average'):
                 # NCHW tensors broadcast exactly as their NHWC originals do (extents of 1 stretch)
@@ -335,7 +348,7 @@ def forward(model_config, weights, x_nhwc, lambda_fns=None, dtype=np.float32, ou
                     y = y / float(len(ins))
             elif cls == 'PReLU':
                 al = torch.from_numpy(np.ascontiguousarray(w[0]))
-                al = al.permute(2, 0, 1) if a.dim() == 4 else al          # (h, w, c) with 1s on the shared axes -> (c, h, w)
+                al = al.permute(2, 0, 1) if a.dim() == 4 and not cf else al          # (h, w, c) with 1s on the shared axes -> (c, h, w); channels_first: (c, h, w) already
                 y = torch.where(a > 0, a, al * a)
             elif cls == 'LayerNormalization':
                 ax = lc.get('axis', -1)
@@ -381,6 +394,7 @@ def forward(model_config, weights, x_nhwc, lambda_fns=None, dtype=np.float32, ou
             elif cls == 'LeakyReLU':
                 y = F.leaky_relu(a, float(lc.get('alpha', 0.3)))
             elif cls == 'Softmax':
+                assert chan(lc.get('axis', -1)) or a.dim() == 2, 'Softmax over the channel axis only'
                 y = F.softmax(a, dim=1)
             elif cls == 'ZeroPadding2D':
                 (t, b), (l, r) = lc['padding']
@@ -396,16 +410,16 @@ def forward(model_config, weights, x_nhwc, lambda_fns=None, dtype=np.float32, ou
                 y = a * float(lc['scale']) + float(lc.get('offset', 0.0))
             else:
                 raise NotImplementedError('Keras layer %s' % cls)
-            vals[name] = y
-            prev = name
+            vals[vkey] = y
+            prev = vkey
         if seq:
             outs = [vals[prev]]
         else:
-            outs = [vals[r[0]][r[2]] if isinstance(vals[r[0]], list) else vals[r[0]] for r in cfg['output_layers']]
+            outs = [vals[okey(r)][r[2]] if isinstance(vals[okey(r)], list) else vals[okey(r)] for r in cfg['output_layers']]
         if output is None:                    # (nested call: torch tensors of every output)
             return outs
         out = outs[[r[0] for r in cfg['output_layers']].index(output)] if isinstance(output, str) else outs[int(output)]
-    if out.dim() == 2:
+    if out.dim() == 2 or cf:
         return out.contiguous().numpy()
     return out.permute(0, 2, 3, 1).contiguous().numpy()
 

@@ -422,3 +422,42 @@ def test_mobilenet_style_fixture_matches_oracle(gpu, golden_dir):
     assert got.shape == want.shape == (5, 3)
     assert np.abs(got - want).max() < 1e-3 and np.abs(got.sum(1) - 1).max() < 1e-5
     assert [int(np.argmax(r)) for r in got] == [int(np.argmax(r)) for r in want]
+
+
+def test_shared_layers_on_the_device(gpu):
+    """Round 6: a convolution and a BatchNormalization that are each called twice (two inbound nodes, shared weights) - the plan runs
+    one op per call; result vs the oracle's call-by-call evaluation."""
+    from oracle import unet as oracle_unet
+    from tests.test_oracle_layers import _shared_model
+    rng = np.random.default_rng(33)
+    c = 16
+    cfg = _shared_model(64, 64, c)
+    w = {'sc': [(rng.normal(size=(3, 3, c, c)) / 12).astype(np.float32), rng.normal(size=c).astype(np.float32)],
+         'sbn': [rng.uniform(.5, 1.5, c).astype(np.float32), rng.normal(size=c).astype(np.float32), rng.normal(size=c).astype(np.float32),
+                 rng.uniform(.5, 1.5, c).astype(np.float32)]}
+    x = rng.integers(0, 256, size=(3, 64, 64, c), dtype=np.uint8)
+    want = oracle_unet.forward(cfg, w, x)
+    for fuse in (True, False):
+        gpu.load_plan(keras_plan.build_plan(cfg, w, fuse=fuse))
+        got = gpu.forward_patches(x)
+        assert got.shape == want.shape and np.abs(got - want).max() < 1e-3 * max(1.0, float(np.abs(want).max())), fuse
+
+
+def test_channels_first_model_on_the_device(gpu):
+    """Round 6: a channels_first Keras U-Net ((N, C, H, W) tensors, channel axis 1) is lowered through its channels_last twin
+    (keras_plan.channels_first_to_last) and MetasegModel transposes at the boundary: predict_on_batch((N, 1, 256, 256)) ->
+    (N, 4, 256, 256), within 1e-3 of the oracle's native channels_first evaluation."""
+    from ecseg_amd.model import MetasegModel
+    from tests.test_oracle_layers import channels_first_twin
+    cfg = channels_first_twin(synth.unet_config(base=16, depth=2, batchnorm=True))
+    w = synth.unet_weights(synth.unet_config(base=16, depth=2, batchnorm=True), seed=6)
+    x = np.stack([synth.dapi_image(300 + i, 256, 256) for i in range(2)])[:, None]          # (N, 1, H, W)
+    want = oracle_unet.forward(cfg, w, x)
+    m = MetasegModel(cfg, w, handle=gpu)
+    assert m.plan.channels_first
+    got = m.predict_on_batch(x)
+    assert got.shape == want.shape == (2, 4, 256, 256) and np.abs(got - want).max() < 1e-3
+    with pytest.raises(keras_plan.PlanError, match='mixes'):
+        bad = channels_first_twin(synth.unet_config(base=16, depth=1))
+        bad['config']['layers'][1]['config']['data_format'] = 'channels_last'
+        keras_plan.build_plan(bad, synth.unet_weights(synth.unet_config(base=16, depth=1)))

@@ -287,8 +287,8 @@ def self_launch(args):
 
 KIND_NAMES = ('conv_mfma_kernel', 'conv_wino_kernel F(2x2)', 'conv_wino4_kernel F(4x4)',
               'conv_wino_res_kernel F(2x2), filter-resident', 'conv_wino16_kernel F(2x2), 16x16x4 MFMA',
-              'conv_wino4s_kernel F(4x4), 3-way bf16 split operands on the bf16 pipe')
-KIND_ISSUED = (1.0, 16.0 / 36.0, 0.25, 16.0 / 36.0, 16.0 / 36.0, 0.25)      # multiplies issued / multiplies of the direct 3x3 convolution (kind 5: each as 6 bf16 products)
+              'conv_wino4s_kernel F(4x4), 3-way bf16 split operands on the bf16 pipe', 'convs_kernel one-tap GEMM, 3-way bf16 split operands on the bf16 pipe')
+KIND_ISSUED = (1.0, 16.0 / 36.0, 0.25, 16.0 / 36.0, 16.0 / 36.0, 0.25, 1.0)      # multiplies issued / multiplies of the direct 3x3 convolution (kind 5: each as 6 bf16 products)
 
 
 def aggregate(recs):
@@ -534,14 +534,15 @@ def split_leg(run, steps, headline, wino_mode):
     the fp32-MFMA headline: images/s, the split kernel's own rate against the BF16 peak (each fp32-equivalent product is issued as
     six bf16 products), max |dp| and raw-label differences against the fp32-MFMA path on two images, and - base 64 with the committed
     float64 adjudicator fixture - how often each path is wrong on the fixture's hard pixels."""
-    hnd = run.hnd
-    out = {'what': 'option winograd = 3: conv_wino4s_kernel on every 3x3 layer with whole 64-channel output blocks (v_mfma_f32_32x32x16_bf16, '
-                   '3-way exact bf16 split of both operands, 6 of the 9 piece products, float32 accumulate); everything else as in the headline run'}
+    hnd = run.hnd                         # (a handle of its own: timed on the headline's handle right after switching modes the same step read 4 % slower
+                                          # in wall time than its own stage timers said - 135.7 vs 124.8 ms - and than a fresh `--wino 3` run measured)
+    out = {'what': 'option winograd = 3: conv_wino4s_kernel on every 3x3 layer with whole 64-channel output blocks and convs_kernel on the 2x2 / stride-2 up-convolutions '
+                   '(v_mfma_f32_32x32x16_bf16, 3-way exact bf16 split of both operands, 6 of the 9 piece products, float32 accumulate); everything else as in the headline run'}
     try:
         hnd.set_option('winograd', 3)
         m = run.timed(steps, 1, profile=True)
         s = model_summary(run, m)
-        r5 = [r for r in m['recs'] if (r['kind'] & 0xff) == 5]
+        r5 = [r for r in m['recs'] if (r['kind'] & 0xff) in (5, 6)]
         ms5, ex5 = sum(r['ms'] for r in r5), sum(r['executed_flops'] for r in r5)
         out.update({'value': s['value'], 'unit': 'images/s', 'ms_per_step': s['ms_per_step'], 'vs_f32_headline': round(s['value'] / headline, 4),
                     'stage_ms_per_image': s['stage_ms_per_image'], 'dtype': 'bf16x3 products, f32 accumulate (f32-accurate)'})
@@ -728,7 +729,9 @@ def main():
                                              'pipeline, post-processed labels + counts back to host memory (D2H), synchronous'
                                              % B}
         if world == 1 and not args.no_narrow and wino_mode == 2:
-            res['split_bf16x3'] = split_leg(run, args.steps, summ['value'], wino_mode)
+            r4 = DeviceRun(args.base, B, args.group, local, rank, world, args)
+            res['split_bf16x3'] = split_leg(r4, args.steps, summ['value'], wino_mode)
+            r4.close()
         if world == 1 and not args.no_narrow:
             res.update(aux_device_legs(hnd, local))
             res['single_image_latency_ms'] = run.single_image_latency()

@@ -26,6 +26,8 @@ struct OpRt {                 // run-time form of one plan operator
     float* wt_wino = nullptr; // Winograd-transformed filter (16 points) when the op is eligible
     float* wt_wino4 = nullptr; // F(4x4,3x3) filter image (36 points, per-wave stage layout of wino4_kernel.hip)
     float* wt_wino16 = nullptr; // F(2x2,3x3) filter image of wino16_kernel.hip (Cin, Cout in {16, 32})
+    void* wt_split1 = nullptr; // bf16x3 image of convs_kernel.hip (one-tap GEMM: the 2x2 / stride-2 up-convolutions), made from `wt` when "winograd" = 3 is asked for
+    int s1_cin = 0, s1_np = 0; // its K and column count (0: not eligible)
     void* wt_wino4s = nullptr; // bf16x3 stage image of wino4s_kernel.hip, made on the device from wt_wino4 when "winograd" = 3 is asked for
     int w4_cin = 0, w4_cout = 0; // the layer wt_wino4 was made for
     int coutp_wino = 0;
@@ -142,7 +144,7 @@ struct ecseg_ctx {
     std::vector<hipEvent_t> grp_events;    // 6 per image group of segment_dev
     size_t prof_used = 0;
     double prof_flops = 0.0, prof_exec_flops = 0.0;
-    struct ProfRec { int op; int kind; double flops, exec_flops; float ms; };   // kind: 0 direct, 1 F(2x2), 2 F(4x4), 3 filter-resident F(2x2), 4 F(2x2) on 16x16x4 MFMAs (wino16), 5 F(4x4) with bf16x3 split operands (wino4s; exec_flops = the fp32-equivalent products, each issued as 6 bf16 products)
+    struct ProfRec { int op; int kind; double flops, exec_flops; float ms; };   // kind: 0 direct, 1 F(2x2), 2 F(4x4), 3 filter-resident F(2x2), 4 F(2x2) on 16x16x4 MFMAs (wino16), 5 F(4x4) with bf16x3 split operands (wino4s; exec_flops = the fp32-equivalent products, each issued as 6 bf16 products), 6 one-tap GEMM with bf16x3 split operands (convs_kernel)
     std::vector<ProfRec> prof_recs;        // one per profiled launch of the last segment / forward call
     double last_conv_ms = 0.0; long long last_conv_launches = 0; double last_conv_flops = 0.0, last_conv_exec_flops = 0.0;
 };
@@ -564,7 +566,7 @@ int run_plan_op(ecseg_ctx* h, size_t& oi, int n_all, StitchPlan* crop, const Lan
                     }
                     const bool wino4 = !first && h->use_winograd >= 2 && o.wt_wino4 && act_core_ok && conv_wino4_supported(p);   // (wt_wino* exist only for stride-1 3x3 'same' layers)
                     const bool wino = !wino4 && h->use_winograd && o.wt_wino && out.h >= 4 && out.w >= 8;
-                    bool w16 = false;
+                    bool w16 = false, split1 = false;
                     // a 3x3 convolution of the cropped chain on a Winograd kernel reads its input only inside the receptive field
                     // of the outputs somebody needs (ConvParams::in_box): results do not depend on what a cropped producer left
                     // outside it
@@ -673,6 +675,10 @@ int run_plan_op(ecseg_ctx* h, size_t& oi, int n_all, StitchPlan* crop, const Lan
                                 p.wt_tap_stride = wt_tap_pitch(o.coutp, o.cin_chunks);
                                 e = launch_conv_mfma(p, s);
                             }
+                        } else if (h->use_winograd >= 3 && o.wt_split1 != nullptr && p.convt == 1 && convs_supported(p)) {
+                            p.wt = reinterpret_cast<const float*>(o.wt_split1);
+                            split1 = true;
+                            e = launch_convs(p, s);
                         } else {
                             e = launch_conv_mfma(p, s);
                         }
@@ -687,7 +693,7 @@ int run_plan_op(ecseg_ctx* h, size_t& oi, int n_all, StitchPlan* crop, const Lan
                         h->prof_exec_flops += ex;
                         const bool res = wino && p.resident && p.coutp == 32 && p.cin_chunks <= 4;
                         // kind: bits 0-7 the kernel, bit 8: the following 2x2 max-pool was written by this launch, bit 9: the following 1x1 head was
-                        h->prof_recs.push_back({(int)oi_first, (wino4s ? 5 : wino4 ? 2 : w16 ? 4 : res ? 3 : wino ? 1 : 0) | (p.pool.p != nullptr ? 0x100 : 0) |
+                        h->prof_recs.push_back({(int)oi_first, (split1 ? 6 : wino4s ? 5 : wino4 ? 2 : w16 ? 4 : res ? 3 : wino ? 1 : 0) | (p.pool.p != nullptr ? 0x100 : 0) |
                                                 (p.head_w != nullptr ? 0x200 : 0) | (first ? 0x400 : 0), o.flops * n + (first ? first->flops * n : 0.0),
                                                 ex + (first ? first->flops * n * 12.0 / 9.0 : 0.0), 0.f});
                     }
@@ -1205,6 +1211,16 @@ static int ensure_split_images(ecseg_ctx* h) {
         o.wt_wino4s = d;
         any = true;
     }
+    for (OpRt& o : h->ops) {
+        if (!o.s1_np || o.wt_split1 || !o.wt) continue;
+        void* d = nullptr;
+        const hipError_t e = hipMalloc(&d, convs_image_bytes(o.s1_cin, o.s1_np));
+        if (e != hipSuccess) return fail(h, ECSEG_E_NOMEM, std::string("hipMalloc(split filter image): ") + hipGetErrorString(e));
+        h->dev_allocs.push_back(reinterpret_cast<float*>(d));
+        HIP_TRY(h, launch_convs_filter(o.wt, d, o.s1_cin, o.s1_np, h->stream));
+        o.wt_split1 = d;
+        any = true;
+    }
     if (any) HIP_TRY(h, hipStreamSynchronize(h->stream));
     return ECSEG_OK;
 }
@@ -1382,6 +1398,7 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
                     o.cin_chunks = (cin + 7) / 8;
                     if ((rc = upload(h, relayout_convt(kw, d.kh, cin, cout, o.cin_chunks, o.coutp), &o.wt))) return rc;
                     h->mfma_flops_per_patch += o.flops;
+                    if (d.kh == 2 && o.coutp % 32 == 0 && cin >= 16 && cin % 4 == 0) { o.s1_cin = cin; o.s1_np = d.kh * d.kh * o.coutp; }
                 } else if (d.kh == d.kw && (d.kh == 3 || d.kh == 4) && d.stride == 2 && in_al && cin >= 8 && d.pad_top >= 0 && d.pad_left >= 0) {
                     // k x k / stride 2, k != stride (a common Keras up-sampler; NuSeT's U-Net: src/model_layers/models.py:78-80):
                     // four sub-pixel convolutions as ONE 2x2-tap convolution over the input with N = 4 x Cout

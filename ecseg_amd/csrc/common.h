@@ -107,6 +107,12 @@ hipError_t launch_conv_wino4s(const ConvParams& p, hipStream_t s);
 bool       conv_wino4s_supported(const ConvParams& p);
 size_t     wino4s_image_bytes(int cin, int cout);
 hipError_t launch_wino4s_filter(const float* wt_wino4, void* dst, int cin, int cout, hipStream_t s);
+// One-tap GEMM (2x2 / stride-2 transposed convolutions, 1x1 convolutions) with 3-way bf16 split operands (convs_kernel.hip, round 6);
+// p.wt = the split image launch_convs_filter writes from the fp32 one-tap image (np = kT * kT * coutp columns; convs_image_bytes bytes)
+hipError_t launch_convs(const ConvParams& p, hipStream_t s);
+bool       convs_supported(const ConvParams& p);
+size_t     convs_image_bytes(int cin, int np);
+hipError_t launch_convs_filter(const float* wt_fp32, void* dst, int cin, int np, hipStream_t s);
 
 hipError_t launch_conv_small_cin(const TView& in, const TView& out, const float* w_hwio, const float* bias, int n,
                                  int R, int S, int pad_top, int pad_left, int act, float alpha, hipStream_t s);

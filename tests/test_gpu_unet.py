@@ -287,6 +287,37 @@ def test_upsample_conv2x2_decoder_runs_as_one_transposed_convolution(gpu, base, 
     np.testing.assert_allclose(fused.sum(-1), 1.0, atol=1e-5)
 
 
+@pytest.mark.parametrize('cin,cout,hw,n', [(64, 32, (16, 16), 3), (128, 64, (32, 32), 2), (72, 96, (16, 32), 2), (1024, 512, (16, 16), 1), (20, 32, (16, 16), 2)])
+def test_up_convolution_split_bf16x3_matches_fp32_kernel_and_oracle(gpu, cin, cout, hw, n):
+    """Round 6 (option winograd = 3): Conv2DTranspose 2x2 / stride 2 as a one-tap GEMM on the bf16 matrix pipe with 3-way split operands
+    (convs_kernel: the A tile is split once per workgroup while it is staged into LDS).  Same bound as the fp32 kernel against the
+    oracle, 1e-5 against that kernel; covers K tails (Cin % 16 = 8 / 4), 1 - 16 column blocks, both tile shapes."""
+    rng = np.random.default_rng(cin * 13 + cout)
+    H, W = hw
+    cfg = {'class_name': 'Functional', 'config': {'name': 'm', 'layers': [
+        {'class_name': 'InputLayer', 'name': 'in', 'config': {'name': 'in', 'batch_input_shape': [None, H, W, cin]}, 'inbound_nodes': []},
+        {'class_name': 'Conv2DTranspose', 'name': 'c', 'config': {'name': 'c', 'filters': cout, 'kernel_size': [2, 2], 'strides': [2, 2],
+                                                                  'padding': 'same', 'activation': 'relu', 'use_bias': True},
+         'inbound_nodes': [[['in', 0, 0, {}]]]}], 'input_layers': [['in', 0, 0]], 'output_layers': [['c', 0, 0]]}}
+    weights = {'c': [(rng.normal(size=(2, 2, cout, cin)) / np.sqrt(cin) / 64).astype(np.float32), rng.normal(size=cout).astype(np.float32)]}
+    x = rng.integers(0, 256, size=(n, H, W, cin), dtype=np.uint8)
+    want = oracle_unet.forward(cfg, weights, x)
+    try:
+        gpu.set_option('winograd', 2)
+        ref, _ = _run(gpu, cfg, weights, x, fuse=True)
+        gpu.set_option('winograd', 3)
+        gpu.set_kernel_profiling(True)
+        got = gpu.forward_patches(x)
+        kinds = [r['kind'] & 0xff for r in gpu.conv_launch_profile()]
+        gpu.set_kernel_profiling(False)
+    finally:
+        gpu.set_option('winograd', 2)
+    assert kinds and set(kinds) == {6}, kinds
+    scale = max(1.0, float(np.abs(want).max()))
+    assert np.abs(got - want).max() < 1e-4 * scale, np.abs(got - want).max()
+    assert np.abs(got - ref).max() < 1e-5 * scale, np.abs(got - ref).max()
+
+
 @pytest.mark.parametrize('act,use_bias', [('linear', True), ('sigmoid', False), ('tanh', True), ('elu', True)])
 def test_winograd_f4x4_activations_and_no_bias(gpu, act, use_bias):
     """The F(4x4) output stage applies the layer's own activation and tolerates a missing bias."""

@@ -165,7 +165,9 @@ int ecseg_set_images_per_group(ecseg_ctx* h, int n);
  * 0 (default): everything on one stream - measured equal, the MFMA convs already fill the chip), "post_chunk"
  * (images per post-processing launch set), "images_per_group", "winograd" (3x3 / stride-1 / 'same'
  * convolutions: 2 (default) Winograd F(4x4,3x3) where the layer allows it (extents % 16, Cin % 4 and >= 8, Cout % 32), else
- * F(2x2,3x3); 1: F(2x2,3x3); 0: the direct implicit-GEMM kernel; all three are fp32 MFMA kernels), "fuse_first" (1 (default): the network's first layer - Conv2D 3x3 'same', 1 -> 16 channels - is computed
+ * F(2x2,3x3); 1: F(2x2,3x3); 0: the direct implicit-GEMM kernel; all three are fp32 MFMA kernels; 3 (round 6): as 2, with the F(4x4) layers of whole
+ * 64-channel output blocks and the 2x2 / stride-2 up-convolutions on the BF16 matrix pipe - both operands split exactly into three bf16 pieces, six of the
+ * nine piece products, float32 accumulation: float32-accurate; the split filter images are made on the device when the option is set), "fuse_first" (1 (default): the network's first layer - Conv2D 3x3 'same', 1 -> 16 channels - is computed
  * by the 16 -> 16 conv_wino16_kernel convolution behind it, on the matrix cores, straight into that kernel's halo buffer; the 16-channel tensor
  * between the two never exists in memory; 0: conv_first_kernel writes it), "wino16" (1 (default):
  * F(2x2,3x3) layers with 16 or 32 input and output channels and extents >= 16 x 32 take conv_wino16_kernel - 16x16x4 MFMAs,

@@ -6,9 +6,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libecseg_hip.so')
-SOURCES = ['api.hip', 'unet_kernels.hip', 'layer_kernels.hip', 'wino4_kernel.hip', 'wino4s_kernel.hip', 'convs_kernel.hip', 'wino16_kernel.hip', 'post_kernels.hip', 'host_codec.cpp', 'host_io.cpp', 'comm.hip']
+SOURCES = ['api.hip', 'unet_kernels.hip', 'layer_kernels.hip', 'wino4_kernel.hip', 'wino4s_kernel.hip', 'wino4r_kernel.hip', 'convs_kernel.hip', 'wino16_kernel.hip', 'post_kernels.hip', 'host_codec.cpp', 'host_io.cpp', 'comm.hip']
 # packed f32 VALU ops stall the SIMD beside MFMAs: keep the transform arithmetic of the Winograd kernels scalar
-EXTRA_FLAGS = {'wino4_kernel.hip': ['-fno-slp-vectorize'], 'wino4s_kernel.hip': ['-fno-slp-vectorize']}
+EXTRA_FLAGS = {'wino4_kernel.hip': ['-fno-slp-vectorize'], 'wino4s_kernel.hip': ['-fno-slp-vectorize'], 'wino4r_kernel.hip': ['-fno-slp-vectorize']}
 HEADERS = [os.path.join(CSRC, f) for f in ('common.h', 'device_util.h', 'wino4_consts.inc', 'wino4_region.inc', 'wino4_combine.inc', 'wino4_head.inc')] + \
     [os.path.join(HERE, '..', 'include', 'ecseg_hip.h')]
 

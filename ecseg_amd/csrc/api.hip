@@ -130,6 +130,7 @@ struct ecseg_ctx {
     int crop = 1;             // segment path: skip output regions of the last full-resolution convolutions that the stitch never reads
     int crop_mask = 1;        // cropped plan: Winograd kernels read zeros outside the receptive field of the needed outputs (0: A/B measurements only - results then depend on stale buffer contents in the last bits)
     int fuse_head = 1;        // 1x1 head (<= 4 classes) computed by the output stage of the last F(4x4) convolution
+    int wino4_rowpass = 1;    // 1 (default since round 6: +1.8 % on the base-64 step, 1 - 6 % per layer): F(4x4) fp32 layers (no lone 32-channel block) on conv_wino4r_kernel - row transform once per workgroup (round 6 A/B)
     int use_winograd = 2;     // 0 direct, 1 Winograd F(2x2,3x3), 2 F(4x4,3x3) where eligible (else F(2x2)), 3: F(4x4) with 3-way bf16 split operands on the bf16 matrix pipe where eligible (else as 2)
     int wino4_split = 1;      // F(4x4) layers with exactly 32 output channels: split-K over the channel-half waves
     int wino16 = 1;           // F(2x2) layers with 16 / 32 input and output channels: conv_wino16_kernel (16x16x4 MFMA, register output stage)
@@ -624,7 +625,7 @@ int run_plan_op(ecseg_ctx* h, size_t& oi, int n_all, StitchPlan* crop, const Lan
                         // a MaxPooling2D(2x2, stride 2) that follows directly is written by the same output stage
                         fuse_following_pool();
                         fuse_following_head(64);
-                        e = wino4s ? launch_conv_wino4s(p, s) : launch_conv_wino4(p, s);
+                        e = wino4s ? launch_conv_wino4s(p, s) : (h->wino4_rowpass && conv_wino4r_supported(p)) ? launch_conv_wino4r(p, s) : launch_conv_wino4(p, s);
                     } else if (wino && h->wino16 && o.wt_wino16 && act_core_ok && (first ? conv_wino16_first_supported(p) : conv_wino16_supported(p))) {
                         w16 = true;
                         p.wt = o.wt_wino16;
@@ -1236,6 +1237,7 @@ int ecseg_set_option(ecseg_ctx* h, const char* key, int value) {
     else if (k == "wino16") h->wino16 = value != 0;
     else if (k == "fuse_first") h->fuse_first = value != 0;
     else if (k == "wino4_split") h->wino4_split = value != 0;
+    else if (k == "wino4_rowpass") h->wino4_rowpass = value != 0;
     else if (k == "crop") h->crop = value != 0;
     else if (k == "winograd") {                            // 0 direct, 1 F(2x2), 2 F(4x4), 3 F(4x4) on the bf16 pipe with 3-way split operands
         h->use_winograd = value < 0 ? 0 : value > 3 ? 3 : (int)value;

@@ -101,6 +101,9 @@ bool       conv_wino16_first_supported(const ConvParams& p);   // with ConvParam
 hipError_t launch_conv_wino4(const ConvParams& p, hipStream_t s);
 bool       conv_wino4_supported(const ConvParams& p);
 bool       conv_wino4_span_ok(const ConvParams& p, int windows);   // the halo's buffer descriptor reaches `windows` consecutive windows
+// F(4x4,3x3) on the fp32 matrix cores with the row transform done once per workgroup (wino4r_kernel.hip, round 6); p.wt as conv_wino4_kernel
+hipError_t launch_conv_wino4r(const ConvParams& p, hipStream_t s);
+bool       conv_wino4r_supported(const ConvParams& p);
 // F(4x4,3x3) with 3-way bf16 split operands on the bf16 matrix pipe (wino4s_kernel.hip, round 6); p.wt = the stage image written
 // on the device by launch_wino4s_filter from the fp32 image of winograd4_filter (wino4s_image_bytes bytes)
 hipError_t launch_conv_wino4s(const ConvParams& p, hipStream_t s);

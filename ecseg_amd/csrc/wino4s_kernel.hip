@@ -146,29 +146,21 @@ __global__ __launch_bounds__(768) void conv_wino4s_kernel(ConvParams p, int regs
         const f32x2* R = reinterpret_cast<const f32x2*>(Hs + (grp & 1) * W4_HS + (tgg * 18 + 4 * tyy) * 36 + 2 * x + h) + cpair;     // raw row 4 tyy + i: + 36 i slots
         const f32x2 d0 = R[2 * 36 * 0], d1 = R[2 * 36 * 1], d2 = R[2 * 36 * 2], d3 = R[2 * 36 * 3], d4 = R[2 * 36 * 4], d5 = R[2 * 36 * 5];
         f32x2* T = reinterpret_cast<f32x2*>(Ts + ((tgg * 6) * 4 + tyy) * 36 + h * 18 + w4_pos(x)) + cpair;                            // + xi * 144 slots
-        f32x2 o, e, q;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) o[c] = __builtin_fmaf(KP, d0[c], __builtin_fmaf(KS, d2[c], d4[c]));
-        T[2 * 0 * 144] = o;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) o[c] = __builtin_fmaf(KP, d1[c], __builtin_fmaf(KS, d3[c], d5[c]));
-        T[2 * 5 * 144] = o;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) { e[c] = __builtin_fmaf(-KB2, d2[c], d4[c]); q[c] = __builtin_fmaf(-KB2, d1[c], d3[c]); }
-#pragma unroll
-        for (int c = 0; c < 2; ++c) o[c] = __builtin_fmaf(KA, q[c], e[c]);
-        T[2 * 1 * 144] = o;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) o[c] = __builtin_fmaf(-KA, q[c], e[c]);
-        T[2 * 2 * 144] = o;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) { e[c] = __builtin_fmaf(-KA2, d2[c], d4[c]); q[c] = __builtin_fmaf(-KA2, d1[c], d3[c]); }
-#pragma unroll
-        for (int c = 0; c < 2; ++c) o[c] = __builtin_fmaf(KB, q[c], e[c]);
-        T[2 * 3 * 144] = o;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) o[c] = __builtin_fmaf(-KB, q[c], e[c]);
-        T[2 * 4 * 144] = o;
+        // t[xi] = c0 d[r0] + c1 d[r1] + c2 d[r2] + d[r3] as the SAME fma chains conv_wino4_kernel's per-wave row transform runs (innermost term
+        // first): bit-identical t, hence bit-identical results in the fp32 kernel.  (A first version shared the even / odd parts of the +- rows,
+        // 12 instead of 16 fmas per channel: the smooth fixture model's wrong-pixel total rose from 11 to 19 of ~15 hard pixels per image.)
+        f32x2 o;
+#define W4_ROW3(XI, A0, DA, A1, DB, DC) do { _Pragma("unroll") for (int c = 0; c < 2; ++c) o[c] = __builtin_fmaf(A0, DA[c], __builtin_fmaf(A1, DB[c], DC[c])); T[2 * (XI) * 144] = o; } while (0)
+#define W4_ROW4(XI, A0, DA, A1, DB, A2, DC, DD) do { _Pragma("unroll") for (int c = 0; c < 2; ++c) \
+            o[c] = __builtin_fmaf(A0, DA[c], __builtin_fmaf(A1, DB[c], __builtin_fmaf(A2, DC[c], DD[c]))); T[2 * (XI) * 144] = o; } while (0)
+        W4_ROW3(0, KP, d0, KS, d2, d4);
+        W4_ROW3(5, KP, d1, KS, d3, d5);
+        W4_ROW4(1, -KA * KB2, d1, -KB2, d2, KA, d3, d4);
+        W4_ROW4(2, KA * KB2, d1, -KB2, d2, -KA, d3, d4);
+        W4_ROW4(3, -KA2 * KB, d1, -KA2, d2, KB, d3, d4);
+        W4_ROW4(4, KA2 * KB, d1, -KA2, d2, -KB, d3, d4);
+#undef W4_ROW3
+#undef W4_ROW4
     };
     f32x4 t[5];
     auto load_t = [&]() __attribute__((always_inline)) {

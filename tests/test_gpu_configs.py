@@ -34,8 +34,9 @@ MAX_WRONG_PX_PER_IMAGE = {0: 12, 1: 8, 2: 10, 3: 10}     # kernel -> 2 x the wor
 MAX_WRONG_PX_PER_IMAGE_SMOOTH = {0: 4, 1: 4, 2: 4, 3: 4}
 # Totals over the 32 fixture images, measured per kernel in round 6 (tools/experiments/adjudicator_totals.py -> profiles/r06_adjudicator_totals.json;
 # the float32 CPU oracle: 76 random / 13 smooth) + 25 %, VERDICT r05 item 7 - the bound used to be `oracle + 2 + n // 4` for every kernel:
-#   random-weight model: direct 74, F(2x2) 39, F(4x4) 77, F(4x4) bf16x3 76        smooth model: 11, 10, 11, 13
-MAX_WRONG_PX_TOTAL = {0: 93, 1: 49, 2: 97, 3: 95}
+#   random-weight model: direct 74, F(2x2) 39, F(4x4) 77, F(4x4) bf16x3 68        smooth model: 11, 10, 11, 13
+# (F(4x4): conv_wino4r_kernel, bit-identical to conv_wino4_kernel; with the +- rows' even / odd parts shared in the row transform the smooth model read 19)
+MAX_WRONG_PX_TOTAL = {0: 93, 1: 49, 2: 97, 3: 85}
 MAX_WRONG_PX_TOTAL_SMOOTH = {0: 14, 1: 13, 2: 14, 3: 17}
 MAX_RAW_MISMATCH_PX_PER_IMAGE = 14                # device F(4x4) vs the float32 ORACLE: 2 x the worst image measured (7)
 MAX_RAW_MISMATCH_PX_PER_IMAGE_SMOOTH = 3

@@ -9,6 +9,6 @@ for v in "$@"; do n=${v%%:*}; f=${v#*:}; $HC $f -c wino4s_kernel.hip -o /tmp/w4s
 wait
 for v in "$@"; do
   n=${v%%:*}
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libecseg_w4s_$n.so api.o unet_kernels.o layer_kernels.o wino4_kernel.o /tmp/w4s/w4s_$n.o convs_kernel.o wino16_kernel.o post_kernels.o host_codec.o host_io.o comm.o -lz -ldl
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libecseg_w4s_$n.so api.o unet_kernels.o layer_kernels.o wino4_kernel.o /tmp/w4s/w4s_$n.o wino4r_kernel.o convs_kernel.o wino16_kernel.o post_kernels.o host_codec.o host_io.o comm.o -lz -ldl
 done
 ls -la ../libecseg_w4s_*.so

@@ -17,10 +17,20 @@ namespace ecseg {
 // raw image (only row_pass reads it): plain row / column order, the two 16-byte channel halves of a pixel next to each other
 #define W4_HALO_SLOT(r, cc) const int h = (cc) & 1, hy = (r), hx = (cc) >> 1
 #define W4_HALO_UPPER(cc) ((cc) & 1)
+// (timing-only ablations exist only in A/B builds, tools/w4r_variants.sh -DECSEG_W4R_ABL=<bits>: 1 no filter DMA, 2 no halo DMA, 4 no MFMAs)
+#ifdef ECSEG_W4R_ABL
+#define W4_DIAG_SKIP_HALO_DMA() do { if (ECSEG_W4R_ABL & 2) return; } while (0)
+#define W4_DIAG_SKIP_FILTER_DMA() do { if (ECSEG_W4R_ABL & 1) return; } while (0)
+#else
 #define W4_DIAG_SKIP_HALO_DMA()
-#define W4_DIAG_HALO_OFFSET(off, a)
 #define W4_DIAG_SKIP_FILTER_DMA()
+#endif
+#define W4_DIAG_HALO_OFFSET(off, a)
+#if defined(ECSEG_W4R_ABL) && (ECSEG_W4R_ABL & 4)
+#define W4_MFMA(ACC, A, B) asm volatile("" :: "v"(A), "v"(B))
+#else
 #define W4_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A, B, ACC, 0, 0, 0)
+#endif
 #define W4_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define ESTAMP(i)
 #define W4_ESTAMP_BEGIN()
@@ -165,7 +175,8 @@ __global__ __launch_bounds__(768) void conv_wino4r_kernel(ConvParams p, int regs
     //   class 2:   Y(g-1) | t <- image, S0(g)        | X(g) | S1(g), row_pass(g+1)
     // Filter stage s = 2 g + ss lives in buffer ss and is streamed one stage ahead behind the MFMAs of the stage before (as in
     // conv_wino4_kernel).  Waits: the phase right behind Y has the two halo pieces issued behind Y younger than its stage -> vmcnt(2);
-    // the other phase's stage is the youngest thing the wave issued -> vmcnt(0).
+    // the other phase's stage is the youngest thing the wave issued -> vmcnt(0).  (Two stages ahead, as the split kernel streams: -1 %,
+    // tools/experiments/wino4r_filter_two_stages_ahead.patch; s_setprio by rotation class as in conv_wino4_kernel: +-0.)
 #define W4_S(ss, g, H) do { W4_SB(); if (H) W4_WAIT(2); else W4_WAIT(0); W4_SB(); \
                             mfma_stage(ss, ss, (ss) == 0 ? 2 * (g) + 1 : ((g) + 1 < ngroups ? 2 * (g) + 2 : 2 * (g)), -1); W4_SB(); } while (0)
 #define W4_Y() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); W4_BARRIER(); W4_SB(); } while (0)

@@ -13,7 +13,7 @@ import sys
 
 
 def conv_rows(path):
-    rows = [r for r in csv.DictReader(open(path)) if 'conv_wino4_kernel' in r['Kernel_Name'] or 'conv_wino4s_kernel' in r['Kernel_Name'] or 'conv_mfma_kernel' in r['Kernel_Name']
+    rows = [r for r in csv.DictReader(open(path)) if 'conv_wino4_kernel' in r['Kernel_Name'] or 'conv_wino4s_kernel' in r['Kernel_Name'] or 'conv_wino4r_kernel' in r['Kernel_Name'] or 'convs_kernel' in r['Kernel_Name'] or 'conv_mfma_kernel' in r['Kernel_Name']
             or 'conv_wino_kernel' in r['Kernel_Name'] or 'conv_wino_res_kernel' in r['Kernel_Name'] or 'conv_wino16_kernel' in r['Kernel_Name']]
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
     return rows

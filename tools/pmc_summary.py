@@ -45,7 +45,7 @@ def main():
         wb = w.get(k, [n, 0.0])[1] * 1024
         res['kernels'][k] = {'launches': n, 'fetch_bytes_per_launch': fb / n, 'write_bytes_per_launch': wb / n,
                              'hbm_bytes_per_launch': (fb + wb) / n}
-        if 'conv_mfma_kernel' in k or 'conv_wino' in k:
+        if 'conv_mfma_kernel' in k or 'conv_wino' in k or 'convs_kernel' in k:
             tot_conv[0] += n; tot_conv[1] += fb; tot_conv[2] += wb
     if tot_conv[0]:
         res['conv_mfma_all'] = {'launches': tot_conv[0], 'hbm_bytes_per_launch': (tot_conv[1] + tot_conv[2]) / tot_conv[0],

@@ -285,7 +285,7 @@ def self_launch(args):
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
-KIND_NAMES = ('conv_mfma_kernel', 'conv_wino_kernel F(2x2)', 'conv_wino4_kernel F(4x4)',
+KIND_NAMES = ('conv_mfma_kernel', 'conv_wino_kernel F(2x2)', 'conv_wino4r_kernel / conv_wino4_kernel F(4x4)',
               'conv_wino_res_kernel F(2x2), filter-resident', 'conv_wino16_kernel F(2x2), 16x16x4 MFMA',
               'conv_wino4s_kernel F(4x4), 3-way bf16 split operands on the bf16 pipe', 'convs_kernel one-tap GEMM, 3-way bf16 split operands on the bf16 pipe')
 KIND_ISSUED = (1.0, 16.0 / 36.0, 0.25, 16.0 / 36.0, 16.0 / 36.0, 0.25, 1.0)      # multiplies issued / multiplies of the direct 3x3 convolution (kind 5: each as 6 bf16 products)
@@ -693,7 +693,7 @@ def main():
             res['roofline'] = {'bound': r8['bound'] if r8 else 'mfma',
                                'kernel': {0: 'conv_mfma_kernel (direct implicit GEMM)',
                                           1: 'conv_wino_kernel (Winograd F(2x2,3x3)) + conv_mfma_kernel (%s)' % up_desc,
-                                          2: 'conv_wino4_kernel (Winograd F(4x4,3x3)) + conv_mfma_kernel (%s)' % up_desc,
+                                          2: 'conv_wino4r_kernel (Winograd F(4x4,3x3), cooperative row pass; conv_wino4_kernel on the 32-channel layer) + conv_mfma_kernel (%s)' % up_desc,
                                           3: 'conv_wino4s_kernel (Winograd F(4x4,3x3), bf16x3 split operands) + conv_mfma_kernel (%s)' % up_desc}[wino_mode] +
                                          ', fp32 v_mfma_f32_32x32x2_f32',
                                'achieved': round(exe, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',

@@ -717,7 +717,9 @@ int run_plan_op(ecseg_ctx* h, size_t& oi, int n_all, StitchPlan* crop, const Lan
                 } else if (o.path == PATH_HEAD) {
                     e = launch_conv_head(in, out, o.wt, o.bias, n, d.act, d.alpha, s);
                 } else if (d.op == ECSEG_OP_CONV) {
-                    if (d.dilation > 1) e = launch_conv_generic_dil(in, out, o.wt, o.bias, n, d.kh, d.kw, d.stride, d.dilation, d.pad_top, d.pad_left, act, d.alpha, s);
+                    if (d.dilation > 1 || (d.mode & 0xffff))
+                        e = launch_conv_generic_dil(in, out, o.wt, o.bias, n, d.kh, d.kw, d.stride, (d.mode & 0xff) ? (d.mode & 0xff) : d.stride, d.dilation > 1 ? d.dilation : 1,
+                                                    ((d.mode >> 8) & 0xff) ? ((d.mode >> 8) & 0xff) : (d.dilation > 1 ? d.dilation : 1), d.pad_top, d.pad_left, act, d.alpha, s);
                     else e = launch_conv_generic(in, out, o.wt, o.bias, n, d.kh, d.kw, d.stride, d.pad_top, d.pad_left, act, d.alpha, s);
                 } else {
                     e = launch_convt_generic(in, out, o.wt, o.bias, n, d.kh, d.kw, d.stride, d.pad_top, d.pad_left, act, d.alpha, s);
@@ -1310,9 +1312,19 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
             const bool out_al = (to.c_stride % 4 == 0) && (to.c_offset % 4 == 0);
             if (d.op == ECSEG_OP_CONV) {
                 const int dil = d.dilation > 1 ? d.dilation : 1;
-                if ((to.h - 1) * d.stride + 1 > ti.h + (d.kh - 1) * dil || (to.w - 1) * d.stride + 1 > ti.w + (d.kw - 1) * dil)
+                // anisotropic strides / dilation rates (round 6): CONV's `mode` carries the HORIZONTAL stride (bits 0-7) and dilation rate (bits
+                // 8-15) where they differ from the vertical ones in `stride` / `dilation` (0: the same) - such layers take the scalar kernel
+                const int sx = (d.mode & 0xff) ? (d.mode & 0xff) : d.stride, dx = ((d.mode >> 8) & 0xff) ? ((d.mode >> 8) & 0xff) : dil;
+                if ((to.h - 1) * d.stride + 1 > ti.h + (d.kh - 1) * dil || (to.w - 1) * sx + 1 > ti.w + (d.kw - 1) * dx)
                     return fail(h, ECSEG_E_INVALID, "conv output larger than its input in op " + std::to_string(k));
                 o.flops = 2.0 * d.kh * d.kw * cin * cout * (double)to.h * to.w;
+                if (sx != d.stride || dx != dil) {
+                    o.path = PATH_GENERIC;
+                    if ((rc = upload(h, std::vector<float>(kw, kw + (size_t)d.kh * d.kw * cin * cout), &o.wt))) return rc;
+                    h->flops_per_patch += o.flops;
+                    h->ops.push_back(o);
+                    continue;
+                }
                 const bool taps_ok = d.kh == d.kw && (d.kh == 1 || d.kh == 2 || d.kh == 3);
                 // the tap-by-tap MFMA kernel takes whatever the halo-staged kernels do not: dilated taps, taps other than 1x1 / 2x2 /
                 // 3x3 (5x5, 7x7, 1x3 ...), strides above 2
@@ -1547,7 +1559,7 @@ int ecseg_model_load(ecseg_ctx* h, const ecseg_tensor_desc* tensors, int n_tenso
             if (nprod != 1) break;
             OpRt& o = h->ops[prod];
             const ecseg_tensor_desc& ti = tensors[o.d.in0];
-            if (o.d.op != ECSEG_OP_CONV || o.d.dilation > 1 || o.d.stride != 1) break;
+            if (o.d.op != ECSEG_OP_CONV || o.d.dilation > 1 || o.d.stride != 1 || (o.d.mode & 0xffff)) break;
             o.crop_ok = true; o.crop_code = code;
             if (o.d.kh == 3 && o.d.kw == 3 && o.d.pad_top == 1 && o.d.pad_left == 1) code += 'd';
             else if (!(o.d.kh == 1 && o.d.kw == 1)) break;

@@ -141,7 +141,8 @@ hipError_t launch_u8_to_f32(const uint8_t* in, float* out, size_t count, hipStre
 hipError_t launch_conv_mfma_tap(const ConvParams& p, int dilation, hipStream_t s);
 bool       conv_mfma_tap_supported(const ConvParams& p);
 hipError_t launch_conv_generic_dil(const TView& in, const TView& out, const float* w_hwio, const float* bias, int n, int R, int S,
-                                   int stride, int dilation, int pad_top, int pad_left, int act, float alpha, hipStream_t s);
+                                   int stride, int stride_x, int dilation, int dilation_x, int pad_top, int pad_left, int act, float alpha,
+                                   hipStream_t s);       // scalar kernel: vertical / horizontal stride and dilation rate may differ
 // DepthwiseConv2D: kernel (kh, kw, cin, mult), output channel = input channel * mult + j
 hipError_t launch_dwconv(const TView& in, const TView& out, const float* w, const float* bias, int n, int kh, int kw, int stride,
                          int dilation, int pad_top, int pad_left, int mult, int act, float alpha, hipStream_t s);

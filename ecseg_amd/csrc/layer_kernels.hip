@@ -477,10 +477,10 @@ hipError_t launch_pool_pad(const TView& in, const TView& out, int n, int kh, int
     return hipGetLastError();
 }
 
-// conv_generic_kernel (unet_kernels.hip) with a dilation rate: the scalar fall-back of dilated layers the MFMA kernel does
-// not take (Cin % 4 != 0, unaligned views)
+// conv_generic_kernel (unet_kernels.hip) with dilation rates and per-axis strides: the scalar fall-back of dilated layers the MFMA kernel does
+// not take (Cin % 4 != 0, unaligned views) and of every layer with ANISOTROPIC strides / dilation rates (round 6)
 __global__ __launch_bounds__(256) void conv_generic_dil_kernel(TView in, TView out, const float* __restrict__ w, const float* __restrict__ bias,
-                                                               size_t total, int R, int S, int stride, int dil, int pad_top, int pad_left,
+                                                               size_t total, int R, int S, int stride, int stride_x, int dil, int dil_x, int pad_top, int pad_left,
                                                                int act, float alpha) {
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
         const int co = (int)(t % out.c);
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void conv_generic_dil_kernel(TView in, TView o
             const int iy = oy * stride - pad_top + r * dil;
             if (iy < 0 || iy >= in.h) continue;
             for (int s = 0; s < S; ++s) {
-                const int ix = ox * stride - pad_left + s * dil;
+                const int ix = ox * stride_x - pad_left + s * dil_x;
                 if (ix < 0 || ix >= in.w) continue;
                 const float* ip = in.p + ((img * in.h + iy) * in.w + ix) * in.cs;
                 const float* wp = w + (size_t)(r * S + s) * in.c * out.c + co;
@@ -504,12 +504,12 @@ __global__ __launch_bounds__(256) void conv_generic_dil_kernel(TView in, TView o
     }
 }
 
-hipError_t launch_conv_generic_dil(const TView& in, const TView& out, const float* w, const float* bias, int n, int R, int S, int stride,
-                                   int dil, int pad_top, int pad_left, int act, float alpha, hipStream_t s) {
+hipError_t launch_conv_generic_dil(const TView& in, const TView& out, const float* w, const float* bias, int n, int R, int S, int stride, int stride_x,
+                                   int dil, int dil_x, int pad_top, int pad_left, int act, float alpha, hipStream_t s) {
     const size_t total = (size_t)n * out.h * out.w * out.c;
     if (!total) return hipSuccess;
-    hipLaunchKernelGGL(conv_generic_dil_kernel, dim3(lk_grid_for(total)), dim3(256), 0, s, in, out, w, bias, total, R, S, stride,
-                       dil < 1 ? 1 : dil, pad_top, pad_left, act, alpha);
+    hipLaunchKernelGGL(conv_generic_dil_kernel, dim3(lk_grid_for(total)), dim3(256), 0, s, in, out, w, bias, total, R, S, stride, stride_x,
+                       dil < 1 ? 1 : dil, dil_x < 1 ? 1 : dil_x, pad_top, pad_left, act, alpha);
     return hipGetLastError();
 }
 

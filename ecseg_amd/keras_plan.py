@@ -375,22 +375,28 @@ def _tfop_affine(L, lc):
     return None
 
 
-def _conv_geometry(cls, name, lc, h, w):
+def _conv_geometry(cls, name, lc, h, w, aniso=None):
     """Conv2D / DepthwiseConv2D / SeparableConv2D config -> (kh, kw, stride, dilation, pad_top, pad_left, out_h, out_w).
     'same' pads max((ceil(n / s) - 1) s + (k - 1) d + 1 - n, 0) in total, the smaller half in front (TensorFlow's rule with the
-    dilated extent of the kernel)."""
+    dilated extent of the kernel).  ``aniso``: a list (plain Conv2D only) that receives the CONV op's ``mode`` word when the
+    horizontal stride / dilation rate differs from the vertical one returned here - horizontal stride in bits 0-7, horizontal
+    dilation rate in bits 8-15, 0 where equal (include/ecseg_hip.h); without it such layers are rejected."""
     kh, kw = lc['kernel_size']
     sh, sw = lc.get('strides', [1, 1])
     dr = lc.get('dilation_rate', [1, 1])
     dr = [dr, dr] if isinstance(dr, int) else list(dr)
-    if sh != sw or dr[0] != dr[1]:
-        raise PlanError('%s %s: anisotropic strides / dilation rates are not supported' % (cls, name))
+    dil, dilw = int(dr[0]), int(dr[1])
+    if sh != sw or dil != dilw:
+        if aniso is None:
+            raise PlanError('%s %s: anisotropic strides / dilation rates are not supported' % (cls, name))
+        if not (0 < sw < 256 and 0 < dilw < 256):
+            raise PlanError('%s %s: horizontal stride / dilation rate out of range' % (cls, name))
+        aniso.append((sw if sw != sh else 0) | ((dilw if dilw != dil else 0) << 8))
     if lc.get('data_format', 'channels_last') != 'channels_last':
         raise PlanError('channels_first is not supported')
-    dil = int(dr[0])
-    if dil > 1 and sh > 1:
+    if max(dil, dilw) > 1 and max(sh, sw) > 1:
         raise PlanError('%s %s: strides > 1 together with dilation_rate > 1 (Keras rejects it too)' % (cls, name))
-    ekh, ekw = (kh - 1) * dil + 1, (kw - 1) * dil + 1
+    ekh, ekw = (kh - 1) * dil + 1, (kw - 1) * dilw + 1
     if lc['padding'] == 'same':
         pt, pl = _same_pad(ekh, sh, h)[0], _same_pad(ekw, sw, w)[0]
         oh, ow = -(-h // sh), -(-w // sw)
@@ -465,8 +471,9 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
         h, w, c = nodes[ins[0]]['shape']
         ws = weights.get(name, [])
         if cls == 'Conv2D':
-            kh, kw, sh, dil, pt, pl, oh, ow = _conv_geometry(cls, name, lc, h, w)
             groups = int(lc.get('groups', 1) or 1)
+            aniso = [] if groups == 1 else None        # per-axis strides / dilation rates: plain convolutions only (scalar kernel)
+            kh, kw, sh, dil, pt, pl, oh, ow = _conv_geometry(cls, name, lc, h, w, aniso)
             filters = lc['filters']
             if groups < 1 or c % groups or filters % groups:
                 raise PlanError('Conv2D %s: %d groups do not divide %d -> %d channels' % (name, groups, c, filters))
@@ -476,7 +483,8 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
             bias = np.ascontiguousarray(ws[1], np.float32) if lc.get('use_bias', True) else None
             geo = dict(kh=kh, kw=kw, stride=sh, dilation=dil, pad_top=pt, pad_left=pl)
             if groups == 1:
-                idx = add(name, 'conv', ins, (oh, ow, filters), kernel=kernel, bias=bias, **geo, **_act_pair(lc.get('activation')))
+                idx = add(name, 'conv', ins, (oh, ow, filters), kernel=kernel, bias=bias, aniso=aniso[0] if aniso else 0, **geo,
+                          **_act_pair(lc.get('activation')))
             elif groups == c:
                 # one input channel per group: a depthwise convolution with depth multiplier filters / c (output channel
                 # o belongs to group o // (filters / groups): Keras' depthwise channel order)
@@ -751,7 +759,7 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
             u = nodes[i]
             if u['kind'] != 'upsample' or u['stride'] != 2 or u['mode'] != 0 or len(consumers(i)) != 1 or i == out_node:
                 continue
-            if (n['kh'], n['kw'], n.get('stride', 1), n.get('dilation', 1), n['pad_top'], n['pad_left']) != (2, 2, 1, 1, 0, 0) or \
+            if (n['kh'], n['kw'], n.get('stride', 1), n.get('dilation', 1), n['pad_top'], n['pad_left'], n.get('aniso', 0)) != (2, 2, 1, 1, 0, 0, 0) or \
                     n['shape'][:2] != u['shape'][:2]:
                 continue
             w = n['kernel'].astype(np.float64)                   # (2, 2, in, out)
@@ -953,7 +961,8 @@ def build_plan(model_config, weights, input_hw=(256, 256), fuse=True, lambda_ove
             conv_act = 0 if late_act else n.get('act', 0)
             if k == 'conv':
                 op(op=OP_CONV, in0=ins[0], out=t, kh=n['kh'], kw=n['kw'], stride=n.get('stride', 1), pad_top=n['pad_top'], pad_left=n['pad_left'],
-                   act=conv_act, alpha=n['alpha'], w0=add_weight(n['kernel']), w1=add_weight(n['bias']), dilation=n.get('dilation', 1))
+                   act=conv_act, alpha=n['alpha'], w0=add_weight(n['kernel']), w1=add_weight(n['bias']), dilation=n.get('dilation', 1),
+                   mode=n.get('aniso', 0))
             elif k == 'dwconv':
                 op(op=OP_DWCONV, in0=ins[0], out=t, kh=n['kh'], kw=n['kw'], stride=n['stride'], pad_top=n['pad_top'], pad_left=n['pad_left'],
                    act=n['act'], alpha=n['alpha'], mode=n['mult'], w0=add_weight(n['kernel']), w1=add_weight(n['bias']), dilation=n['dilation'])

@@ -115,7 +115,10 @@ typedef struct ecseg_op_desc {
                                    COPY: offset of the input inside the output (>0) or crop (<0) */
     int32_t act;
     int32_t mode;               /* UPSAMPLE interpolation; MAXPOOL / GLOBALPOOL: 0 max, 1 average; ADD: ECSEG_BIN_*; DWCONV: depth
-                                   multiplier; PRELU: 0 per channel, 1 per element */
+                                   multiplier; PRELU: 0 per channel, 1 per element; CONV (round 6): per-axis strides / dilation
+                                   rates - bits 0-7 the HORIZONTAL stride, bits 8-15 the HORIZONTAL dilation rate where they differ
+                                   from the vertical ones in `stride` / `dilation` (0: the same; such layers run on the scalar
+                                   kernel, any taps / channels) */
     int32_t w0, w1;             /* weight array indices: CONV/CONVT kernel + bias (-1 none); AFFINE scale + shift */
     float   alpha;              /* LEAKY slope / RELU_CLIP maximum / ELU alpha; LAYERNORM epsilon */
     int32_t dilation;           /* CONV / DWCONV: dilation_rate (0 or 1: none) */

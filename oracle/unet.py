@@ -543,20 +543,22 @@ def conv_general_numpy(x_nhwc, kernel, bias, padding='same', stride=1, dilation=
     output channel o reads the input channels of group o // (filters / groups)."""
     x = np.asarray(x_nhwc, np.float32)
     kh, kw, cg, co = kernel.shape
-    s, d, g = int(stride), int(dilation), int(groups)
-    ekh, ekw = (kh - 1) * d + 1, (kw - 1) * d + 1
+    # ``stride`` / ``dilation``: one number, or (vertical, horizontal) as Keras' strides / dilation_rate lists
+    (s, sx), (d, dx) = [(int(v), int(v)) if np.isscalar(v) else (int(v[0]), int(v[1])) for v in (stride, dilation)]
+    g = int(groups)
+    ekh, ekw = (kh - 1) * d + 1, (kw - 1) * dx + 1
     if padding == 'same':
         pt, pb = _same_pad(ekh, s, x.shape[1])
-        pl, pr = _same_pad(ekw, s, x.shape[2])
+        pl, pr = _same_pad(ekw, sx, x.shape[2])
         x = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
     N, H, W, C = x.shape
     assert C == cg * g and co % g == 0
-    Ho, Wo = (H - ekh) // s + 1, (W - ekw) // s + 1
+    Ho, Wo = (H - ekh) // s + 1, (W - ekw) // sx + 1
     fg = co // g
     y = np.zeros((N, Ho, Wo, co), np.float64)
     for i in range(kh):
         for j in range(kw):
-            win = x[:, i * d:i * d + (Ho - 1) * s + 1:s, j * d:j * d + (Wo - 1) * s + 1:s, :].astype(np.float64)
+            win = x[:, i * d:i * d + (Ho - 1) * s + 1:s, j * dx:j * dx + (Wo - 1) * sx + 1:sx, :].astype(np.float64)
             for q in range(g):
                 y[..., q * fg:(q + 1) * fg] += np.einsum('nhwc,co->nhwo', win[..., q * cg:(q + 1) * cg], kernel[i, j, :, q * fg:(q + 1) * fg].astype(np.float64))
     return (y + (0 if bias is None else np.asarray(bias, np.float64))).astype(np.float32)

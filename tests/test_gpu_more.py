@@ -311,6 +311,29 @@ def test_dilated_and_odd_tap_convolutions(gpu, case):
 
 
 @pytest.mark.parametrize('case', [
+    # (H, W, cin, cout, (kh, kw), (stride_y, stride_x), (dilation_y, dilation_x), padding): per-axis strides / dilation rates (round 6)
+    (32, 48, 16, 32, (3, 3), (2, 1), (1, 1), 'same'), (33, 47, 8, 24, (3, 3), (1, 3), (1, 1), 'valid'), (24, 40, 16, 16, (3, 3), (1, 1), (2, 3), 'same'),
+    (20, 64, 4, 8, (1, 5), (1, 2), (1, 1), 'same'), (31, 29, 12, 20, (2, 3), (3, 2), (1, 1), 'same'), (40, 24, 32, 64, (3, 1), (1, 1), (4, 1), 'valid'),
+    (16, 16, 1, 4, (3, 3), (1, 1), (1, 2), 'same'), (256, 256, 1, 8, (3, 3), (2, 1), (1, 1), 'same')])
+def test_anisotropic_convolutions(gpu, case):
+    """Conv2D with strides / dilation_rate that differ per axis runs on the device (the scalar kernel: the
+    horizontal values travel in the CONV op's `mode`), followed by an isotropic 3x3 so that the shapes reach the fast kernels too."""
+    H, W, cin, cout, kk, st, dil, pad = case
+    rng = np.random.default_rng(hash(case) % 2 ** 31)
+    layers = [_L('InputLayer', 'in', [], batch_input_shape=[None, H, W, cin]),
+              _L('Conv2D', 'c', ['in'], filters=cout, kernel_size=list(kk), strides=list(st), dilation_rate=list(dil), padding=pad,
+                 activation='relu', use_bias=True),
+              _L('Conv2D', 'c3', ['c'], filters=16, kernel_size=[3, 3], strides=[1, 1], padding='same', activation='linear', use_bias=True)]
+    w = {'c': [_he(rng, kk[0], kk[1], cin, cout), _he(rng, cout)], 'c3': [_he(rng, 3, 3, cout, 16), _he(rng, 16)]}
+    x = rng.normal(size=(3, H, W, cin)).astype(np.float32)
+    _check(gpu, _F(layers, ['in'], ['c3']), w, x)
+    # the anisotropic layer alone, and the restatement without torch on it (oracle/unet.py conv_general_numpy)
+    alone = _check(gpu, _F(layers[:2], ['in'], ['c']), {'c': w['c']}, x)
+    first = np.maximum(oracle_unet.conv_general_numpy(x, w['c'][0], w['c'][1], pad, st, dil), 0)
+    assert first.shape == alone.shape and float(np.abs(first - alone).max()) < 1e-4
+
+
+@pytest.mark.parametrize('case', [
     # (H, W, c, k, stride, dilation, multiplier, padding)
     (32, 32, 32, 3, 1, 1, 1, 'same'), (33, 47, 64, 3, 2, 1, 1, 'same'), (24, 24, 24, 5, 1, 1, 1, 'same'), (20, 28, 96, 3, 1, 2, 1, 'same'),
     (16, 16, 6, 3, 1, 1, 1, 'same'), (16, 16, 8, 3, 1, 1, 2, 'valid'), (40, 40, 128, 7, 2, 1, 1, 'same'), (32, 32, 16, 3, 1, 6, 1, 'same'),

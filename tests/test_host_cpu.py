@@ -155,12 +155,13 @@ def test_plan_rejects_what_it_cannot_lower():
     with pytest.raises(keras_plan.PlanError):
         keras_plan.build_plan(bad, w)
     bad = json.loads(json.dumps(cfg))
-    bad['config']['layers'][1]['config']['strides'] = [2, 1]              # (isotropic strides are lowered since r02)
-    with pytest.raises(keras_plan.PlanError):
+    bad['config']['layers'][1]['config']['strides'] = [2, 1]              # strides > 1 together with a dilation rate > 1 (on any axes)
+    bad['config']['layers'][1]['config']['dilation_rate'] = [1, 2]
+    with pytest.raises(keras_plan.PlanError, match='Keras rejects'):
         keras_plan.build_plan(bad, w)
     bad = json.loads(json.dumps(cfg))
-    bad['config']['layers'][1]['config']['dilation_rate'] = [2, 3]        # (isotropic dilation rates are lowered since r05)
-    with pytest.raises(keras_plan.PlanError):
+    bad['config']['layers'][1]['config']['strides'] = [1, 300]            # the horizontal stride travels in 8 bits of `mode`
+    with pytest.raises(keras_plan.PlanError, match='out of range'):
         keras_plan.build_plan(bad, w)
     bad = json.loads(json.dumps(cfg))
     bad['config']['layers'][1]['config']['groups'] = 3                    # 3 groups do not divide 1 -> 16 channels
@@ -168,6 +169,35 @@ def test_plan_rejects_what_it_cannot_lower():
         keras_plan.build_plan(bad, w)
     with pytest.raises(keras_plan.PlanError):
         keras_plan.build_plan(cfg, w, output=1)                           # the model has one output
+
+
+def test_plan_lowers_anisotropic_convolutions():
+    """Round 6: per-axis strides / dilation rates of a plain Conv2D lower to a CONV op whose `mode` carries the
+    horizontal values (include/ecseg_hip.h); 'same' padding and the output extent follow each axis' own stride and dilated kernel extent.
+    DepthwiseConv2D / grouped convolutions with per-axis values still end in PlanError."""
+    def one(cls='Conv2D', **kw):
+        layers = [dict(class_name='InputLayer', name='in', inbound_nodes=[], config=dict(name='in', batch_input_shape=[None, 20, 30, 8])),
+                  dict(class_name=cls, name='c', inbound_nodes=[[['in', 0, 0, {}]]],
+                       config=dict(name='c', kernel_size=[3, 3], padding='same', activation='linear', use_bias=True, **kw))]
+        return {'class_name': 'Functional', 'config': {'name': 'm', 'layers': layers, 'input_layers': [['in', 0, 0]], 'output_layers': [['c', 0, 0]]}}
+    w = {'c': [np.zeros((3, 3, 8, 16), np.float32), np.zeros(16, np.float32)]}
+    plan = keras_plan.build_plan(one(filters=16, strides=[2, 1]), w)
+    (op,) = [o for o in plan.ops if o['op'] == keras_plan.OP_CONV]
+    assert (op['stride'], op['dilation'], op['mode'], op['pad_top'], op['pad_left']) == (2, 1, 1, 0, 1)      # 20 rows, stride 2: pads (0, 1)
+    to = plan.tensors[op['out']]
+    assert (to['h'], to['w'], to['c']) == (10, 30, 16)
+    plan = keras_plan.build_plan(one(filters=16, strides=[1, 3]), w)
+    (op,) = [o for o in plan.ops if o['op'] == keras_plan.OP_CONV]
+    assert (op['stride'], op['mode']) == (1, 3) and (plan.tensors[op['out']]['h'], plan.tensors[op['out']]['w']) == (20, 10)
+    plan = keras_plan.build_plan(one(filters=16, dilation_rate=[2, 3]), w)
+    (op,) = [o for o in plan.ops if o['op'] == keras_plan.OP_CONV]
+    assert (op['stride'], op['dilation'], op['mode'], op['pad_top'], op['pad_left']) == (1, 2, 3 << 8, 2, 3)
+    plan = keras_plan.build_plan(one(filters=16, strides=[2, 2], dilation_rate=[1, 1]), w)                    # isotropic: mode stays 0
+    assert [o['mode'] for o in plan.ops if o['op'] == keras_plan.OP_CONV] == [0]
+    with pytest.raises(keras_plan.PlanError, match='anisotropic'):
+        keras_plan.build_plan(one('DepthwiseConv2D', strides=[2, 1], depth_multiplier=1), {'c': [np.zeros((3, 3, 8, 1), np.float32), np.zeros(8, np.float32)]})
+    with pytest.raises(keras_plan.PlanError, match='anisotropic'):
+        keras_plan.build_plan(one(filters=16, strides=[2, 1], groups=2), {'c': [np.zeros((3, 3, 4, 16), np.float32), np.zeros(16, np.float32)]})
 
 
 def test_plan_lowers_round5_vocabulary(golden_dir):

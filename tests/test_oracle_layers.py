@@ -274,6 +274,27 @@ def test_dilated_conv_known_answer():
     assert unet.forward(cfgv, {'L': [k]}, x).shape == (1, 1, 1, 1)
 
 
+def test_anisotropic_conv_known_answers():
+    """strides (2, 1): every second row, every column; dilation_rate (1, 2) on a 1x3 kernel: taps two columns apart in one row.
+    'same' pads per axis with that axis' stride and dilated kernel extent."""
+    x = np.arange(30, dtype=np.float32).reshape(1, 5, 6, 1)
+    one = np.ones((1, 1, 1, 1), np.float32)
+    cfg = _model('Conv2D', (5, 6, 1), filters=1, kernel_size=[1, 1], strides=[2, 1], padding='same', activation='linear', use_bias=False)
+    got = unet.forward(cfg, {'L': [one]}, x)
+    assert got.shape == (1, 3, 6, 1) and np.array_equal(got[0, :, :, 0], x[0, ::2, :, 0])
+    assert np.array_equal(unet.conv_general_numpy(x, one, None, 'same', (2, 1), 1), got)
+    cfg = _model('Conv2D', (5, 6, 1), filters=1, kernel_size=[1, 1], strides=[1, 3], padding='valid', activation='linear', use_bias=False)
+    assert np.array_equal(unet.forward(cfg, {'L': [one]}, x)[0, :, :, 0], x[0, :, ::3, 0])
+    k = np.array([1, 10, 100], np.float32).reshape(1, 3, 1, 1)
+    cfg = _model('Conv2D', (5, 6, 1), filters=1, kernel_size=[1, 3], strides=[1, 1], dilation_rate=[1, 2], padding='same',
+                 activation='linear', use_bias=False)
+    got = unet.forward(cfg, {'L': [k]}, x)[0, :, :, 0]
+    assert got.shape == (5, 6)
+    assert got[1, 2] == x[0, 1, 0, 0] + 10 * x[0, 1, 2, 0] + 100 * x[0, 1, 4, 0]
+    assert got[3, 0] == 10 * x[0, 3, 0, 0] + 100 * x[0, 3, 2, 0]            # the tap at column -2 falls into the padding
+    assert np.array_equal(unet.conv_general_numpy(x, k, None, 'same', 1, (1, 2))[0, :, :, 0], got)
+
+
 def test_grouped_and_depthwise_conv_known_answers():
     """groups = 2 on 4 -> 2 channels, 1x1: output 0 sees input channels {0, 1}, output 1 sees {2, 3}.  DepthwiseConv2D with
     depth multiplier 2: output channel ci * 2 + j = input channel ci times kernel[0, 0, ci, j]."""
@@ -306,6 +327,16 @@ def test_round5_numpy_restatements_match_torch_path(seed):
         got = unet.forward(cfg, {'L': [ker, b]}, x)
         want = unet.conv_general_numpy(x, ker, b, pad, s, d, g)
         assert got.shape == want.shape and np.abs(got - want).max() < 1e-4, (k, s, d, g, pad)
+    # per-axis strides / dilation rates / taps
+    for (kk, s, d, pad) in [((3, 3), (2, 1), (1, 1), 'same'), ((3, 3), (1, 3), (1, 1), 'valid'), ((3, 3), (1, 1), (2, 3), 'same'),
+                            ((1, 5), (1, 1), (1, 2), 'same'), ((2, 3), (3, 2), (1, 1), 'same'), ((3, 1), (1, 1), (3, 1), 'valid')]:
+        ker = rng.normal(size=(kk[0], kk[1], 8, 16)).astype(np.float32)
+        b = rng.normal(size=16).astype(np.float32)
+        cfg = _model('Conv2D', (9, 11, 8), filters=16, kernel_size=list(kk), strides=list(s), dilation_rate=list(d), padding=pad,
+                     activation='linear', use_bias=True)
+        got = unet.forward(cfg, {'L': [ker, b]}, x)
+        want = unet.conv_general_numpy(x, ker, b, pad, s, d)
+        assert got.shape == want.shape and np.abs(got - want).max() < 1e-4, (kk, s, d, pad)
     # DepthwiseConv2D / SeparableConv2D
     for (k, s, d, m, pad) in [(3, 1, 1, 1, 'same'), (3, 2, 1, 1, 'same'), (5, 1, 1, 2, 'valid'), (3, 1, 2, 1, 'same')]:
         dk = rng.normal(size=(k, k, 8, m)).astype(np.float32)

@@ -247,14 +247,12 @@ __global__ __launch_bounds__(768) void conv_wino4r_kernel(ConvParams p, int regs
     float* Rs = reinterpret_cast<float*>(smem);
     const int Cout = p.out.c;
     W4_ESTAMP_BEGIN();
-    // Work split of the combine step: per pass 2048 "half items" (channel quad q, column x, tile n, row pair yh) over the
-    // 768 threads in three rounds (the last one 2/3 full) - with whole items (1024 over 768 threads) the first four
-    // waves did two rounds of 4 rows while the others idled behind them.
-    float hl[3][2][4];                                       // fused 1x1 head: partial logits [round][row of the pair][class]
+    // Work split of the combine step: wino4_combine.inc (1024 whole items per pass, a wave owns tile pairs).
+    float hl[2][4][4];                                       // fused 1x1 head: partial logits [round][row of the tile][class]
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int c = 0; c < 4; ++c) hl[a][b][c] = 0.f;
     // the bias quads of both passes are fetched here, under the K loop's drain and the first barrier: a global load inside

@@ -348,11 +348,11 @@ __global__ __launch_bounds__(768) void conv_wino4s_kernel(ConvParams p, int regs
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the compiler does not see the asm LDS-DMAs
     float* Rs = reinterpret_cast<float*>(smem);
     const int Cout = p.out.c;
-    float hl[3][2][4];
+    float hl[2][4][4];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int c = 0; c < 4; ++c) hl[a][b][c] = 0.f;
     f32x4 bvp[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};

@@ -28,16 +28,17 @@ for v in "$@"; do
 done
 wait
 LK="/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC"
+REST="layer_kernels.o wino4s_kernel.o wino4r_kernel.o convs_kernel.o post_kernels.o host_codec.o host_io.o comm.o -lz -ldl"   # objects of the product build
 for v in "$@"; do
   if [ "$v" = diag ]; then
-    $LK -o ../libecseg_diag.so /tmp/w4/api_diag.o unet_kernels.o /tmp/w4/wino4_diag.o /tmp/w4/wino16_diag.o post_kernels.o host_codec.o host_io.o comm.o -lz -ldl
+    $LK -o ../libecseg_diag.so /tmp/w4/api_diag.o unet_kernels.o /tmp/w4/wino4_diag.o /tmp/w4/wino16_diag.o $REST
   elif [ "$v" = points12 ]; then
-    $LK -o ../libecseg_points12.so /tmp/w4/api_p12.o unet_kernels.o /tmp/w4/wino4_p12.o wino16_kernel.o post_kernels.o host_codec.o host_io.o comm.o -lz -ldl
+    $LK -o ../libecseg_points12.so /tmp/w4/api_p12.o unet_kernels.o /tmp/w4/wino4_p12.o wino16_kernel.o $REST
   elif [[ "$v" == *:* ]]; then
     n=${v%%:*}
-    $LK -o ../libecseg_v$n.so /tmp/w4/api_v$n.o unet_kernels.o /tmp/w4/wino4_v$n.o wino16_kernel.o post_kernels.o host_codec.o host_io.o comm.o -lz -ldl
+    $LK -o ../libecseg_v$n.so /tmp/w4/api_v$n.o unet_kernels.o /tmp/w4/wino4_v$n.o wino16_kernel.o $REST
   else
-    $LK -o ../libecseg_v$v.so api.o unet_kernels.o /tmp/w4/wino4_v$v.o wino16_kernel.o post_kernels.o host_codec.o host_io.o comm.o -lz -ldl
+    $LK -o ../libecseg_v$v.so api.o unet_kernels.o /tmp/w4/wino4_v$v.o wino16_kernel.o $REST
   fi
 done
 ls -la ../libecseg_*.so

@@ -23,6 +23,7 @@ def main():
         m = MetasegModel(cfg_for(cin, cout, hw), w)
         x = rng.integers(0, 256, size=(npat, hw, hw, cin), dtype=np.uint8)
         m.handle.set_option('winograd', 2)
+        m.handle.set_option('wino4_rowpass', 0)          # the stamps live in conv_wino4_kernel (same output stage as conv_wino4r_kernel)
         m.handle.forward_patches(x)
         m.handle.forward_patches(x)
         raw = m.handle.debug_peek(168)

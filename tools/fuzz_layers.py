@@ -232,6 +232,102 @@ def random_graph_r5(rng):
     return cfg, weights, (h, w, c)
 
 
+def channels_first_twin(cfg):
+    """The channels_first edition of a flat channels_last Functional config: (N, C, H, W) input, data_format on every spatial layer,
+    channel axis 1; a softmax fused into a convolution becomes a Softmax(axis=1) layer behind it (Keras applies a FUSED softmax
+    over the last axis - W for such tensors)."""
+    import json
+    c = json.loads(json.dumps(cfg))
+    extra = []
+    for L in c['config']['layers']:
+        lc = L['config']
+        if L['class_name'] == 'InputLayer':
+            b = lc['batch_input_shape']
+            lc['batch_input_shape'] = [b[0], b[3], b[1], b[2]]
+        if L['class_name'] in ('Conv2D', 'Conv2DTranspose', 'MaxPooling2D', 'UpSampling2D', 'DepthwiseConv2D', 'SeparableConv2D', 'AveragePooling2D'):
+            lc['data_format'] = 'channels_first'
+            if lc.get('activation') == 'softmax':
+                lc['activation'] = 'linear'
+                extra.append({'class_name': 'Softmax', 'name': lc['name'] + '_sm', 'config': {'name': lc['name'] + '_sm', 'axis': 1},
+                              'inbound_nodes': [[[lc['name'], 0, 0, {}]]]})
+                c['config']['output_layers'] = [[lc['name'] + '_sm', 0, 0] if o[0] == lc['name'] else o for o in c['config']['output_layers']]
+        if L['class_name'] == 'Concatenate':
+            lc['axis'] = 1
+        if L['class_name'] == 'BatchNormalization':
+            lc['axis'] = [1]
+    c['config']['layers'] += extra
+    return c
+
+
+def random_graph_r6(rng):
+    """-> (model_config, weights, input shape, channels_first): the loader corners of round 6 in one chain - Conv2D with per-axis
+    strides / dilation rates / taps (scalar kernel), a convolution CALLED TWICE (shared weights: one layer entry with two inbound
+    nodes, listed before the layer that feeds its second call, as Keras lists it), plain 3x3 convolutions and pools between them
+    (so that the fast kernels see the odd shapes), BatchNormalization behind a shared call; half of the graphs as their
+    channels_first twin (the device then takes and returns (N, C, H, W))."""
+    h = int(rng.choice((16, 24, 32, 40, 33, 50))); w = int(rng.choice((16, 32, 48, 20, 37, 64)))
+    c = int(rng.choice((1, 3, 4, 8, 16, 32)))
+    layers, weights, shape = [_L('InputLayer', 'in', [], batch_input_shape=[None, h, w, c])], {}, {'in': (h, w, c)}
+    he = lambda *s: (rng.normal(size=s) / np.sqrt(np.prod(s[:-1]))).astype(np.float32)
+
+    def ext(n, k, s, d, pad):
+        e = (k - 1) * d + 1
+        return -(-n // s) if pad == 'same' else (n - e) // s + 1
+
+    def conv(name, src, f, kk=(3, 3), st=(1, 1), dil=(1, 1), pad='same', act='relu'):
+        hh, ww, cc = shape[src]
+        layers.append(_L('Conv2D', name, [src], filters=f, kernel_size=list(kk), strides=list(st), dilation_rate=list(dil), padding=pad,
+                         activation=act, use_bias=True))
+        weights[name] = [he(kk[0], kk[1], cc, f), he(f)]
+        shape[name] = (ext(hh, kk[0], st[0], dil[0], pad), ext(ww, kk[1], st[1], dil[1], pad), f)
+        return name
+
+    prev = conv('c0', 'in', int(rng.choice((8, 16, 32))), act='relu')
+    weights['c0'][0] = weights['c0'][0] / 64.0
+    for b in range(int(rng.integers(2, 5))):
+        hh, ww, cc = shape[prev]
+        kind = str(rng.choice(('aniso', 'aniso', 'shared', 'conv', 'pool')))
+        n = 'b%d' % b
+        if kind == 'aniso':
+            kk = [(3, 3), (3, 3), (1, 3), (3, 1), (2, 3), (1, 5), (1, 1)][int(rng.integers(0, 7))]
+            if rng.random() < 0.5:
+                st, dil = [(2, 1), (1, 2), (1, 3), (3, 2), (3, 1)][int(rng.integers(0, 5))], (1, 1)
+            else:
+                st, dil = (1, 1), [(2, 3), (1, 2), (3, 1), (2, 1), (1, 4)][int(rng.integers(0, 5))]
+            pad = str(rng.choice(('same', 'same', 'valid')))
+            if ext(hh, kk[0], st[0], dil[0], pad) < 4 or ext(ww, kk[1], st[1], dil[1], pad) < 4:
+                pad = 'same'
+            if ext(hh, kk[0], st[0], dil[0], pad) < 2 or ext(ww, kk[1], st[1], dil[1], pad) < 2:
+                st, dil, pad = (1, 1), (1, 1), 'same'
+            prev = conv(n, prev, int(rng.choice((8, 16, 24, 32, 64))), kk, st, dil, pad, act=str(rng.choice(('relu', 'linear', 'tanh', 'elu'))))
+        elif kind == 'shared':
+            # y0 = L(x); a = tanh-ish(y0); y1 = L(a); out = y0 + y1 (+ a BatchNormalization called on the sum)
+            k = int(rng.choice((3, 3, 1)))
+            layers.append({'class_name': 'Conv2D', 'name': n, 'config': dict(name=n, filters=cc, kernel_size=[k, k], strides=[1, 1], padding='same',
+                                                                             activation=str(rng.choice(('relu', 'linear'))), use_bias=True),
+                           'inbound_nodes': [[[prev, 0, 0, {}]], [[n + '_a', 0, 0, {}]]]})
+            weights[n] = [he(k, k, cc, cc), he(cc)]
+            layers.append(_L('Activation', n + '_a', [n], activation=str(rng.choice(('tanh', 'sigmoid', 'relu')))))
+            layers.append({'class_name': 'Add', 'name': n + '_s', 'config': {'name': n + '_s'}, 'inbound_nodes': [[[n, 0, 0, {}], [n, 1, 0, {}]]]})
+            shape[n + '_s'] = (hh, ww, cc)
+            prev = n + '_s'
+            if rng.random() < 0.5:
+                layers.append(_L('BatchNormalization', n + '_bn', [prev], axis=[3], epsilon=1e-3, center=True, scale=True))
+                weights[n + '_bn'] = [rng.uniform(.5, 1.5, cc).astype(np.float32), he(cc), he(cc), rng.uniform(.5, 1.5, cc).astype(np.float32)]
+                shape[n + '_bn'] = (hh, ww, cc)
+                prev = n + '_bn'
+        elif kind == 'conv':
+            prev = conv(n, prev, int(rng.choice((16, 32, 64, 96))), act='relu')
+        elif hh >= 8 and ww >= 8 and hh % 2 == 0 and ww % 2 == 0:
+            layers.append(_L('MaxPooling2D', n, [prev], pool_size=[2, 2], strides=[2, 2], padding='valid'))
+            shape[n] = (hh // 2, ww // 2, cc)
+            prev = n
+    head = conv('head', prev, int(rng.choice((2, 3, 4))), (1, 1), act=str(rng.choice(('softmax', 'sigmoid'))))
+    weights['head'][0] = weights['head'][0] * 3
+    cfg = {'class_name': 'Functional', 'config': {'name': 'fuzz6', 'layers': layers, 'input_layers': [['in', 0, 0]], 'output_layers': [[head, 0, 0]]}}
+    return cfg, weights, (h, w, c), bool(rng.random() < 0.5)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--seconds', type=float, default=300)
@@ -239,6 +335,7 @@ def main():
     ap.add_argument('--seeds', default=None)
     ap.add_argument('--wide', action='store_true', help='wider layers / larger extents')
     ap.add_argument('--vocab', action='store_true', help='graphs from the round-5 vocabulary (random_graph_r5)')
+    ap.add_argument('--loader', action='store_true', help='the loader corners of round 6 (random_graph_r6): per-axis strides / dilation, shared layers, channels_first')
     a = ap.parse_args()
     import torch  # noqa: F401
     from ecseg_amd.model import MetasegModel
@@ -254,7 +351,10 @@ def main():
                 break
             seed = todo.pop(0)
         rng = np.random.default_rng(5 * 10 ** 6 + seed)
-        if a.vocab:
+        cf = False
+        if a.loader:
+            cfg, weights, (h, w, cin), cf = random_graph_r6(rng)
+        elif a.vocab:
             cfg, weights, (h, w, cin) = random_graph_r5(rng)
         else:
             cfg, weights, (h, w, cin) = random_graph(rng, seed_kind=1 if seed >= 10 ** 5 else 0, wide=a.wide)
@@ -264,6 +364,16 @@ def main():
             x = (x.astype(np.float32) - 128) / 64            # (these graphs carry no input scaling of their own)
         out_sel = int(rng.integers(0, len(cfg['config']['output_layers'])))
         want = oracle_unet.forward(cfg, weights, x.astype(np.float32), output=out_sel)
+        if cf:
+            # the channels_first twin with the SAME weights: the oracle evaluates it natively in (N, C, H, W) and must agree with the
+            # channels_last graph; the device is then fed (N, C, H, W) and checked against the transposed result
+            cfg = channels_first_twin(cfg)
+            x = np.ascontiguousarray(np.moveaxis(x, -1, 1))
+            want_cf = oracle_unet.forward(cfg, weights, x.astype(np.float32), output=out_sel)
+            if float(np.abs(np.moveaxis(want_cf, 1, -1) - want).max()) > 2e-4 * max(1.0, float(np.abs(want).max())):
+                print('ORACLE MISMATCH seed %d: channels_first twin differs from the channels_last graph' % seed, flush=True)
+                fails += 1
+            want = want_cf
         scale = max(1.0, float(np.abs(want).max()))
         try:
             m = MetasegModel(cfg, weights, device=0, output=out_sel)
@@ -272,7 +382,7 @@ def main():
                 for fuse in (1, 0):
                     m.handle.set_option('fuse_pool', fuse)
                     m.handle.set_option('fuse_head', fuse)
-                    got = m.handle.forward_patches(x)
+                    got = m.predict_on_batch(x) if cf else m.handle.forward_patches(x)
                     err = float(np.abs(got - want).max()) / scale
                     worst = max(worst, err)
                     if not np.isfinite(got).all() or err > 1e-3:

@@ -130,7 +130,7 @@ int abort_comm(ecseg_comm* c, const std::string& what) {
 struct InitState {
     std::mutex m;
     std::condition_variable cv;
-    bool done = false, abandoned = false;
+    bool done = false, abandoned = false, caller_aborted = false;      // caller_aborted: the waiting side has already called ncclCommAbort(early)
     volatile ncclComm_t early = nullptr;
     ncclComm_t comm = nullptr;
     ncclResult_t res = ncclSuccess;
@@ -149,7 +149,7 @@ int init_with_deadline(ecseg_comm* c, const ncclUniqueId& id) {
         ncclResult_t res = hipSetDevice(device) == hipSuccess ? init(const_cast<ncclComm_t*>(&st->early), world, id, rank) : ncclUnhandledCudaError;
         std::unique_lock<std::mutex> lk(st->m);
         st->comm = st->early; st->res = res; st->done = true;
-        const bool orphan = st->abandoned;
+        const bool orphan = st->abandoned && !st->caller_aborted;          // (never abort one communicator twice)
         lk.unlock();
         st->cv.notify_all();
         if (orphan && res == ncclSuccess && st->comm) { if (abort_fn) (void)abort_fn(st->comm); else (void)destroy_fn(st->comm); }
@@ -160,6 +160,7 @@ int init_with_deadline(ecseg_comm* c, const ncclUniqueId& id) {
         st->abandoned = true;
         c->dead = true;
         const ncclComm_t early = st->early;
+        if (early && abort_fn) st->caller_aborted = true;
         lk.unlock();
         if (early && abort_fn) {
             // ask the stuck initialisation to give up and give the helper a moment to unwind: a process that exits while a
@@ -278,9 +279,12 @@ int ecseg_allgather_records(ecseg_comm* c, const int64_t* send, int n_records, i
     if (hipMemcpyAsync(c->d_send, send, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) return comm_fail(ECSEG_E_HIP, "hipMemcpy H2D");
     const ncclResult_t e = rccl().AllGather(c->d_send, c->d_recv, (size_t)n_records * ECSEG_RECORD_INT64, ncclInt64, c->comm, c->stream);
     if (e != ncclSuccess) return nccl_fail(e, "ncclAllGather");
-    if (hipMemcpyAsync(recv, c->d_recv, bytes * (size_t)c->world, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
-        return comm_fail(ECSEG_E_HIP, "hipMemcpy D2H");
-    return wait_stream(c, c->stream, deadline, "ncclAllGather");
+    // the copy into the caller's memory is issued only after the collective has COMPLETED: a copy queued behind a collective that
+    // times out would run once the abort unblocks the stream - into a buffer the caller may have freed by then
+    rc = wait_stream(c, c->stream, deadline, "ncclAllGather");
+    if (rc != ECSEG_OK) return rc;
+    if (hipMemcpy(recv, c->d_recv, bytes * (size_t)c->world, hipMemcpyDeviceToHost) != hipSuccess) return comm_fail(ECSEG_E_HIP, "hipMemcpy D2H");
+    return ECSEG_OK;
 }
 
 }  // extern "C"

@@ -182,6 +182,18 @@ def test_fuzz_layer_graphs(seed0):
         del m
 
 
+def test_fuzz_loader_corners(monkeypatch):
+    """24 graphs of `tools/fuzz_layers.py --loader` (round 6: Conv2D with per-axis strides / dilation rates, layers called twice,
+    channels_first twins fed (N, C, H, W)), every kernel mode and fusion setting; the 420-second campaign is profiles/r06_fuzz_loader.log."""
+    import os
+    import runpy
+    import sys
+    monkeypatch.setattr(sys, 'argv', ['fuzz_layers.py', '--loader', '--seeds', ','.join(str(s) for s in range(24)), '--seconds', '600'])
+    with pytest.raises(SystemExit) as e:
+        runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'fuzz_layers.py'), run_name='__main__')
+    assert e.value.code == 0
+
+
 def test_fuzz_pipeline_cases(monkeypatch):
     """Six cases of tools/fuzz_pipeline.py (random small U-Nets x random image sizes: the cropped plan vs itself (history, lanes) and vs the uncropped plan, probabilities vs the
     oracle, clean-up / counts on the device raw labels, meta_preprocess, overlay rows)."""

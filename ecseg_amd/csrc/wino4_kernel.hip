@@ -428,9 +428,6 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(ConvParams p, int regs_
             __syncthreads();
             if (ch == 1) write_R(std::true_type{});
         } else if (ch == pass) {
-#if defined(ECSEG_W4_EPI_ABL) && (ECSEG_W4_EPI_ABL & 8)     // (timing-only A/B builds: the folded rows are not written to the exchange image)
-            if (p.n < 0)
-#endif
             write_R(std::false_type{});
         }
         ESTAMP(1);                                           // [1] fold own row + write R to LDS

@@ -1,5 +1,5 @@
 """Kernel time of conv_wino4_kernel (wino4_rowpass = 0) on three short-K layer shapes: the A/B harness of the output-stage
-ablation builds (apply tools/experiments/w4_epilogue_ablation_hooks.patch, then tools/build_variants.sh ECSEG_W4_EPI_ABL=<bits>: 1 no output stores, 2 no LDS reads in the combine step, 4 no
+ablation builds (git apply -p0 tools/experiments/w4_epilogue_ablation_hooks.patch, then tools/build_variants.sh ECSEG_W4_EPI_ABL=<bits>: 1 no output stores, 2 no LDS reads in the combine step, 4 no
 combine step, 8 no fold + write of the exchange image; results are wrong on purpose)."""
 import os
 import sys

@@ -172,7 +172,7 @@ def test_fuzz_layer_graphs(seed0):
         want = oracle_unet.forward(cfg, weights, x.astype(np.float32))
         scale = max(1.0, float(np.abs(want).max()))
         m = MetasegModel(cfg, weights, device=0)
-        for mode in (2, 1, 0):
+        for mode in (2, 3, 1, 0):
             m.handle.set_option('winograd', mode)
             for fuse in (1, 0):
                 m.handle.set_option('fuse_pool', fuse)

@@ -377,7 +377,7 @@ def main():
         scale = max(1.0, float(np.abs(want).max()))
         try:
             m = MetasegModel(cfg, weights, device=0, output=out_sel)
-            for mode in (2, 1, 0):
+            for mode in (2, 3, 1, 0):            # 3: the bf16x3 split kernels where they apply (round 6)
                 m.handle.set_option('winograd', mode)
                 for fuse in (1, 0):
                     m.handle.set_option('fuse_pool', fuse)
@@ -397,7 +397,7 @@ def main():
             fails += 1
         n_graphs += 1
         seed += 1
-    print('layer fuzz: %d random graphs x 3 kernel modes x 2 fusion settings, worst relative error %.2e, %d failure(s), %.0f s'
+    print('layer fuzz: %d random graphs x 4 kernel modes x 2 fusion settings, worst relative error %.2e, %d failure(s), %.0f s'
           % (n_graphs, worst, fails, time.time() - t0), flush=True)
     sys.exit(1 if fails else 0)
 

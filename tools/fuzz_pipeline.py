@@ -68,7 +68,7 @@ def main():
             h = m.handle
             # random execution options: none of them may change a single label
             opts = {'images_per_group': int(rng.integers(1, 4)), 'overlap_post': int(rng.integers(0, 2)),
-                    'post_graph': int(rng.integers(0, 2)), 'winograd': int(rng.choice((2, 2, 1, 0)))}
+                    'post_graph': int(rng.integers(0, 2)), 'winograd': int(rng.choice((2, 2, 1, 0, 3)))}
             if rng.random() < 0.5:
                 opts['post_chunk'] = int(rng.integers(1, 4))
             for kk, vv in opts.items():

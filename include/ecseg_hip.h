@@ -37,6 +37,9 @@ extern "C" {
  * ECSEG_COMM_TIMEOUT_S bounds ecseg_comm_create / ecseg_allgather_records*. */
 /* 5 (round 5): ecseg_meta_segment (pre-process + segment in one call), ecseg_prefetch_input, ecseg_host_alloc / ecseg_host_free
  * (page-locked host buffers); ecseg_create sets the device's scheduling flag to hipDeviceScheduleBlockingSync (see there). */
+/* (round 6, still 5 - additions a round-5 caller never triggers: option "winograd" = 3 and "wino4_rowpass"; ecseg_get_conv_launch_profile kinds 5 / 6
+ * (the split kernels); CONV ops read their so far unused `mode` word as the horizontal stride / dilation rate (0 = as before); CONVT kernels larger than
+ * their stride run phase by phase.) */
 #define ECSEG_ABI_VERSION 5
 
 #define ECSEG_OK             0

@@ -31,10 +31,13 @@ def main():
         w = {'c': [(rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin) / 64).astype(np.float32), rng.normal(size=cout).astype(np.float32)]}
         mm = MetasegModel(cfg_for(cin, cout, hw), w)
         x = rng.integers(0, 256, size=(n, hw, hw, cin), dtype=np.uint8)
-        r0 = mm.handle.forward_patches(x)
-        nb = sum(not np.array_equal(r0, mm.handle.forward_patches(x)) for _ in range(reps))
-        print('layer %d->%d@%d: %d repetitions, %d mismatching' % (cin, cout, hw, reps, nb))
-        bad += nb
+        for mode, rowpass in ((2, 1), (2, 0), (3, 1)):       # conv_wino4r_kernel (default), conv_wino4_kernel, conv_wino4s_kernel (bf16x3 split)
+            mm.handle.set_option('winograd', mode)
+            mm.handle.set_option('wino4_rowpass', rowpass)
+            r0 = mm.handle.forward_patches(x)
+            nb = sum(not np.array_equal(r0, mm.handle.forward_patches(x)) for _ in range(reps))
+            print('layer %d->%d@%d winograd=%d rowpass=%d: %d repetitions, %d mismatching' % (cin, cout, hw, mode, rowpass, reps, nb))
+            bad += nb
         del mm
     sys.exit(1 if bad else 0)
 

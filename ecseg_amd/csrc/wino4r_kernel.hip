@@ -1,9 +1,10 @@
 // Winograd F(4x4, 3x3) on the fp32 matrix cores with the ROW transform done once per workgroup (round 6): conv_wino4_kernel's arithmetic -
-// the same filter image, the same column transform, MFMA order and output stage, bit-identical results are NOT promised (the row
-// transform sums in another order) - in the loop structure of conv_wino4s_kernel (wino4s_kernel.hip): per 8-channel group all 768 threads
+// the same filter image, the same fma chains in the row and column transforms, MFMA order and output stage: results are BIT-IDENTICAL
+// (tools/w4r_time.py) - in the loop structure of conv_wino4s_kernel (wino4s_kernel.hip): per 8-channel group all 768 threads
 // turn the raw halo into a t image in LDS (row_pass: 576 half items, 24 fmas each), a wave reads the six 16-byte columns of ITS row instead
-// of 24 raw slots + 72 fmas; two barriers per group, raw halo double-buffered and fetched two groups ahead.  See DESIGN.md 5.1c for what
-// it measures against the kernel it came from.
+// of 24 raw slots + 72 fmas; two barriers per group, raw halo double-buffered and fetched two groups ahead.  See DESIGN.md 5.1 for what
+// it measures against the kernel it came from.  (A SPLIT variant for lone 32-channel blocks was built and measured 2 - 6 % SLOWER than
+// conv_wino4_kernel<false, true>, which keeps those layers: tools/experiments/wino4r_split_variant.patch.)
 #include <cstdlib>
 #include <type_traits>
 

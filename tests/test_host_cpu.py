@@ -200,6 +200,36 @@ def test_plan_lowers_anisotropic_convolutions():
         keras_plan.build_plan(one(filters=16, strides=[2, 1], groups=2), {'c': [np.zeros((3, 3, 4, 16), np.float32), np.zeros(16, np.float32)]})
 
 
+def test_loader_corner_graphs_lower_and_their_channels_first_twins_agree():
+    """The generator of `tools/fuzz_layers.py --loader` on the CPU: 24 random chains of per-axis convolutions, shared layers, pools and
+    BatchNorm lower to plans (anisotropic CONV ops carry their `mode` word, a shared layer becomes one op per call on ONE weight index), and
+    the oracle evaluates the channels_first twin natively to the transposed result of the channels_last graph."""
+    from oracle import unet
+    from tools.fuzz_layers import channels_first_twin, random_graph_r6
+    seen = {'aniso': 0, 'shared': 0, 'cf': 0}
+    for seed in range(24):
+        rng = np.random.default_rng(5 * 10 ** 6 + seed)
+        cfg, w, (h, ww, c), cf = random_graph_r6(rng)
+        plan = keras_plan.build_plan(cfg, w)
+        convs = [o for o in plan.ops if o['op'] == keras_plan.OP_CONV]
+        seen['aniso'] += any(o['mode'] for o in convs)
+        for L in cfg['config']['layers']:
+            if len(L['inbound_nodes']) == 2:                       # a layer called twice: two ops, one kernel
+                seen['shared'] += 1
+                k = w[L['name']][0]
+                twins = [o for o in convs if plan.weights[o['w0']].size == k.size and np.array_equal(np.ravel(plan.weights[o['w0']]), k.ravel())]
+                assert len(twins) >= 2 and len({o['w0'] for o in twins}) == 1, (seed, L['name'])
+        if cf and seed % 2 == 0:                                   # (the oracle pass is the slow part: every second twin)
+            seen['cf'] += 1
+            x = rng.integers(0, 256, size=(1, h, ww, c), dtype=np.uint8).astype(np.float32)
+            want = unet.forward(cfg, w, x)
+            twin = channels_first_twin(cfg)
+            assert keras_plan.build_plan(twin, w).channels_first
+            got = unet.forward(twin, w, np.ascontiguousarray(np.moveaxis(x, -1, 1)))
+            assert np.abs(np.moveaxis(got, 1, -1) - want).max() <= 2e-4 * max(1.0, float(np.abs(want).max())), seed
+    assert seen['aniso'] >= 5 and seen['shared'] >= 5 and seen['cf'] >= 2, seen
+
+
 def test_plan_lowers_round5_vocabulary(golden_dir):
     """dilation_rate, groups, DepthwiseConv2D / SeparableConv2D, Multiply, PReLU, Normalization,
     LayerNormalization, nested sub-models and several outputs lower to a plan (they ended in PlanError before); the h5py-written

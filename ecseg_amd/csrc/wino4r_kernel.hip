@@ -281,6 +281,97 @@ __global__ __launch_bounds__(768) void conv_wino4r_kernel(ConvParams p, int regs
             }
         }
     };
+    if constexpr (!HEAD && !SPLIT) {
+        // Passes by TILE half instead of channel half (round 6): pass P takes the accumulator rows e = 8 P .. 8 P + 7 (tiles 16 P .. 16 P + 15) of ALL
+        // 64 output channels, exchange image [xi][x][16 tiles][64 couts] - every wave folds and writes in BOTH passes (half as many rows each)
+        // where the channel-half passes left six of the twelve waves waiting behind the other six's fold.  The same sums element by element:
+        // bit-identical.  (Not for a fused head: its per-pixel class sums would then be spread over two waves.)
+        const int cq = tid & 7, cx = (tid >> 3) & 3, nlo = (tid >> 5) & 1;          // channel quad, column of the tile, tile of the pair
+        const int cwave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const float* rlane = Rs + cx * W4_RPLANE + nlo * 64 + 4 * cq;
+        const unsigned out_row = (unsigned)(W * p.out.cs);
+        auto tile_pass = [&](auto pc) __attribute__((always_inline)) {
+            constexpr int P = decltype(pc)::value;
+            __syncthreads();                                 // main-loop LDS reads / previous pass's combine are done
+#pragma unroll
+            for (int e8 = 0; e8 < 8; ++e8) {
+                constexpr int dummy = 0; (void)dummy;
+                const int e = 8 * P + e8;
+                const int tl = (e8 & 3) + 8 * (e8 >> 2) + 4 * lh;         // tile slot within the half: 0..15
+                const float m0 = acc[0][e], m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e], m5 = acc[5][e];
+                const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                float* o = Rs + (xi * 4) * W4_RPLANE + tl * 64 + ch * 32 + li;
+                const float r0 = m0 + s12 + s34, r1 = __builtin_fmaf(KA, d12, KB * d34), r2 = __builtin_fmaf(KA2, s12, KB2 * s34),
+                            r3 = __builtin_fmaf(KA3, d12, __builtin_fmaf(KB3, d34, m5));
+                o[0 * W4_RPLANE] = r0; o[1 * W4_RPLANE] = r1; o[2 * W4_RPLANE] = r2; o[3 * W4_RPLANE] = r3;
+            }
+            __syncthreads();
+            if (P == 0) asm volatile("" :: "v"(bvp[0]), "v"(bvp[1]));      // (the bias wait in straight-line code: wino4_combine.inc)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int u = cwave + 12 * k;                // unit: tile pair u & 7 of this half x channel half u >> 3
+                if (u >= 16) break;
+                const int tp = u & 7, chh = u >> 3;
+                const int nq8 = 4 * P + (tp >> 1);           // tile row pair index of the 32 tiles
+                const int g = (0x96 >> nq8) & 1, nty = nq8 >> 1;
+                const int img = g ? r_img[1] : r_img[0];
+                if (img < 0) continue;
+                const int co = nb * 64 + chh * 32 + 4 * cq;
+                if (co + 3 >= Cout) continue;                // (the missing channel half of a Cout % 64 == 32 block; wave-uniform per lane group: co_ok is all or nothing for chh)
+                const f32x4 bv = chh ? bvp[1] : bvp[0];
+                const float* r = rlane + tp * 128 + chh * 32;
+                const f32x4 q0 = *reinterpret_cast<const f32x4*>(r);
+                const f32x4 q1 = *reinterpret_cast<const f32x4*>(r + 1 * 4 * W4_RPLANE);
+                const f32x4 q2 = *reinterpret_cast<const f32x4*>(r + 2 * 4 * W4_RPLANE);
+                const f32x4 q3 = *reinterpret_cast<const f32x4*>(r + 3 * 4 * W4_RPLANE);
+                const f32x4 q4 = *reinterpret_cast<const f32x4*>(r + 4 * 4 * W4_RPLANE);
+                const f32x4 q5 = *reinterpret_cast<const f32x4*>(r + 5 * 4 * W4_RPLANE);
+                const f32x4 s12 = q1 + q2, d12 = q1 - q2, s34 = q3 + q4, d34 = q3 - q4;
+                f32x4 y[4];                                  // (wino4_combine.inc's expressions, term for term)
+                y[0] = q0 + s12 + s34 + bv;
+                y[1] = KA * d12 + KB * d34 + bv;
+                y[2] = KA2 * s12 + KB2 * s34 + bv;
+                y[3] = KA3 * d12 + KB3 * d34 + q5 + bv;
+                if (p.act == ECSEG_ACT_RELU) {
+#pragma unroll
+                    for (int yy = 0; yy < 4; ++yy)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            float tv = y[yy][c];
+                            asm("v_max_f32_e32 %0, 0, %1" : "=v"(tv) : "v"(tv));
+                            y[yy][c] = tv;
+                        }
+                } else if (p.act != ECSEG_ACT_LINEAR) {
+#pragma unroll
+                    for (int yy = 0; yy < 4; ++yy)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) y[yy][c] = apply_act_core(y[yy][c], p.act, p.alpha);
+                }
+                const int oy = (g ? r_y0[1] : r_y0[0]) + 4 * nty, ox = (g ? r_x0[1] : r_x0[0]) + 8 * (tp & 1);       // wave-uniform
+                const unsigned out_lane = (unsigned)((4 * nlo + cx) * p.out.cs + co);
+                float* ob = p.out.p + (((size_t)img * H + oy) * W + ox) * p.out.cs;
+#pragma unroll
+                for (int yy = 0; yy < 4; ++yy)
+                    __builtin_nontemporal_store(y[yy], reinterpret_cast<f32x4*>(ob + (size_t)(out_lane + (unsigned)yy * out_row)));
+                if (p.pool.p != nullptr) {                  // fused MaxPooling2D(2x2, stride 2), as in wino4_combine.inc
+                    float* pb = p.pool.p + (((size_t)img * p.pool.h + (oy >> 1)) * p.pool.w + (ox >> 1)) * p.pool.cs;
+                    const unsigned pool_lane = (unsigned)((2 * nlo + (cx >> 1)) * p.pool.cs + co);
+#pragma unroll
+                    for (int yp = 0; yp < 2; ++yp) {
+                        f32x4 m;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float a = fmaxf(y[2 * yp][c], y[2 * yp + 1][c]);
+                            m[c] = fmaxf(a, __shfl_xor(a, 8));
+                        }
+                        if (!(cx & 1)) *reinterpret_cast<f32x4*>(pb + (size_t)(pool_lane + (unsigned)(yp * p.pool.w * p.pool.cs))) = m;
+                    }
+                }
+            }
+        };
+        tile_pass(std::integral_constant<int, 0>{});
+        tile_pass(std::integral_constant<int, 1>{});
+    } else
     for (int pass = 0; pass < (SPLIT ? 1 : 2); ++pass) {
         __syncthreads();                                     // main-loop LDS reads / previous pass's combine are done
         ESTAMP(0);                                           // [0] barrier (K-loop skew / previous combine)

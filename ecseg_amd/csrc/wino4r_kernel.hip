@@ -295,7 +295,6 @@ __global__ __launch_bounds__(768) void conv_wino4r_kernel(ConvParams p, int regs
             __syncthreads();                                 // main-loop LDS reads / previous pass's combine are done
 #pragma unroll
             for (int e8 = 0; e8 < 8; ++e8) {
-                constexpr int dummy = 0; (void)dummy;
                 const int e = 8 * P + e8;
                 const int tl = (e8 & 3) + 8 * (e8 >> 2) + 4 * lh;         // tile slot within the half: 0..15
                 const float m0 = acc[0][e], m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e], m5 = acc[5][e];
